@@ -1,0 +1,965 @@
+/*
+ * dreamzs_oracle.c -- CPU restatement of PyDREAM's MT-DREAM(ZS) hot path
+ * (pydream/Dream.py:193-422 `Dream.astep` and everything it calls, driven as
+ * pydream/core.py:89-129 `_sample_dream` drives it).
+ *
+ * TEST INFRASTRUCTURE ONLY -- see dreamzs_oracle.h.  Parity status: PINNED
+ * against the reference run in the build container (tests/golden/).
+ *
+ * Plain scalar C, one chain at a time, written to be read next to the
+ * reference.  The only things that are NOT the reference's are the ones the
+ * reference leaves unpinned: the random bit-stream
+ * (here: Philox4x32-10 counters, DESIGN.md "Random contract") and the order of
+ * floating-point reductions (DESIGN.md "Reduction contract").  Both are
+ * restated here independently of the HIP sources from the written contract.
+ *
+ * Compile with -ffp-contract=off (see oracle/Makefile): every fused
+ * multiply-add below is an explicit fma()/fmaf() call.
+ */
+#include "dreamzs_oracle.h"
+
+#include <math.h>
+#include <float.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_VERSION 1
+#define HOT __attribute__((target_clones("default", "fma")))
+
+static __thread char g_err[512];
+static int fail(const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); return -1; }
+int orc_version(void) { return ORC_VERSION; }
+const char* orc_last_error(void) { return g_err; }
+
+/* ------------------------------------------------------------------ */
+/* Random contract                                                     */
+/* ------------------------------------------------------------------ */
+
+/* Philox4x32-10 (Salmon et al., SC'11).  key = 64-bit seed. */
+void orc_philox4x32_10(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4])
+{
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* stream id = kind | try<<4 | phase<<12 | round<<16 */
+enum { K_CTRL = 0, K_PT = 1, K_DIM = 2, K_BND = 3 };
+uint32_t orc_stream_id(int kind, int tr, int phase, int round)
+{
+    return (uint32_t)kind | ((uint32_t)tr << 4) | ((uint32_t)phase << 12) | ((uint32_t)round << 16);
+}
+
+/* 53-bit uniform in [0,1) from two words (27 high bits of hi, 26 of lo). */
+double orc_u53(uint32_t hi, uint32_t lo)
+{
+    return ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) * (1.0 / 9007199254740992.0);
+}
+/* 32-bit uniform in (0,1): (w + 1/2) 2^-32, exact in double. */
+double orc_u32(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0); }
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint64_t d2u(double f) { uint64_t u; memcpy(&u, &f, 8); return u; }
+static inline double u2d(uint64_t u) { double f; memcpy(&f, &u, 8); return f; }
+
+/* Standard normal in binary32 from two words: Box-Muller, cosine branch, with
+ * the polynomial log / cos(2 pi u) of DESIGN.md "Elementary functions". */
+HOT float orc_normal32(uint32_t w1, uint32_t w2)
+{
+    float u1 = ((float)(w1 >> 9) + 0.5f) * 1.1920928955078125e-07f; /* 2^-23 */
+    float u2 = ((float)(w2 >> 9) + 0.5f) * 1.1920928955078125e-07f;
+    /* log(u1), u1 in (0,1) */
+    uint32_t b = f2u(u1);
+    int e = (int)(b >> 23) - 127;
+    float m = u2f((b & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    float f = m - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float p = 1.0f / 11.0f;
+    p = fmaf(p, z, 1.0f / 9.0f);
+    p = fmaf(p, z, 1.0f / 7.0f);
+    p = fmaf(p, z, 1.0f / 5.0f);
+    p = fmaf(p, z, 1.0f / 3.0f);
+    float t = 2.0f * s;
+    float lm = fmaf(t * z, p, t);
+    float ef = (float)e;
+    float lg = fmaf(ef, 0.693145751953125f, fmaf(ef, 1.42860682030941723e-06f, lm));
+    float rad = sqrtf(-2.0f * lg);
+    /* cos(2 pi u2) by octants */
+    float t8 = u2 * 8.0f;
+    float fo = floorf(t8);
+    int o = (int)fo;
+    float r = t8 - fo;
+    if (o & 1) r = 1.0f - r;
+    float y = r * 0.785398163397448309616f;
+    float y2 = y * y;
+    float sp = 1.0f / 362880.0f;
+    sp = fmaf(sp, y2, -1.0f / 5040.0f);
+    sp = fmaf(sp, y2, 1.0f / 120.0f);
+    sp = fmaf(sp, y2, -1.0f / 6.0f);
+    float sn = fmaf(y * y2, sp, y);
+    float cp = -1.0f / 3628800.0f;
+    cp = fmaf(cp, y2, 1.0f / 40320.0f);
+    cp = fmaf(cp, y2, -1.0f / 720.0f);
+    cp = fmaf(cp, y2, 1.0f / 24.0f);
+    cp = fmaf(cp, y2, -0.5f);
+    float cs = fmaf(y2, cp, 1.0f);
+    float c = (((o + 1) >> 1) & 1) ? sn : cs;
+    if (((o + 2) >> 2) & 1) c = -c;
+    return rad * c;
+}
+
+/* ------------------------------------------------------------------ */
+/* Elementary functions (binary64), DESIGN.md "Elementary functions"   */
+/* ------------------------------------------------------------------ */
+#define LN2_HI 6.93147180369123816490e-01 /* low 32 bits zero */
+#define LN2_LO 1.90821492927058770002e-10
+
+HOT double orc_exp(double x)
+{
+    if (x != x) return x;
+    if (x > 709.782712893384) return INFINITY;
+    if (x < -745.2) return 0.0;
+    double kf = floor(x * 1.4426950408889634 + 0.5);
+    double r = fma(-kf, LN2_HI, x);
+    r = fma(-kf, LN2_LO, r);
+    double p = 1.0 / 6227020800.0;        /* 1/13! */
+    p = fma(p, r, 1.0 / 479001600.0);     /* 1/12! */
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    int k = (int)kf;
+    if (k < -1000) { p = p * u2d((uint64_t)(1023 - 1000) << 52); k += 1000; }
+    return p * u2d((uint64_t)(k + 1023) << 52);
+}
+
+HOT double orc_log(double x)
+{
+    if (x != x) return x;
+    if (x < 0.0) return NAN;
+    if (x == 0.0) return -INFINITY;
+    if (x == INFINITY) return x;
+    int e = 0;
+    uint64_t b = d2u(x);
+    if ((b >> 52) == 0) { x = x * 18014398509481984.0; e = -54; b = d2u(x); } /* 2^54 */
+    e += (int)(b >> 52) - 1023;
+    double m = u2d((b & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double p = 1.0 / 23.0;
+    p = fma(p, z, 1.0 / 21.0);
+    p = fma(p, z, 1.0 / 19.0);
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    double t = 2.0 * s;
+    double lm = fma(t * z, p, t);
+    double ef = (double)e;
+    return fma(ef, LN2_HI, fma(ef, LN2_LO, lm));
+}
+
+/* numpy.nan_to_num (Dream.py:323, 332, 334, 481, 820) */
+static inline double nan_to_num(double x)
+{
+    if (x != x) return 0.0;
+    if (x == INFINITY) return DBL_MAX;
+    if (x == -INFINITY) return -DBL_MAX;
+    return x;
+}
+
+/* ------------------------------------------------------------------ */
+/* Reduction contract: lane(j) = (j>>1)&63, sequential within a lane,   */
+/* xor-butterfly over the 64 lane partials.                            */
+/* ------------------------------------------------------------------ */
+static inline double butterfly64(double* p)
+{
+    double q[64];
+    for (int off = 32; off >= 1; off >>= 1) {
+        for (int l = 0; l < 64; ++l) q[l] = p[l] + p[l ^ off];
+        memcpy(p, q, sizeof q);
+    }
+    return p[0];
+}
+HOT double orc_wave_dot(const double* a, const double* b, int d)
+{
+    double p[64];
+    for (int l = 0; l < 64; ++l) p[l] = 0.0;
+    for (int j = 0; j < d; ++j) { int l = (j >> 1) & 63; p[l] = fma(a[j], b[j], p[l]); }
+    return butterfly64(p);
+}
+static double wave_sum(const double* a, int d)
+{
+    double p[64];
+    for (int l = 0; l < 64; ++l) p[l] = 0.0;
+    for (int j = 0; j < d; ++j) { int l = (j >> 1) & 63; p[l] = p[l] + a[j]; }
+    return butterfly64(p);
+}
+
+/* first category m with u < p0+..+pm (sequential cumulative sum); stands in
+ * for np.random.multinomial(1, p) (Dream.py:545, 565, 595, 615, 908). */
+int orc_invcdf(const double* p, int n, double u)
+{
+    double c = 0.0;
+    for (int m = 0; m < n; ++m) { c = c + p[m]; if (u < c) return m; }
+    return n - 1;
+}
+
+/* n distinct indices from range(M); stands in for random.sample(range(M), n)
+ * (Dream.py:662): t-th index = mulhi(word_t, M-t), then skipped over the
+ * previously chosen ones in ascending order. */
+int orc_sample_distinct(const uint32_t* words, int n, uint32_t M, uint32_t* out)
+{
+    uint32_t sorted[16];
+    if (n > 16 || (uint32_t)n > M) return -1;
+    for (int t = 0; t < n; ++t) {
+        uint32_t r = (uint32_t)(((uint64_t)words[t] * (uint64_t)(M - (uint32_t)t)) >> 32);
+        int pos = 0;
+        for (int s = 0; s < t; ++s) { if (r >= sorted[s]) { r++; pos = s + 1; } else break; }
+        for (int s = t; s > pos; --s) sorted[s] = sorted[s - 1];
+        sorted[pos] = r;
+        out[t] = r;
+    }
+    return 0;
+}
+
+/* gamma table, Dream.py:172-179 */
+void orc_gamma_table(int ngamma, int depairs, int d, double* out)
+{
+    double dec = 1.0;
+    for (int lev = 1; lev <= ngamma; ++lev) {
+        for (int delta = 1; delta <= depairs; ++delta)
+            for (int dp = 1; dp <= d; ++dp)
+                out[((size_t)(lev - 1) * depairs + (delta - 1)) * d + (dp - 1)] =
+                    (2.38 / sqrt((double)(2 * delta) * (double)dp)) / dec;
+        dec = dec * 2.0;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* Engine state                                                        */
+/* ------------------------------------------------------------------ */
+enum { LK_NONE = 0, LK_MVN_DENSE = 1, LK_MVN_TRI = 2, LK_MIX = 3, LK_HOST = 4 };
+
+struct orc_engine {
+    orc_config c;
+    int d, nl, N, k;
+    double *mins, *maxs;
+    double* gtab;
+    double* Z; int64_t M;
+    double *X, *lprior, *llike; int have_logp;
+    double *cp_prev, *cp_new;   /* [N,d] published positions (Dream.py:424-449) */
+    double *cr_probs, *cr_delta, *cr_n;         /* shared (core.py:287-289) */
+    double *g_probs, *g_delta, *g_n;            /* shared (core.py:291-293) */
+    double *own_cr, *own_g;                     /* per-chain copies, schedule S1 only */
+    int32_t* pkind; double *pa, *pb; int have_prior;
+    int lk; double* mu; double* Mx; double logF; int J; double* mixF;
+    orc_logp_cb cb; void* cb_user;
+    orc_exchange_cb xcb; void* xcb_user;
+    int64_t gen;         /* generations done */
+    int64_t ntrace;
+    double *tX, *tlogp; uint8_t *tmoved, *tsnk; int32_t *ttry, *tcr;
+    /* scratch */
+    double *pts, *refs, *work;
+};
+
+static void* zalloc(size_t n) { void* p = calloc(n ? n : 1, 1); return p; }
+
+int orc_create(const orc_config* cfg, orc_engine** out)
+{
+    if (!cfg || !out) return fail("null argument");
+    if (cfg->ndim < 1 || cfg->nchains < 1 || cfg->nchains_local < 1 || cfg->multitry < 1) return fail("bad sizes");
+    if (cfg->multitry == 2) return fail("multitry=2 is broken in the reference (Dream.py:867-868); rejected");
+    if (cfg->depairs < 1 || cfg->depairs > 8) return fail("DEpairs must be 1..8");
+    if (cfg->ncr < 1 || cfg->ngamma < 1) return fail("bad nCR/gamma_levels");
+    if (cfg->schedule != 1 && cfg->schedule != 2) return fail("schedule must be 1 or 2");
+    if (cfg->chain_offset < 0 || cfg->chain_offset + cfg->nchains_local > cfg->nchains) return fail("bad shard");
+    orc_engine* e = zalloc(sizeof *e);
+    e->c = *cfg; e->d = cfg->ndim; e->nl = cfg->nchains_local; e->N = cfg->nchains; e->k = cfg->multitry;
+    int d = e->d, nl = e->nl, N = e->N, k = e->k;
+    e->mins = zalloc(sizeof(double) * d); e->maxs = zalloc(sizeof(double) * d);
+    for (int j = 0; j < d; ++j) { e->mins[j] = -INFINITY; e->maxs[j] = INFINITY; }
+    e->gtab = zalloc(sizeof(double) * cfg->ngamma * cfg->depairs * d);
+    orc_gamma_table(cfg->ngamma, cfg->depairs, d, e->gtab);
+    e->Z = zalloc(sizeof(double) * (size_t)cfg->history_capacity * d);
+    e->X = zalloc(sizeof(double) * nl * d); e->lprior = zalloc(sizeof(double) * nl); e->llike = zalloc(sizeof(double) * nl);
+    e->cp_prev = zalloc(sizeof(double) * N * d); e->cp_new = zalloc(sizeof(double) * N * d);
+    e->cr_probs = zalloc(sizeof(double) * cfg->ncr); e->cr_delta = zalloc(sizeof(double) * cfg->ncr); e->cr_n = zalloc(sizeof(double) * cfg->ncr);
+    e->g_probs = zalloc(sizeof(double) * cfg->ngamma); e->g_delta = zalloc(sizeof(double) * cfg->ngamma); e->g_n = zalloc(sizeof(double) * cfg->ngamma);
+    for (int m = 0; m < cfg->ncr; ++m) e->cr_probs[m] = 1.0 / (double)cfg->ncr;          /* Dream.py:134 */
+    for (int m = 0; m < cfg->ngamma; ++m) e->g_probs[m] = 1.0 / (double)cfg->ngamma;     /* Dream.py:143 */
+    e->own_cr = zalloc(sizeof(double) * nl * cfg->ncr); e->own_g = zalloc(sizeof(double) * nl * cfg->ngamma);
+    e->pkind = zalloc(sizeof(int32_t) * d); e->pa = zalloc(sizeof(double) * d); e->pb = zalloc(sizeof(double) * d);
+    size_t tc = (size_t)cfg->trace_capacity;
+    e->tX = zalloc(sizeof(double) * tc * nl * d); e->tlogp = zalloc(sizeof(double) * tc * nl);
+    e->tmoved = zalloc(tc * nl); e->tsnk = zalloc(tc * nl);
+    e->ttry = zalloc(sizeof(int32_t) * tc * nl); e->tcr = zalloc(sizeof(int32_t) * tc * nl);
+    e->pts = zalloc(sizeof(double) * k * d); e->refs = zalloc(sizeof(double) * k * d); e->work = zalloc(sizeof(double) * 8 * d);
+    *out = e;
+    return 0;
+}
+
+int orc_destroy(orc_engine* e)
+{
+    if (!e) return 0;
+    free(e->mins); free(e->maxs); free(e->gtab); free(e->Z); free(e->X); free(e->lprior); free(e->llike);
+    free(e->cp_prev); free(e->cp_new); free(e->cr_probs); free(e->cr_delta); free(e->cr_n);
+    free(e->g_probs); free(e->g_delta); free(e->g_n); free(e->own_cr); free(e->own_g);
+    free(e->pkind); free(e->pa); free(e->pb); free(e->mu); free(e->Mx); free(e->mixF);
+    free(e->tX); free(e->tlogp); free(e->tmoved); free(e->tsnk); free(e->ttry); free(e->tcr);
+    free(e->pts); free(e->refs); free(e->work); free(e);
+    return 0;
+}
+
+int orc_set_bounds(orc_engine* e, const double* mins, const double* maxs)
+{   /* Dream.py:86-105 */
+    memcpy(e->mins, mins, sizeof(double) * e->d); memcpy(e->maxs, maxs, sizeof(double) * e->d); return 0;
+}
+int orc_set_gamma_table(orc_engine* e, const double* t)
+{
+    if (t) memcpy(e->gtab, t, sizeof(double) * e->c.ngamma * e->c.depairs * e->d);
+    else orc_gamma_table(e->c.ngamma, e->c.depairs, e->d, e->gtab);
+    return 0;
+}
+int orc_set_history(orc_engine* e, const double* Z, int64_t rows)
+{   /* core.py:255-263, 281-283: seed rows first */
+    if (rows > e->c.history_capacity) return fail("history exceeds capacity");
+    memcpy(e->Z, Z, sizeof(double) * (size_t)rows * e->d); e->M = rows; return 0;
+}
+int orc_set_state(orc_engine* e, const double* X, const double* prior, const double* like)
+{
+    memcpy(e->X, X, sizeof(double) * e->nl * e->d);
+    if (prior && like) { memcpy(e->lprior, prior, sizeof(double) * e->nl); memcpy(e->llike, like, sizeof(double) * e->nl); e->have_logp = 1; }
+    else e->have_logp = 0;       /* evaluated at the first step, Dream.py:266-268 */
+    return 0;
+}
+int orc_set_cr_probs(orc_engine* e, const double* p, int32_t n)
+{   /* Dream.py:128-134 */
+    if (n != e->c.ncr) return fail("nCR mismatch");
+    memcpy(e->cr_probs, p, sizeof(double) * n);
+    for (int c = 0; c < e->nl; ++c) memcpy(e->own_cr + (size_t)c * n, p, sizeof(double) * n);
+    return 0;
+}
+int orc_set_gamma_probs(orc_engine* e, const double* p, int32_t n)
+{   /* Dream.py:138-143 */
+    if (n != e->c.ngamma) return fail("ngamma mismatch");
+    memcpy(e->g_probs, p, sizeof(double) * n);
+    for (int c = 0; c < e->nl; ++c) memcpy(e->own_g + (size_t)c * n, p, sizeof(double) * n);
+    return 0;
+}
+int orc_set_prior(orc_engine* e, const int32_t* kind, const double* a, const double* b)
+{
+    memcpy(e->pkind, kind, sizeof(int32_t) * e->d); memcpy(e->pa, a, sizeof(double) * e->d); memcpy(e->pb, b, sizeof(double) * e->d);
+    e->have_prior = 1; return 0;
+}
+int orc_set_likelihood_mvn(orc_engine* e, const double* mu, const double* M, int32_t kind, double log_F)
+{
+    int d = e->d;
+    free(e->mu); free(e->Mx);
+    e->mu = zalloc(sizeof(double) * d); e->Mx = zalloc(sizeof(double) * d * d);
+    memcpy(e->mu, mu, sizeof(double) * d); memcpy(e->Mx, M, sizeof(double) * d * d);
+    e->logF = log_F; e->lk = kind == 0 ? LK_MVN_DENSE : LK_MVN_TRI; return 0;
+}
+int orc_set_likelihood_mixture(orc_engine* e, int32_t J, const double* mu, const double* log_F)
+{
+    int d = e->d;
+    free(e->mu); free(e->mixF);
+    e->mu = zalloc(sizeof(double) * J * d); e->mixF = zalloc(sizeof(double) * J);
+    memcpy(e->mu, mu, sizeof(double) * J * d); memcpy(e->mixF, log_F, sizeof(double) * J);
+    e->J = J; e->lk = LK_MIX; return 0;
+}
+int orc_set_likelihood_host(orc_engine* e, orc_logp_cb cb, void* user) { e->cb = cb; e->cb_user = user; e->lk = LK_HOST; return 0; }
+int orc_set_exchange(orc_engine* e, orc_exchange_cb cb, void* user) { e->xcb = cb; e->xcb_user = user; return 0; }
+int64_t orc_generation(orc_engine* e) { return e->gen; }
+
+/* ------------------------------------------------------------------ */
+/* Log densities                                                       */
+/* ------------------------------------------------------------------ */
+
+/* Built-in target densities.
+ * MVN: examples/ndim_gaussian/dream_ex_ndim_gaussian.py:49-52
+ *      logp = log_F - .5 * sum(x * dot(invC, x));  kind 0 takes invC itself,
+ *      kind 1 an upper-triangular U with invC = U^T U (Q = |U v|^2).
+ *      Order: y_r = sum_c M[r][c] v_c ascending c (fma chain), Q = sum_r y_r s_r
+ *      ascending r (fma chain), s = v (dense) or y (triangular).
+ * Mixture: examples/mixturemodel/mixturemodel.py:37-48. */
+HOT double orc_loglike(orc_engine* e, const double* x)
+{
+    int d = e->d;
+    if (e->lk == LK_MVN_DENSE || e->lk == LK_MVN_TRI) {
+        int tri = e->lk == LK_MVN_TRI;
+        double* v = e->work + 6 * (size_t)d;
+        for (int j = 0; j < d; ++j) v[j] = x[j] - e->mu[j];
+        double Q = 0.0;
+        for (int r = 0; r < d; ++r) {
+            const double* row = e->Mx + (size_t)r * d;
+            double y = 0.0;
+            for (int c = tri ? r : 0; c < d; ++c) y = fma(row[c], v[c], y);
+            Q = fma(y, tri ? y : v[r], Q);
+        }
+        return e->logF - 0.5 * Q;
+    }
+    if (e->lk == LK_MIX) {
+        double lh[64]; double mx = -INFINITY;
+        for (int j = 0; j < e->J; ++j) {
+            const double* mu = e->mu + (size_t)j * d;
+            double S = 0.0;
+            for (int i = 0; i < d; ++i) { double t = x[i] - mu[i]; S = fma(t, t, S); }
+            lh[j] = -0.5 * S + e->mixF[j];
+            if (lh[j] > mx) mx = lh[j];
+        }
+        double dens = 0.0;
+        for (int j = 0; j < e->J; ++j) dens = dens + orc_exp(lh[j] - mx);
+        return orc_log(dens) + mx;
+    }
+    return 0.0;
+}
+
+/* Per-dimension priors: 0 flat (parameters.py:62-63), 1 scipy.stats.norm(loc=a,
+ * scale=b), 2 scipy.stats.uniform(loc=a, scale=b); summed over dims
+ * (parameters.py:37-47) in the lane/butterfly order. */
+static double prior_logp(orc_engine* e, const double* x)
+{
+    if (!e->have_prior) return 0.0;
+    int d = e->d; double* t = e->work + 7 * (size_t)d;
+    for (int j = 0; j < d; ++j) {
+        if (e->pkind[j] == 1) {
+            double z = (x[j] - e->pa[j]) / e->pb[j];
+            t[j] = (-(z * z) / 2.0 - 0.91893853320467274178) - orc_log(e->pb[j]);
+        } else if (e->pkind[j] == 2) {
+            t[j] = (x[j] >= e->pa[j] && x[j] <= e->pa[j] + e->pb[j]) ? -orc_log(e->pb[j]) : -INFINITY;
+        } else t[j] = 0.0;
+    }
+    return wave_sum(t, d);
+}
+
+/* Model.total_logp (model.py:17-32) over a batch; NaN is mapped to -inf. */
+static int eval_points(orc_engine* e, const double* P, int n, double* prior, double* like)
+{
+    if (e->lk == LK_HOST) {
+        int rc = e->cb(P, n, e->d, prior, like, e->cb_user);
+        if (rc) return fail("host likelihood callback failed");
+        if (e->have_prior) for (int i = 0; i < n; ++i) prior[i] = prior[i] + prior_logp(e, P + (size_t)i * e->d);   /* built-in priors add to the callback's */
+    } else {
+        for (int i = 0; i < n; ++i) { prior[i] = prior_logp(e, P + (size_t)i * e->d); like[i] = orc_loglike(e, P + (size_t)i * e->d); }
+    }
+    for (int i = 0; i < n; ++i) { if (prior[i] != prior[i]) prior[i] = -INFINITY; if (like[i] != like[i]) like[i] = -INFINITY; }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Proposal generation (Dream.py:670-796, 798-837)                     */
+/* ------------------------------------------------------------------ */
+typedef struct { double u_snk, u_cr, u_de, u_glev, u_sel, u_acc; } ctrl_draws;
+
+static void draw_ctrl(uint64_t seed, uint32_t gc, uint32_t g, ctrl_draws* o)
+{
+    uint32_t w[4]; uint32_t s = orc_stream_id(K_CTRL, 0, 0, 0);
+    orc_philox4x32_10(seed, 0, s, gc, g, w); o->u_snk = orc_u53(w[0], w[1]); o->u_cr = orc_u53(w[2], w[3]);
+    orc_philox4x32_10(seed, 1, s, gc, g, w); o->u_de = orc_u53(w[0], w[1]); o->u_glev = orc_u53(w[2], w[3]);
+    orc_philox4x32_10(seed, 2, s, gc, g, w); o->u_sel = orc_u53(w[0], w[1]); o->u_acc = orc_u53(w[2], w[3]);
+}
+
+/* generate_proposal_points(n, base, CR, DEpairs, gamma_level, snooker)
+ * out: pts[n,d]; slogp[n] (snooker_logp, 0 for DE); gammas[n]; cur_norm_log =
+ * (d-1) log|base - z_0| for the single-try snooker ratio (Dream.py:328-329). */
+static int gen_points(orc_engine* e, uint32_t gc, uint32_t g, int phase, int n, const double* base, int64_t M,
+                      int snk, int cr_idx, int delta, int glev,
+                      double* pts, double* slogp, double* gammas, double* cur_snk_logp, int64_t* zidx)
+{
+    const int d = e->d; const uint64_t seed = e->c.seed;
+    const double CR = (double)(cr_idx + 1) / (double)e->c.ncr;     /* Dream.py:146 */
+    double *U = e->work, *e1 = e->work + d, *zt = e->work + 2 * (size_t)d, *v = e->work + 3 * (size_t)d,
+           *dz = e->work + 4 * (size_t)d, *tmp = e->work + 5 * (size_t)d;
+    uint32_t w[4];
+    if (M > 0xffffffffll) return fail("history too long for 32-bit index draw");
+    double gamma_snk = 0.0;
+    if (snk) {   /* one set_gamma call per generate call, Dream.py:730 -> :615-618 (try 0's point stream) */
+        orc_philox4x32_10(seed, 0, orc_stream_id(K_PT, 0, phase, 0), gc, g, w);
+        double u_gs = orc_u53(w[2], w[3]);
+        gamma_snk = 1.2 + (2.2 - 1.2) * u_gs;
+    }
+    for (int i = 0; i < n; ++i) {
+        double* P = pts + (size_t)i * d;
+        uint32_t s_pt = orc_stream_id(K_PT, i, phase, 0), s_dim = orc_stream_id(K_DIM, i, phase, 0), s_bnd = orc_stream_id(K_BND, i, phase, 0);
+        if (!snk) {
+            /* sample_from_history, Dream.py:646-668: 2*delta distinct rows */
+            uint32_t words[16], rows[16];
+            for (int q = 0; q * 4 < 2 * delta; ++q) orc_philox4x32_10(seed, 1 + q, s_pt, gc, g, words + 4 * q);
+            if (orc_sample_distinct(words, 2 * delta, (uint32_t)M, rows)) return fail("history shorter than 2*DEpairs");
+            if (zidx) for (int t = 0; t < 2 * delta; ++t) zidx[(size_t)i * 16 + t] = rows[t];
+            /* chain_differences, Dream.py:692 (rows added in order) */
+            for (int j = 0; j < d; ++j) {
+                double a = e->Z[(size_t)rows[0] * d + j], b = e->Z[(size_t)rows[delta] * d + j];
+                for (int t = 1; t < delta; ++t) { a = a + e->Z[(size_t)rows[t] * d + j]; b = b + e->Z[(size_t)rows[delta + t] * d + j]; }
+                dz[j] = a - b;
+            }
+            /* zeta, e, U: Dream.py:694-700 */
+            int dprime = 0;
+            for (int j = 0; j < d; ++j) {
+                orc_philox4x32_10(seed, (uint32_t)j, s_dim, gc, g, w);
+                U[j] = orc_u32(w[0]);
+                e1[j] = (-e->c.lamb + (e->c.lamb - (-e->c.lamb)) * orc_u32(w[1])) + 1.0;      /* :696-697 */
+                zt[j] = e->c.zeta * (double)orc_normal32(w[2], w[3]);                           /* :694 */
+                if (U[j] < CR) dprime++;                                                       /* :704, :709 */
+            }
+            /* set_gamma, Dream.py:601-626 */
+            orc_philox4x32_10(seed, 0, s_pt, gc, g, w);
+            double u_gu = orc_u53(w[0], w[1]);
+            double gamma;
+            if (u_gu < e->c.p_gamma_unity) gamma = 1.0;
+            else { int dp = dprime == 0 ? d : dprime;   /* index -1 wraps to the last entry, :624 */
+                   gamma = e->gtab[((size_t)(glev - 1) * e->c.depairs + (delta - 1)) * d + (dp - 1)]; }
+            gammas[i] = gamma; slogp[i] = 0.0;
+            /* :714/:717 then crossover :720-726 */
+            for (int j = 0; j < d; ++j) {
+                double t = e1[j] * gamma; t = t * dz[j];
+                double p = base[j] + t; p = p + zt[j];
+                P[j] = (U[j] < CR) ? p : base[j];
+            }
+        } else {
+            /* snooker_update, Dream.py:798-837 */
+            orc_philox4x32_10(seed, 1, s_pt, gc, g, w);
+            uint32_t iz = (uint32_t)(((uint64_t)w[0] * (uint64_t)M) >> 32);
+            uint32_t i1 = (uint32_t)(((uint64_t)w[1] * (uint64_t)M) >> 32);
+            uint32_t i2 = (uint32_t)(((uint64_t)w[2] * (uint64_t)M) >> 32);
+            if (zidx) { zidx[(size_t)i * 16] = iz; zidx[(size_t)i * 16 + 1] = i1; zidx[(size_t)i * 16 + 2] = i2; }
+            const double *z = e->Z + (size_t)iz * d, *r1 = e->Z + (size_t)i1 * d, *r2 = e->Z + (size_t)i2 * d;
+            for (int j = 0; j < d; ++j) { v[j] = base[j] - z[j]; dz[j] = r1[j] - r2[j]; }      /* :813, :819 */
+            double D = orc_wave_dot(v, v, d);                                                 /* :816 / :827 */
+            if (n > 1) {
+                double s = orc_wave_dot(dz, v, d);
+                double c = s / D;
+                for (int j = 0; j < d; ++j) { double zp = nan_to_num(c * v[j]); P[j] = base[j] + gamma_snk * zp; }   /* :820-822 */
+            } else {
+                double s = 0.0;
+                if (D != 0.0) { for (int j = 0; j < d; ++j) tmp[j] = (dz[j] * v[j]) / D; s = wave_sum(tmp, d); }     /* :831 */
+                s = nan_to_num(s);
+                for (int j = 0; j < d; ++j) { double zp = s * v[j]; P[j] = base[j] + gamma_snk * zp; }
+            }
+            for (int j = 0; j < d; ++j) tmp[j] = P[j] - z[j];
+            double norm = sqrt(orc_wave_dot(tmp, tmp, d));                                    /* :823 / :834 */
+            slogp[i] = norm != 0.0 ? orc_log(norm) * (double)(d - 1) : 0.0;                   /* :824 / :835 */
+            gammas[i] = gamma_snk;
+            if (i == 0 && cur_snk_logp) { double nc = sqrt(D); *cur_snk_logp = nc != 0.0 ? orc_log(nc) * (double)(d - 1) : 0.0; }  /* :328-329 */
+        }
+        /* hard boundaries, Dream.py:733-791: reflect once, then redraw uniformly */
+        if (e->c.hardboundaries) {
+            for (int j = 0; j < d; ++j) {
+                double x = P[j];
+                int lo = x < e->mins[j], hi = x > e->maxs[j];
+                if (lo) x = 2 * e->mins[j] - x;
+                if (hi) x = 2 * e->maxs[j] - x;
+                if (x < e->mins[j] || x > e->maxs[j]) {
+                    orc_philox4x32_10(seed, (uint32_t)j, s_bnd, gc, g, w);
+                    x = e->mins[j] + orc_u32(w[0]) * (e->maxs[j] - e->mins[j]);
+                }
+                P[j] = x;
+            }
+        }
+    }
+    return 0;
+}
+
+int orc_debug_propose(orc_engine* e, int32_t chain_local, int64_t gen, int phase, const double* base,
+                      int run_snooker, int cr_idx, int delta, int glev,
+                      double* pts, double* slogp, double* gammas, int64_t* zidx)
+{
+    int n = phase == 0 ? e->k : e->k - 1;
+    return gen_points(e, (uint32_t)(e->c.chain_offset + chain_local), (uint32_t)gen, phase, n, base, e->M,
+                      run_snooker, cr_idx, delta, glev, pts, slogp, gammas, NULL, zidx);
+}
+
+/* ------------------------------------------------------------------ */
+/* One chain transition, Dream.py:238-347                              */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    int snk, cr_idx, delta, glev, sel, accept, moved, gamma_unity;
+    double prior_new, like_new;
+} step_res;
+
+static int chain_step(orc_engine* e, int c, uint32_t g, int64_t M, const double* cr_probs, const double* g_probs,
+                      double* xnew, step_res* R)
+{
+    const int d = e->d, k = e->k; const double T = e->c.temperature;
+    const uint32_t gc = (uint32_t)(e->c.chain_offset + c);
+    const double* q0 = e->X + (size_t)c * d;
+    ctrl_draws u; draw_ctrl(e->c.seed, gc, g, &u);
+    R->snk = (e->c.snooker != 0.0) && (u.u_snk < e->c.snooker);                   /* set_snooker :542-554 */
+    R->cr_idx = orc_invcdf(cr_probs, e->c.ncr, u.u_cr);                            /* set_CR :556-569 */
+    R->delta = e->c.depairs > 1 ? 1 + (int)floor(u.u_de * (double)e->c.depairs) : 1;   /* set_DEpair :571-583 */
+    R->glev = 1 + orc_invcdf(g_probs, e->c.ngamma, u.u_glev);                      /* set_gamma_level :585-599 */
+    double slp[64], slr[64], gam[64], cur_snk = 0.0;
+    double pri[64], lik[64], rpri[64], rlik[64];
+    if (k > 63) return fail("multitry too large");
+    if (gen_points(e, gc, g, 0, k, q0, M, R->snk, R->cr_idx, R->delta, R->glev, e->pts, slp, gam, &cur_snk, NULL)) return -1;   /* :258-264 */
+    R->gamma_unity = 0;
+    for (int i = 0; i < k; ++i) if (gam[i] == 1.0) R->gamma_unity = 1;
+    if (eval_points(e, e->pts, k, pri, lik)) return -1;                                                             /* :270-279 */
+    double last_logp = T * e->llike[c] + e->lprior[c];                                                              /* :243, :268 */
+    double ratio; const double* qprop; int sel = 0;
+    if (k == 1) {
+        double q_logp = T * lik[0] + pri[0];                                                                        /* :274 */
+        if (R->snk) ratio = nan_to_num((q_logp + slp[0]) - (last_logp + cur_snk));                                    /* :326-332 */
+        else ratio = nan_to_num(q_logp) - nan_to_num(last_logp);                                                    /* :334 */
+        qprop = e->pts;
+    } else {
+        double lp[64] = {0}; int anyfinite = 0;
+        for (int i = 0; i < k; ++i) { lp[i] = pri[i] + T * lik[i]; if (isfinite(lp[i])) anyfinite = 1; }            /* :279, :900 */
+        /* mt_choose_proposal_pt :883-917 */
+        double mx = lp[0]; for (int i = 1; i < k; ++i) if (lp[i] > mx) mx = lp[i];
+        double wgt[64], S = 0.0;
+        for (int i = 0; i < k; ++i) { wgt[i] = orc_exp(lp[i] - mx); S = S + wgt[i]; }
+        for (int i = 0; i < k; ++i) wgt[i] = wgt[i] / S;
+        sel = orc_invcdf(wgt, k, u.u_sel);
+        qprop = e->pts + (size_t)sel * d;
+        /* reference set :295-303 */
+        if (gen_points(e, gc, g, 1, k - 1, qprop, M, R->snk, R->cr_idx, R->delta, R->glev, e->refs, slr, gam, NULL, NULL)) return -1;
+        R->gamma_unity = 0;                                   /* self.gamma is overwritten by this call, :705/:730 */
+        for (int i = 0; i < k - 1; ++i) if (gam[i] == 1.0) R->gamma_unity = 1;
+        if (eval_points(e, e->refs, k - 1, rpri, rlik)) return -1;
+        double A[64], B[64];
+        for (int i = 0; i < k - 1; ++i) B[i] = T * rlik[i] + rpri[i];
+        B[k - 1] = T * e->llike[c] + e->lprior[c];                                                                   /* :877-879, :303 */
+        if (R->snk) {                                                                                                /* :306-313 */
+            slr[k - 1] = 0.0;
+            for (int i = 0; i < k; ++i) { A[i] = lp[i] + slp[i]; B[i] = (B[i] + slr[i]) + slp[i]; }
+        } else for (int i = 0; i < k; ++i) A[i] = lp[i];
+        double m2 = A[0]; for (int i = 0; i < k; ++i) { if (A[i] > m2) m2 = A[i]; if (B[i] > m2) m2 = B[i]; }          /* :320 */
+        double SA = 0.0, SB = 0.0;
+        for (int i = 0; i < k; ++i) SA = SA + orc_exp(A[i] - m2);                                                   /* :321 */
+        for (int i = 0; i < k; ++i) SB = SB + orc_exp(B[i] - m2);                                                   /* :322 */
+        ratio = nan_to_num(orc_log(SA / SB));                                                                       /* :323 */
+        if (!anyfinite) ratio = -INFINITY;   /* DESIGN.md deviation D1: the reference's unbounded regenerate loop (:282-289) is a forced reject */
+    }
+    /* metrop_select :980-998 */
+    R->accept = isfinite(ratio) && (orc_log(u.u_acc) < ratio);
+    R->sel = sel;
+    R->moved = 0;
+    if (R->accept) {
+        memcpy(xnew, qprop, sizeof(double) * d);
+        for (int j = 0; j < d; ++j) if (xnew[j] != q0[j]) R->moved = 1;
+        R->prior_new = pri[sel]; R->like_new = lik[sel];                                                             /* :345-347 */
+    } else {
+        memcpy(xnew, q0, sizeof(double) * d);
+        R->prior_new = e->lprior[c]; R->like_new = e->llike[c];
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Adaptation (Dream.py:451-499, 501-540)                              */
+/* ------------------------------------------------------------------ */
+/* population std per dimension of pos[N,d] (np.std axis=0, ddof=0, :476).
+ * strip > 0: two-level sums (strips of `strip` rows, then strips in order);
+ * strip == 0: plain row order (numpy's order; schedule S1). */
+static void std_by_dim(const double* pos, int N, int d, int strip, double* sd)
+{
+    for (int j = 0; j < d; ++j) {
+        double tot = 0.0;
+        if (strip) { for (int s = 0; s < N; s += strip) { double ps = 0.0; for (int c = s; c < N && c < s + strip; ++c) ps = ps + pos[(size_t)c * d + j]; tot = tot + ps; } }
+        else for (int c = 0; c < N; ++c) tot = tot + pos[(size_t)c * d + j];
+        double mean = tot / (double)N;
+        tot = 0.0;
+        if (strip) { for (int s = 0; s < N; s += strip) { double ps = 0.0; for (int c = s; c < N && c < s + strip; ++c) { double t = pos[(size_t)c * d + j] - mean; ps = fma(t, t, ps); } tot = tot + ps; } }
+        else for (int c = 0; c < N; ++c) { double t = pos[(size_t)c * d + j] - mean; tot = tot + t * t; }
+        sd[j] = sqrt(tot / (double)N);
+    }
+}
+/* sum(((q_new - q0)/sd)**2) (:481, :527) in the lane/butterfly order */
+static double jump_norm(const double* xn, const double* xo, const double* sd, int d, double* tmp)
+{
+    for (int j = 0; j < d; ++j) tmp[j] = (xn[j] - xo[j]) / sd[j];
+    return nan_to_num(orc_wave_dot(tmp, tmp, d));
+}
+static void renorm_probs(double* probs, const double* delta, const double* n, int nb, int N)
+{   /* :487-493 / :531-536 */
+    for (int m = 0; m < nb; ++m) if (delta[m] == 0.0) return;
+    double S = 0.0;
+    for (int m = 0; m < nb; ++m) { probs[m] = (delta[m] / n[m]) * (double)N; S = S + probs[m]; }
+    for (int m = 0; m < nb; ++m) probs[m] = probs[m] / S;
+}
+static int adapt_cr_now(const orc_engine* e, uint32_t g, int gamma_unity)
+{   /* :371 and :385/:395 */
+    if (!e->c.adapt_crossover) return 0;
+    if ((int64_t)g == e->c.crossover_burnin) return 1;
+    return g > 10 && (int64_t)g < e->c.crossover_burnin && !gamma_unity;
+}
+static int adapt_gamma_now(const orc_engine* e, uint32_t g, int gamma_unity, int snk)
+{   /* :381 and :385/:391 */
+    if (!e->c.adapt_gamma) return 0;
+    if ((int64_t)g == e->c.crossover_burnin) return 1;
+    return g > 10 && (int64_t)g < e->c.crossover_burnin && !gamma_unity && !snk;
+}
+
+/* chain flags of ANY global chain at generation g, recomputed from the random
+ * contract (used for chains owned by other ranks in schedule S2). */
+static void chain_flags(const orc_engine* e, uint32_t gc, uint32_t g, int* snk, int* cr_idx, int* glev, int* gamma_unity)
+{
+    ctrl_draws u; draw_ctrl(e->c.seed, gc, g, &u);
+    *snk = (e->c.snooker != 0.0) && (u.u_snk < e->c.snooker);
+    *cr_idx = orc_invcdf(e->cr_probs, e->c.ncr, u.u_cr);
+    *glev = 1 + orc_invcdf(e->g_probs, e->c.ngamma, u.u_glev);
+    int phase = e->k > 1 ? 1 : 0, n = e->k > 1 ? e->k - 1 : 1;
+    *gamma_unity = 0;
+    if (!*snk) for (int i = 0; i < n; ++i) {
+        uint32_t w[4]; orc_philox4x32_10(e->c.seed, 0, orc_stream_id(K_PT, i, phase, 0), gc, g, w);
+        if (orc_u53(w[0], w[1]) < e->c.p_gamma_unity) *gamma_unity = 1;
+    }
+}
+
+static int exchange(orc_engine* e, const double* send_local, double* recv_global, size_t row_doubles)
+{
+    size_t bytes = sizeof(double) * (size_t)e->nl * row_doubles;
+    if (e->nl == e->N) { memcpy(recv_global, send_local, bytes); return 0; }
+    if (!e->xcb) return fail("sharded run needs an exchange callback");
+    if (e->xcb(send_local, recv_global, (int64_t)bytes, e->xcb_user)) return fail("exchange callback failed");
+    return 0;
+}
+
+static void record_trace(orc_engine* e, int c, const double* xnew, const step_res* R)
+{   /* core.py:114-116 */
+    if (e->c.trace_capacity == 0) return;
+    size_t t = (size_t)e->ntrace, nl = (size_t)e->nl, d = (size_t)e->d;
+    memcpy(e->tX + (t * nl + c) * d, xnew, sizeof(double) * d);
+    e->tlogp[t * nl + c] = R->like_new + R->prior_new;
+    e->tmoved[t * nl + c] = (uint8_t)R->moved; e->ttry[t * nl + c] = R->sel; e->tcr[t * nl + c] = R->cr_idx; e->tsnk[t * nl + c] = (uint8_t)R->snk;
+}
+
+static int first_logp(orc_engine* e)
+{   /* Dream.py:266-268 */
+    if (e->have_logp) return 0;
+    for (int c = 0; c < e->nl; ++c) if (eval_points(e, e->X + (size_t)c * e->d, 1, e->lprior + c, e->llike + c)) return -1;
+    e->have_logp = 1; return 0;
+}
+
+/* schedule S2: every chain of generation g sees the shared state as of the end
+ * of generation g-1; end-of-generation updates in the order positions ->
+ * adaptation -> history append. */
+static int generation_s2(orc_engine* e)
+{
+    const int d = e->d, nl = e->nl, N = e->N; const uint32_t g = (uint32_t)e->gen;
+    double* Xn = zalloc(sizeof(double) * nl * d); step_res* R = zalloc(sizeof(step_res) * nl);
+    int rc = 0;
+    if (g == 0 && (e->c.adapt_crossover || e->c.adapt_gamma)) rc = exchange(e, e->X, e->cp_new, d);
+    for (int c = 0; c < nl && !rc; ++c) rc = chain_step(e, c, g, e->M, e->cr_probs, e->g_probs, Xn + (size_t)c * d, &R[c]);
+    if (rc) { free(Xn); free(R); return rc; }
+    for (int c = 0; c < nl; ++c) {
+        record_trace(e, c, Xn + (size_t)c * d, &R[c]);
+        memcpy(e->X + (size_t)c * d, Xn + (size_t)c * d, sizeof(double) * d);
+        e->lprior[c] = R[c].prior_new; e->llike[c] = R[c].like_new;
+    }
+    if (e->c.trace_capacity) e->ntrace++;
+    /* set_current_position_arr :364-366 */
+    if ((e->c.adapt_crossover || e->c.adapt_gamma) && (int64_t)g < (int64_t)e->c.crossover_burnin + 1) {
+        double* t = e->cp_prev; e->cp_prev = e->cp_new; e->cp_new = t;
+        rc = exchange(e, e->X, e->cp_new, d);
+        if (rc) { free(Xn); free(R); return rc; }
+        /* estimate_crossover_probabilities / estimate_gamma_level_probs for all N chains */
+        double* sd = zalloc(sizeof(double) * d); double* sdg = zalloc(sizeof(double) * d); double* tmp = zalloc(sizeof(double) * d);
+        double* dl = zalloc(sizeof(double) * N); double* dlg = zalloc(sizeof(double) * N);
+        int* binc = zalloc(sizeof(int) * N); int* bing = zalloc(sizeof(int) * N);
+        std_by_dim(e->cp_new, N, d, 64, sdg);
+        for (int j = 0; j < d; ++j) sd[j] = sdg[j] == 0.0 ? 1e-12 : sdg[j];      /* :479 (crossover only) */
+        for (int gcn = 0; gcn < N; ++gcn) {
+            int snk, cr, gl, gu; chain_flags(e, (uint32_t)gcn, g, &snk, &cr, &gl, &gu);
+            binc[gcn] = adapt_cr_now(e, g, gu) ? (snk ? e->c.ncr - 1 : cr) : -1;     /* :374-378 */
+            bing[gcn] = adapt_gamma_now(e, g, gu, snk) ? gl - 1 : -1;
+            if (binc[gcn] >= 0) dl[gcn] = jump_norm(e->cp_new + (size_t)gcn * d, e->cp_prev + (size_t)gcn * d, sd, d, tmp);
+            if (bing[gcn] >= 0) dlg[gcn] = jump_norm(e->cp_new + (size_t)gcn * d, e->cp_prev + (size_t)gcn * d, sdg, d, tmp);
+        }
+        int anyc = 0, anyg = 0;
+        for (int m = 0; m < e->c.ncr; ++m) {
+            double tot = 0.0; int cnt = 0;
+            for (int s = 0; s < N; s += 64) { double ps = 0.0; for (int c = s; c < N && c < s + 64; ++c) if (binc[c] == m) { ps = ps + dl[c]; cnt++; } tot = tot + ps; }
+            if (cnt) { e->cr_delta[m] = e->cr_delta[m] + tot; e->cr_n[m] += cnt; anyc = 1; }
+        }
+        for (int m = 0; m < e->c.ngamma; ++m) {
+            double tot = 0.0; int cnt = 0;
+            for (int s = 0; s < N; s += 64) { double ps = 0.0; for (int c = s; c < N && c < s + 64; ++c) if (bing[c] == m) { ps = ps + dlg[c]; cnt++; } tot = tot + ps; }
+            if (cnt) { e->g_delta[m] = e->g_delta[m] + tot; e->g_n[m] += cnt; anyg = 1; }
+        }
+        if (anyc) renorm_probs(e->cr_probs, e->cr_delta, e->cr_n, e->c.ncr, N);
+        if (anyg) renorm_probs(e->g_probs, e->g_delta, e->g_n, e->c.ngamma, N);
+        free(sd); free(sdg); free(tmp); free(dl); free(dlg); free(binc); free(bing);
+    }
+    /* record_history :360-362, :919-938 */
+    if (g % (uint32_t)e->c.history_thin == 0) {
+        if (e->M + N > e->c.history_capacity) { free(Xn); free(R); return fail("history capacity exceeded"); }
+        rc = exchange(e, e->X, e->Z + (size_t)e->M * d, d);
+        e->M += N;
+    }
+    free(Xn); free(R);
+    e->gen++;
+    return rc;
+}
+
+/* schedule S1: chains run to completion one after the other inside a
+ * generation, exactly what the unmodified reference does when `astep` is
+ * driven round-robin in one process. */
+static int generation_s1(orc_engine* e)
+{
+    const int d = e->d, nl = e->nl, N = e->N; const uint32_t g = (uint32_t)e->gen;
+    if (nl != N) return fail("schedule S1 is single-rank only");
+    double* xn = zalloc(sizeof(double) * d); double* sd = zalloc(sizeof(double) * d); double* sdz = zalloc(sizeof(double) * d); double* tmp = zalloc(sizeof(double) * d);
+    int rc = 0;
+    for (int c = 0; c < nl && !rc; ++c) {
+        step_res R; double* q0 = e->X + (size_t)c * d;
+        double* ocr = e->own_cr + (size_t)c * e->c.ncr; double* og = e->own_g + (size_t)c * e->c.ngamma;
+        if (g == 0) { memcpy(ocr, e->cr_probs, sizeof(double) * e->c.ncr); memcpy(og, e->g_probs, sizeof(double) * e->c.ngamma); }
+        rc = chain_step(e, c, g, e->M, ocr, og, xn, &R);
+        if (rc) break;
+        record_trace(e, c, xn, &R);
+        if (g % (uint32_t)e->c.history_thin == 0) {                                   /* :360-362 */
+            if (e->M + 1 > e->c.history_capacity) { rc = fail("history capacity exceeded"); break; }
+            memcpy(e->Z + (size_t)e->M * d, xn, sizeof(double) * d); e->M += 1;
+        }
+        if ((int64_t)g < (int64_t)e->c.crossover_burnin + 1) memcpy(e->cp_new + (size_t)c * d, xn, sizeof(double) * d);   /* :364-366 */
+        if (adapt_cr_now(e, g, R.gamma_unity)) {                                      /* :371-378, :395-401 */
+            int m = R.snk ? e->c.ncr - 1 : R.cr_idx;
+            e->cr_n[m] += 1.0;
+            std_by_dim(e->cp_new, N, d, 0, sd);
+            for (int j = 0; j < d; ++j) if (sd[j] == 0.0) sd[j] = 1e-12;
+            e->cr_delta[m] = e->cr_delta[m] + jump_norm(xn, q0, sd, d, tmp);
+            renorm_probs(e->cr_probs, e->cr_delta, e->cr_n, e->c.ncr, N);
+            memcpy(ocr, e->cr_probs, sizeof(double) * e->c.ncr);                      /* :497 */
+        }
+        if (adapt_gamma_now(e, g, R.gamma_unity, R.snk)) {                             /* :381-383, :391-393 */
+            int m = R.glev - 1;
+            std_by_dim(e->cp_new, N, d, 0, sdz);
+            e->g_n[m] += 1.0;
+            e->g_delta[m] = e->g_delta[m] + jump_norm(xn, q0, sdz, d, tmp);
+            renorm_probs(e->g_probs, e->g_delta, e->g_n, e->c.ngamma, N);
+            memcpy(og, e->g_probs, sizeof(double) * e->c.ngamma);
+        }
+        if ((int64_t)g == e->c.crossover_burnin) {                                     /* :409-415 */
+            if (e->c.adapt_gamma) memcpy(og, e->g_probs, sizeof(double) * e->c.ngamma);
+            if (e->c.adapt_crossover) memcpy(ocr, e->cr_probs, sizeof(double) * e->c.ncr);
+        }
+        memcpy(q0, xn, sizeof(double) * d);
+        e->lprior[c] = R.prior_new; e->llike[c] = R.like_new;
+    }
+    if (!rc && e->c.trace_capacity) e->ntrace++;
+    free(xn); free(sd); free(sdz); free(tmp);
+    if (!rc) e->gen++;
+    return rc;
+}
+
+int orc_step(orc_engine* e, int64_t generations)
+{
+    if (!e) return fail("null engine");
+    if (e->lk == LK_NONE) return fail("no likelihood set");
+    if (e->M < 2 * e->c.depairs) return fail("history not seeded");
+    if (e->c.trace_capacity && e->ntrace + generations > e->c.trace_capacity) return fail("trace capacity exceeded");
+    if (first_logp(e)) return -1;
+    for (int64_t i = 0; i < generations; ++i) {
+        int rc = e->c.schedule == 1 ? generation_s1(e) : generation_s2(e);
+        if (rc) return rc;
+    }
+    return 0;
+}
+int orc_trace_reset(orc_engine* e) { e->ntrace = 0; return 0; }
+
+int orc_get_state(orc_engine* e, double* X, double* prior, double* like)
+{
+    if (X) memcpy(X, e->X, sizeof(double) * e->nl * e->d);
+    if (prior) memcpy(prior, e->lprior, sizeof(double) * e->nl);
+    if (like) memcpy(like, e->llike, sizeof(double) * e->nl);
+    return 0;
+}
+int orc_get_trace(orc_engine* e, int64_t g0, int64_t ng, double* X, double* logp, uint8_t* moved, int32_t* try_idx, int32_t* cr_idx, uint8_t* snooker)
+{
+    if (g0 < 0 || g0 + ng > e->ntrace) return fail("trace range");
+    size_t nl = (size_t)e->nl, d = (size_t)e->d, o = (size_t)g0 * nl, n = (size_t)ng * nl;
+    if (X) memcpy(X, e->tX + o * d, sizeof(double) * n * d);
+    if (logp) memcpy(logp, e->tlogp + o, sizeof(double) * n);
+    if (moved) memcpy(moved, e->tmoved + o, n);
+    if (try_idx) memcpy(try_idx, e->ttry + o, sizeof(int32_t) * n);
+    if (cr_idx) memcpy(cr_idx, e->tcr + o, sizeof(int32_t) * n);
+    if (snooker) memcpy(snooker, e->tsnk + o, n);
+    return 0;
+}
+int orc_get_history(orc_engine* e, double* Z, int64_t cap_rows, int64_t* rows)
+{
+    if (rows) *rows = e->M;
+    if (Z) { if (cap_rows < e->M) return fail("buffer too small"); memcpy(Z, e->Z, sizeof(double) * (size_t)e->M * e->d); }
+    return 0;
+}
+int orc_get_cr_state(orc_engine* e, double* probs, double* delta_m, double* n_updates)
+{
+    if (probs) memcpy(probs, e->cr_probs, sizeof(double) * e->c.ncr);
+    if (delta_m) memcpy(delta_m, e->cr_delta, sizeof(double) * e->c.ncr);
+    if (n_updates) memcpy(n_updates, e->cr_n, sizeof(double) * e->c.ncr);
+    return 0;
+}
+int orc_get_gamma_state(orc_engine* e, double* probs, double* delta_m, double* n_updates)
+{
+    if (probs) memcpy(probs, e->g_probs, sizeof(double) * e->c.ngamma);
+    if (delta_m) memcpy(delta_m, e->g_delta, sizeof(double) * e->c.ngamma);
+    if (n_updates) memcpy(n_updates, e->g_n, sizeof(double) * e->c.ngamma);
+    return 0;
+}
+
+/* Gelman_Rubin, convergence.py:3-20: second half of each chain, ddof=0
+ * variances, var_est = W (1 - 1/n) + B with n the FULL length. */
+int orc_gelman_rubin(const double* tr, int nchains, int nsamples, int d, double* rhat)
+{
+    int nb = nsamples / 2, n2 = nsamples - nb;
+    double* means = zalloc(sizeof(double) * nchains);
+    for (int j = 0; j < d; ++j) {
+        double W = 0.0;
+        for (int c = 0; c < nchains; ++c) {
+            const double* x = tr + ((size_t)c * nsamples + nb) * d + j;
+            double s = 0.0; for (int t = 0; t < n2; ++t) s = s + x[(size_t)t * d];
+            double mean = s / (double)n2; means[c] = mean;
+            double v = 0.0; for (int t = 0; t < n2; ++t) { double q = x[(size_t)t * d] - mean; v = v + q * q; }
+            W = W + v / (double)n2;
+        }
+        W = W / (double)nchains;
+        double mm = 0.0; for (int c = 0; c < nchains; ++c) mm = mm + means[c];
+        mm = mm / (double)nchains;
+        double B = 0.0; for (int c = 0; c < nchains; ++c) { double q = means[c] - mm; B = B + q * q; }
+        B = B / (double)nchains;
+        double var_est = W * (1.0 - 1.0 / (double)nsamples) + B;
+        rhat[j] = sqrt(var_est / W);
+    }
+    free(means);
+    return 0;
+}
+int orc_get_rhat(orc_engine* e, double* rhat)
+{
+    int nl = e->nl, d = e->d, n = (int)e->ntrace;
+    if (n < 2) return fail("need at least 2 traced generations");
+    double* tr = zalloc(sizeof(double) * (size_t)nl * n * d);
+    for (int t = 0; t < n; ++t) for (int c = 0; c < nl; ++c)
+        memcpy(tr + ((size_t)c * n + t) * d, e->tX + ((size_t)t * nl + c) * d, sizeof(double) * d);
+    int rc = orc_gelman_rubin(tr, nl, n, d, rhat);
+    free(tr); return rc;
+}

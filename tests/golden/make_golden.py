@@ -1,0 +1,554 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE.
+
+Runs only in the build container: it imports PyDREAM read-only from
+/root/reference (nothing from it is copied here), drives its unmodified
+``Dream.astep`` / ``generate_proposal_points`` / ``Gelman_Rubin`` / example
+likelihoods, and stores INPUTS and the reference's OUTPUTS as small ``.npz``
+files.  The GPU box only ever sees those files.
+
+How the reference is made deterministic:
+  * single process: ``_setup_mp_dream_pool`` + ``pool._initializer`` in the
+    parent, the reference's own test idiom (pydream/tests/test_dream.py:507-508);
+  * the module globals ``pydream.Dream.np`` / ``pydream.Dream.random`` are
+    rebound to proxies whose draws come from this repo's counter-based random
+    contract (DESIGN.md "Random contract"; evaluated through the oracle's
+    building blocks), so reference, oracle and HIP engine consume identical
+    numbers;
+  * schedule S1 = round-robin over chains (the unmodified class); schedule S2 =
+    a test-side subclass that defers record_history / set_current_position_arr
+    / estimate_*_probs to the end of the generation and replays the base-class
+    methods in chain order.
+
+Usage:  python tests/golden/make_golden.py        (writes tests/golden/*.npz)
+"""
+import copy
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from oracle import oracle as O  # noqa: E402  (test infrastructure)
+
+import pydream.Dream as RD  # noqa: E402
+from pydream import Dream_shared_vars as SV  # noqa: E402
+from pydream.core import _setup_mp_dream_pool  # noqa: E402
+from pydream.model import Model  # noqa: E402
+from pydream.parameters import FlatParam, SampledParam  # noqa: E402
+from pydream.convergence import Gelman_Rubin  # noqa: E402
+
+
+# --------------------------------------------------------------------------
+# the random contract, as seen through numpy.random / random (App. B order)
+# --------------------------------------------------------------------------
+class ContractRandom:
+    """Stands in for ``np.random`` AND for the ``random`` module inside pydream.Dream."""
+
+    def __init__(self, seed, k, ncr_ctrl_has_snooker=True):
+        self.seed = seed
+        self.k = k
+        self.has_snk = ncr_ctrl_has_snooker
+        self.log = {}
+
+    def begin_step(self, gc, g, p_gamma_unity):
+        self.gc, self.g = gc, g
+        self.pgu = p_gamma_unity
+        self.phase = 0
+        self.n_ctrl = 0
+        self.cnt = {}
+        self.snk = False
+        self.log = dict(snooker=0, cr_idx=-1, sel=0, glev=1, delta=1)
+        s = O.stream_id(O.K_CTRL)
+        w0 = O.philox(self.seed, 0, s, gc, g)
+        w1 = O.philox(self.seed, 1, s, gc, g)
+        w2 = O.philox(self.seed, 2, s, gc, g)
+        self.u_snk, self.u_cr = O.u53(w0[0], w0[1]), O.u53(w0[2], w0[3])
+        self.u_de, self.u_glev = O.u53(w1[0], w1[1]), O.u53(w1[2], w1[3])
+        self.u_sel, self.u_acc = O.u53(w2[0], w2[1]), O.u53(w2[2], w2[3])
+
+    def _next(self, name):
+        key = (name, self.phase)
+        v = self.cnt.get(key, 0)
+        self.cnt[key] = v + 1
+        return v
+
+    def _ntries(self):
+        return self.k if self.phase == 0 else self.k - 1
+
+    def _pt(self, tr, idx):
+        return O.philox(self.seed, idx, O.stream_id(O.K_PT, tr, self.phase), self.gc, self.g)
+
+    def _dim(self, tr, d):
+        s = O.stream_id(O.K_DIM, tr, self.phase)
+        return np.array([O.philox(self.seed, j, s, self.gc, self.g) for j in range(d)], dtype=np.uint32)
+
+    @staticmethod
+    def _onehot(n, m):
+        out = np.zeros(n, dtype=int)
+        out[m] = 1
+        return out
+
+    # ---- numpy.random API used by pydream/Dream.py ----
+    def multinomial(self, n, pvals):
+        pvals = np.asarray(pvals, dtype=float)
+        ctrl_order = (["snk"] if self.has_snk else []) + ["cr", "glev"]
+        if self.n_ctrl < len(ctrl_order):
+            which = ctrl_order[self.n_ctrl]
+            self.n_ctrl += 1
+            if which == "snk":      # Dream.py:545
+                m = O.invcdf(pvals, self.u_snk)
+                self.snk = (m == 0)
+                self.log["snooker"] = int(self.snk)
+            elif which == "cr":     # Dream.py:565
+                m = O.invcdf(pvals, self.u_cr)
+                self.log["cr_idx"] = m
+            else:                   # Dream.py:595
+                m = O.invcdf(pvals, self.u_glev)
+                self.log["glev"] = m + 1
+            return self._onehot(len(pvals), m)
+        if len(pvals) == 2 and pvals[0] == self.pgu and self.k != 2:      # set_gamma, Dream.py:615
+            tr = self._next("gu")
+            w = self._pt(tr, 0)
+            return self._onehot(2, O.invcdf(pvals, O.u53(w[0], w[1])))
+        # mt_choose_proposal_pt, Dream.py:908
+        m = O.invcdf(pvals, self.u_sel)
+        self.log["sel"] = m
+        self.phase = 1
+        return self._onehot(len(pvals), m)
+
+    def randint(self, lo, hi, size=None):                                    # set_DEpair, Dream.py:580
+        v = lo + int(np.floor(self.u_de * (hi - lo)))
+        self.log["delta"] = v
+        return np.array([v])
+
+    def normal(self, loc, scale, size):                                      # Dream.py:694
+        tr = self._next("normal")
+        w = self._dim(tr, size)
+        return np.array([loc + scale * float(np.float32(O.normal32(a[2], a[3]))) for a in w])
+
+    def uniform(self, low=None, high=None, size=None):
+        if low is None:                                                      # metrop_select, Dream.py:993
+            return self.u_acc
+        if size is None:                                                     # snooker gamma, Dream.py:618
+            w = self._pt(0, 0)
+            return low + (high - low) * O.u53(w[2], w[3])
+        if isinstance(size, tuple):                                          # U, Dream.py:700
+            n, d = size
+            return np.array([[O.u32(a[0]) for a in self._dim(tr, d)] for tr in range(n)])
+        tr = self._next("e")                                                 # e, Dream.py:696
+        w = self._dim(tr, size)
+        return np.array([low + (high - low) * O.u32(a[1]) for a in w])
+
+    def rand(self, n):                                                       # bounds redraw, Dream.py:749-751, 773-775
+        fr = sys._getframe(1).f_locals
+        tr = int(fr.get("pt_num", 0)) if self._ntries() > 1 else 0
+        masks = [m for m in (fr["x_lower"], fr["x_upper"]) if np.any(m)]
+        key = ("bnd", self.phase, tr)
+        c = self.cnt.get(key, 0)
+        self.cnt[key] = c + 1
+        mask = np.atleast_1d(masks[c])
+        dims = np.where(mask)[0]
+        assert len(dims) == n
+        s = O.stream_id(O.K_BND, tr, self.phase)
+        return np.array([O.u32(O.philox(self.seed, int(j), s, self.gc, self.g)[0]) for j in dims])
+
+    # ---- random.sample used by sample_from_history, Dream.py:662-664 ----
+    def sample(self, rng, n):
+        M = len(rng)
+        if not self.snk:
+            tr = self._next("sample")
+            words = np.concatenate([self._pt(tr, 1 + q) for q in range((n + 3) // 4)])[:n]
+            return [int(x) for x in O.sample_distinct(words, M)]
+        c = self._next("sample")
+        nt = self._ntries()
+        if c < nt:
+            tr, word = c, 0
+        else:
+            tr, word = (c - nt) // 2, 1 + (c - nt) % 2
+        w = self._pt(tr, 1)
+        return [int((int(w[word]) * M) >> 32)]
+
+
+class NPProxy:
+    """Forwards to numpy, except ``.random`` (the contract) and the two ufunc calls the reference makes with a
+    ``where=`` mask and no ``out=`` (Dream.py:329, :824, :831, :835): numpy leaves the masked-out result
+    UNINITIALISED there (whenever |x - z| == 0, i.e. a chain draws its own archived state), so the reference's
+    value is whatever was in memory.  The contract defines it as 0; the proxy makes
+    the reference do exactly that by supplying a zeroed ``out``."""
+
+    def __init__(self, rnd):
+        self.random = rnd
+
+    @staticmethod
+    def _masked(ufunc, args, where, kw):
+        if where is True:
+            return ufunc(*args, **kw)
+        shape = np.broadcast(*[np.asarray(a) for a in args], np.asarray(where)).shape
+        out = np.zeros(shape, dtype=float)
+        ufunc(*args, out=out, where=where, **kw)
+        return out if shape else float(out)
+
+    def log(self, x, where=True, **kw):
+        return self._masked(np.log, (x,), where, kw)
+
+    def divide(self, a, b, where=True, **kw):
+        return self._masked(np.divide, (a, b), where, kw)
+
+    def __getattr__(self, n):
+        return getattr(np, n)
+
+
+class NoSleep:
+    @staticmethod
+    def sleep(_):
+        return None
+
+
+def install(rnd):
+    RD.np = NPProxy(rnd)
+    RD.random = rnd
+    RD.time = NoSleep
+
+
+def uninstall():
+    import random as pyrandom
+    import time as pytime
+    RD.np = np
+    RD.random = pyrandom
+    RD.time = pytime
+
+
+# --------------------------------------------------------------------------
+# schedule S2 from the reference
+# --------------------------------------------------------------------------
+class DeferredDream(RD.Dream):
+    queue = None
+
+    def record_history(self, *a, **k):
+        self.queue.append(("hist", a, k))
+
+    def set_current_position_arr(self, ndimensions, q_new):
+        if self.nchains is None:
+            cp = np.frombuffer(SV.current_positions.get_obj())
+            self.nchains = len(cp) // ndimensions
+        self.queue.append(("pos", (ndimensions, np.array(q_new).copy()), {}))
+
+    def estimate_crossover_probabilities(self, *a, **k):
+        self.queue.append(("cr", a, k))
+        return self.CR_probabilities
+
+    def estimate_gamma_level_probs(self, *a, **k):
+        self.queue.append(("gam", a, k))
+        return self.gamma_probabilities
+
+
+BASE = {"hist": RD.Dream.record_history, "pos": RD.Dream.set_current_position_arr,
+        "cr": RD.Dream.estimate_crossover_probabilities, "gam": RD.Dream.estimate_gamma_level_probs}
+
+
+def run_reference(params, likelihood, Z0, starts, N, G, seed, schedule, dream_kwargs, workdir):
+    """Drive the reference's astep for G generations; return everything it produced."""
+    d = Z0.shape[1]
+    hist_file = os.path.join(workdir, "seed_hist.npy")
+    np.save(hist_file, Z0)
+    cls = RD.Dream if schedule == 1 else DeferredDream
+    model = Model(likelihood=likelihood, sampled_parameters=params)
+    step = cls(model=model, variables=None, history_file=hist_file, start_random=False, save_history=False,
+               verbose=False, **dream_kwargs)
+    k = step.multitry
+    rnd = ContractRandom(seed, k, ncr_ctrl_has_snooker=(step.snooker != 0))
+    install(rnd)
+    try:
+        pool = _setup_mp_dream_pool(N, G, step, start_pt=[starts[i] for i in range(N)])
+        pool._initializer(*pool._initargs)
+        pool.close()
+        pool.join()
+        burnin = step.crossover_burnin
+        chains = [copy.copy(step) for _ in range(N)]
+        for c in chains:
+            c.queue = []
+        x = [np.array(starts[i], dtype=float).copy() for i in range(N)]
+        out = dict(X=np.zeros((G, N, d)), logp=np.zeros((G, N)), prior=np.zeros((G, N)), like=np.zeros((G, N)),
+                   moved=np.zeros((G, N), np.uint8), try_idx=np.zeros((G, N), np.int32),
+                   cr_idx=np.zeros((G, N), np.int32), snooker=np.zeros((G, N), np.uint8),
+                   cross_probs=np.zeros((G, step.nCR)), gamma_probs=np.zeros((G, step.ngamma)),
+                   hist_rows=np.zeros(G, np.int64))
+        for g in range(G):
+            for ci, c in enumerate(chains):
+                rnd.begin_step(ci, g, step.p_gamma_unity)
+                if g == burnin:
+                    SV.nchains.value = N - 1          # lets the barrier at Dream.py:403 fall through
+                xn, lp, ll = c.astep(x[ci])
+                xn = np.array(xn, dtype=float).copy()
+                out["X"][g, ci] = xn
+                out["prior"][g, ci], out["like"][g, ci] = lp, ll
+                out["logp"][g, ci] = ll + lp                       # core.py:115
+                out["moved"][g, ci] = int(np.any(xn != x[ci]))     # core.py:120
+                out["try_idx"][g, ci] = rnd.log["sel"]
+                out["cr_idx"][g, ci] = rnd.log["cr_idx"]
+                out["snooker"][g, ci] = rnd.log["snooker"]
+                x[ci] = xn
+            if schedule == 2:
+                for kind in ("pos", "cr", "gam", "hist"):
+                    for c in chains:
+                        for (kk, a, kw) in c.queue:
+                            if kk == kind:
+                                c.iter -= 1           # astep already advanced iter (Dream.py:417); the
+                                BASE[kind](c, *a, **kw)   # base methods must see this generation's value (:446)
+                                c.iter += 1
+                for c in chains:
+                    c.queue = []
+                    if g <= burnin:
+                        if step.adapt_crossover:
+                            c.CR_probabilities = list(SV.cross_probs[0:step.nCR])
+                        if step.adapt_gamma:
+                            c.gamma_probabilities = list(SV.gamma_level_probs[0:step.ngamma])
+            out["cross_probs"][g] = SV.cross_probs[0:step.nCR]
+            out["gamma_probs"][g] = SV.gamma_level_probs[0:step.ngamma]
+            out["hist_rows"][g] = SV.count.value + int(step.nseedchains)
+        M = int(SV.count.value + step.nseedchains)
+        out["Z_tail"] = np.array(SV.history[0:M * d]).reshape(M, d)[len(Z0):]      # rows appended during the run
+        out["delta_m"] = np.array(SV.delta_m[:])
+        out["ncr_updates"] = np.array(SV.ncr_updates[:])
+        out["delta_m_gamma"] = np.array(SV.delta_m_gamma[:])
+        out["ngamma_updates"] = np.array(SV.ngamma_updates[:])
+        out["burnin"] = burnin
+        out["gamma_arr"] = step.gamma_arr
+        if step.boundaries:
+            out["mins"], out["maxs"] = np.asarray(step.mins, float), np.asarray(step.maxs, float)
+        return out
+    finally:
+        uninstall()
+
+
+# --------------------------------------------------------------------------
+# target densities of the examples (restated from the cited lines; the d=200
+# MVN and the 2-component mixture below call the reference modules themselves)
+# --------------------------------------------------------------------------
+def mvn_target(d):
+    """examples/ndim_gaussian/dream_ex_ndim_gaussian.py:29-52 at dimension d."""
+    A = .5 * np.identity(d) + .5 * np.ones((d, d))
+    C = np.zeros((d, d))
+    for i in range(d):
+        for j in range(d):
+            C[i][j] = A[i][j] * np.sqrt((i + 1) * (j + 1))
+    invC = np.linalg.inv(C)
+    log_F = 0 if d > 150 else np.log(((2 * np.pi) ** (-d / 2)) * np.linalg.det(C) ** (- 1. / 2))
+
+    def likelihood(param_vec):
+        return log_F - .5 * np.sum(param_vec * np.dot(invC, param_vec))
+    return invC, float(log_F), likelihood
+
+
+def mixture_target(d, means, weights):
+    """examples/mixturemodel/mixturemodel.py:18-48 generalised to J components."""
+    J = len(weights)
+    mu = np.array([np.linspace(m, m, num=d) for m in means])
+    log_F = np.log(np.array(weights)) - (d / 2.) * np.log(2 * np.pi)
+
+    def likelihood(params):
+        log_lh = np.zeros((J))
+        for j in range(J):
+            log_lh[j] = -.5 * np.sum((params - mu[j, :]) ** 2) + log_F[j]
+        maxll = np.max(log_lh)
+        post = np.array(np.exp(log_lh - maxll), dtype='float64')
+        density = np.sum(post)
+        return np.log(density) + maxll
+    return mu, log_F, likelihood
+
+
+def simple_likelihood(param):
+    """pydream/tests/test_models.py:47-50"""
+    return np.sum(param + 3)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def trace_case(name, *, d, N, G, k, schedule, seed, target, dream_kwargs=None, prior="flat", rng_seed=0, nseed=None):
+    from scipy.stats import norm, uniform
+    dream_kwargs = dict(dream_kwargs or {})
+    rng = np.random.default_rng(rng_seed)
+    cfg = dict(d=d, N=N, G=G, k=k, schedule=schedule, seed=seed)
+    extra = {}
+    nseed = nseed or max(10 * d, 2 * N * dream_kwargs.get("DEpairs", 1))
+    if prior == "flat":
+        params = [FlatParam(test_value=np.zeros(d))]
+        Z0 = rng.uniform(-5, 15, (nseed, d))
+        pk, pa, pb = np.zeros(d, np.int32), np.zeros(d), np.ones(d)
+    elif prior == "uniform":           # pydream/tests/test_models.py:35-45
+        lower = np.array([-5., -9., 5., 3.])[:d]
+        upper = np.array([10., 2., 7., 8.])[:d]
+        params = [SampledParam(uniform, loc=lower, scale=upper - lower)]
+        Z0 = lower + rng.uniform(0, 1, (nseed, d)) * (upper - lower)
+        pk, pa, pb = np.full(d, 2, np.int32), lower, upper - lower
+    elif prior == "normal":            # pydream/tests/test_models.py:24-33
+        mu = np.resize(np.array([-6.6, 3, 1.0, -.12]), d)
+        sd = np.resize(np.array([.13, 5, .9, 1.0]), d)
+        params = [SampledParam(norm, loc=mu, scale=sd)]
+        Z0 = mu + sd * rng.standard_normal((nseed, d))
+        pk, pa, pb = np.full(d, 1, np.int32), mu, sd
+    if target[0] == "mvn":
+        invC, log_F, like = mvn_target(d)
+        extra.update(lk_kind="mvn", invC=invC, log_F=log_F)
+    elif target[0] == "mix":
+        mu_m, lF, like = mixture_target(d, target[1], target[2])
+        extra.update(lk_kind="mix", mix_mu=mu_m, mix_logF=lF)
+    else:
+        like = simple_likelihood
+        extra.update(lk_kind="simple")
+    starts = Z0[:N].copy()
+    mt = k if k > 1 else False
+    with tempfile.TemporaryDirectory() as wd:
+        cwd = os.getcwd()
+        os.chdir(wd)
+        try:
+            out = run_reference(params, like, Z0, starts, N, G, seed, schedule, dict(multitry=mt, **dream_kwargs), wd)
+        finally:
+            os.chdir(cwd)
+    kw = dict(nCR=3, adapt_crossover=True, adapt_gamma=False, DEpairs=1, lamb=.05, zeta=1e-12, history_thin=10,
+              snooker=.10, p_gamma_unity=.20, gamma_levels=1, hardboundaries=True)
+    kw.update(dream_kwargs)
+    cfgarr = {("cfg_" + a): np.asarray(b) for a, b in {**cfg, **kw}.items() if b is not None}
+    save(name, Z0=Z0, starts=starts, prior_kind=pk, prior_a=pa, prior_b=pb, **cfgarr, **extra, **out)
+    print("   ", name, "acc", out["moved"].mean(), "snk", out["snooker"].mean(), "cross_probs", out["cross_probs"][-1])
+
+
+def function_cases():
+    """Function-level vectors: generate_proposal_points / snooker_update on hand-built shared
+    arrays (the reference tests' own style, pydream/tests/test_dream.py:207-211)."""
+    import multiprocessing as mp
+    from scipy.stats import uniform
+    cases = {}
+    rng = np.random.default_rng(7)
+    for tag, d, k, bounded in (("d100k5", 100, 5, False), ("d4k5b", 4, 5, True), ("d4k1b", 4, 1, True), ("d10k1", 10, 1, False)):
+        if bounded:
+            lower = np.array([-5., -9., 5., 3.]); upper = np.array([10., 2., 7., 8.])
+            params = [SampledParam(uniform, loc=lower, scale=upper - lower)]
+            Z = lower + rng.uniform(0, 1, (40, d)) * (upper - lower)
+            q0 = lower + rng.uniform(0, 1, d) * (upper - lower)
+        else:
+            params = [FlatParam(test_value=np.zeros(d))]
+            Z = rng.uniform(-5, 15, (300, d)); q0 = rng.uniform(-5, 15, d)
+        model = Model(likelihood=simple_likelihood, sampled_parameters=params)
+        dream = RD.Dream(model=model, multitry=(k if k > 1 else False), DEpairs=2 if tag == "d10k1" else 1,
+                         gamma_levels=2 if tag == "d10k1" else 1, lamb=(0.6 if bounded else .05))
+        dream.nseedchains = len(Z)
+        SV.history = mp.Array('d', list(Z.flatten()))
+        SV.count = mp.Value('i', 0)
+        seed = 1234
+        rnd = ContractRandom(seed, k)
+        install(rnd)
+        try:
+            recs = []
+            for trial in range(12):
+                snk = trial % 3 == 2
+                cr_idx = trial % 3
+                delta = 2 if (tag == "d10k1" and trial % 2) else 1
+                glev = 2 if (tag == "d10k1" and trial % 4 > 1) else 1
+                for phase in ((0, 1) if k > 1 else (0,)):
+                    n = k if phase == 0 else k - 1
+                    rnd.begin_step(3, trial, dream.p_gamma_unity)
+                    rnd.n_ctrl = 99; rnd.phase = phase; rnd.snk = snk
+                    CR = dream.CR_values[cr_idx]
+                    res = dream.generate_proposal_points(n, q0.copy(), CR, delta, glev, snooker=snk)
+                    if snk:
+                        pts, slogp, z = res
+                        pts = np.array(pts, dtype=float).reshape(n, d); slogp = np.atleast_1d(np.array(slogp, float))
+                    else:
+                        pts = np.array(res, dtype=float).reshape(n, d); slogp = np.zeros(n)
+                    gam = np.atleast_1d(np.array(dream.gamma, float))
+                    gam = np.resize(gam, n)
+                    recs.append((trial, phase, int(snk), cr_idx, delta, glev, pts, slogp, gam))
+        finally:
+            uninstall()
+        cases[tag] = dict(Z=Z, q0=q0, d=d, k=k, seed=seed, bounded=int(bounded), lamb=dream.lamb,
+                          depairs=len(dream.DEpairs), ngamma=dream.ngamma,
+                          mins=np.asarray(dream.mins, float), maxs=np.asarray(dream.maxs, float),
+                          meta=np.array([r[:6] for r in recs]),
+                          pts=np.concatenate([r[6].reshape(-1) for r in recs]),
+                          slogp=np.concatenate([r[7] for r in recs]),
+                          gam=np.concatenate([r[8] for r in recs]))
+    flat = {}
+    for tag, c in cases.items():
+        for a, b in c.items():
+            flat[tag + "__" + a] = np.asarray(b)
+    save("proposals", **flat)
+
+
+def density_cases():
+    rng = np.random.default_rng(11)
+    out = {}
+    for d in (10, 100):
+        invC, log_F, like = mvn_target(d)
+        X = rng.normal(0, 3, (32, d))
+        out["mvn%d_invC" % d] = invC; out["mvn%d_logF" % d] = log_F
+        out["mvn%d_X" % d] = X; out["mvn%d_logp" % d] = np.array([like(x) for x in X])
+    # the shipped examples themselves (d=200 log_F=0 branch; 2-component mixture, d=10)
+    with tempfile.TemporaryDirectory() as wd:
+        cwd = os.getcwd(); os.chdir(wd)
+        try:
+            from pydream.examples.ndim_gaussian import dream_ex_ndim_gaussian as EX
+            from pydream.examples.mixturemodel import mixturemodel as MX
+        finally:
+            os.chdir(cwd)
+    X = rng.normal(0, 3, (16, EX.d))
+    out["mvn200_invC"] = EX.invC; out["mvn200_logF"] = float(EX.log_F); out["mvn200_X"] = X
+    out["mvn200_logp"] = np.array([EX.likelihood(x) for x in X])
+    X = np.concatenate([rng.normal(-5, 1, (8, MX.d)), rng.normal(5, 1, (8, MX.d)), rng.normal(0, 4, (8, MX.d))])
+    out["mix2_mu"] = MX.mu; out["mix2_logF"] = MX.log_F; out["mix2_X"] = X
+    out["mix2_logp"] = np.array([MX.likelihood(x) for x in X])
+    mu3, lF3, like3 = mixture_target(100, (-5, 0, 5), (1 / 6., 1 / 3., 1 / 2.))
+    X = np.concatenate([rng.normal(m, 1, (8, 100)) for m in (-5, 0, 5)])
+    out["mix3_mu"] = mu3; out["mix3_logF"] = lF3; out["mix3_X"] = X
+    out["mix3_logp"] = np.array([like3(x) for x in X])
+    # gamma table (Dream.py:172-179; pinned by pydream/tests/test_dream.py:68-76)
+    m = Model(likelihood=simple_likelihood, sampled_parameters=[FlatParam(test_value=np.zeros(7))])
+    out["gamma_arr_7_5_4"] = RD.Dream(model=m, DEpairs=5, gamma_levels=4).gamma_arr
+    # Gelman-Rubin (convergence.py:3-20)
+    tr = rng.normal(0, 1, (5, 101, 6)).cumsum(axis=1) * 0.05 + rng.normal(0, 1, (5, 1, 6))
+    out["gr_traces"] = tr; out["gr_rhat"] = Gelman_Rubin([tr[c] for c in range(5)])
+    # mt_choose_proposal_pt known answer (pydream/tests/test_dream.py:345-355) + metrop_select
+    save("densities", **out)
+
+
+def main():
+    function_cases()
+    density_cases()
+    # T1: the C1 plumbing config (3 chains, 10-D MVN, multitry 5), unmodified reference, schedule S1
+    trace_case("trace_s1_c1", d=10, N=3, G=200, k=5, schedule=1, seed=20260929, target=("mvn",),
+               dream_kwargs=dict(adapt_crossover=False, crossover_burnin=10 ** 9))
+    # T1b: S1 with crossover adaptation and the burn-in hand-over inside the run
+    trace_case("trace_s1_adapt", d=10, N=4, G=120, k=5, schedule=1, seed=7, target=("mvn",),
+               dream_kwargs=dict(adapt_crossover=True, crossover_burnin=60))
+    # T2: lockstep S2 with adaptation, burn-in inside the run
+    trace_case("trace_s2_adapt", d=10, N=4, G=120, k=5, schedule=2, seed=11, target=("mvn",),
+               dream_kwargs=dict(adapt_crossover=True, crossover_burnin=40))
+    # T3: single-try, uniform prior + hard boundaries (pydream/tests/test_models.py:35-50)
+    trace_case("trace_s2_k1_bounds", d=4, N=5, G=150, k=1, schedule=2, seed=3, target=("simple",), prior="uniform",
+               dream_kwargs=dict(adapt_crossover=True, crossover_burnin=50, snooker=.3))
+    # T3b: multi-try with uniform prior + boundaries
+    trace_case("trace_s2_k3_bounds", d=4, N=5, G=100, k=3, schedule=2, seed=5, target=("simple",), prior="uniform",
+               dream_kwargs=dict(adapt_crossover=False, crossover_burnin=10 ** 9, lamb=.3))
+    # T4: DEpairs=2, 3 gamma levels with gamma adaptation, normal prior
+    trace_case("trace_s2_depairs_gamma", d=6, N=6, G=120, k=5, schedule=2, seed=13, target=("mvn",), prior="normal",
+               dream_kwargs=dict(adapt_crossover=True, adapt_gamma=True, gamma_levels=3, DEpairs=2, crossover_burnin=50))
+    # T5: C2-shaped, small: 100-D MVN, 8 chains
+    trace_case("trace_s2_mvn100", d=100, N=8, G=40, k=5, schedule=2, seed=20260929, target=("mvn",), nseed=160,
+               dream_kwargs=dict(adapt_crossover=False, crossover_burnin=10 ** 9))
+    # T6: C3-shaped, small: 3-component mixture with crossover adaptation
+    trace_case("trace_s2_mix3", d=20, N=8, G=80, k=5, schedule=2, seed=17, target=("mix", (-5, 0, 5), (1 / 6., 1 / 3., 1 / 2.)),
+               dream_kwargs=dict(adapt_crossover=True, crossover_burnin=30))
+
+
+if __name__ == "__main__":
+    main()

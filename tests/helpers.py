@@ -1,0 +1,62 @@
+"""Shared by the CPU (oracle) and GPU (HIP engine) parity tests: build an engine from a golden
+fixture's recorded inputs, run it, and compare with what the REFERENCE produced."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def simple_logp(X):
+    """pydream/tests/test_models.py:47-50 (likelihood) -- prior handled by the engine's built-in prior."""
+    return np.zeros(len(X)), np.sum(X + 3, axis=1)
+
+
+def engine_from_trace_fixture(EngineCls, fx, schedule=None, trace=True, **over):
+    d, N, G, k = int(fx["cfg_d"]), int(fx["cfg_N"]), int(fx["cfg_G"]), int(fx["cfg_k"])
+    thin = int(fx["cfg_history_thin"])
+    Z0 = fx["Z0"]
+    kw = dict(nchains=N, ndim=d, multitry=k, depairs=int(fx["cfg_DEpairs"]), ncr=int(fx["cfg_nCR"]),
+              ngamma=int(fx["cfg_gamma_levels"]), history_thin=thin, crossover_burnin=int(min(fx["burnin"], 2 ** 31 - 1)),
+              adapt_crossover=int(fx["cfg_adapt_crossover"]), adapt_gamma=int(fx["cfg_adapt_gamma"]),
+              hardboundaries=int(fx["cfg_hardboundaries"]), schedule=int(fx["cfg_schedule"]) if schedule is None else schedule,
+              history_capacity=len(Z0) + N * (G // thin + 2), trace_capacity=G if trace else 0, seed=int(fx["cfg_seed"]),
+              lamb=float(fx["cfg_lamb"]), zeta=float(fx["cfg_zeta"]), snooker=float(fx["cfg_snooker"]),
+              p_gamma_unity=float(fx["cfg_p_gamma_unity"]))
+    kw.update(over)
+    e = EngineCls(**kw)
+    if "mins" in fx:
+        e.set_bounds(fx["mins"], fx["maxs"])
+    e.set_gamma_table(fx["gamma_arr"])
+    e.set_history(Z0)
+    e.set_prior(fx["prior_kind"], fx["prior_a"], fx["prior_b"])
+    lk = str(fx["lk_kind"])
+    if lk == "mvn":
+        e.set_likelihood_mvn(np.zeros(d), fx["invC"], 0, float(fx["log_F"]))
+    elif lk == "mix":
+        e.set_likelihood_mixture(fx["mix_mu"], fx["mix_logF"])
+    else:
+        e.set_likelihood_host(simple_logp)
+    nl = kw.get("nchains_local", N)
+    off = kw.get("chain_offset", 0)
+    e.set_state(fx["starts"][off:off + nl])
+    return e
+
+
+def compare_with_reference(tr, fx, Z, cr_probs, gamma_probs=None, x_rtol=1e-9, logp_atol=1e-10):
+    """tr: engine trace dict; fx: fixture (reference outputs)."""
+    np.testing.assert_array_equal(tr["snooker"], fx["snooker"])
+    np.testing.assert_array_equal(tr["cr_idx"], fx["cr_idx"])
+    if int(fx["cfg_k"]) > 1:
+        np.testing.assert_array_equal(tr["try_idx"], fx["try_idx"])
+    np.testing.assert_array_equal(tr["moved"], fx["moved"])
+    np.testing.assert_allclose(tr["X"], fx["X"], rtol=x_rtol, atol=1e-11)
+    np.testing.assert_allclose(tr["logp"], fx["logp"], rtol=0, atol=logp_atol)
+    np.testing.assert_allclose(Z[len(fx["Z0"]):], fx["Z_tail"], rtol=x_rtol, atol=1e-11)
+    np.testing.assert_allclose(cr_probs, fx["cross_probs"][-1], rtol=1e-11, atol=0)
+    if gamma_probs is not None:
+        np.testing.assert_allclose(gamma_probs, fx["gamma_probs"][-1], rtol=1e-11, atol=0)

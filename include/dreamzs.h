@@ -1,0 +1,136 @@
+/*
+ * dreamzs.h -- C ABI of libdreamzs.so, the MI355X (gfx950) MT-DREAM(ZS) engine.
+ *
+ * The reference (LoLab-MSM/PyDREAM) is pure Python and has no FFI of its own: its
+ * boundary for the hot path is the Python API `pydream.core.run_dream()` /
+ * `pydream.Dream.Dream.astep()` (pydream/core.py:11-86, pydream/Dream.py:193-422).
+ * This header is the interface a maintainer binds with ctypes underneath that API
+ * (INTEGRATION.md shows the stub); each entry point names the reference code it
+ * replaces.  Conventions: every function returns 0 on success and a negative code on
+ * error (text via dz_last_error(), thread-local); nothing throws across the boundary;
+ * host pointers are borrowed for the duration of the call; one handle per GPU; calls
+ * on one handle are not thread-safe, distinct handles are.  All matrices are
+ * row-major float64.
+ */
+#ifndef DREAMZS_H
+#define DREAMZS_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DZ_VERSION 1
+
+/* Sampler configuration: the keyword arguments of Dream.__init__ (Dream.py:63-67) that
+ * act on the hot path, plus the sizes `_setup_mp_dream_pool` derives (core.py:250-314). */
+typedef struct dz_config {
+    int32_t nchains;          /* global number of chains N (run_dream nchains, core.py:11)     */
+    int32_t nchains_local;    /* chains owned by this handle (= N on one GPU)                  */
+    int32_t chain_offset;     /* global id of local chain 0 (rank * nchains_local)             */
+    int32_t ndim;             /* total_var_dimension (Dream.py:81-83)                          */
+    int32_t multitry;         /* 1, or >= 3 (Dream.py:155-161; 2 is broken upstream, :867)     */
+    int32_t depairs;          /* DEpairs (Dream.py:150)                                        */
+    int32_t ncr;              /* nCR (Dream.py:108-113)                                        */
+    int32_t ngamma;           /* gamma_levels (Dream.py:120)                                   */
+    int32_t history_thin;     /* Dream.py:188, :360                                            */
+    int32_t crossover_burnin; /* Dream.py:122; default niterations/10 (core.py:299-300)        */
+    int32_t adapt_crossover;  /* Dream.py:125                                                  */
+    int32_t adapt_gamma;      /* Dream.py:137                                                  */
+    int32_t hardboundaries;   /* Dream.py:80                                                   */
+    int32_t schedule;         /* must be 2 (lockstep generations, DESIGN.md "Schedule")        */
+    int32_t device;           /* HIP device ordinal                                            */
+    int32_t reserved0;
+    int64_t history_capacity; /* rows the Z archive can hold (core.py:260-268)                 */
+    int64_t trace_capacity;   /* generations the device trace buffer holds (0 = no trace)      */
+    uint64_t seed;            /* key of the counter-based random contract                      */
+    double lamb;              /* Dream.py:164                                                  */
+    double zeta;              /* Dream.py:165                                                  */
+    double snooker;           /* Dream.py:152                                                  */
+    double p_gamma_unity;     /* Dream.py:153                                                  */
+    double temperature;       /* T of astep (Dream.py:193); 1.0                                */
+} dz_config;
+
+typedef struct dz_engine dz_engine;
+
+/* Batch replacement for Model.total_logp (model.py:17-32) evaluated on the host:
+ * X is [n,d]; fill prior[n] and like[n]; return 0. */
+typedef int (*dz_logp_cb)(const double* X, int64_t n, int32_t d, double* prior, double* like, void* user);
+/* Host-staged all-gather used when no RCCL communicator is attached (tests, gloo):
+ * send = this rank's block, recv = all blocks in rank order, bytes = one block. */
+typedef int (*dz_exchange_cb)(const void* send, void* recv, int64_t bytes, void* user);
+
+int         dz_version(void);
+const char* dz_last_error(void);
+int         dz_device_count(int32_t* count);
+
+/* Dream.__init__ + _setup_mp_dream_pool + _mp_dream_init: allocate the Z archive, chain
+ * states and adaptation accumulators in HBM (replaces core.py:281-297, 316-327). */
+int dz_create(const dz_config* cfg, dz_engine** out);
+int dz_destroy(dz_engine* e);
+
+int dz_set_bounds(dz_engine* e, const double* mins, const double* maxs);            /* Dream.py:86-105; [d] each, +-inf ok */
+int dz_set_gamma_table(dz_engine* e, const double* table);                          /* Dream.py:172-179; [ngamma,depairs,d]; NULL = compute */
+int dz_set_history(dz_engine* e, const double* Z, int64_t rows);                    /* core.py:255-263, 282-283: seed rows */
+int dz_set_state(dz_engine* e, const double* X, const double* prior, const double* like); /* start points (core.py:74-78); NULL logps => evaluated at first step (Dream.py:266-268) */
+int dz_set_cr_probs(dz_engine* e, const double* p, int32_t ncr);                    /* Dream.py:128-134 */
+int dz_set_gamma_probs(dz_engine* e, const double* p, int32_t ngamma);              /* Dream.py:138-143 */
+/* per-dimension priors evaluated on the device (parameters.py:37-47, 62-63):
+ * kind 0 flat, 1 scipy.stats.norm(loc=a, scale=b), 2 scipy.stats.uniform(loc=a, scale=b) */
+int dz_set_prior(dz_engine* e, const int32_t* kind, const double* a, const double* b);
+/* built-in device likelihoods ("batched device callback"):
+ * MVN, examples/ndim_gaussian/dream_ex_ndim_gaussian.py:49-52: kind 0 = precision matrix
+ * invC [d,d]; kind 1 = upper-triangular U with invC = U^T U.  logp = log_F - Q/2. */
+int dz_set_likelihood_mvn(dz_engine* e, const double* mu, const double* M, int32_t kind, double log_F);
+/* Gaussian mixture with identity covariances, examples/mixturemodel/mixturemodel.py:37-48 */
+int dz_set_likelihood_mixture(dz_engine* e, int32_t J, const double* mu, const double* log_F);
+/* arbitrary host likelihood (any Python callable behind ctypes) */
+int dz_set_likelihood_host(dz_engine* e, dz_logp_cb cb, void* user);
+
+/* Multi-GPU: chains are sharded, Z / positions are replicated by an all-gather at the
+ * end of appending generations (replaces the multiprocessing shared arrays,
+ * Dream.py:919-938, 424-449).  Attach ONE of the two transports before dz_step. */
+int dz_comm_unique_id(void* id128);                                                 /* rank 0: 128-byte RCCL unique id */
+int dz_comm_init_rccl(dz_engine* e, int32_t rank, int32_t world, const void* id128);
+int dz_set_exchange(dz_engine* e, dz_exchange_cb cb, void* user);
+
+/* _sample_dream's loop (core.py:103-116): advance every local chain by `generations`
+ * MT-DREAM(ZS) transitions (Dream.astep, Dream.py:193-422). Asynchronous on the engine's
+ * stream; dz_sync() or any getter waits. */
+int     dz_step(dz_engine* e, int64_t generations);
+int     dz_sync(dz_engine* e);
+int     dz_trace_reset(dz_engine* e);
+int64_t dz_generation(dz_engine* e);
+
+int dz_get_state(dz_engine* e, double* X, double* prior, double* like);             /* [nl,d],[nl],[nl] */
+/* trace of generations [g0,g0+ng) since the last reset: sampled_params / log_ps of
+ * core.py:98-116 plus the decision sequences the parity contract is stated on */
+int dz_get_trace(dz_engine* e, int64_t g0, int64_t ng, double* X, double* logp,
+                 uint8_t* moved, int32_t* try_idx, int32_t* cr_idx, uint8_t* snooker);
+int dz_get_history(dz_engine* e, double* Z, int64_t cap_rows, int64_t* rows);       /* Dream_shared_vars.history / count */
+int dz_get_cr_state(dz_engine* e, double* probs, double* delta_m, double* n_updates);     /* cross_probs, delta_m, ncr_updates */
+int dz_get_gamma_state(dz_engine* e, double* probs, double* delta_m, double* n_updates);  /* gamma_level_probs, ... */
+/* Gelman_Rubin (convergence.py:3-20) over the traced generations of the local chains */
+int dz_get_rhat(dz_engine* e, double* rhat);
+/* per-chain second-half mean / population variance [nl,d] each (inputs of R-hat, for multi-rank reduction) */
+int dz_get_chain_moments(dz_engine* e, double* mean, double* var);
+
+/* evaluate the configured log densities on arbitrary points (testing / first-step logp) */
+int dz_eval_logp(dz_engine* e, const double* X, int64_t n, double* prior, double* like);
+/* one proposal set of one chain, for parity tests (generate_proposal_points, Dream.py:670-796) */
+int dz_debug_propose(dz_engine* e, int32_t chain_local, int64_t gen, int32_t phase, const double* base,
+                     int32_t run_snooker, int32_t cr_idx, int32_t delta, int32_t glev,
+                     double* pts, double* slogp);
+
+/* HIP-event timing of the engine's kernels over the launches since the last reset.
+ * which: 0 propose, 1 logp, 2 accept, 3 adapt, 4 exchange.  Returns total ms and count. */
+int dz_profile_enable(dz_engine* e, int32_t on);
+int dz_profile_get(dz_engine* e, int32_t which, double* total_ms, int64_t* launches);
+int dz_profile_reset(dz_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -409,7 +409,8 @@ int64_t orc_generation(orc_engine* e) { return e->gen; }
  *      kind 1 an upper-triangular U with invC = U^T U (Q = |U v|^2).
  *      Order: y_r = sum_c M[r][c] v_c ascending c (fma chain), Q = sum_r y_r s_r
  *      ascending r (fma chain), s = v (dense) or y (triangular).
- * Mixture: examples/mixturemodel/mixturemodel.py:37-48. */
+ * Mixture: examples/mixturemodel/mixturemodel.py:37-48; the squared distances are
+ *      summed in the lane/butterfly order of the reduction contract. */
 HOT double orc_loglike(orc_engine* e, const double* x)
 {
     int d = e->d;
@@ -430,8 +431,9 @@ HOT double orc_loglike(orc_engine* e, const double* x)
         double lh[64]; double mx = -INFINITY;
         for (int j = 0; j < e->J; ++j) {
             const double* mu = e->mu + (size_t)j * d;
-            double S = 0.0;
-            for (int i = 0; i < d; ++i) { double t = x[i] - mu[i]; S = fma(t, t, S); }
+            double* t = e->work + 6 * (size_t)d;
+            for (int i = 0; i < d; ++i) t[i] = x[i] - mu[i];
+            double S = orc_wave_dot(t, t, d);          /* lane/butterfly order */
             lh[j] = -0.5 * S + e->mixF[j];
             if (lh[j] > mx) mx = lh[j];
         }

@@ -1,0 +1,327 @@
+"""ctypes binding of libdreamzs.so (include/dreamzs.h) -- the only way the Python host talks to the GPU.
+
+There is no CPU fallback: if the library cannot be loaded, or no MI355X is present, every
+entry point raises.  The library is built in-tree by ``python -m pydream_amd.build``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdreamzs.so")
+
+
+class DreamZSError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    """dz_config (include/dreamzs.h)"""
+    _fields_ = [
+        ("nchains", C.c_int32), ("nchains_local", C.c_int32), ("chain_offset", C.c_int32), ("ndim", C.c_int32),
+        ("multitry", C.c_int32), ("depairs", C.c_int32), ("ncr", C.c_int32), ("ngamma", C.c_int32),
+        ("history_thin", C.c_int32), ("crossover_burnin", C.c_int32), ("adapt_crossover", C.c_int32),
+        ("adapt_gamma", C.c_int32), ("hardboundaries", C.c_int32), ("schedule", C.c_int32), ("device", C.c_int32),
+        ("reserved0", C.c_int32), ("history_capacity", C.c_int64), ("trace_capacity", C.c_int64),
+        ("seed", C.c_uint64), ("lamb", C.c_double), ("zeta", C.c_double), ("snooker", C.c_double),
+        ("p_gamma_unity", C.c_double), ("temperature", C.c_double),
+    ]
+
+
+LOGP_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+XCHG_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+# every symbol include/dreamzs.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "dz_version", "dz_last_error", "dz_device_count", "dz_create", "dz_destroy", "dz_set_bounds", "dz_set_gamma_table",
+    "dz_set_history", "dz_set_state", "dz_set_cr_probs", "dz_set_gamma_probs", "dz_set_prior", "dz_set_likelihood_mvn",
+    "dz_set_likelihood_mixture", "dz_set_likelihood_host", "dz_comm_unique_id", "dz_comm_init_rccl", "dz_set_exchange",
+    "dz_step", "dz_sync", "dz_trace_reset", "dz_generation", "dz_get_state", "dz_get_trace", "dz_get_history",
+    "dz_get_cr_state", "dz_get_gamma_state", "dz_get_rhat", "dz_get_chain_moments", "dz_eval_logp", "dz_debug_propose",
+    "dz_profile_enable", "dz_profile_get", "dz_profile_reset",
+]
+
+_lib = None
+
+
+def load_library():
+    """Load libdreamzs.so; raises DreamZSError (never falls back to a CPU path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DreamZSError("%s is missing: build it with `python -m pydream_amd.build` (needs hipcc); "
+                           "pydream_amd has no CPU fallback" % LIB_PATH)
+    try:
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as exc:
+        raise DreamZSError("cannot load %s: %s" % (LIB_PATH, exc))
+    V = C.c_void_p
+    L.dz_last_error.restype = C.c_char_p
+    L.dz_generation.restype = C.c_int64
+    L.dz_generation.argtypes = [V]
+    L.dz_create.argtypes = [C.POINTER(Config), C.POINTER(V)]
+    L.dz_destroy.argtypes = [V]
+    L.dz_set_bounds.argtypes = [V, V, V]
+    L.dz_set_gamma_table.argtypes = [V, V]
+    L.dz_set_history.argtypes = [V, V, C.c_int64]
+    L.dz_set_state.argtypes = [V, V, V, V]
+    L.dz_set_cr_probs.argtypes = [V, V, C.c_int32]
+    L.dz_set_gamma_probs.argtypes = [V, V, C.c_int32]
+    L.dz_set_prior.argtypes = [V, V, V, V]
+    L.dz_set_likelihood_mvn.argtypes = [V, V, V, C.c_int32, C.c_double]
+    L.dz_set_likelihood_mixture.argtypes = [V, C.c_int32, V, V]
+    L.dz_set_likelihood_host.argtypes = [V, LOGP_CB, V]
+    L.dz_comm_unique_id.argtypes = [V]
+    L.dz_comm_init_rccl.argtypes = [V, C.c_int32, C.c_int32, V]
+    L.dz_set_exchange.argtypes = [V, XCHG_CB, V]
+    L.dz_step.argtypes = [V, C.c_int64]
+    L.dz_sync.argtypes = [V]
+    L.dz_trace_reset.argtypes = [V]
+    L.dz_get_state.argtypes = [V, V, V, V]
+    L.dz_get_trace.argtypes = [V, C.c_int64, C.c_int64] + [V] * 6
+    L.dz_get_history.argtypes = [V, V, C.c_int64, V]
+    L.dz_get_cr_state.argtypes = [V, V, V, V]
+    L.dz_get_gamma_state.argtypes = [V, V, V, V]
+    L.dz_get_rhat.argtypes = [V, V]
+    L.dz_get_chain_moments.argtypes = [V, V, V]
+    L.dz_eval_logp.argtypes = [V, V, C.c_int64, V, V]
+    L.dz_debug_propose.argtypes = [V, C.c_int32, C.c_int64, C.c_int32, V, C.c_int32, C.c_int32, C.c_int32, C.c_int32, V, V]
+    L.dz_profile_enable.argtypes = [V, C.c_int32]
+    L.dz_profile_get.argtypes = [V, C.c_int32, V, V]
+    L.dz_profile_reset.argtypes = [V]
+    L.dz_device_count.argtypes = [V]
+    _lib = L
+    return L
+
+
+def device_count():
+    n = C.c_int32(0)
+    load_library().dz_device_count(C.byref(n))
+    return n.value
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    L = load_library()
+    if L.dz_comm_unique_id(buf) != 0:
+        raise DreamZSError(L.dz_last_error().decode())
+    return buf.raw
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+PROFILE_CLASSES = {"propose": 0, "logp": 1, "accept": 2, "adapt": 3, "exchange": 4}
+
+
+class Engine:
+    """One dz_engine handle (one GPU).  Keyword arguments are the fields of dz_config."""
+
+    def __init__(self, **kw):
+        self.L = load_library()
+        cfg = Config()
+        defaults = dict(nchains_local=kw.get("nchains"), chain_offset=0, multitry=1, depairs=1, ncr=3, ngamma=1,
+                        history_thin=10, crossover_burnin=0, adapt_crossover=0, adapt_gamma=0, hardboundaries=1,
+                        schedule=2, device=0, reserved0=0, trace_capacity=0, seed=0, lamb=0.05, zeta=1e-12,
+                        snooker=0.1, p_gamma_unity=0.2, temperature=1.0)
+        defaults.update(kw)
+        for k, v in defaults.items():
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self.N, self.nl, self.d, self.k = cfg.nchains, cfg.nchains_local, cfg.ndim, cfg.multitry
+        self.h = C.c_void_p()
+        self._keep = []
+        self._chk(self.L.dz_create(C.byref(cfg), C.byref(self.h)))
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DreamZSError(self.L.dz_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.dz_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- setters ----
+    def set_bounds(self, mins, maxs):
+        mins, maxs = _f64(mins), _f64(maxs)
+        self._chk(self.L.dz_set_bounds(self.h, _p(mins), _p(maxs)))
+
+    def set_gamma_table(self, table):
+        t = None if table is None else _f64(table)
+        self._chk(self.L.dz_set_gamma_table(self.h, _p(t)))
+
+    def set_history(self, Z):
+        Z = _f64(Z).reshape(-1, self.d)
+        self._chk(self.L.dz_set_history(self.h, _p(Z), Z.shape[0]))
+
+    def set_state(self, X, prior=None, like=None):
+        X = _f64(X).reshape(self.nl, self.d)
+        pr = None if prior is None else _f64(prior)
+        lk = None if like is None else _f64(like)
+        self._chk(self.L.dz_set_state(self.h, _p(X), _p(pr), _p(lk)))
+
+    def set_cr_probs(self, p):
+        p = _f64(p)
+        self._chk(self.L.dz_set_cr_probs(self.h, _p(p), len(p)))
+
+    def set_gamma_probs(self, p):
+        p = _f64(p)
+        self._chk(self.L.dz_set_gamma_probs(self.h, _p(p), len(p)))
+
+    def set_prior(self, kind, a, b):
+        kind = np.ascontiguousarray(kind, dtype=np.int32)
+        a, b = _f64(a), _f64(b)
+        self._chk(self.L.dz_set_prior(self.h, _p(kind), _p(a), _p(b)))
+
+    def set_likelihood_mvn(self, mu, M, kind=0, log_F=0.0):
+        mu, M = _f64(mu), _f64(M)
+        if M.shape != (self.d, self.d):
+            raise ValueError("matrix must be [d,d]")
+        self._chk(self.L.dz_set_likelihood_mvn(self.h, _p(mu), _p(M), int(kind), float(log_F)))
+
+    def set_likelihood_mixture(self, mu, log_F):
+        mu, log_F = _f64(mu), _f64(log_F)
+        self._chk(self.L.dz_set_likelihood_mixture(self.h, mu.shape[0], _p(mu), _p(log_F)))
+
+    def set_likelihood_host(self, fn):
+        """fn(X[n,d]) -> (prior[n], like[n]); evaluated on the host for each batch of proposals."""
+        d = self.d
+
+        def tramp(Xp, n, dd, pp, lp, user):
+            try:
+                X = np.ctypeslib.as_array(Xp, shape=(n, d))
+                pr, lk = fn(X.copy())
+                np.ctypeslib.as_array(pp, shape=(n,))[:] = pr
+                np.ctypeslib.as_array(lp, shape=(n,))[:] = lk
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = LOGP_CB(tramp)
+        self._keep.append(cb)
+        self._chk(self.L.dz_set_likelihood_host(self.h, cb, None))
+
+    def set_exchange(self, fn):
+        """fn(send_bytes, nbytes) -> bytes of all ranks' blocks in rank order (host-staged all-gather)."""
+        def tramp(send, recv, nbytes, user):
+            try:
+                buf = (C.c_char * nbytes).from_address(send)
+                out = fn(bytes(buf), nbytes)
+                C.memmove(recv, out, len(out))
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = XCHG_CB(tramp)
+        self._keep.append(cb)
+        self._chk(self.L.dz_set_exchange(self.h, cb, None))
+
+    def comm_init_rccl(self, rank, world, unique_id):
+        self._chk(self.L.dz_comm_init_rccl(self.h, rank, world, C.c_char_p(unique_id)))
+
+    # ---- stepping ----
+    def step(self, generations=1):
+        self._chk(self.L.dz_step(self.h, int(generations)))
+
+    def sync(self):
+        self._chk(self.L.dz_sync(self.h))
+
+    def trace_reset(self):
+        self._chk(self.L.dz_trace_reset(self.h))
+
+    @property
+    def generation(self):
+        return int(self.L.dz_generation(self.h))
+
+    # ---- getters ----
+    def get_state(self):
+        X = np.zeros((self.nl, self.d)); pr = np.zeros(self.nl); lk = np.zeros(self.nl)
+        self._chk(self.L.dz_get_state(self.h, _p(X), _p(pr), _p(lk)))
+        return X, pr, lk
+
+    def get_trace(self, g0, ng, with_X=True):
+        nl, d = self.nl, self.d
+        out = dict(X=np.zeros((ng, nl, d)) if with_X else None, logp=np.zeros((ng, nl)), moved=np.zeros((ng, nl), np.uint8),
+                   try_idx=np.zeros((ng, nl), np.int32), cr_idx=np.zeros((ng, nl), np.int32),
+                   snooker=np.zeros((ng, nl), np.uint8))
+        self._chk(self.L.dz_get_trace(self.h, g0, ng, _p(out["X"]), _p(out["logp"]), _p(out["moved"]),
+                                      _p(out["try_idx"]), _p(out["cr_idx"]), _p(out["snooker"])))
+        return out
+
+    def get_history(self):
+        rows = C.c_int64()
+        self._chk(self.L.dz_get_history(self.h, None, 0, C.byref(rows)))
+        Z = np.zeros((rows.value, self.d))
+        self._chk(self.L.dz_get_history(self.h, _p(Z), rows.value, C.byref(rows)))
+        return Z
+
+    def history_rows(self):
+        rows = C.c_int64()
+        self._chk(self.L.dz_get_history(self.h, None, 0, C.byref(rows)))
+        return rows.value
+
+    def get_cr_state(self):
+        n = self.cfg.ncr
+        p, dm, nu = np.zeros(n), np.zeros(n), np.zeros(n)
+        self._chk(self.L.dz_get_cr_state(self.h, _p(p), _p(dm), _p(nu)))
+        return p, dm, nu
+
+    def get_gamma_state(self):
+        n = self.cfg.ngamma
+        p, dm, nu = np.zeros(n), np.zeros(n), np.zeros(n)
+        self._chk(self.L.dz_get_gamma_state(self.h, _p(p), _p(dm), _p(nu)))
+        return p, dm, nu
+
+    def get_rhat(self):
+        r = np.zeros(self.d)
+        self._chk(self.L.dz_get_rhat(self.h, _p(r)))
+        return r
+
+    def get_chain_moments(self):
+        m, v = np.zeros((self.nl, self.d)), np.zeros((self.nl, self.d))
+        self._chk(self.L.dz_get_chain_moments(self.h, _p(m), _p(v)))
+        return m, v
+
+    def eval_logp(self, X):
+        X = _f64(X).reshape(-1, self.d)
+        pr, lk = np.zeros(len(X)), np.zeros(len(X))
+        self._chk(self.L.dz_eval_logp(self.h, _p(X), len(X), _p(pr), _p(lk)))
+        return pr, lk
+
+    def loglike(self, x):
+        return float(self.eval_logp(np.asarray(x)[None, :])[1][0])
+
+    def debug_propose(self, chain, gen, phase, base, snooker, cr_idx, delta=1, glev=1):
+        n = self.k if phase == 0 else self.k - 1
+        base = _f64(base)
+        pts = np.zeros((n, self.d)); slogp = np.zeros(n)
+        self._chk(self.L.dz_debug_propose(self.h, chain, gen, phase, _p(base), int(snooker), cr_idx, delta, glev, _p(pts), _p(slogp)))
+        return pts, slogp, None, None
+
+    # ---- HIP-event kernel timing ----
+    def profile_enable(self, on=True):
+        self._chk(self.L.dz_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self.L.dz_profile_reset(self.h))
+
+    def profile_get(self, which):
+        ms, n = C.c_double(), C.c_int64()
+        self._chk(self.L.dz_profile_get(self.h, PROFILE_CLASSES[which], C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,194 @@
+// dz_device.h -- device-side building blocks of the gfx950 MT-DREAM(ZS) engine:
+// the counter-based random contract, the bit-reproducible elementary functions and
+// the wave-64 reduction order (DESIGN.md "Random contract", "Elementary functions",
+// "Reduction contract").  Compiled with -ffp-contract=off: every fused multiply-add
+// is an explicit fma()/fmaf().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DZ_DEV __device__ __forceinline__
+
+namespace dz {
+
+// ---------------------------------------------------------------- random contract
+struct u32x4 { uint32_t x, y, z, w; };
+
+// Philox4x32-10, key = 64-bit seed, counter = (idx, stream, chain, generation).
+DZ_DEV u32x4 philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+enum : uint32_t { K_CTRL = 0, K_PT = 1, K_DIM = 2, K_BND = 3 };
+DZ_DEV uint32_t stream_id(uint32_t kind, uint32_t tr, uint32_t phase) { return kind | (tr << 4) | (phase << 12); }
+
+DZ_DEV double u53(uint32_t hi, uint32_t lo)
+{
+    return ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) * (1.0 / 9007199254740992.0);
+}
+DZ_DEV double u32d(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0); }
+
+// standard normal (binary32): Box-Muller cosine branch on two 23-bit uniforms
+DZ_DEV float normal32(uint32_t w1, uint32_t w2)
+{
+    const float u1 = ((float)(w1 >> 9) + 0.5f) * 1.1920928955078125e-07f;
+    const float u2 = ((float)(w2 >> 9) + 0.5f) * 1.1920928955078125e-07f;
+    const uint32_t b = __float_as_uint(u1);
+    int e = (int)(b >> 23) - 127;
+    float m = __uint_as_float((b & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    const float f = m - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    float p = 1.0f / 11.0f;
+    p = fmaf(p, z, 1.0f / 9.0f);
+    p = fmaf(p, z, 1.0f / 7.0f);
+    p = fmaf(p, z, 1.0f / 5.0f);
+    p = fmaf(p, z, 1.0f / 3.0f);
+    const float t = 2.0f * s;
+    const float lm = fmaf(t * z, p, t);
+    const float ef = (float)e;
+    const float lg = fmaf(ef, 0.693145751953125f, fmaf(ef, 1.42860682030941723e-06f, lm));
+    const float rad = sqrtf(-2.0f * lg);
+    const float t8 = u2 * 8.0f;
+    const float fo = floorf(t8);
+    const int o = (int)fo;
+    float r = t8 - fo;
+    if (o & 1) r = 1.0f - r;
+    const float y = r * 0.785398163397448309616f;
+    const float y2 = y * y;
+    float sp = 1.0f / 362880.0f;
+    sp = fmaf(sp, y2, -1.0f / 5040.0f);
+    sp = fmaf(sp, y2, 1.0f / 120.0f);
+    sp = fmaf(sp, y2, -1.0f / 6.0f);
+    const float sn = fmaf(y * y2, sp, y);
+    float cp = -1.0f / 3628800.0f;
+    cp = fmaf(cp, y2, 1.0f / 40320.0f);
+    cp = fmaf(cp, y2, -1.0f / 720.0f);
+    cp = fmaf(cp, y2, 1.0f / 24.0f);
+    cp = fmaf(cp, y2, -0.5f);
+    const float cs = fmaf(y2, cp, 1.0f);
+    float c = (((o + 1) >> 1) & 1) ? sn : cs;
+    if (((o + 2) >> 2) & 1) c = -c;
+    return rad * c;
+}
+
+// ---------------------------------------------------------------- elementary functions
+#define DZ_LN2_HI 6.93147180369123816490e-01
+#define DZ_LN2_LO 1.90821492927058770002e-10
+#define DZ_DBL_MAX 1.7976931348623157e308
+
+DZ_DEV double dexp(double x)
+{
+    if (x != x) return x;
+    if (x > 709.782712893384) return __builtin_huge_val();
+    if (x < -745.2) return 0.0;
+    const double kf = floor(x * 1.4426950408889634 + 0.5);
+    double r = fma(-kf, DZ_LN2_HI, x);
+    r = fma(-kf, DZ_LN2_LO, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    int k = (int)kf;
+    if (k < -1000) { p = p * __longlong_as_double((long long)(1023 - 1000) << 52); k += 1000; }
+    return p * __longlong_as_double((long long)(k + 1023) << 52);
+}
+
+DZ_DEV double dlog(double x)
+{
+    if (x != x) return x;
+    if (x < 0.0) return __builtin_nan("");
+    if (x == 0.0) return -__builtin_huge_val();
+    if (x == __builtin_huge_val()) return x;
+    int e = 0;
+    unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    if ((b >> 52) == 0) { x = x * 18014398509481984.0; e = -54; b = (unsigned long long)__double_as_longlong(x); }
+    e += (int)(b >> 52) - 1023;
+    double m = __longlong_as_double((long long)((b & 0x000fffffffffffffull) | 0x3ff0000000000000ull));
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    double p = 1.0 / 23.0;
+    p = fma(p, z, 1.0 / 21.0);
+    p = fma(p, z, 1.0 / 19.0);
+    p = fma(p, z, 1.0 / 17.0);
+    p = fma(p, z, 1.0 / 15.0);
+    p = fma(p, z, 1.0 / 13.0);
+    p = fma(p, z, 1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0);
+    p = fma(p, z, 1.0 / 5.0);
+    p = fma(p, z, 1.0 / 3.0);
+    const double t = 2.0 * s;
+    const double lm = fma(t * z, p, t);
+    const double ef = (double)e;
+    return fma(ef, DZ_LN2_HI, fma(ef, DZ_LN2_LO, lm));
+}
+
+DZ_DEV double nan_to_num(double x)
+{
+    if (x != x) return 0.0;
+    if (x == __builtin_huge_val()) return DZ_DBL_MAX;
+    if (x == -__builtin_huge_val()) return -DZ_DBL_MAX;
+    return x;
+}
+DZ_DEV bool is_finite(double x) { return (x == x) && (x != __builtin_huge_val()) && (x != -__builtin_huge_val()); }
+
+// ---------------------------------------------------------------- wave-64 reductions
+// lane(j) = (j >> 1) & 63; a lane adds its own dimensions in increasing j; the 64 lane
+// partials are combined by an xor butterfly (32,16,...,1).  Every lane ends with the total.
+DZ_DEV double wave_bfly(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    return v;
+}
+DZ_DEV int wave_isum(int v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// first category m with u < p0 + .. + pm
+DZ_DEV int invcdf(const double* __restrict__ p, int n, double u)
+{
+    double c = 0.0;
+    for (int m = 0; m < n; ++m) { c = c + p[m]; if (u < c) return m; }
+    return n - 1;
+}
+
+struct Ctrl { double u_snk, u_cr, u_de, u_glev, u_sel, u_acc; };
+DZ_DEV Ctrl draw_ctrl(uint32_t k0, uint32_t k1, uint32_t gc, uint32_t g)
+{
+    const uint32_t s = stream_id(K_CTRL, 0, 0);
+    Ctrl c;
+    u32x4 w = philox(k0, k1, 0, s, gc, g); c.u_snk = u53(w.x, w.y); c.u_cr = u53(w.z, w.w);
+    w = philox(k0, k1, 1, s, gc, g); c.u_de = u53(w.x, w.y); c.u_glev = u53(w.z, w.w);
+    w = philox(k0, k1, 2, s, gc, g); c.u_sel = u53(w.x, w.y); c.u_acc = u53(w.z, w.w);
+    return c;
+}
+
+}  // namespace dz

@@ -1,0 +1,655 @@
+// dz_engine.hip -- host side of libdreamzs.so: device-resident state of the MT-DREAM(ZS)
+// sampler (Z archive, chain states, adaptation accumulators, trace) and the per-generation
+// launch sequence, behind the C ABI of include/dreamzs.h.
+//
+// Replaces, for the hot path: pydream/core.py:250-327 (_setup_mp_dream_pool / _mp_dream_init:
+// shared arrays -> HBM buffers), core.py:89-129 (_sample_dream loop -> dz_step) and
+// pydream/Dream.py:193-422 (astep -> the kernels of dz_kernels.h).
+#include "../../include/dreamzs.h"
+#include "dz_kernels.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string& m) { g_err = m; return -1; }
+
+#define HIPCK(expr)                                                                                   \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(_e));         \
+    } while (0)
+#define DZCK(expr) do { int _r = (expr); if (_r) return _r; } while (0)
+
+enum { LK_NONE = 0, LK_MVN = 1, LK_MIX = 2, LK_HOST = 3 };
+enum { PR_PROPOSE = 0, PR_LOGP = 1, PR_ACCEPT = 2, PR_ADAPT = 3, PR_EXCHANGE = 4, PR_COUNT = 5 };
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    int load()
+    {
+        if (lib) return 0;
+        lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return fail(std::string("cannot load librccl: ") + dlerror());
+        GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
+        AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy) return fail("librccl lacks required symbols");
+        return 0;
+    }
+};
+Rccl g_rccl;
+
+template <class T> int dalloc(T** p, size_t n)
+{
+    HIPCK(hipMalloc((void**)p, sizeof(T) * (n ? n : 1)));
+    HIPCK(hipMemset(*p, 0, sizeof(T) * (n ? n : 1)));
+    return 0;
+}
+
+}  // namespace
+
+struct dz_engine {
+    dz_config c{};
+    dz::Params p{};
+    hipStream_t stream = nullptr;
+    int nch = 1;
+    int64_t M = 0, gen = 0, ntrace = 0;
+    bool have_logp = false, adapt = false;
+    int lk = LK_NONE;
+    dz_logp_cb cb = nullptr; void* cb_user = nullptr;
+    dz_exchange_cb xcb = nullptr; void* xcb_user = nullptr;
+    ncclComm_t comm = nullptr; int rank = 0, world = 1;
+    // owned device buffers (also referenced from p)
+    double *d_mins = nullptr, *d_maxs = nullptr, *d_gtab = nullptr, *d_mu = nullptr, *d_Mt = nullptr, *d_mixF = nullptr;
+    double *d_pa = nullptr, *d_pb = nullptr; int32_t* d_pkind = nullptr;
+    double *d_shared = nullptr;      // cr_probs|cr_delta|cr_n|g_probs|g_delta|g_n
+    double *d_partial = nullptr, *d_mean = nullptr, *d_sd = nullptr, *d_sdc = nullptr, *d_dl = nullptr, *d_dlg = nullptr;
+    int *d_binc = nullptr, *d_bing = nullptr;
+    double *d_scratch = nullptr; size_t scratch_rows = 0;   // debug / eval staging [rows, ld]
+    double *d_cmean = nullptr, *d_cvar = nullptr, *d_rhat = nullptr;
+    std::vector<double> h_stage;     // host staging (callback likelihood / exchange)
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[PR_COUNT];
+    std::vector<void*> to_free;
+};
+
+namespace {
+
+struct ProfScope {
+    dz_engine* e; int which; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(dz_engine* e_, int w) : e(e_), which(w)
+    {
+        if (e->prof) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, e->stream); }
+    }
+    ~ProfScope() { if (e->prof) { hipEventRecord(b, e->stream); e->ev[which].emplace_back(a, b); } }
+};
+
+template <class T> int ealloc(dz_engine* e, T** p, size_t n)
+{
+    DZCK(dalloc(p, n));
+    e->to_free.push_back((void*)*p);
+    return 0;
+}
+
+int upload_padded(dz_engine* e, double* dst, const double* src, int rows, double padval)
+{   // src [rows,d] -> dst [rows,ld]
+    const int d = e->p.d, ld = e->p.ld;
+    std::vector<double> h((size_t)rows * ld, padval);
+    for (int r = 0; r < rows; ++r) memcpy(&h[(size_t)r * ld], src + (size_t)r * d, sizeof(double) * d);
+    HIPCK(hipMemcpyAsync(dst, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+int download_rows(dz_engine* e, double* dst, const double* src, size_t rows)
+{   // src [rows,ld] device -> dst [rows,d] host
+    HIPCK(hipMemcpy2DAsync(dst, sizeof(double) * e->p.d, src, sizeof(double) * e->p.ld, sizeof(double) * e->p.d, rows,
+                           hipMemcpyDeviceToHost, e->stream));
+    HIPCK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+#define NCH_DISPATCH(e, CALL)                      \
+    switch ((e)->nch) {                            \
+        case 1: { constexpr int NCH = 1; CALL; } break; \
+        case 2: { constexpr int NCH = 2; CALL; } break; \
+        case 4: { constexpr int NCH = 4; CALL; } break; \
+        default: { constexpr int NCH = 8; CALL; } break; \
+    }
+
+int launch_check(const char* what)
+{
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(std::string(what) + ": " + hipGetErrorString(err));
+    return 0;
+}
+
+// Model.total_logp for n points stored [n,ld] on the device
+int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* like)
+{
+    if (n <= 0) return 0;
+    ProfScope ps(e, PR_LOGP);
+    const dim3 grid((n + 3) / 4), block(256);
+    if (e->lk == LK_MVN) {
+        const size_t lds = sizeof(double) * 4 * 2 * e->p.ld;
+        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_logp_mvn<NCH>, grid, block, lds, e->stream, e->p, pts, n, prior, like));
+    } else if (e->lk == LK_MIX) {
+        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_logp_mix<NCH>, grid, block, 0, e->stream, e->p, pts, n, prior, like));
+    } else if (e->lk == LK_HOST) {
+        const int d = e->p.d;
+        e->h_stage.resize((size_t)n * (d + 2));
+        double* hx = e->h_stage.data(); double* hp = hx + (size_t)n * d; double* hl = hp + n;
+        DZCK(download_rows(e, hx, pts, (size_t)n));
+        for (int i = 0; i < n; ++i) { hp[i] = 0.0; hl[i] = 0.0; }
+        if (e->cb(hx, n, d, hp, hl, e->cb_user)) return fail("host likelihood callback failed");
+        HIPCK(hipMemcpyAsync(prior, hp, sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
+        HIPCK(hipMemcpyAsync(like, hl, sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
+        HIPCK(hipStreamSynchronize(e->stream));
+        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_prior_add<NCH>, grid, block, 0, e->stream, e->p, pts, n, prior, like));
+    } else return fail("no likelihood set");
+    return launch_check("logp kernel");
+}
+
+// in-place all-gather of `rows_local` rows per rank inside buf (global layout [N,ld])
+int allgather_rows(dz_engine* e, double* buf)
+{
+    if (e->world == 1 && e->p.nl == e->p.N) return 0;
+    ProfScope ps(e, PR_EXCHANGE);
+    const size_t cnt = (size_t)e->p.nl * e->p.ld;
+    double* mine = buf + (size_t)e->p.off * e->p.ld;
+    if (e->comm) {
+        ncclResult_t r = g_rccl.AllGather(mine, buf, cnt, ncclDouble, e->comm, e->stream);
+        if (r != ncclSuccess) return fail(std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+        return 0;
+    }
+    if (!e->xcb) return fail("sharded run needs dz_comm_init_rccl or dz_set_exchange");
+    const size_t nranks = (size_t)e->p.N / e->p.nl;
+    e->h_stage.resize(cnt * (nranks + 1));
+    double* hs = e->h_stage.data(); double* hr = hs + cnt;
+    HIPCK(hipMemcpyAsync(hs, mine, sizeof(double) * cnt, hipMemcpyDeviceToHost, e->stream));
+    HIPCK(hipStreamSynchronize(e->stream));
+    if (e->xcb(hs, hr, (int64_t)(sizeof(double) * cnt), e->xcb_user)) return fail("exchange callback failed");
+    HIPCK(hipMemcpyAsync(buf, hr, sizeof(double) * cnt * nranks, hipMemcpyHostToDevice, e->stream));
+    HIPCK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int adapt_generation(dz_engine* e, uint32_t g)
+{
+    ProfScope ps(e, PR_ADAPT);
+    const dz::Params& p = e->p;
+    const int nstrips = (p.N + 63) / 64;
+    const dim3 b(128), gcol((p.d + 127) / 128, nstrips), gfin((p.d + 127) / 128);
+    hipLaunchKernelGGL(dz::k_strip_partial, gcol, b, 0, e->stream, p.cp_new, p.N, p.d, p.ld, e->d_mean, 0, e->d_partial);
+    hipLaunchKernelGGL(dz::k_strip_finish, gfin, b, 0, e->stream, e->d_partial, nstrips, p.N, p.d, p.ld, 0, e->d_mean, e->d_sd, e->d_sdc);
+    hipLaunchKernelGGL(dz::k_strip_partial, gcol, b, 0, e->stream, p.cp_new, p.N, p.d, p.ld, e->d_mean, 1, e->d_partial);
+    hipLaunchKernelGGL(dz::k_strip_finish, gfin, b, 0, e->stream, e->d_partial, nstrips, p.N, p.d, p.ld, 1, e->d_mean, e->d_sd, e->d_sdc);
+    NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_jump<NCH>, dim3((p.N + 3) / 4), dim3(256), 0, e->stream, p, g, e->d_sdc, e->d_sd, e->d_dl, e->d_dlg, e->d_binc, e->d_bing));
+    hipLaunchKernelGGL(dz::k_adapt_update, dim3(1), dim3(64), 0, e->stream, p, e->d_dl, e->d_dlg, e->d_binc, e->d_bing);
+    return launch_check("adaptation kernels");
+}
+
+int one_generation(dz_engine* e)
+{
+    dz::Params& p = e->p;
+    const uint32_t g = (uint32_t)e->gen;
+    const int nl = p.nl, k = p.k;
+    if (g == 0 && e->adapt) {   // publish the start positions (Dream_shared_vars.current_positions)
+        const size_t n = (size_t)nl * p.ld;
+        hipLaunchKernelGGL(dz::k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, p.X, p.cp_new + (size_t)p.off * p.ld, n);
+        DZCK(allgather_rows(e, p.cp_new));
+    }
+    {
+        ProfScope ps(e, PR_PROPOSE);
+        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((nl * k + 3) / 4), dim3(256), 0, e->stream, p, 0, g, (uint32_t)e->M, 0, nl));
+    }
+    DZCK(launch_check("propose"));
+    DZCK(eval_logp(e, p.P, nl * k, p.p_prior, p.p_like));
+    if (k > 1) {
+        {
+            ProfScope ps(e, PR_PROPOSE);
+            NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((nl * (k - 1) + 3) / 4), dim3(256), 0, e->stream, p, 1, g, (uint32_t)e->M, 0, nl));
+        }
+        DZCK(launch_check("propose(ref)"));
+        DZCK(eval_logp(e, p.R, nl * (k - 1), p.r_prior, p.r_like));
+    }
+    const bool append = (g % (uint32_t)p.thin) == 0;                           // Dream.py:360
+    const bool publish = e->adapt && (int64_t)g < (int64_t)p.burnin + 1;      // Dream.py:364
+    if (append && e->M + p.N > e->c.history_capacity) return fail("history capacity exceeded");
+    if (publish) std::swap(p.cp_prev, p.cp_new);
+    const int64_t slot = e->c.trace_capacity ? e->ntrace : -1;
+    {
+        ProfScope ps(e, PR_ACCEPT);
+        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_accept<NCH>, dim3((nl + 3) / 4), dim3(256), 0, e->stream, p, g, e->M, 0, nl, slot, append ? 1 : 0, publish ? 1 : 0));
+    }
+    DZCK(launch_check("accept"));
+    if (publish) { DZCK(allgather_rows(e, p.cp_new)); DZCK(adapt_generation(e, g)); }
+    if (append) { DZCK(allgather_rows(e, p.Z + (size_t)e->M * p.ld)); e->M += p.N; }
+    e->gen++;
+    if (e->c.trace_capacity) e->ntrace++;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dz_version(void) { return DZ_VERSION; }
+const char* dz_last_error(void) { return g_err.c_str(); }
+int dz_device_count(int32_t* count)
+{
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess) { *count = 0; return fail(std::string("hipGetDeviceCount: ") + hipGetErrorString(err)); }
+    *count = n; return 0;
+}
+
+int dz_create(const dz_config* cfg, dz_engine** out)
+{
+    if (!cfg || !out) return fail("null argument");
+    if (cfg->ndim < 1 || cfg->nchains < 1 || cfg->nchains_local < 1 || cfg->multitry < 1) return fail("bad sizes");
+    if (cfg->ndim > 1024) return fail("ndim > 1024 not supported by this build");
+    if (cfg->multitry == 2) return fail("multitry=2 is broken in the reference (Dream.py:867-868); rejected");
+    if (cfg->multitry > dz::MAXK) return fail("multitry too large");
+    if (cfg->depairs < 1 || cfg->depairs > dz::MAXPAIR) return fail("DEpairs must be 1..8");
+    if (cfg->ncr < 1 || cfg->ngamma < 1 || cfg->ncr > 32 || cfg->ngamma > 32) return fail("bad nCR/gamma_levels");
+    if (cfg->schedule != 2) return fail("the device engine runs schedule 2 (lockstep generations) only");
+    if (cfg->chain_offset < 0 || cfg->chain_offset + cfg->nchains_local > cfg->nchains) return fail("bad shard");
+    if (cfg->nchains % cfg->nchains_local) return fail("nchains must be a multiple of nchains_local");
+    if (cfg->history_thin < 1) return fail("history_thin must be >= 1");
+    int ndev = 0;
+    hipError_t derr = hipGetDeviceCount(&ndev);
+    if (derr != hipSuccess || ndev < 1) return fail("no HIP device available: libdreamzs has no CPU fallback");
+    HIPCK(hipSetDevice(cfg->device));
+    dz_engine* e = new dz_engine();
+    e->c = *cfg;
+    dz::Params& p = e->p;
+    p.N = cfg->nchains; p.nl = cfg->nchains_local; p.off = cfg->chain_offset; p.d = cfg->ndim;
+    p.ld = (cfg->ndim + 15) / 16 * 16;
+    p.k = cfg->multitry; p.depairs = cfg->depairs; p.ncr = cfg->ncr; p.ngamma = cfg->ngamma; p.thin = cfg->history_thin;
+    p.burnin = cfg->crossover_burnin; p.adapt_cr = cfg->adapt_crossover; p.adapt_g = cfg->adapt_gamma; p.hard = cfg->hardboundaries;
+    p.k0 = (uint32_t)cfg->seed; p.k1 = (uint32_t)(cfg->seed >> 32);
+    p.lamb = cfg->lamb; p.zeta = cfg->zeta; p.snooker = cfg->snooker; p.pgu = cfg->p_gamma_unity; p.T = cfg->temperature;
+    const int chunks = (p.ld + 127) / 128;
+    e->nch = chunks <= 1 ? 1 : chunks <= 2 ? 2 : chunks <= 4 ? 4 : 8;
+    e->adapt = cfg->adapt_crossover || cfg->adapt_gamma;
+    e->world = cfg->nchains / cfg->nchains_local; e->rank = cfg->chain_offset / cfg->nchains_local;
+    HIPCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    const size_t ld = p.ld, nl = p.nl, N = p.N, k = p.k, tc = (size_t)cfg->trace_capacity;
+    int rc = 0;
+    rc |= ealloc(e, &p.Z, (size_t)cfg->history_capacity * ld);
+    rc |= ealloc(e, &p.X, nl * ld); rc |= ealloc(e, &p.lprior, nl); rc |= ealloc(e, &p.llike, nl);
+    rc |= ealloc(e, &p.P, nl * k * ld); rc |= ealloc(e, &p.R, nl * k * ld);
+    rc |= ealloc(e, &p.p_prior, nl * k); rc |= ealloc(e, &p.p_like, nl * k); rc |= ealloc(e, &p.p_slogp, nl * k);
+    rc |= ealloc(e, &p.r_prior, nl * k); rc |= ealloc(e, &p.r_like, nl * k); rc |= ealloc(e, &p.r_slogp, nl * k);
+    rc |= ealloc(e, &p.cur_snk, nl);
+    rc |= ealloc(e, &e->d_mins, ld); rc |= ealloc(e, &e->d_maxs, ld);
+    rc |= ealloc(e, &e->d_gtab, (size_t)cfg->ngamma * cfg->depairs * p.d);
+    rc |= ealloc(e, &e->d_shared, (size_t)3 * (cfg->ncr + cfg->ngamma));
+    rc |= ealloc(e, &e->d_pkind, ld); rc |= ealloc(e, &e->d_pa, ld); rc |= ealloc(e, &e->d_pb, ld);
+    if (e->adapt) {
+        rc |= ealloc(e, &p.cp_prev, N * ld); rc |= ealloc(e, &p.cp_new, N * ld);
+        rc |= ealloc(e, &e->d_partial, (size_t)((N + 63) / 64) * ld);
+        rc |= ealloc(e, &e->d_mean, ld); rc |= ealloc(e, &e->d_sd, ld); rc |= ealloc(e, &e->d_sdc, ld);
+        rc |= ealloc(e, &e->d_dl, N); rc |= ealloc(e, &e->d_dlg, N); rc |= ealloc(e, &e->d_binc, N); rc |= ealloc(e, &e->d_bing, N);
+    }
+    if (tc) {
+        rc |= ealloc(e, &p.tX, tc * nl * ld); rc |= ealloc(e, &p.tlogp, tc * nl);
+        rc |= ealloc(e, &p.tmoved, tc * nl); rc |= ealloc(e, &p.tsnk, tc * nl); rc |= ealloc(e, &p.ttry, tc * nl); rc |= ealloc(e, &p.tcr, tc * nl);
+    }
+    rc |= ealloc(e, &e->d_cmean, nl * (size_t)p.d); rc |= ealloc(e, &e->d_cvar, nl * (size_t)p.d); rc |= ealloc(e, &e->d_rhat, (size_t)p.d);
+    if (rc) { dz_destroy(e); return -1; }
+    p.mins = e->d_mins; p.maxs = e->d_maxs; p.gtab = e->d_gtab;
+    p.cr_probs = e->d_shared; p.cr_delta = p.cr_probs + cfg->ncr; p.cr_n = p.cr_delta + cfg->ncr;
+    p.g_probs = p.cr_n + cfg->ncr; p.g_delta = p.g_probs + cfg->ngamma; p.g_n = p.g_delta + cfg->ngamma;
+    p.pkind = e->d_pkind; p.pa = e->d_pa; p.pb = e->d_pb; p.have_prior = 0;
+    // defaults: unbounded, uniform CR / gamma-level probabilities (Dream.py:134, :143), computed gamma table
+    {
+        std::vector<double> lo(ld, -HUGE_VAL), hi(ld, HUGE_VAL);
+        HIPCK(hipMemcpy(e->d_mins, lo.data(), sizeof(double) * ld, hipMemcpyHostToDevice));
+        HIPCK(hipMemcpy(e->d_maxs, hi.data(), sizeof(double) * ld, hipMemcpyHostToDevice));
+        std::vector<double> sh((size_t)3 * (cfg->ncr + cfg->ngamma), 0.0);
+        for (int m = 0; m < cfg->ncr; ++m) sh[m] = 1.0 / (double)cfg->ncr;
+        for (int m = 0; m < cfg->ngamma; ++m) sh[(size_t)3 * cfg->ncr + m] = 1.0 / (double)cfg->ngamma;
+        HIPCK(hipMemcpy(e->d_shared, sh.data(), sizeof(double) * sh.size(), hipMemcpyHostToDevice));
+    }
+    *out = e;
+    return dz_set_gamma_table(e, nullptr);
+}
+
+int dz_destroy(dz_engine* e)
+{
+    if (!e) return 0;
+    hipSetDevice(e->c.device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    for (auto& v : e->ev) for (auto& pr : v) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
+    for (void* q : e->to_free) hipFree(q);
+    if (e->d_scratch) hipFree(e->d_scratch);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+    return 0;
+}
+
+int dz_set_bounds(dz_engine* e, const double* mins, const double* maxs)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    DZCK(upload_padded(e, e->d_mins, mins, 1, -HUGE_VAL));
+    return upload_padded(e, e->d_maxs, maxs, 1, HUGE_VAL);
+}
+
+int dz_set_gamma_table(dz_engine* e, const double* table)
+{   // Dream.py:172-179
+    HIPCK(hipSetDevice(e->c.device));
+    const int d = e->p.d, ng = e->c.ngamma, np = e->c.depairs;
+    std::vector<double> t((size_t)ng * np * d);
+    if (table) memcpy(t.data(), table, sizeof(double) * t.size());
+    else {
+        double dec = 1.0;
+        for (int lev = 1; lev <= ng; ++lev) {
+            for (int delta = 1; delta <= np; ++delta)
+                for (int dp = 1; dp <= d; ++dp)
+                    t[((size_t)(lev - 1) * np + (delta - 1)) * d + (dp - 1)] = (2.38 / std::sqrt((double)(2 * delta) * (double)dp)) / dec;
+            dec = dec * 2.0;
+        }
+    }
+    HIPCK(hipMemcpy(e->d_gtab, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int dz_set_history(dz_engine* e, const double* Z, int64_t rows)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    if (rows > e->c.history_capacity) return fail("history exceeds capacity");
+    if (rows > 0xffffffffll) return fail("history too long");
+    DZCK(upload_padded(e, e->p.Z, Z, (int)rows, 0.0));
+    e->M = rows;
+    return 0;
+}
+
+int dz_set_state(dz_engine* e, const double* X, const double* prior, const double* like)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    DZCK(upload_padded(e, e->p.X, X, e->p.nl, 0.0));
+    if (prior && like) {
+        HIPCK(hipMemcpy(e->p.lprior, prior, sizeof(double) * e->p.nl, hipMemcpyHostToDevice));
+        HIPCK(hipMemcpy(e->p.llike, like, sizeof(double) * e->p.nl, hipMemcpyHostToDevice));
+        e->have_logp = true;
+    } else e->have_logp = false;
+    return 0;
+}
+
+int dz_set_cr_probs(dz_engine* e, const double* pr, int32_t n)
+{
+    if (n != e->c.ncr) return fail("nCR mismatch");
+    HIPCK(hipSetDevice(e->c.device));
+    HIPCK(hipStreamSynchronize(e->stream));
+    HIPCK(hipMemcpy(e->p.cr_probs, pr, sizeof(double) * n, hipMemcpyHostToDevice));
+    return 0;
+}
+int dz_set_gamma_probs(dz_engine* e, const double* pr, int32_t n)
+{
+    if (n != e->c.ngamma) return fail("ngamma mismatch");
+    HIPCK(hipSetDevice(e->c.device));
+    HIPCK(hipStreamSynchronize(e->stream));
+    HIPCK(hipMemcpy(e->p.g_probs, pr, sizeof(double) * n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int dz_set_prior(dz_engine* e, const int32_t* kind, const double* a, const double* b)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    const int d = e->p.d;
+    bool any = false;
+    for (int j = 0; j < d; ++j) { if (kind[j] < 0 || kind[j] > 2) return fail("prior kind must be 0,1,2"); any = any || kind[j] != 0; }
+    HIPCK(hipMemcpy(e->d_pkind, kind, sizeof(int32_t) * d, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(e->d_pa, a, sizeof(double) * d, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(e->d_pb, b, sizeof(double) * d, hipMemcpyHostToDevice));
+    e->p.have_prior = any ? 1 : 0;
+    return 0;
+}
+
+int dz_set_likelihood_mvn(dz_engine* e, const double* mu, const double* M, int32_t kind, double log_F)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    const int d = e->p.d, ld = e->p.ld;
+    if (!e->d_mu) DZCK(ealloc(e, &e->d_mu, (size_t)32 * ld));
+    if (!e->d_Mt) DZCK(ealloc(e, &e->d_Mt, (size_t)d * ld));
+    std::vector<double> mt((size_t)d * ld, 0.0), m(ld, 0.0);
+    for (int r = 0; r < d; ++r) for (int c = 0; c < d; ++c) mt[(size_t)c * ld + r] = M[(size_t)r * d + c];
+    memcpy(m.data(), mu, sizeof(double) * d);
+    HIPCK(hipMemcpy(e->d_Mt, mt.data(), sizeof(double) * mt.size(), hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(e->d_mu, m.data(), sizeof(double) * ld, hipMemcpyHostToDevice));
+    e->p.mu = e->d_mu; e->p.Mt = e->d_Mt; e->p.logF = log_F; e->p.tri = kind != 0; e->lk = LK_MVN;
+    return 0;
+}
+
+int dz_set_likelihood_mixture(dz_engine* e, int32_t J, const double* mu, const double* log_F)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    if (J < 1 || J > 32) return fail("mixture components must be 1..32");
+    const int d = e->p.d, ld = e->p.ld;
+    if (!e->d_mu) DZCK(ealloc(e, &e->d_mu, (size_t)32 * ld));
+    if (!e->d_mixF) DZCK(ealloc(e, &e->d_mixF, 32));
+    std::vector<double> m((size_t)J * ld, 0.0);
+    for (int j = 0; j < J; ++j) memcpy(&m[(size_t)j * ld], mu + (size_t)j * d, sizeof(double) * d);
+    HIPCK(hipMemcpy(e->d_mu, m.data(), sizeof(double) * m.size(), hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(e->d_mixF, log_F, sizeof(double) * J, hipMemcpyHostToDevice));
+    e->p.mu = e->d_mu; e->p.mixF = e->d_mixF; e->p.J = J; e->lk = LK_MIX;
+    return 0;
+}
+
+int dz_set_likelihood_host(dz_engine* e, dz_logp_cb cb, void* user)
+{
+    if (!cb) return fail("null callback");
+    e->cb = cb; e->cb_user = user; e->lk = LK_HOST;
+    return 0;
+}
+
+int dz_comm_unique_id(void* id128)
+{
+    DZCK(g_rccl.load());
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return fail("ncclGetUniqueId failed");
+    static_assert(sizeof(ncclUniqueId) == 128, "unexpected ncclUniqueId size");
+    memcpy(id128, &id, 128);
+    return 0;
+}
+
+int dz_comm_init_rccl(dz_engine* e, int32_t rank, int32_t world, const void* id128)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    if (world != e->world || rank != e->rank) return fail("rank/world do not match the chain shard in dz_config");
+    DZCK(g_rccl.load());
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclResult_t r = g_rccl.CommInitRank(&e->comm, world, id, rank);
+    if (r != ncclSuccess) return fail(std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+    return 0;
+}
+
+int dz_set_exchange(dz_engine* e, dz_exchange_cb cb, void* user) { e->xcb = cb; e->xcb_user = user; return 0; }
+
+int dz_step(dz_engine* e, int64_t generations)
+{
+    if (!e) return fail("null engine");
+    HIPCK(hipSetDevice(e->c.device));
+    if (e->lk == LK_NONE) return fail("no likelihood set");
+    if (e->M < 2 * e->c.depairs) return fail("history not seeded");
+    if (e->c.trace_capacity && e->ntrace + generations > e->c.trace_capacity) return fail("trace capacity exceeded");
+    if (!e->have_logp) {   // Dream.py:266-268
+        DZCK(eval_logp(e, e->p.X, e->p.nl, e->p.lprior, e->p.llike));
+        e->have_logp = true;
+    }
+    for (int64_t i = 0; i < generations; ++i) DZCK(one_generation(e));
+    return 0;
+}
+
+int dz_sync(dz_engine* e)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    HIPCK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+int dz_trace_reset(dz_engine* e) { e->ntrace = 0; return 0; }
+int64_t dz_generation(dz_engine* e) { return e->gen; }
+
+int dz_get_state(dz_engine* e, double* X, double* prior, double* like)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    if (X) DZCK(download_rows(e, X, e->p.X, (size_t)e->p.nl));
+    HIPCK(hipStreamSynchronize(e->stream));
+    if (prior) HIPCK(hipMemcpy(prior, e->p.lprior, sizeof(double) * e->p.nl, hipMemcpyDeviceToHost));
+    if (like) HIPCK(hipMemcpy(like, e->p.llike, sizeof(double) * e->p.nl, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int dz_get_trace(dz_engine* e, int64_t g0, int64_t ng, double* X, double* logp, uint8_t* moved, int32_t* try_idx, int32_t* cr_idx, uint8_t* snooker)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    if (g0 < 0 || ng < 0 || g0 + ng > e->ntrace) return fail("trace range");
+    const size_t nl = e->p.nl, o = (size_t)g0 * nl, n = (size_t)ng * nl;
+    if (X) DZCK(download_rows(e, X, e->p.tX + o * e->p.ld, n));
+    HIPCK(hipStreamSynchronize(e->stream));
+    if (logp) HIPCK(hipMemcpy(logp, e->p.tlogp + o, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (moved) HIPCK(hipMemcpy(moved, e->p.tmoved + o, n, hipMemcpyDeviceToHost));
+    if (try_idx) HIPCK(hipMemcpy(try_idx, e->p.ttry + o, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    if (cr_idx) HIPCK(hipMemcpy(cr_idx, e->p.tcr + o, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    if (snooker) HIPCK(hipMemcpy(snooker, e->p.tsnk + o, n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int dz_get_history(dz_engine* e, double* Z, int64_t cap_rows, int64_t* rows)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    if (rows) *rows = e->M;
+    if (Z) { if (cap_rows < e->M) return fail("buffer too small"); DZCK(download_rows(e, Z, e->p.Z, (size_t)e->M)); }
+    return 0;
+}
+
+static int get_shared(dz_engine* e, const double* probs, const double* delta, const double* n, int nb, double* o_probs, double* o_delta, double* o_n)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    HIPCK(hipStreamSynchronize(e->stream));
+    if (o_probs) HIPCK(hipMemcpy(o_probs, probs, sizeof(double) * nb, hipMemcpyDeviceToHost));
+    if (o_delta) HIPCK(hipMemcpy(o_delta, delta, sizeof(double) * nb, hipMemcpyDeviceToHost));
+    if (o_n) HIPCK(hipMemcpy(o_n, n, sizeof(double) * nb, hipMemcpyDeviceToHost));
+    return 0;
+}
+int dz_get_cr_state(dz_engine* e, double* probs, double* delta_m, double* n_updates)
+{
+    return get_shared(e, e->p.cr_probs, e->p.cr_delta, e->p.cr_n, e->c.ncr, probs, delta_m, n_updates);
+}
+int dz_get_gamma_state(dz_engine* e, double* probs, double* delta_m, double* n_updates)
+{
+    return get_shared(e, e->p.g_probs, e->p.g_delta, e->p.g_n, e->c.ngamma, probs, delta_m, n_updates);
+}
+
+static int chain_moments(dz_engine* e)
+{
+    if (e->ntrace < 2) return fail("need at least 2 traced generations");
+    const dz::Params& p = e->p;
+    hipLaunchKernelGGL(dz::k_chain_moments, dim3((p.d + 127) / 128, p.nl), dim3(128), 0, e->stream, p.tX, p.nl, p.d, p.ld, (int)e->ntrace, e->d_cmean, e->d_cvar);
+    return launch_check("chain moments");
+}
+int dz_get_chain_moments(dz_engine* e, double* mean, double* var)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    DZCK(chain_moments(e));
+    HIPCK(hipStreamSynchronize(e->stream));
+    const size_t n = (size_t)e->p.nl * e->p.d;
+    HIPCK(hipMemcpy(mean, e->d_cmean, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(var, e->d_cvar, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+int dz_get_rhat(dz_engine* e, double* rhat)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    DZCK(chain_moments(e));
+    const dz::Params& p = e->p;
+    hipLaunchKernelGGL(dz::k_rhat, dim3((p.d + 127) / 128), dim3(128), 0, e->stream, e->d_cmean, e->d_cvar, p.nl, p.d, (int)e->ntrace, e->d_rhat);
+    DZCK(launch_check("rhat"));
+    HIPCK(hipStreamSynchronize(e->stream));
+    HIPCK(hipMemcpy(rhat, e->d_rhat, sizeof(double) * p.d, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static int need_scratch(dz_engine* e, size_t rows)
+{
+    if (e->scratch_rows >= rows) return 0;
+    if (e->d_scratch) hipFree(e->d_scratch);
+    e->d_scratch = nullptr; e->scratch_rows = 0;
+    HIPCK(hipMalloc((void**)&e->d_scratch, sizeof(double) * (rows * e->p.ld + 4 * rows)));
+    e->scratch_rows = rows;
+    return 0;
+}
+
+int dz_eval_logp(dz_engine* e, const double* X, int64_t n, double* prior, double* like)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    if (n > (1 << 22)) return fail("too many points in one call");
+    DZCK(need_scratch(e, (size_t)n));
+    double* pts = e->d_scratch; double* dp = pts + (size_t)n * e->p.ld; double* dl = dp + n;
+    DZCK(upload_padded(e, pts, X, (int)n, 0.0));
+    DZCK(eval_logp(e, pts, (int)n, dp, dl));
+    HIPCK(hipStreamSynchronize(e->stream));
+    HIPCK(hipMemcpy(prior, dp, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(like, dl, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int dz_debug_propose(dz_engine* e, int32_t chain_local, int64_t gen, int32_t phase, const double* base,
+                     int32_t run_snooker, int32_t cr_idx, int32_t delta, int32_t glev, double* pts, double* slogp)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    const int n = phase == 0 ? e->p.k : e->p.k - 1;
+    if (n < 1) return fail("no reference phase for multitry=1");
+    DZCK(need_scratch(e, (size_t)n + 1));
+    double* dbase = e->d_scratch; double* dout = dbase + e->p.ld; double* dsl = dout + (size_t)n * e->p.ld;
+    DZCK(upload_padded(e, dbase, base, 1, 0.0));
+    NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose_debug<NCH>, dim3((n + 3) / 4), dim3(256), 0, e->stream, e->p, phase, (uint32_t)gen, (uint32_t)e->M,
+                                       chain_local, n, dbase, dout, dsl, run_snooker, cr_idx, delta, glev));
+    DZCK(launch_check("propose(debug)"));
+    DZCK(download_rows(e, pts, dout, (size_t)n));
+    HIPCK(hipMemcpy(slogp, dsl, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int dz_profile_enable(dz_engine* e, int32_t on) { e->prof = on != 0; return 0; }
+int dz_profile_reset(dz_engine* e)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    HIPCK(hipStreamSynchronize(e->stream));
+    for (auto& v : e->ev) { for (auto& pr : v) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); } v.clear(); }
+    return 0;
+}
+int dz_profile_get(dz_engine* e, int32_t which, double* total_ms, int64_t* launches)
+{
+    if (which < 0 || which >= PR_COUNT) return fail("bad profile class");
+    HIPCK(hipSetDevice(e->c.device));
+    HIPCK(hipStreamSynchronize(e->stream));
+    double tot = 0.0;
+    for (auto& pr : e->ev[which]) { float ms = 0.f; HIPCK(hipEventElapsedTime(&ms, pr.first, pr.second)); tot += ms; }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int64_t)e->ev[which].size();
+    return 0;
+}
+
+}  // extern "C"

@@ -60,3 +60,17 @@ def compare_with_reference(tr, fx, Z, cr_probs, gamma_probs=None, x_rtol=1e-9, l
     np.testing.assert_allclose(cr_probs, fx["cross_probs"][-1], rtol=1e-11, atol=0)
     if gamma_probs is not None:
         np.testing.assert_allclose(gamma_probs, fx["gamma_probs"][-1], rtol=1e-11, atol=0)
+
+
+def mvn_precision(d):
+    """Precision matrix of the reference's correlated MVN target
+    (pydream/examples/ndim_gaussian/dream_ex_ndim_gaussian.py:30-38) at dimension d."""
+    i = np.arange(1, d + 1, dtype=float)
+    C = (.5 * np.identity(d) + .5 * np.ones((d, d))) * np.sqrt(np.outer(i, i))
+    return np.linalg.inv(C)
+
+
+def seed_history(rows, d, seed, lo=-5.0, hi=15.0):
+    """iid U(lo,hi) seed archive (the shipped example uses a Latin hypercube on [-5,15],
+    dream_ex_ndim_gaussian.py:17-26, 45)."""
+    return np.random.default_rng(seed).uniform(lo, hi, (rows, d))

@@ -1,0 +1,160 @@
+"""Parity tests proper: the HIP engine (through the C ABI) against (a) the vectors produced by the
+REFERENCE (tests/golden) and (b) the CPU oracle on the same seeded inputs -- bit-exact."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+S2_TRACES = ["trace_s2_adapt", "trace_s2_k1_bounds", "trace_s2_k3_bounds", "trace_s2_depairs_gamma",
+             "trace_s2_mvn100", "trace_s2_mix3"]
+
+
+@pytest.fixture(scope="module")
+def G():
+    from pydream_amd import _capi
+    return _capi
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def assert_traces_identical(a, b):
+    for key in ("snooker", "cr_idx", "try_idx", "moved", "X", "logp"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+
+
+@pytest.mark.parametrize("name", S2_TRACES)
+def test_golden_traces(name, G, O):
+    """HIP == reference (decision sequences exact, logp 1e-10) and HIP == oracle bit-for-bit."""
+    fx = H.load(name)
+    n = int(fx["cfg_G"])
+    e = H.engine_from_trace_fixture(G.Engine, fx)
+    e.step(n)
+    tr = e.get_trace(0, n)
+    gp = e.get_gamma_state()[0] if int(fx["cfg_adapt_gamma"]) else None
+    H.compare_with_reference(tr, fx, e.get_history(), e.get_cr_state()[0], gp)
+    o = H.engine_from_trace_fixture(O.Engine, fx)
+    o.step(n)
+    assert_traces_identical(tr, o.get_trace(0, n))
+    np.testing.assert_array_equal(e.get_history(), o.get_history())
+    for a, b in zip(e.get_cr_state(), o.get_cr_state()):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(e.get_gamma_state(), o.get_gamma_state()):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(e.get_rhat(), o.get_rhat())
+    for a, b in zip(e.get_state(), o.get_state()):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("tag", ["d100k5", "d4k5b", "d4k1b", "d10k1"])
+def test_generate_proposal_points(tag, G, O):
+    fx = H.load("proposals")
+    g = lambda a: fx[tag + "__" + a]
+    d, k = int(g("d")), int(g("k"))
+    Z, q0 = g("Z"), g("q0")
+    kw = dict(nchains=4, ndim=d, multitry=k, depairs=int(g("depairs")), ngamma=int(g("ngamma")),
+              history_capacity=len(Z) + 8, seed=int(g("seed")), lamb=float(g("lamb")))
+    e, o = G.Engine(**kw), O.Engine(**kw)
+    for x in (e, o):
+        x.set_history(Z)
+        if int(g("bounded")):
+            x.set_bounds(g("mins"), g("maxs"))
+    pos = 0
+    for (trial, phase, snk, cr_idx, delta, glev) in g("meta"):
+        n = k if phase == 0 else k - 1
+        args = (3, int(trial), int(phase), q0, int(snk), int(cr_idx), int(delta), int(glev))
+        pts, slogp = e.debug_propose(*args)[:2]
+        opts, oslogp = o.debug_propose(*args)[:2]
+        np.testing.assert_array_equal(pts, opts)
+        np.testing.assert_array_equal(slogp, oslogp)
+        ref = g("pts")[pos:pos + n * d].reshape(n, d)
+        pos += n * d
+        if snk:
+            np.testing.assert_allclose(pts, ref, rtol=1e-12, atol=1e-14)
+        else:
+            np.testing.assert_array_equal(pts, ref)       # DE proposals: bit-exact against the reference
+
+
+def test_logpdf_kernels(G, O):
+    """MVN d=10/100/200 (dense precision and triangular factor) and mixtures: 1e-10 vs the reference,
+    bit-exact vs the oracle."""
+    fx = H.load("densities")
+    for d in (10, 100, 200):
+        P, X, ref = fx["mvn%d_invC" % d], fx["mvn%d_X" % d], fx["mvn%d_logp" % d]
+        logF = float(fx["mvn%d_logF" % d])
+        e, o = G.Engine(nchains=3, ndim=d, history_capacity=8), O.Engine(nchains=3, ndim=d, history_capacity=8)
+        U = np.linalg.cholesky((P + P.T) / 2).T
+        for M, kind in ((P, 0), (U, 1)):
+            e.set_likelihood_mvn(np.zeros(d), M, kind, logF)
+            o.set_likelihood_mvn(np.zeros(d), M, kind, logF)
+            got = e.eval_logp(X)[1]
+            np.testing.assert_allclose(got, ref, rtol=1e-13, atol=1e-10)
+            np.testing.assert_array_equal(got, np.array([o.loglike(x) for x in X]))
+    for tag, d in (("mix2", 10), ("mix3", 100)):
+        e, o = G.Engine(nchains=3, ndim=d, history_capacity=8), O.Engine(nchains=3, ndim=d, history_capacity=8)
+        e.set_likelihood_mixture(fx[tag + "_mu"], fx[tag + "_logF"])
+        o.set_likelihood_mixture(fx[tag + "_mu"], fx[tag + "_logF"])
+        got = e.eval_logp(fx[tag + "_X"])[1]
+        np.testing.assert_allclose(got, fx[tag + "_logp"], rtol=0, atol=1e-10)
+        np.testing.assert_array_equal(got, np.array([o.loglike(x) for x in fx[tag + "_X"]]))
+
+
+def _c2_like(Cls, N, d, G_, seed, k=5, **kw):
+    P = H.mvn_precision(d)
+    Z0 = H.seed_history(max(10 * d, 2 * N), d, seed)
+    e = Cls(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (G_ // 10 + 2), trace_capacity=G_, seed=seed, **kw)
+    e.set_history(Z0)
+    e.set_state(Z0[:N])
+    e.set_likelihood_mvn(np.zeros(d), P, 0, 0.0)
+    return e
+
+
+def test_c2_config_against_oracle(G, O):
+    """BASELINE configs[1] (1024 chains, 100-D MVN, multitry 5, DE+snooker): 30 generations, everything bit-exact."""
+    n = 30
+    e, o = _c2_like(G.Engine, 1024, 100, n, 20260929), _c2_like(O.Engine, 1024, 100, n, 20260929)
+    e.step(n); o.step(n)
+    assert_traces_identical(e.get_trace(0, n), o.get_trace(0, n))
+    np.testing.assert_array_equal(e.get_history(), o.get_history())
+    acc = e.get_trace(0, n)["moved"].mean()
+    assert 0.1 < acc < 0.6
+
+
+def test_c3_config_against_oracle(G, O):
+    """BASELINE configs[2] shape (mixture of 3 Gaussians, CR adaptation on) at 512 chains x 100-D."""
+    N, d, n, seed = 512, 100, 40, 5
+    mu = np.array([np.full(d, m) for m in (-5.0, 0.0, 5.0)])
+    logF = np.log(np.array([1 / 6., 1 / 3., 1 / 2.])) - (d / 2.) * np.log(2 * np.pi)
+    Z0 = H.seed_history(2 * N, d, seed, lo=-8, hi=8)
+    out = []
+    for Cls in (G.Engine, O.Engine):
+        e = Cls(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
+                adapt_crossover=1, crossover_burnin=25)
+        e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mixture(mu, logF)
+        e.step(n)
+        out.append((e.get_trace(0, n), e.get_cr_state(), e.get_history()))
+    assert_traces_identical(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    assert not np.allclose(out[0][1][0], 1 / 3.)       # crossover probabilities did adapt
+
+
+def test_d1000_stress_shape_against_oracle(G, O):
+    """BASELINE configs[4] shape (1000-D correlated MVN, triangular-factor logpdf) at 16 chains."""
+    N, d, n, seed = 16, 1000, 6, 9
+    P = H.mvn_precision(d)
+    U = np.linalg.cholesky((P + P.T) / 2).T
+    Z0 = H.seed_history(64, d, seed)
+    out = []
+    for Cls in (G.Engine, O.Engine):
+        e = Cls(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * 3, trace_capacity=n, seed=seed)
+        e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), U, 1, 0.0)
+        e.step(n)
+        out.append(e.get_trace(0, n))
+    assert_traces_identical(out[0], out[1])

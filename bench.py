@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- proposals/s of the MT-DREAM(ZS) hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one generation: every chain makes one MT-DREAM(ZS) transition (multitry proposals,
+reference set, Metropolis accept, Z append every `thin` generations).  Workload at N GPUs (weak
+scaling, BASELINE.json north_star / configs[3]): 4096 chains per GPU on the 100-D correlated MVN of
+pydream/examples/ndim_gaussian, multitry=5, DE+snooker, reference defaults otherwise.  Inputs
+(seed archive, start states, precision matrix) are resident in HBM before the timed region.
+
+For N>1 the driver launches one rank per GPU with torch.distributed.run; torch is used ONLY for the
+rendezvous (gloo: barrier, max-reduce of the time, broadcast of the RCCL unique id) -- the engine
+itself is libdreamzs.so (HIP + RCCL), loaded through ctypes.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def mvn_precision(d):
+    """pydream/examples/ndim_gaussian/dream_ex_ndim_gaussian.py:30-38 at dimension d"""
+    i = np.arange(1, d + 1, dtype=float)
+    C = (.5 * np.identity(d) + .5 * np.ones((d, d))) * np.sqrt(np.outer(i, i))
+    return np.linalg.inv(C)
+
+
+def setup_engine(Cls, args, n_global, n_local, offset, steps_total, device=0, **extra):
+    d, k = args.dim, args.multitry
+    rng = np.random.default_rng(args.seed)
+    m0 = max(10 * d, 2 * n_global)                        # Dream.py:168-170, core.py:270-273
+    Z0 = rng.uniform(-5.0, 15.0, (m0, d))                 # seed archive, iid U(-5,15)
+    cap = m0 + n_global * (steps_total // args.thin + 2)
+    kw = dict(nchains=n_global, nchains_local=n_local, chain_offset=offset, ndim=d, multitry=k,
+              history_thin=args.thin, history_capacity=cap, trace_capacity=max(args.steps, args.warmup, 2),
+              seed=args.seed, device=device, adapt_crossover=0, crossover_burnin=0)
+    kw.update(extra)
+    e = Cls(**kw)
+    e.set_history(Z0)
+    e.set_state(Z0[offset:offset + n_local])              # starts = first N seed rows (dream_ex_ndim_gaussian.py:54)
+    if args.target == "mvn":
+        P = mvn_precision(d)
+        if args.mvn_kind == "tri":
+            e.set_likelihood_mvn(np.zeros(d), np.linalg.cholesky((P + P.T) / 2).T, 1, 0.0)
+        else:
+            e.set_likelihood_mvn(np.zeros(d), P, 0, 0.0)
+    else:
+        mu = np.array([np.full(d, m) for m in (-5.0, 0.0, 5.0)])
+        logF = np.log(np.array([1 / 6., 1 / 3., 1 / 2.])) - (d / 2.) * np.log(2 * np.pi)
+        e.set_likelihood_mixture(mu, logF)
+    return e
+
+
+def algorithmic_bytes(args, n_local):
+    """Per-launch algorithmic HBM bytes of each kernel class (DESIGN.md "Roofline accounting",
+    from SURVEY.md section 8(d)'s per-unit figures; rows unpadded, snooker fraction s)."""
+    d, k, s = args.dim, args.multitry, 0.1
+    row = 8.0 * d
+    rows_z = 2 * (1 - s) + 3 * s
+    pts = n_local * (2 * k - 1)
+    return {
+        # both propose launches of a generation: Z gathers + base row read + proposal write
+        "propose": pts * row * (rows_z + 2.0) / 2.0,
+        # both logp launches: proposal read + 2 scalars written
+        "logp": pts * (row + 16.0) / 2.0,
+        # accept: state read + (accepted) proposal read + state/trace write + append/thin + logp scalars
+        "accept": n_local * (row * (2.0 + 1.0 + 1.0 / args.thin) + 16.0 * (2 * k - 1) + 8.0),
+    }
+
+
+def cpu_baseline(args):
+    """The CPU restatement (oracle, scalar C, one core) on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    nc, g = args.cpu_chains, args.cpu_steps
+    e = setup_engine(O.Engine, args, nc, nc, 0, g + 2, schedule=2, trace_capacity=0)
+    e.step(2)
+    t0 = time.perf_counter()
+    e.step(g)
+    dt = time.perf_counter() - t0
+    return {"value": nc * args.multitry * g / dt, "unit": "proposals/s", "cores": 1, "kind": "port",
+            "sample": "%d chains x %d generations of the same %d-D %s target, multitry=%d, oracle/dreamzs_oracle.c, %.1f s"
+                      % (nc, g, args.dim, args.target, args.multitry, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--chains-per-gpu", type=int, default=4096)
+    ap.add_argument("--dim", type=int, default=100)
+    ap.add_argument("--multitry", type=int, default=5)
+    ap.add_argument("--thin", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=20260929)
+    ap.add_argument("--target", choices=["mvn", "mix3"], default="mvn")
+    ap.add_argument("--mvn-kind", choices=["dense", "tri"], default="dense")
+    ap.add_argument("--cpu-chains", type=int, default=256)
+    ap.add_argument("--cpu-steps", type=int, default=150)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="do not time individual kernels with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    from pydream_amd import _capi            # loads libdreamzs.so (system ROCm runtime) BEFORE torch
+    _capi.load_library()
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
+
+    n_local = args.chains_per_gpu
+    n_global = n_local * world
+    total = args.steps + args.warmup
+    e = setup_engine(_capi.Engine, args, n_global, n_local, rank * n_local, total, device=local_rank)
+    if world > 1:
+        ids = [_capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        e.comm_init_rccl(rank, world, ids[0])
+
+    def barrier():
+        e.sync()
+        if dist is not None:
+            dist.barrier()
+
+    e.step(args.warmup)
+    barrier()
+    e.trace_reset()
+    if not args.no_events:
+        e.profile_enable(True, prealloc_pairs=8 * args.steps)
+        e.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    e.step(args.steps)
+    e.sync()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+
+    prof = {}
+    if not args.no_events:
+        e.profile_enable(False)
+        for name in ("propose", "logp", "accept", "adapt", "exchange"):
+            ms, n = e.profile_get(name)
+            prof[name] = {"total_ms": ms, "launches": n, "avg_us": (1e3 * ms / n) if n else None}
+    tr = e.get_trace(0, args.steps, with_X=False)
+    acc = float(tr["moved"].mean())
+    rhat = e.get_rhat()
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    value = n_global * args.multitry * args.steps / dt
+    out = {
+        "metric": "proposals/sec (all chains), 100D MVN logpdf, MT-DREAM(ZS) multitry=%d" % args.multitry,
+        "value": value, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%d chains/GPU x %d-D %s target (%s), multitry=%d, DE+snooker(0.1), nCR=3, history_thin=%d, "
+                               "seed archive max(10d,2N) rows U(-5,15); BASELINE north_star target / configs[3] per-GPU shard"
+                               % (n_local, args.dim, "correlated MVN" if args.target == "mvn" else "3-Gaussian mixture",
+                                  args.mvn_kind if args.target == "mvn" else "identity cov", args.multitry, args.thin),
+                   "chains_global": n_global, "chains_per_gpu": n_local, "ndim": args.dim, "multitry": args.multitry,
+                   "parallelism": "chains sharded x%d, Z replicated by RCCL all-gather" % world if world > 1 else "single GPU"},
+        "logp_points_per_s": n_global * (2 * args.multitry - 1) * args.steps / dt,
+        "acceptance_rate": acc, "rhat_max": float(np.max(rhat)),
+    }
+    if prof:
+        ab = algorithmic_bytes(args, n_local)
+        cand = {k: v for k, v in prof.items() if k in ab and v["launches"]}
+        dom = max(cand, key=lambda k: cand[k]["total_ms"])
+        avg_s = cand[dom]["total_ms"] / cand[dom]["launches"] * 1e-3
+        achieved = ab[dom] / avg_s / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_launch": ab[dom], "avg_launch_us": avg_s * 1e6}
+        out["kernel_times"] = prof
+        gen_bytes = n_local * (176.0 * args.dim + 152.0)        # B = 176 d + 152 per chain-generation
+        out["generation_hbm"] = {"algorithmic_bytes_per_generation": gen_bytes,
+                                 "achieved_GBps": gen_bytes * args.steps / dt / 1e9,
+                                 "frac_of_8TBps": gen_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBS}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

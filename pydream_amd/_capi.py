@@ -315,8 +315,9 @@ class Engine:
         return pts, slogp, None, None
 
     # ---- HIP-event kernel timing ----
-    def profile_enable(self, on=True):
-        self._chk(self.L.dz_profile_enable(self.h, 1 if on else 0))
+    def profile_enable(self, on=True, prealloc_pairs=0):
+        """prealloc_pairs > 1 pre-creates that many HIP event pairs so the timed region only records them."""
+        self._chk(self.L.dz_profile_enable(self.h, (max(2, int(prealloc_pairs)) if prealloc_pairs else 1) if on else 0))
 
     def profile_reset(self):
         self._chk(self.L.dz_profile_reset(self.h))

@@ -71,7 +71,8 @@ struct dz_engine {
     dz::Params p{};
     hipStream_t stream = nullptr;
     int nch = 1;
-    int64_t M = 0, gen = 0, ntrace = 0;
+    int64_t M = 0, gen = 0, ntrace = 0, draws_gen = -1;
+    uint4* d_draws[2] = {nullptr, nullptr};
     bool have_logp = false, adapt = false;
     int lk = LK_NONE;
     dz_logp_cb cb = nullptr; void* cb_user = nullptr;
@@ -87,6 +88,8 @@ struct dz_engine {
     double *d_cmean = nullptr, *d_cvar = nullptr, *d_rhat = nullptr;
     std::vector<double> h_stage;     // host staging (callback likelihood / exchange)
     bool prof = false;
+    bool mvn_wave_kernel = false;
+    std::vector<hipEvent_t> ev_pool;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[PR_COUNT];
     std::vector<void*> to_free;
 };
@@ -97,7 +100,13 @@ struct ProfScope {
     dz_engine* e; int which; hipEvent_t a = nullptr, b = nullptr;
     ProfScope(dz_engine* e_, int w) : e(e_), which(w)
     {
-        if (e->prof) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, e->stream); }
+        if (e->prof) {
+            for (hipEvent_t* x : {&a, &b}) {
+                if (!e->ev_pool.empty()) { *x = e->ev_pool.back(); e->ev_pool.pop_back(); }
+                else hipEventCreate(x);
+            }
+            hipEventRecord(a, e->stream);
+        }
     }
     ~ProfScope() { if (e->prof) { hipEventRecord(b, e->stream); e->ev[which].emplace_back(a, b); } }
 };
@@ -148,8 +157,32 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
     ProfScope ps(e, PR_LOGP);
     const dim3 grid((n + 3) / 4), block(256);
     if (e->lk == LK_MVN) {
-        const size_t lds = sizeof(double) * 4 * 2 * e->p.ld;
-        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_logp_mvn<NCH>, grid, block, lds, e->stream, e->p, pts, n, prior, like));
+        if (e->mvn_wave_kernel) {      // v1 kernel (one wave per point), kept for A/B measurements
+            const size_t lds = sizeof(double) * 4 * 2 * e->p.ld;
+            NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_logp_mvn<NCH>, grid, block, lds, e->stream, e->p, pts, n, prior, like));
+        } else {
+            const int nrt = e->p.ld / 16;
+            if (nrt <= 8) {
+                const int ntiles = (n + 15) / 16;
+                const int pt = ntiles > 1024 ? 2 : 1;       // 1024 SIMDs: share B operands between two point tiles once every SIMD has work
+                const dim3 g2((n + 64 * pt - 1) / (64 * pt));
+                const size_t lds = sizeof(double) * 4 * 16 * pt * (nrt * 16 + 1);
+#define DZ_MFMA_CASE(NRT_)                                                                                                                     \
+    case NRT_:                                                                                                                                 \
+        if (pt == 2) { if (e->p.tri) hipLaunchKernelGGL((dz::k_logp_mvn_mfma<2, NRT_, true>), g2, block, lds, e->stream, e->p, pts, n, prior, like);   \
+                       else hipLaunchKernelGGL((dz::k_logp_mvn_mfma<2, NRT_, false>), g2, block, lds, e->stream, e->p, pts, n, prior, like); }  \
+        else { if (e->p.tri) hipLaunchKernelGGL((dz::k_logp_mvn_mfma<1, NRT_, true>), g2, block, lds, e->stream, e->p, pts, n, prior, like);           \
+               else hipLaunchKernelGGL((dz::k_logp_mvn_mfma<1, NRT_, false>), g2, block, lds, e->stream, e->p, pts, n, prior, like); }          \
+        break;
+                switch (nrt) { DZ_MFMA_CASE(1) DZ_MFMA_CASE(2) DZ_MFMA_CASE(3) DZ_MFMA_CASE(4) DZ_MFMA_CASE(5) DZ_MFMA_CASE(6) DZ_MFMA_CASE(7) DZ_MFMA_CASE(8) }
+#undef DZ_MFMA_CASE
+            } else {
+                constexpr int RTC = 8;
+                const size_t lds = sizeof(double) * 4 * 16 * (RTC * 16 + 1);
+                hipLaunchKernelGGL(dz::k_logp_mvn_mfma_big<RTC>, dim3((n + 63) / 64), block, lds, e->stream, e->p, pts, n, prior, like);
+            }
+            if (e->p.have_prior) NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_prior_only<NCH>, grid, block, 0, e->stream, e->p, pts, n, prior));
+        }
     } else if (e->lk == LK_MIX) {
         NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_logp_mix<NCH>, grid, block, 0, e->stream, e->p, pts, n, prior, like));
     } else if (e->lk == LK_HOST) {
@@ -216,6 +249,11 @@ int one_generation(dz_engine* e)
         hipLaunchKernelGGL(dz::k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, p.X, p.cp_new + (size_t)p.off * p.ld, n);
         DZCK(allgather_rows(e, p.cp_new));
     }
+    p.draws = e->d_draws[g & 1]; p.draws_next = e->d_draws[(g + 1) & 1];
+    if (e->draws_gen != (int64_t)g) {   // first generation (later ones are prepared by k_accept of the previous generation)
+        hipLaunchKernelGGL(dz::k_draws, dim3((nl * p.nslots + 255) / 256), dim3(256), 0, e->stream, p, g, 0, nl, e->d_draws[g & 1]);
+        e->draws_gen = g;
+    }
     {
         ProfScope ps(e, PR_PROPOSE);
         NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((nl * k + 3) / 4), dim3(256), 0, e->stream, p, 0, g, (uint32_t)e->M, 0, nl));
@@ -240,6 +278,7 @@ int one_generation(dz_engine* e)
         NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_accept<NCH>, dim3((nl + 3) / 4), dim3(256), 0, e->stream, p, g, e->M, 0, nl, slot, append ? 1 : 0, publish ? 1 : 0));
     }
     DZCK(launch_check("accept"));
+    e->draws_gen = (int64_t)g + 1;
     if (publish) { DZCK(allgather_rows(e, p.cp_new)); DZCK(adapt_generation(e, g)); }
     if (append) { DZCK(allgather_rows(e, p.Z + (size_t)e->M * p.ld)); e->M += p.N; }
     e->gen++;
@@ -300,6 +339,8 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     rc |= ealloc(e, &p.p_prior, nl * k); rc |= ealloc(e, &p.p_like, nl * k); rc |= ealloc(e, &p.p_slogp, nl * k);
     rc |= ealloc(e, &p.r_prior, nl * k); rc |= ealloc(e, &p.r_like, nl * k); rc |= ealloc(e, &p.r_slogp, nl * k);
     rc |= ealloc(e, &p.cur_snk, nl);
+    p.npt = 1 + (2 * cfg->depairs + 3) / 4; p.nslots = 3 + (2 * cfg->multitry - 1) * p.npt;
+    rc |= ealloc(e, &e->d_draws[0], nl * (size_t)p.nslots); rc |= ealloc(e, &e->d_draws[1], nl * (size_t)p.nslots);
     rc |= ealloc(e, &e->d_mins, ld); rc |= ealloc(e, &e->d_maxs, ld);
     rc |= ealloc(e, &e->d_gtab, (size_t)cfg->ngamma * cfg->depairs * p.d);
     rc |= ealloc(e, &e->d_shared, (size_t)3 * (cfg->ncr + cfg->ngamma));
@@ -340,6 +381,7 @@ int dz_destroy(dz_engine* e)
     hipSetDevice(e->c.device);
     if (e->stream) hipStreamSynchronize(e->stream);
     for (auto& v : e->ev) for (auto& pr : v) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (hipEvent_t x : e->ev_pool) hipEventDestroy(x);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     for (void* q : e->to_free) hipFree(q);
     if (e->d_scratch) hipFree(e->d_scratch);
@@ -431,8 +473,8 @@ int dz_set_likelihood_mvn(dz_engine* e, const double* mu, const double* M, int32
     HIPCK(hipSetDevice(e->c.device));
     const int d = e->p.d, ld = e->p.ld;
     if (!e->d_mu) DZCK(ealloc(e, &e->d_mu, (size_t)32 * ld));
-    if (!e->d_Mt) DZCK(ealloc(e, &e->d_Mt, (size_t)d * ld));
-    std::vector<double> mt((size_t)d * ld, 0.0), m(ld, 0.0);
+    if (!e->d_Mt) DZCK(ealloc(e, &e->d_Mt, (size_t)ld * ld));
+    std::vector<double> mt((size_t)ld * ld, 0.0), m(ld, 0.0);
     for (int r = 0; r < d; ++r) for (int c = 0; c < d; ++c) mt[(size_t)c * ld + r] = M[(size_t)r * d + c];
     memcpy(m.data(), mu, sizeof(double) * d);
     HIPCK(hipMemcpy(e->d_Mt, mt.data(), sizeof(double) * mt.size(), hipMemcpyHostToDevice));
@@ -632,12 +674,20 @@ int dz_debug_propose(dz_engine* e, int32_t chain_local, int64_t gen, int32_t pha
     return 0;
 }
 
-int dz_profile_enable(dz_engine* e, int32_t on) { e->prof = on != 0; return 0; }
+int dz_profile_enable(dz_engine* e, int32_t on)
+{
+    e->prof = on != 0;
+    if (on > 1) {   // on = number of event pairs to pre-create, so that the timed region only records
+        HIPCK(hipSetDevice(e->c.device));
+        while ((int64_t)e->ev_pool.size() < 2 * (int64_t)on) { hipEvent_t x; HIPCK(hipEventCreate(&x)); e->ev_pool.push_back(x); }
+    }
+    return 0;
+}
 int dz_profile_reset(dz_engine* e)
 {
     HIPCK(hipSetDevice(e->c.device));
     HIPCK(hipStreamSynchronize(e->stream));
-    for (auto& v : e->ev) { for (auto& pr : v) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); } v.clear(); }
+    for (auto& v : e->ev) { for (auto& pr : v) { e->ev_pool.push_back(pr.first); e->ev_pool.push_back(pr.second); } v.clear(); }
     return 0;
 }
 int dz_profile_get(dz_engine* e, int32_t which, double* total_ms, int64_t* launches)

@@ -30,6 +30,9 @@ struct Params {
     // likelihood / prior
     const int32_t* pkind; const double *pa, *pb; int have_prior;
     const double *mu, *Mt; double logF; int tri; int J; const double* mixF;
+    // wave-uniform Philox outputs of one generation, precomputed lane-parallel (k_draws / k_accept):
+    // [nl][nslots] uint4; slot 0..2 = control stream idx 0..2, then npt slots per (phase, try)
+    const uint4* draws; uint4* draws_next; int nslots, npt;
 };
 
 struct StepFlags { bool snk; int cr_idx, delta, glev; };
@@ -44,26 +47,51 @@ DZ_DEV StepFlags step_flags(const Params& p, const Ctrl& u)
     return f;
 }
 
-// mt_choose_proposal_pt :883-917 (every lane computes the same scalars)
-DZ_DEV int mt_select(const Params& p, int c, double u_sel, bool* anyfinite)
+// mt_choose_proposal_pt :883-917.  Lane i < k evaluates try i's weight (one dexp per wave instead of
+// k); the sums run over the tries in order, so every lane ends with the same scalars.
+DZ_DEV int mt_select(const Params& p, int c, double u_sel, int lane, bool* anyfinite)
 {
-    double lp[MAXK];
-    double mx = -__builtin_huge_val();
-    bool fin = false;
-    for (int i = 0; i < p.k; ++i) {
-        lp[i] = p.p_prior[c * p.k + i] + p.T * p.p_like[c * p.k + i];
-        if (i == 0 || lp[i] > mx) mx = lp[i];
-        fin = fin || is_finite(lp[i]);
-    }
+    const int k = p.k;
+    double lp = -__builtin_huge_val();
+    if (lane < k) lp = p.p_prior[c * k + lane] + p.T * p.p_like[c * k + lane];
+    double mx = lp;
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));   // MAXK = 16 lanes
+    mx = __shfl(mx, 0, 64);
+    *anyfinite = __any(lane < k && is_finite(lp)) != 0;
+    const double w = dexp(lp - mx);
     double S = 0.0;
-    for (int i = 0; i < p.k; ++i) { lp[i] = dexp(lp[i] - mx); S = S + lp[i]; }
-    double cum = 0.0; int sel = p.k - 1;
-    for (int i = 0; i < p.k; ++i) { cum = cum + lp[i] / S; if (u_sel < cum) { sel = i; break; } }
-    *anyfinite = fin;
+    for (int i = 0; i < k; ++i) S = S + __shfl(w, i, 64);
+    double cum = 0.0; int sel = k - 1;
+    for (int i = 0; i < k; ++i) { cum = cum + __shfl(w, i, 64) / S; if (u_sel < cum) { sel = i; break; } }
     return sel;
 }
 
 DZ_DEV uint32_t mulhi_idx(uint32_t w, uint32_t M) { return (uint32_t)(((uint64_t)w * (uint64_t)M) >> 32); }
+
+// slot layout of the precomputed uniform draws
+DZ_DEV int pt_slot(const Params& p, int phase, int tr, int idx) { return 3 + ((phase ? p.k + tr : tr) * p.npt + idx); }
+DZ_DEV u32x4 slot_counter_draw(const Params& p, int slot, uint32_t gc, uint32_t g)
+{   // the Philox call a slot stands for
+    if (slot < 3) return philox(p.k0, p.k1, (uint32_t)slot, stream_id(K_CTRL, 0, 0), gc, g);
+    const int q = (slot - 3) / p.npt, idx = (slot - 3) % p.npt;
+    const int phase = q >= p.k ? 1 : 0, tr = phase ? q - p.k : q;
+    return philox(p.k0, p.k1, (uint32_t)idx, stream_id(K_PT, (uint32_t)tr, (uint32_t)phase), gc, g);
+}
+// uniform draw: from the precomputed table when available (dr != nullptr), else evaluated in place
+DZ_DEV u32x4 uniform_draw(const Params& p, const uint4* dr, int slot, uint32_t gc, uint32_t g)
+{
+    if (dr) { const uint4 t = dr[slot]; return u32x4{t.x, t.y, t.z, t.w}; }
+    return slot_counter_draw(p, slot, gc, g);
+}
+DZ_DEV Ctrl ctrl_from(const Params& p, const uint4* dr, uint32_t gc, uint32_t g)
+{
+    Ctrl c;
+    u32x4 w = uniform_draw(p, dr, 0, gc, g); c.u_snk = u53(w.x, w.y); c.u_cr = u53(w.z, w.w);
+    w = uniform_draw(p, dr, 1, gc, g); c.u_de = u53(w.x, w.y); c.u_glev = u53(w.z, w.w);
+    w = uniform_draw(p, dr, 2, gc, g); c.u_sel = u53(w.x, w.y); c.u_acc = u53(w.z, w.w);
+    return c;
+}
 
 // ------------------------------------------------------------------------------------------
 // generate_proposal_points :670-796 (+ snooker_update :798-837, sample_from_history :646-668,
@@ -72,12 +100,12 @@ DZ_DEV uint32_t mulhi_idx(uint32_t w, uint32_t M) { return (uint32_t)(((uint64_t
 template <int NCH>
 DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, int c, int i, int n, int lane,
                           const double* __restrict__ base, double* __restrict__ out, double* slogp_out,
-                          double* cur_snk_out, bool snk, int cr_idx, int delta, int glev)
+                          double* cur_snk_out, bool snk, int cr_idx, int delta, int glev, const uint4* dr)
 {
     const int d = p.d, ld = p.ld;
     const uint32_t gc = (uint32_t)(p.off + c);
     const double CR = (double)(cr_idx + 1) / (double)p.ncr;                   // :146
-    const uint32_t s_pt = stream_id(K_PT, (uint32_t)i, (uint32_t)phase), s_dim = stream_id(K_DIM, (uint32_t)i, (uint32_t)phase),
+    const uint32_t s_dim = stream_id(K_DIM, (uint32_t)i, (uint32_t)phase),
                    s_bnd = stream_id(K_BND, (uint32_t)i, (uint32_t)phase);
     double xb[NCH][2], pr[NCH][2];
 #pragma unroll
@@ -92,9 +120,9 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
         {   // random.sample(range(M), 2*delta) :662
             uint32_t sorted[2 * MAXPAIR];
             const int nidx = 2 * delta;
-            u32x4 w = philox(p.k0, p.k1, 1, s_pt, gc, g);
+            u32x4 w = uniform_draw(p, dr, pt_slot(p, phase, i, 1), gc, g);
             for (int t = 0; t < nidx; ++t) {
-                if (t && (t & 3) == 0) w = philox(p.k0, p.k1, 1 + (t >> 2), s_pt, gc, g);
+                if (t && (t & 3) == 0) w = uniform_draw(p, dr, pt_slot(p, phase, i, 1 + (t >> 2)), gc, g);
                 const uint32_t word = (t & 3) == 0 ? w.x : (t & 3) == 1 ? w.y : (t & 3) == 2 ? w.z : w.w;
                 uint32_t r = mulhi_idx(word, M - (uint32_t)t);
                 int pos = 0;
@@ -136,7 +164,7 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
                 }
             }
         const int dprime = wave_isum(cnt);                                     // :704 / :709
-        const u32x4 wg = philox(p.k0, p.k1, 0, s_pt, gc, g);                   // set_gamma :615
+        const u32x4 wg = uniform_draw(p, dr, pt_slot(p, phase, i, 0), gc, g);  // set_gamma :615
         double gamma = 1.0;
         if (!(u53(wg.x, wg.y) < p.pgu))
             gamma = p.gtab[((size_t)(glev - 1) * p.depairs + (delta - 1)) * d + ((dprime == 0 ? d : dprime) - 1)];   // :624
@@ -149,9 +177,9 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
                 pr[it][s] = keep[it][s] ? q : xb[it][s];
             }
     } else {
-        const u32x4 wg = philox(p.k0, p.k1, 0, stream_id(K_PT, 0, (uint32_t)phase), gc, g);
+        const u32x4 wg = uniform_draw(p, dr, pt_slot(p, phase, 0, 0), gc, g);
         const double gamma_s = 1.2 + (2.2 - 1.2) * u53(wg.z, wg.w);            // :618
-        const u32x4 wi = philox(p.k0, p.k1, 1, s_pt, gc, g);                   // :808-810
+        const u32x4 wi = uniform_draw(p, dr, pt_slot(p, phase, i, 1), gc, g);  // :808-810
         const uint32_t iz = mulhi_idx(wi.x, M), i1 = mulhi_idx(wi.y, M), i2 = mulhi_idx(wi.z, M);
         double v[NCH][2], dzz[NCH][2], zz[NCH][2];
         double accD = 0.0, accS = 0.0;
@@ -235,20 +263,21 @@ template <int NCH>
 __global__ __launch_bounds__(256) void k_propose(Params p, int phase, uint32_t g, uint32_t M, int c0, int nc)
 {
     const int n = phase == 0 ? p.k : p.k - 1;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform: scalar Philox for the control draws
     if (wave >= nc * n) return;
     const int lane = threadIdx.x & 63;
     const int c = c0 + wave / n, i = wave % n;
-    const Ctrl u = draw_ctrl(p.k0, p.k1, (uint32_t)(p.off + c), g);
+    const uint4* dr = p.draws + (size_t)c * p.nslots;
+    const Ctrl u = ctrl_from(p, dr, (uint32_t)(p.off + c), g);
     const StepFlags f = step_flags(p, u);
     const double* base; double* out; double* sl;
     if (phase == 0) { base = p.X + (size_t)c * p.ld; out = p.P + ((size_t)c * p.k + i) * p.ld; sl = p.p_slogp + (size_t)c * p.k + i; }
     else {
-        bool fin; const int sel = mt_select(p, c, u.u_sel, &fin);
+        bool fin; const int sel = mt_select(p, c, u.u_sel, lane, &fin);
         base = p.P + ((size_t)c * p.k + sel) * p.ld; out = p.R + ((size_t)c * (p.k - 1) + i) * p.ld; sl = p.r_slogp + (size_t)c * (p.k - 1) + i;
     }
     propose_point<NCH>(p, phase, g, M, c, i, n, lane, base, out, sl, (phase == 0 && p.k == 1) ? p.cur_snk + c : nullptr,
-                       f.snk, f.cr_idx, f.delta, f.glev);
+                       f.snk, f.cr_idx, f.delta, f.glev, dr);
 }
 
 // debug entry: flags supplied by the host (function-level parity tests)
@@ -258,7 +287,7 @@ __global__ __launch_bounds__(256) void k_propose_debug(Params p, int phase, uint
 {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
-    propose_point<NCH>(p, phase, g, M, c, i, n, threadIdx.x & 63, base, out + (size_t)i * p.ld, sl + i, nullptr, snk != 0, cr_idx, delta, glev);
+    propose_point<NCH>(p, phase, g, M, c, i, n, threadIdx.x & 63, base, out + (size_t)i * p.ld, sl + i, nullptr, snk != 0, cr_idx, delta, glev, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -333,6 +362,162 @@ __global__ __launch_bounds__(256) void k_logp_mvn(Params p, const double* __rest
     if (pt < npts && lane == 0) { prior_out[pt] = nan_to_ninf(prior); like_out[pt] = nan_to_ninf(p.logF - 0.5 * Q); }
 }
 
+// MVN on the matrix pipe.  v_mfma_f64_16x16x4_f64 accumulates exactly like an ascending-k fma chain
+// (tools/mfma_f64_layout.hip, measured on gfx950: 0 mismatches in 51200, 77.6 TFLOP/s), so
+// Y[p][r] = sum_c M[r][c] v[p][c] comes out bit-identical to the scalar contract.  One wave = 16 points:
+//   A operand (16 points x 4 cols): lane l supplies v[p0 + l%16][4 ks + l/16]
+//   B operand (4 cols x 16 rows):   lane l supplies Mt[4 ks + l/16][16 rt + l%16]
+//   D: lane l, element e holds Y[p0 + l/16 + 4 e][16 rt + l%16]
+// Row tiles are produced RTC at a time, spilled to LDS and folded into the per-point chain
+// Q = fma(y_r, s_r, Q) (ascending r) by lanes 0..15.  For the triangular factor the k-steps left of the
+// diagonal tile are skipped (their entries are structural zeros).
+typedef double dz_double4 __attribute__((ext_vector_type(4)));
+
+// Specialisation for ld <= 128 (NRT = ld/16 row tiles, all accumulators live in registers):
+// PT point tiles (16 points each) per wave share every B operand; the A operands of all k-steps are
+// loaded up front; the k loop is fully unrolled so the B loads are hoisted ahead of the MFMAs.
+template <int PT, int NRT, bool TRI>
+__global__ __launch_bounds__(256) void k_logp_mvn_mfma(Params p, const double* __restrict__ pts, int npts, double* prior_out, double* like_out)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int YS = NRT * 16 + 1;
+    constexpr int KSP = NRT * 4;
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int p0 = (blockIdx.x * 4 + wv) * 16 * PT;
+    if (p0 >= npts) return;
+    const int pi = l & 15, kq = l >> 4;
+    const int ld = p.ld, d = p.d;
+    const int KS = (d + 3) >> 2;
+    double* Ys = lds + (size_t)wv * 16 * PT * YS;
+    double A[PT][KSP];
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+        const double* xr = pts + (size_t)min(p0 + 16 * u + pi, npts - 1) * ld;
+#pragma unroll
+        for (int ks = 0; ks < KSP; ++ks) A[u][ks] = xr[4 * ks + kq] - p.mu[4 * ks + kq];
+    }
+    dz_double4 acc[PT][NRT];
+#pragma unroll
+    for (int u = 0; u < PT; ++u)
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) acc[u][t] = dz_double4{0.0, 0.0, 0.0, 0.0};
+    const double* mbase = p.Mt + (size_t)kq * ld + pi;
+#pragma unroll
+    for (int ks = 0; ks < KSP; ++ks) {
+        if (ks < KSP - 4 || ks < KS) {     // only the last tile column can lie beyond d
+            const double* mrow = mbase + (size_t)(4 * ks) * ld;
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) {
+                if (!TRI || ks >= 4 * t) {
+                    const double b = mrow[16 * t];
+#pragma unroll
+                    for (int u = 0; u < PT; ++u) acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[u][ks], b, acc[u][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PT; ++u)
+#pragma unroll
+        for (int t = 0; t < NRT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Ys[(16 * u + kq + 4 * e) * YS + 16 * t + pi] = acc[u][t][e];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (l < 16 * PT && p0 + l < npts) {
+        const double* xr = pts + (size_t)(p0 + l) * ld;
+        double Q = 0.0;
+        for (int r = 0; r < d; ++r) {
+            const double y = Ys[l * YS + r];
+            Q = fma(y, TRI ? y : xr[r] - p.mu[r], Q);
+        }
+        like_out[p0 + l] = nan_to_ninf(p.logF - 0.5 * Q);
+        if (!p.have_prior) prior_out[p0 + l] = 0.0;
+    }
+}
+
+// Generic variant (any ld <= 1024): row tiles RTC at a time, operands fetched one k-step ahead.
+template <int RTC>
+__global__ __launch_bounds__(256) void k_logp_mvn_mfma_big(Params p, const double* __restrict__ pts, int npts, double* prior_out, double* like_out)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int YS = RTC * 16 + 1;
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int p0 = (blockIdx.x * 4 + wv) * 16;
+    if (p0 >= npts) return;
+    const int pi = l & 15, kq = l >> 4;
+    const int ld = p.ld, d = p.d;
+    const double* xrow = pts + (size_t)min(p0 + pi, npts - 1) * ld;
+    double* Ys = lds + (size_t)wv * 16 * YS;
+    const int KS = (d + 3) >> 2, NRT = (d + 15) >> 4;
+    double Q = 0.0;
+    for (int rt0 = 0; rt0 < NRT; rt0 += RTC) {
+        dz_double4 acc[RTC];
+#pragma unroll
+        for (int t = 0; t < RTC; ++t) acc[t] = dz_double4{0.0, 0.0, 0.0, 0.0};
+        const int ks0 = p.tri ? 4 * rt0 : 0;
+        double a_n = xrow[4 * ks0 + kq] - p.mu[4 * ks0 + kq];
+        double b_n[RTC];
+#pragma unroll
+        for (int t = 0; t < RTC; ++t) b_n[t] = p.Mt[(size_t)(4 * ks0 + kq) * ld + 16 * min(rt0 + t, NRT - 1) + pi];
+        for (int ks = ks0; ks < KS; ++ks) {
+            const double a = a_n;
+            double b[RTC];
+#pragma unroll
+            for (int t = 0; t < RTC; ++t) b[t] = b_n[t];
+            if (ks + 1 < KS) {
+                const int c = 4 * (ks + 1) + kq;
+                a_n = xrow[c] - p.mu[c];
+#pragma unroll
+                for (int t = 0; t < RTC; ++t) b_n[t] = p.Mt[(size_t)c * ld + 16 * min(rt0 + t, NRT - 1) + pi];
+            }
+#pragma unroll
+            for (int t = 0; t < RTC; ++t) {
+                const int rt = rt0 + t;
+                if (rt < NRT && (!p.tri || ks >= 4 * rt)) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t], acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < RTC; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Ys[(kq + 4 * e) * YS + 16 * t + pi] = acc[t][e];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (l < 16) {
+            const int nr = min(16 * RTC, d - 16 * rt0);
+            for (int rr = 0; rr < nr; ++rr) {
+                const double y = Ys[l * YS + rr];
+                const int r = 16 * rt0 + rr;
+                Q = fma(y, p.tri ? y : xrow[r] - p.mu[r], Q);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (l < 16 && p0 + l < npts) {
+        like_out[p0 + l] = nan_to_ninf(p.logF - 0.5 * Q);
+        if (!p.have_prior) prior_out[p0 + l] = 0.0;
+    }
+}
+
+// prior only (wave per point), used beside the MFMA likelihood kernel when priors are not flat
+template <int NCH>
+__global__ __launch_bounds__(256) void k_prior_only(Params p, const double* __restrict__ pts, int npts, double* prior_out)
+{
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pt = blockIdx.x * 4 + wv;
+    if (pt >= npts) return;
+    double x[NCH][2];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int jj = 128 * it + 2 * lane;
+        x[it][0] = 0.0; x[it][1] = 0.0;
+        if (jj < p.ld) { const double2 t = *reinterpret_cast<const double2*>(pts + (size_t)pt * p.ld + jj); x[it][0] = t.x; x[it][1] = t.y; }
+    }
+    const double prior = prior_of_point<NCH>(p, x, lane);
+    if (lane == 0) prior_out[pt] = nan_to_ninf(prior);
+}
+
 // Gaussian mixture, identity covariances (examples/mixturemodel/mixturemodel.py:37-48)
 template <int NCH>
 __global__ __launch_bounds__(256) void k_logp_mix(Params p, const double* __restrict__ pts, int npts, double* prior_out, double* like_out)
@@ -393,13 +578,18 @@ __global__ __launch_bounds__(256) void k_prior_add(Params p, const double* __res
 template <int NCH>
 __global__ __launch_bounds__(256) void k_accept(Params p, uint32_t g, int64_t M, int c0, int nc, int64_t trace_slot, int append, int publish)
 {
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (wave >= nc) return;
     const int lane = threadIdx.x & 63;
     const int c = c0 + wave, k = p.k, ld = p.ld;
     const uint32_t gc = (uint32_t)(p.off + c);
-    const Ctrl u = draw_ctrl(p.k0, p.k1, gc, g);
+    const Ctrl u = ctrl_from(p, p.draws + (size_t)c * p.nslots, gc, g);
     const StepFlags f = step_flags(p, u);
+    // lane-parallel: the wave-uniform Philox outputs this chain needs in generation g+1
+    for (int slot = lane; slot < p.nslots; slot += 64) {
+        const u32x4 w = slot_counter_draw(p, slot, gc, g + 1);
+        p.draws_next[(size_t)c * p.nslots + slot] = make_uint4(w.x, w.y, w.z, w.w);
+    }
     const double last_prior = p.lprior[c], last_like = p.llike[c];
     const double last_logp = p.T * last_like + last_prior;                     // :243, :268
     double ratio; int sel = 0;
@@ -408,23 +598,26 @@ __global__ __launch_bounds__(256) void k_accept(Params p, uint32_t g, int64_t M,
         if (f.snk) ratio = nan_to_num((q_logp + p.p_slogp[c]) - (last_logp + p.cur_snk[c]));   // :326-332
         else ratio = nan_to_num(q_logp) - nan_to_num(last_logp);               // :334
     } else {
-        bool fin; sel = mt_select(p, c, u.u_sel, &fin);
-        double A[MAXK], B[MAXK];
-        for (int i = 0; i < k; ++i) A[i] = p.p_prior[c * k + i] + p.T * p.p_like[c * k + i];                    // :279
-        for (int i = 0; i < k - 1; ++i) B[i] = p.T * p.r_like[c * (k - 1) + i] + p.r_prior[c * (k - 1) + i];   // :303
-        B[k - 1] = p.T * last_like + last_prior;                               // :877-879
-        if (f.snk) {                                                           // :306-313
-            for (int i = 0; i < k; ++i) {
-                const double sp = p.p_slogp[c * k + i];
-                const double sr = i < k - 1 ? p.r_slogp[c * (k - 1) + i] : 0.0;
-                A[i] = A[i] + sp; B[i] = (B[i] + sr) + sp;
-            }
+        bool fin; sel = mt_select(p, c, u.u_sel, lane, &fin);
+        // lane i < k holds proposal term A_i, lane 16+i holds reference term B_i (:306-317)
+        double val = -__builtin_huge_val();
+        if (lane < k) {
+            val = p.p_prior[c * k + lane] + p.T * p.p_like[c * k + lane];                                  // :279
+            if (f.snk) val = val + p.p_slogp[c * k + lane];                                              // :307
+        } else if (lane >= 16 && lane < 16 + k) {
+            const int i = lane - 16;
+            val = i < k - 1 ? p.T * p.r_like[c * (k - 1) + i] + p.r_prior[c * (k - 1) + i]              // :303
+                            : p.T * last_like + last_prior;                                              // :877-879
+            if (f.snk) { const double sr = i < k - 1 ? p.r_slogp[c * (k - 1) + i] : 0.0; val = (val + sr) + p.p_slogp[c * k + i]; }   // :312-313
         }
-        double m2 = A[0];
-        for (int i = 0; i < k; ++i) { if (A[i] > m2) m2 = A[i]; if (B[i] > m2) m2 = B[i]; }   // :320
+        double m2 = val;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) m2 = fmax(m2, __shfl_xor(m2, off, 64));                    // :320
+        m2 = __shfl(m2, 0, 64);
+        const double ev = dexp(val - m2);                                                                // :321-322
         double SA = 0.0, SB = 0.0;
-        for (int i = 0; i < k; ++i) SA = SA + dexp(A[i] - m2);                 // :321
-        for (int i = 0; i < k; ++i) SB = SB + dexp(B[i] - m2);                 // :322
+        for (int i = 0; i < k; ++i) SA = SA + __shfl(ev, i, 64);
+        for (int i = 0; i < k; ++i) SB = SB + __shfl(ev, 16 + i, 64);
         ratio = nan_to_num(dlog(SA / SB));                                     // :323
         if (!fin) ratio = -__builtin_huge_val();                               // DESIGN.md deviation D1 (:282-289)
     }
@@ -466,6 +659,16 @@ __global__ __launch_bounds__(256) void k_accept(Params p, uint32_t g, int64_t M,
             p.tmoved[o] = moved ? 1 : 0; p.ttry[o] = sel; p.tcr[o] = f.cr_idx; p.tsnk[o] = f.snk ? 1 : 0;
         }
     }
+}
+
+// uniform draws of generation g for local chains [c0, c0+nc): one lane per (chain, slot)
+__global__ void k_draws(Params p, uint32_t g, int c0, int nc, uint4* __restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nc * p.nslots) return;
+    const int c = c0 + t / p.nslots, slot = t % p.nslots;
+    const u32x4 w = slot_counter_draw(p, slot, (uint32_t)(p.off + c), g);
+    out[(size_t)c * p.nslots + slot] = make_uint4(w.x, w.y, w.z, w.w);
 }
 
 // copy rows [nl,ld] (used for publishing start positions and the sharded exchange staging)

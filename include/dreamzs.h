@@ -100,6 +100,12 @@ int dz_set_exchange(dz_engine* e, dz_exchange_cb cb, void* user);
  * MT-DREAM(ZS) transitions (Dream.astep, Dream.py:193-422). Asynchronous on the engine's
  * stream; dz_sync() or any getter waits. */
 int     dz_step(dz_engine* e, int64_t generations);
+/* Dream.astep for ONE chain (or a contiguous range): a transition whose end-of-step updates
+ * (history append, published position, crossover statistics) take effect immediately, i.e. the
+ * reference's semantics when astep is driven round-robin in one process (test_dream.py:507-518). */
+int     dz_step_range(dz_engine* e, int32_t chain0, int32_t nchains);
+int     dz_set_chain_state(dz_engine* e, int32_t chain, const double* x, const double* prior, const double* like); /* NULL logps => evaluate */
+int     dz_get_chain_state(dz_engine* e, int32_t chain, double* x, double* prior, double* like);
 int     dz_sync(dz_engine* e);
 int     dz_trace_reset(dz_engine* e);
 int64_t dz_generation(dz_engine* e);

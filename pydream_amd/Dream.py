@@ -1,0 +1,176 @@
+"""The DREAM step object -- same constructor and ``astep`` signature as pydream/Dream.py.
+
+In the reference a ``Dream`` instance *is* the sampler: ``astep`` advances one chain with numpy.
+Here it is the host-side description of the sampler; the transitions themselves run on the GPU
+(libdreamzs.so).  ``astep`` remains callable as the single-chain view of the engine (one chain
+advanced through ``dz_step_range``), which is how the reference's own tests drive it
+(pydream/tests/test_dream.py:507-518).
+"""
+import numpy as np
+
+from . import Dream_shared_vars
+
+
+class Dream():
+    """An implementation of the MT-DREAM\\ :sub:`(ZS)`\\  algorithm (Laloy & Vrugt 2012) -- options as in
+    pydream/Dream.py:12-67 (same names, defaults and meaning).
+
+    Parameters
+    ----------
+    model : Model, variables : iterable of SampledParam (default: all of the model's)
+    nseedchains : int, history seed rows (default 10 * dimension)
+    nCR : int, adapt_crossover : bool, adapt_gamma : bool, crossover_burnin : int
+    DEpairs : int, lamb : float, zeta : float, history_thin : int, snooker : float, p_gamma_unity : float
+    gamma_levels : int, start_random : bool, save_history : bool, history_file / crossover_file / gamma_file : str
+    multitry : bool or int, parallel : bool (accepted, ignored: every try is evaluated in one device batch)
+    verbose : bool, model_name : str, hardboundaries : bool, mp_context : ignored
+    """
+
+    def __init__(self, model, variables=None, nseedchains=None, nCR=3, adapt_crossover=True, adapt_gamma=False,
+                 crossover_burnin=None, DEpairs=1, lamb=.05, zeta=1e-12, history_thin=10, snooker=.10,
+                 p_gamma_unity=.20, gamma_levels=1, start_random=True, save_history=True, history_file=False,
+                 crossover_file=False, gamma_file=False, multitry=False, parallel=False, verbose=False,
+                 model_name=False, hardboundaries=True, mp_context=None, **kwargs):
+        self.mp_context = mp_context
+        self.model = model
+        self.model_name = model_name
+        if variables is None:
+            self.variables = self.model.sampled_parameters
+        else:
+            self.variables = variables
+
+        # total variable dimension and boundaries (Dream.py:79-105)
+        self.boundaries = hardboundaries
+        self.total_var_dimension = 0
+        for var in self.variables:
+            self.total_var_dimension += var.dsize
+        if self.boundaries:
+            if self.total_var_dimension == 1:
+                self.boundary_mask = True
+            else:
+                self.boundary_mask = np.ones((self.total_var_dimension), dtype=bool)
+            self.mins = []
+            self.maxs = []
+            for var in self.variables:
+                interval = var.interval(1)
+                if var.dsize > 1:
+                    self.mins += list(interval[0])
+                    self.maxs += list(interval[1])
+                else:
+                    self.mins.append(np.ravel(interval[0])[0])
+                    self.maxs.append(np.ravel(interval[1])[0])
+            self.mins = np.array(self.mins, dtype=float)
+            self.maxs = np.array(self.maxs, dtype=float)
+
+        self.nseedchains = nseedchains
+        self.nCR = nCR
+        if self.nCR > self.total_var_dimension:      # Dream.py:110-113
+            self.nCR = self.total_var_dimension
+            print('Warning: the total number of crossover values specified (' + str(nCR) + ') is less than the total dimension of all variables (' + str(self.total_var_dimension) + ').  Setting the number of crossover values to be equal to the total variable dimension.')
+        if self.total_var_dimension == 1 and adapt_crossover:     # Dream.py:115-118
+            adapt_crossover = False
+            print('Warning: the total variable dimension = 1, so crossover values will not be adapted, even though crossover adaptation was requested.')
+
+        self.ngamma = gamma_levels
+        self.njoint_cr_gamma_probs = nCR * gamma_levels
+        self.crossover_burnin = crossover_burnin
+        self.crossover_file = crossover_file
+        self.adapt_crossover = adapt_crossover
+
+        if crossover_file:                            # Dream.py:127-134
+            self.CR_probabilities = np.load(crossover_file)
+            self.nCR = len(self.CR_probabilities)
+            if self.adapt_crossover:
+                print('Warning: Crossover values loaded and adapt_crossover = True.  Crossover values will be further adapted.')
+        else:
+            self.CR_probabilities = [1 / float(self.nCR) for i in range(self.nCR)]
+
+        self.adapt_gamma = adapt_gamma                # Dream.py:136-143
+        self.gamma_file = gamma_file
+        if gamma_file:
+            self.gamma_probabilities = np.load(gamma_file)
+            if adapt_gamma:
+                print('Warning: Gamma values loaded and adapt gamma = True.  Gamma values will be further adapted.')
+        else:
+            self.gamma_probabilities = [1 / float(self.ngamma) for i in range(self.ngamma)]
+
+        self.CR_values = np.array([m / float(self.nCR) for m in range(1, self.nCR + 1)])
+        self.gamma_level_values = np.array([m for m in range(1, self.ngamma + 1)])
+        self.DEpairs = np.linspace(1, DEpairs, num=DEpairs, dtype=int)
+        self.snooker = snooker
+        self.p_gamma_unity = p_gamma_unity
+
+        if multitry == False:                         # noqa: E712  (Dream.py:155-161)
+            self.multitry = 1
+        elif multitry == True:                        # noqa: E712
+            self.multitry = 5
+        else:
+            self.multitry = multitry
+        if self.multitry == 2:
+            raise Exception('multitry=2 fails inside the reference (Dream.py:867-868); use 1 or >= 3.')
+
+        self.parallel = parallel
+        self.lamb = lamb
+        self.zeta = zeta
+        self.last_logp = None
+        if self.nseedchains is None:                  # Dream.py:168-170
+            self.nseedchains = self.total_var_dimension * 10
+
+        # gamma table, Dream.py:172-179
+        gamma_array = np.zeros((self.ngamma, DEpairs, self.total_var_dimension))
+        gamma_level_decrease = 1
+        for gamma_level in range(1, self.ngamma + 1):
+            for delta in range(1, DEpairs + 1):
+                gamma_array[gamma_level - 1, delta - 1, :] = (2.38 / np.sqrt(2 * delta * np.linspace(1, self.total_var_dimension, num=self.total_var_dimension))) / gamma_level_decrease
+            gamma_level_decrease = gamma_level_decrease * 2
+        self.gamma_arr = gamma_array
+        self.gamma = None
+
+        self.iter = 0
+        self.chain_n = None
+        self.nchains = None
+        self.len_history = 0
+        self.save_history = save_history
+        self.history_file = history_file
+        self.history_thin = history_thin
+        self.start_random = start_random
+        self.verbose = verbose
+        self.logp = self.model.total_logp
+        self.last_prior = None
+        self.last_like = None
+
+    # ------------------------------------------------------------------
+    def astep(self, q0, T=1., last_loglike=None, last_logprior=None):
+        """One MT-DREAM(ZS) transition of ONE chain (Dream.py:193-422): returns (q_new, last_prior, last_like).
+
+        The engine must have been set up by ``core._setup_mp_dream_pool`` + ``pool._initializer`` (the
+        reference's single-process idiom).  The chain is advanced on the GPU with immediate effect on
+        the shared state (history append, published position, crossover statistics), i.e. the
+        sequential round-robin semantics the reference has when driven this way."""
+        eng = getattr(Dream_shared_vars, "engine", None)
+        if eng is None:
+            raise Exception('Dream should be run with multiple chains in parallel.  Set nchains > 1.')   # Dream.py:236
+        if T != 1.:
+            raise NotImplementedError('parallel tempering (T != 1) is outside the accelerated hot path')
+        if self.chain_n is None:                      # Dream.py:198-200: claim a chain id, counting down
+            Dream_shared_vars.nchains_counter -= 1
+            self.chain_n = Dream_shared_vars.nchains_counter
+            if self.chain_n < 0:
+                raise Exception('more Dream instances than chains')
+            self.nchains = eng.N
+            if q0 is None or self.start_random:       # Dream.py:221-225
+                q0 = Dream_shared_vars.draw_from_prior(self.variables)
+        q0 = np.asarray(q0, dtype=float).reshape(-1)
+        c = self.chain_n
+        cur = Dream_shared_vars.host_state.get(c)
+        if last_loglike is not None:                  # Dream.py:240-243
+            eng.set_chain_state(c, q0, last_logprior, last_loglike)
+        elif cur is None or not np.array_equal(cur, q0):
+            eng.set_chain_state(c, q0, None, None)    # log density evaluated on the device (Dream.py:266-268)
+        eng.step_range(c, 1)
+        q_new, pr, lk = eng.get_chain_state(c)
+        Dream_shared_vars.host_state[c] = q_new.copy()
+        self.last_prior, self.last_like = float(pr), float(lk)
+        self.last_logp = self.last_prior + self.last_like
+        self.iter += 1
+        return q_new, self.last_prior, self.last_like

@@ -37,7 +37,7 @@ SYMBOLS = [
     "dz_version", "dz_last_error", "dz_device_count", "dz_create", "dz_destroy", "dz_set_bounds", "dz_set_gamma_table",
     "dz_set_history", "dz_set_state", "dz_set_cr_probs", "dz_set_gamma_probs", "dz_set_prior", "dz_set_likelihood_mvn",
     "dz_set_likelihood_mixture", "dz_set_likelihood_host", "dz_comm_unique_id", "dz_comm_init_rccl", "dz_set_exchange",
-    "dz_step", "dz_sync", "dz_trace_reset", "dz_generation", "dz_get_state", "dz_get_trace", "dz_get_history",
+    "dz_step", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_sync", "dz_trace_reset", "dz_generation", "dz_get_state", "dz_get_trace", "dz_get_history",
     "dz_get_cr_state", "dz_get_gamma_state", "dz_get_rhat", "dz_get_chain_moments", "dz_eval_logp", "dz_debug_propose",
     "dz_profile_enable", "dz_profile_get", "dz_profile_reset",
 ]
@@ -78,6 +78,9 @@ def load_library():
     L.dz_set_exchange.argtypes = [V, XCHG_CB, V]
     L.dz_step.argtypes = [V, C.c_int64]
     L.dz_sync.argtypes = [V]
+    L.dz_step_range.argtypes = [V, C.c_int32, C.c_int32]
+    L.dz_set_chain_state.argtypes = [V, C.c_int32, V, V, V]
+    L.dz_get_chain_state.argtypes = [V, C.c_int32, V, V, V]
     L.dz_trace_reset.argtypes = [V]
     L.dz_get_state.argtypes = [V, V, V, V]
     L.dz_get_trace.argtypes = [V, C.c_int64, C.c_int64] + [V] * 6
@@ -238,6 +241,20 @@ class Engine:
     # ---- stepping ----
     def step(self, generations=1):
         self._chk(self.L.dz_step(self.h, int(generations)))
+
+    def step_range(self, chain0, nchains=1):
+        self._chk(self.L.dz_step_range(self.h, int(chain0), int(nchains)))
+
+    def set_chain_state(self, chain, x, prior=None, like=None):
+        x = _f64(x).reshape(self.d)
+        pr = None if prior is None else np.array([prior], dtype=np.float64)
+        lk = None if like is None else np.array([like], dtype=np.float64)
+        self._chk(self.L.dz_set_chain_state(self.h, int(chain), _p(x), _p(pr), _p(lk)))
+
+    def get_chain_state(self, chain):
+        x = np.zeros(self.d); pr = np.zeros(1); lk = np.zeros(1)
+        self._chk(self.L.dz_get_chain_state(self.h, int(chain), _p(x), _p(pr), _p(lk)))
+        return x, float(pr[0]), float(lk[0])
 
     def sync(self):
         self._chk(self.L.dz_sync(self.h))

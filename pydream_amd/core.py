@@ -1,0 +1,212 @@
+# -*- coding: utf-8 -*-
+"""run_dream -- same signature and return convention as pydream/core.py:11-86, executed on the GPU."""
+import os
+import time
+from datetime import datetime
+
+import numpy as np
+
+from . import Dream_shared_vars
+from . import _capi
+from .Dream import Dream
+from .model import Model
+
+
+def run_dream(parameters, likelihood, nchains=5, niterations=50000, start=None, restart=False, verbose=True, nverbose=10, tempering=False, mp_context=None, **kwargs):
+    """Run DREAM given a set of parameters with priors and a likelihood function (pydream/core.py:11-44).
+
+    Parameters
+    ----------
+    parameters: iterable of SampledParam class
+    likelihood: function ``f(vec[d]) -> float`` -- or one of ``pydream_amd.likelihoods`` to evaluate it on the device
+    nchains, niterations, start, restart, verbose, nverbose: as in the reference
+    tempering: only False is supported (the reference's parallel tempering is untested upstream, core.py:30-31)
+    mp_context: accepted for compatibility, ignored (there are no worker processes)
+    kwargs: passed to Dream (see Dream).  Extra keys understood here: ``seed`` (int, key of the random
+        contract; default drawn from the OS), ``device`` (HIP device ordinal).
+
+    Returns
+    -------
+    sampled_params : list of arrays [niterations, d], one per chain
+    log_ps : list of arrays [niterations, 1], log probability of every sampled point
+    """
+    if restart:
+        if start is None:
+            raise Exception('Restart run specified but no start positions given.')
+        if 'model_name' not in kwargs:
+            raise Exception('Restart run specified but no model name to load history and crossover value files from given.')
+    if tempering:
+        raise NotImplementedError('parallel tempering is outside the accelerated hot path (core.py:131-248)')
+
+    if type(parameters) is not list:
+        parameters = [parameters]
+
+    model = Model(likelihood=likelihood, sampled_parameters=parameters)
+
+    if restart:
+        step_instance = Dream(model=model, variables=parameters,
+                              history_file=kwargs['model_name'] + '_DREAM_chain_history.npy',
+                              crossover_file=kwargs['model_name'] + '_DREAM_chain_adapted_crossoverprob.npy',
+                              gamma_file=kwargs['model_name'] + '_DREAM_chain_adapted_gammalevelprob.npy',
+                              verbose=verbose, mp_context=mp_context, **kwargs)
+    else:
+        step_instance = Dream(model=model, variables=parameters, verbose=verbose, mp_context=mp_context, **kwargs)
+
+    pool = _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=start, mp_context=mp_context,
+                                seed=kwargs.get('seed'), device=kwargs.get('device', 0))
+    try:
+        pool._initializer(*pool._initargs)
+        sampled_params, log_ps = _sample_dream_batched(pool.engine, step_instance, nchains, niterations, verbose, nverbose)
+    finally:
+        pool.close()
+        pool.join()
+    return sampled_params, log_ps
+
+
+def _sample_dream_batched(eng, step, nchains, niterations, verbose, nverbose):
+    """The per-chain loop of core._sample_dream (core.py:89-129) for all chains at once: advance the
+    engine in chunks that fit the device trace buffer and collect trace / log_ps per chain."""
+    d = step.total_var_dimension
+    sampled = [np.empty((niterations, d)) for _ in range(nchains)]
+    log_ps = [np.empty((niterations, 1)) for _ in range(nchains)]
+    chunk = eng.cfg.trace_capacity
+    done = 0
+    naccepts = 0
+    while done < niterations:
+        n = min(chunk, niterations - done)
+        eng.trace_reset()
+        eng.step(n)
+        tr = eng.get_trace(0, n)
+        for c in range(nchains):
+            sampled[c][done:done + n] = tr["X"][:, c, :]
+            log_ps[c][done:done + n, 0] = tr["logp"][:, c]
+        naccepts += int(tr["moved"].sum())
+        done += n
+        if verbose:
+            print('Iteration: ', done, ' acceptance rate: ', naccepts / float(done * nchains),
+                  ' acceptance rate over last %d iterations: ' % n, float(tr["moved"].mean()))
+    if step.save_history:
+        _save_history_to_disc(eng, step)
+    return sampled, log_ps
+
+
+def _save_history_to_disc(eng, step):
+    """Dream.save_history_to_disc (Dream.py:947-969): the three .npy files a restart reads back."""
+    if not step.model_name:
+        prefix = datetime.now().strftime('%Y_%m_%d_%H:%M:%S') + '_'
+    else:
+        prefix = step.model_name + '_'
+    filename = prefix + 'DREAM_chain_history.npy'
+    if step.verbose:
+        print('Saving history to file: ', filename)
+    np.save(filename, eng.get_history().reshape(-1))
+    cr = eng.get_cr_state()[0]
+    filename = prefix + 'DREAM_chain_adapted_crossoverprob.npy'
+    if step.verbose:
+        print('Saving fitted crossover values: ', cr, ' to file: ', filename)
+    np.save(filename, cr)
+    gp = eng.get_gamma_state()[0]
+    filename = prefix + 'DREAM_chain_adapted_gammalevelprob.npy'
+    if step.verbose:
+        print('Saving fitted gamma level values: ', gp, ' to file: ', filename)
+    np.save(filename, gp)
+
+
+class _EnginePool:
+    """Stands in for the DreamPool that core._setup_mp_dream_pool returns (core.py:307-314): the
+    "workers" are the GPU; ``_initializer(*_initargs)`` publishes the engine the way _mp_dream_init
+    publishes the shared arrays (core.py:316-327); ``close``/``join`` release it."""
+
+    def __init__(self, engine, nchains):
+        self.engine = engine
+        self._initializer = _mp_dream_init
+        self._initargs = (engine, nchains)
+
+    def close(self):
+        pass
+
+    def join(self):
+        if Dream_shared_vars.engine is self.engine:
+            Dream_shared_vars.engine = None
+        if self.engine is not None:
+            self.engine.close()
+            self.engine = None
+
+
+def _mp_dream_init(engine, nchains):
+    Dream_shared_vars.engine = engine
+    Dream_shared_vars.nchains_counter = nchains
+    Dream_shared_vars.host_state = {}
+
+
+def _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=None, mp_context=None, seed=None, device=0,
+                         chain_offset=0, nchains_local=None):
+    """Validate, size and allocate the shared sampler state (core.py:250-314) -- in HBM."""
+    min_njobs = (2 * len(step_instance.DEpairs)) + 1
+    if nchains < min_njobs:
+        raise Exception('Dream should be run with at least (2*DEpairs)+1 number of chains.  For current algorithmic settings, set njobs>=%s.' % str(min_njobs))
+    d = step_instance.total_var_dimension
+    if seed is None:
+        seed = int.from_bytes(os.urandom(8), 'little')
+    rng = np.random.RandomState(seed % (2 ** 32))
+    Dream_shared_vars.rng = rng
+    if step_instance.history_file != False:          # noqa: E712  (core.py:255-259)
+        old_history = np.load(step_instance.history_file)
+        seed_rows = np.asarray(old_history, dtype=float).reshape(-1, d)
+        step_instance.nseedchains = len(seed_rows)
+    else:
+        seed_rows = None
+    min_nseedchains = 2 * len(step_instance.DEpairs) * nchains
+    if step_instance.nseedchains < min_nseedchains:
+        raise Exception('The size of the seeded starting history is insufficient.  Increase nseedchains>=%s.' % str(min_nseedchains))
+    if seed_rows is None:                             # Dream.py:203-214: seed the history with draws from the prior
+        seed_rows = np.array([Dream_shared_vars.draw_from_prior(step_instance.variables) for _ in range(int(step_instance.nseedchains))])
+    if step_instance.crossover_burnin is None:        # core.py:299-300
+        step_instance.crossover_burnin = int(np.floor(niterations / 10))
+    if start_pt is not None:
+        if step_instance.start_random:
+            print('Warning: start position provided but random_start set to True.  Overrode random_start value and starting walk at provided start position.')
+            step_instance.start_random = False
+
+    nl = nchains if nchains_local is None else nchains_local
+    thin = step_instance.history_thin
+    n_appends = (niterations + thin - 1) // thin + 1
+    ld = (d + 15) // 16 * 16
+    trace_cap = int(max(1, min(niterations, (2 << 30) // (nl * ld * 8))))
+    eng = _capi.Engine(nchains=nchains, nchains_local=nl, chain_offset=chain_offset, ndim=d, multitry=int(step_instance.multitry),
+                       depairs=len(step_instance.DEpairs), ncr=int(step_instance.nCR), ngamma=int(step_instance.ngamma),
+                       history_thin=int(thin), crossover_burnin=int(min(step_instance.crossover_burnin, 2 ** 31 - 1)),
+                       adapt_crossover=int(bool(step_instance.adapt_crossover)), adapt_gamma=int(bool(step_instance.adapt_gamma)),
+                       hardboundaries=int(bool(step_instance.boundaries)), schedule=2, device=int(device),
+                       history_capacity=len(seed_rows) + nchains * n_appends, trace_capacity=trace_cap, seed=int(seed),
+                       lamb=float(step_instance.lamb), zeta=float(step_instance.zeta), snooker=float(step_instance.snooker),
+                       p_gamma_unity=float(step_instance.p_gamma_unity))
+    eng.nseed = len(seed_rows)
+    if step_instance.boundaries:
+        eng.set_bounds(step_instance.mins, step_instance.maxs)
+    eng.set_gamma_table(step_instance.gamma_arr)
+    eng.set_history(seed_rows)
+    eng.set_cr_probs(np.asarray(step_instance.CR_probabilities, dtype=float))
+    eng.set_gamma_probs(np.asarray(step_instance.gamma_probabilities, dtype=float))
+
+    model = step_instance.model
+    dev_prior = model.device_prior() if step_instance.variables is model.sampled_parameters or list(step_instance.variables) == list(model.sampled_parameters) else None
+    if dev_prior is not None:
+        eng.set_prior(*dev_prior)
+    like = model.likelihood
+    if hasattr(like, "_dz_apply") and dev_prior is not None:
+        like._dz_apply(eng)                           # likelihood AND priors on the device
+    else:
+        eng.set_likelihood_host(lambda X: model.batch_logp(X, with_prior=dev_prior is None))
+
+    # start positions (core.py:74-78; Dream.py:221-225 for random starts)
+    if start_pt is None:
+        X0 = np.array([Dream_shared_vars.draw_from_prior(step_instance.variables) for _ in range(nchains)])
+    elif type(start_pt) is list:
+        X0 = np.array([np.asarray(s, dtype=float).reshape(-1) for s in start_pt])
+    else:
+        X0 = np.array([np.asarray(start_pt, dtype=float).reshape(-1)] * nchains)
+    if len(X0) != nchains:
+        raise Exception('start must be one vector or a list of nchains vectors')
+    eng.set_state(X0[chain_offset:chain_offset + nl])
+    return _EnginePool(eng, nchains)

@@ -72,7 +72,9 @@ struct dz_engine {
     hipStream_t stream = nullptr;
     int nch = 1;
     int64_t M = 0, gen = 0, ntrace = 0, draws_gen = -1;
+    std::vector<int64_t> gen_c;     // per-chain generation counters (differ only under single-chain stepping)
     uint4* d_draws[2] = {nullptr, nullptr};
+    dz::ChainCtl* d_ctl[2] = {nullptr, nullptr};
     bool have_logp = false, adapt = false;
     int lk = LK_NONE;
     dz_logp_cb cb = nullptr; void* cb_user = nullptr;
@@ -224,7 +226,7 @@ int allgather_rows(dz_engine* e, double* buf)
     return 0;
 }
 
-int adapt_generation(dz_engine* e, uint32_t g)
+int adapt_generation(dz_engine* e, uint32_t g, int gc0, int ngc)
 {
     ProfScope ps(e, PR_ADAPT);
     const dz::Params& p = e->p;
@@ -234,55 +236,78 @@ int adapt_generation(dz_engine* e, uint32_t g)
     hipLaunchKernelGGL(dz::k_strip_finish, gfin, b, 0, e->stream, e->d_partial, nstrips, p.N, p.d, p.ld, 0, e->d_mean, e->d_sd, e->d_sdc);
     hipLaunchKernelGGL(dz::k_strip_partial, gcol, b, 0, e->stream, p.cp_new, p.N, p.d, p.ld, e->d_mean, 1, e->d_partial);
     hipLaunchKernelGGL(dz::k_strip_finish, gfin, b, 0, e->stream, e->d_partial, nstrips, p.N, p.d, p.ld, 1, e->d_mean, e->d_sd, e->d_sdc);
-    NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_jump<NCH>, dim3((p.N + 3) / 4), dim3(256), 0, e->stream, p, g, e->d_sdc, e->d_sd, e->d_dl, e->d_dlg, e->d_binc, e->d_bing));
+    if (ngc != p.N) {   // single-chain stepping: every other chain contributes nothing this time
+        HIPCK(hipMemsetAsync(e->d_binc, 0xFF, sizeof(int) * p.N, e->stream));
+        HIPCK(hipMemsetAsync(e->d_bing, 0xFF, sizeof(int) * p.N, e->stream));
+    }
+    NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_jump<NCH>, dim3((ngc + 3) / 4), dim3(256), 0, e->stream, p, g, gc0, ngc, e->d_sdc, e->d_sd, e->d_dl, e->d_dlg, e->d_binc, e->d_bing));
     hipLaunchKernelGGL(dz::k_adapt_update, dim3(1), dim3(64), 0, e->stream, p, e->d_dl, e->d_dlg, e->d_binc, e->d_bing);
     return launch_check("adaptation kernels");
 }
 
-int one_generation(dz_engine* e)
+// one transition of local chains [c0, c0+nc) at generation g.  Full range = a lockstep generation
+// (schedule S2); a sub-range is the single-chain view used by Dream.astep: its end-of-generation
+// updates (append, publish, adaptation) take effect immediately, as when the reference is driven
+// round-robin in one process.
+int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced)
 {
     dz::Params& p = e->p;
-    const uint32_t g = (uint32_t)e->gen;
-    const int nl = p.nl, k = p.k;
-    if (g == 0 && e->adapt) {   // publish the start positions (Dream_shared_vars.current_positions)
-        const size_t n = (size_t)nl * p.ld;
+    const int k = p.k;
+    const bool full = (c0 == 0 && nc == p.nl);
+    if (!full && e->world > 1) return fail("single-chain stepping is not available on a sharded engine");
+    if (full && g == 0 && e->adapt) {   // publish the start positions (Dream_shared_vars.current_positions)
+        const size_t n = (size_t)p.nl * p.ld;
         hipLaunchKernelGGL(dz::k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, p.X, p.cp_new + (size_t)p.off * p.ld, n);
         DZCK(allgather_rows(e, p.cp_new));
     }
     p.draws = e->d_draws[g & 1]; p.draws_next = e->d_draws[(g + 1) & 1];
-    if (e->draws_gen != (int64_t)g) {   // first generation (later ones are prepared by k_accept of the previous generation)
-        hipLaunchKernelGGL(dz::k_draws, dim3((nl * p.nslots + 255) / 256), dim3(256), 0, e->stream, p, g, 0, nl, e->d_draws[g & 1]);
-        e->draws_gen = g;
+    p.ctl = e->d_ctl[g & 1]; p.ctl_next = e->d_ctl[(g + 1) & 1];
+    if (!full || e->draws_gen != (int64_t)g) {   // not prepared by k_accept of the previous generation
+        hipLaunchKernelGGL(dz::k_draws, dim3((nc * p.nslots + 255) / 256), dim3(256), 0, e->stream, p, g, c0, nc, e->d_draws[g & 1], e->d_ctl[g & 1]);
+        e->draws_gen = full ? (int64_t)g : -1;
     }
     {
         ProfScope ps(e, PR_PROPOSE);
-        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((nl * k + 3) / 4), dim3(256), 0, e->stream, p, 0, g, (uint32_t)e->M, 0, nl));
+        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((nc * k + 3) / 4), dim3(256), 0, e->stream, p, 0, g, (uint32_t)e->M, c0, nc));
     }
     DZCK(launch_check("propose"));
-    DZCK(eval_logp(e, p.P, nl * k, p.p_prior, p.p_like));
+    DZCK(eval_logp(e, p.P + (size_t)c0 * k * p.ld, nc * k, p.p_prior + (size_t)c0 * k, p.p_like + (size_t)c0 * k));
     if (k > 1) {
         {
             ProfScope ps(e, PR_PROPOSE);
-            NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((nl * (k - 1) + 3) / 4), dim3(256), 0, e->stream, p, 1, g, (uint32_t)e->M, 0, nl));
+            NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((nc * (k - 1) + 3) / 4), dim3(256), 0, e->stream, p, 1, g, (uint32_t)e->M, c0, nc));
         }
         DZCK(launch_check("propose(ref)"));
-        DZCK(eval_logp(e, p.R, nl * (k - 1), p.r_prior, p.r_like));
+        DZCK(eval_logp(e, p.R + (size_t)c0 * (k - 1) * p.ld, nc * (k - 1), p.r_prior + (size_t)c0 * (k - 1), p.r_like + (size_t)c0 * (k - 1)));
     }
     const bool append = (g % (uint32_t)p.thin) == 0;                           // Dream.py:360
     const bool publish = e->adapt && (int64_t)g < (int64_t)p.burnin + 1;      // Dream.py:364
-    if (append && e->M + p.N > e->c.history_capacity) return fail("history capacity exceeded");
-    if (publish) std::swap(p.cp_prev, p.cp_new);
-    const int64_t slot = e->c.trace_capacity ? e->ntrace : -1;
+    const int nrows = full ? p.N : nc;
+    if (append && e->M + nrows > e->c.history_capacity) return fail("history capacity exceeded");
+    if (publish) {
+        if (full) std::swap(p.cp_prev, p.cp_new);
+        else {   // the jump of a single chain is measured from its state at the start of the step
+            const size_t n = (size_t)nc * p.ld;
+            hipLaunchKernelGGL(dz::k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, p.X + (size_t)c0 * p.ld, p.cp_prev + (size_t)(p.off + c0) * p.ld, n);
+        }
+    }
+    const int64_t slot = (traced && e->c.trace_capacity) ? e->ntrace : -1;
+    const int64_t zbase = full ? e->M : e->M - (int64_t)(p.off + c0);
     {
         ProfScope ps(e, PR_ACCEPT);
-        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_accept<NCH>, dim3((nl + 3) / 4), dim3(256), 0, e->stream, p, g, e->M, 0, nl, slot, append ? 1 : 0, publish ? 1 : 0));
+        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_accept<NCH>, dim3((nc + 3) / 4), dim3(256), 0, e->stream, p, g, zbase, c0, nc, slot, append ? 1 : 0, publish ? 1 : 0, (full && !publish) ? 1 : 0));
     }
     DZCK(launch_check("accept"));
-    e->draws_gen = (int64_t)g + 1;
-    if (publish) { DZCK(allgather_rows(e, p.cp_new)); DZCK(adapt_generation(e, g)); }
-    if (append) { DZCK(allgather_rows(e, p.Z + (size_t)e->M * p.ld)); e->M += p.N; }
-    e->gen++;
-    if (e->c.trace_capacity) e->ntrace++;
+    if (full && !publish) e->draws_gen = (int64_t)g + 1;     // while adapting, next generation's decisions must wait for the new probabilities
+    if (publish) {
+        if (full) DZCK(allgather_rows(e, p.cp_new));
+        DZCK(adapt_generation(e, g, full ? 0 : p.off + c0, full ? p.N : nc));
+        if (!full) e->draws_gen = -1;
+    }
+    if (append) { if (full) DZCK(allgather_rows(e, p.Z + (size_t)e->M * p.ld)); e->M += nrows; }
+    for (int c = c0; c < c0 + nc; ++c) e->gen_c[c] = (int64_t)g + 1;
+    if (full) e->gen = (int64_t)g + 1;
+    if (slot >= 0) e->ntrace++;
     return 0;
 }
 
@@ -319,6 +344,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     HIPCK(hipSetDevice(cfg->device));
     dz_engine* e = new dz_engine();
     e->c = *cfg;
+    e->gen_c.assign((size_t)cfg->nchains_local, 0);
     dz::Params& p = e->p;
     p.N = cfg->nchains; p.nl = cfg->nchains_local; p.off = cfg->chain_offset; p.d = cfg->ndim;
     p.ld = (cfg->ndim + 15) / 16 * 16;
@@ -341,6 +367,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     rc |= ealloc(e, &p.cur_snk, nl);
     p.npt = 1 + (2 * cfg->depairs + 3) / 4; p.nslots = 3 + (2 * cfg->multitry - 1) * p.npt;
     rc |= ealloc(e, &e->d_draws[0], nl * (size_t)p.nslots); rc |= ealloc(e, &e->d_draws[1], nl * (size_t)p.nslots);
+    rc |= ealloc(e, &e->d_ctl[0], nl); rc |= ealloc(e, &e->d_ctl[1], nl);
     rc |= ealloc(e, &e->d_mins, ld); rc |= ealloc(e, &e->d_maxs, ld);
     rc |= ealloc(e, &e->d_gtab, (size_t)cfg->ngamma * cfg->depairs * p.d);
     rc |= ealloc(e, &e->d_shared, (size_t)3 * (cfg->ncr + cfg->ngamma));
@@ -444,6 +471,7 @@ int dz_set_cr_probs(dz_engine* e, const double* pr, int32_t n)
     HIPCK(hipSetDevice(e->c.device));
     HIPCK(hipStreamSynchronize(e->stream));
     HIPCK(hipMemcpy(e->p.cr_probs, pr, sizeof(double) * n, hipMemcpyHostToDevice));
+    e->draws_gen = -1;
     return 0;
 }
 int dz_set_gamma_probs(dz_engine* e, const double* pr, int32_t n)
@@ -452,6 +480,7 @@ int dz_set_gamma_probs(dz_engine* e, const double* pr, int32_t n)
     HIPCK(hipSetDevice(e->c.device));
     HIPCK(hipStreamSynchronize(e->stream));
     HIPCK(hipMemcpy(e->p.g_probs, pr, sizeof(double) * n, hipMemcpyHostToDevice));
+    e->draws_gen = -1;
     return 0;
 }
 
@@ -540,7 +569,45 @@ int dz_step(dz_engine* e, int64_t generations)
         DZCK(eval_logp(e, e->p.X, e->p.nl, e->p.lprior, e->p.llike));
         e->have_logp = true;
     }
-    for (int64_t i = 0; i < generations; ++i) DZCK(one_generation(e));
+    for (int c = 1; c < e->p.nl; ++c) if (e->gen_c[c] != e->gen_c[0]) return fail("chains are out of lockstep (single-chain stepping in progress)");
+    e->gen = e->gen_c[0];
+    for (int64_t i = 0; i < generations; ++i) DZCK(one_generation(e, 0, e->p.nl, (uint32_t)e->gen, true));
+    return 0;
+}
+
+int dz_step_range(dz_engine* e, int32_t c0, int32_t nc)
+{
+    if (!e) return fail("null engine");
+    HIPCK(hipSetDevice(e->c.device));
+    if (c0 < 0 || nc < 1 || c0 + nc > e->p.nl) return fail("bad chain range");
+    if (e->lk == LK_NONE) return fail("no likelihood set");
+    if (e->M < 2 * e->c.depairs) return fail("history not seeded");
+    if (!e->have_logp) { DZCK(eval_logp(e, e->p.X, e->p.nl, e->p.lprior, e->p.llike)); e->have_logp = true; }
+    for (int c = c0 + 1; c < c0 + nc; ++c) if (e->gen_c[c] != e->gen_c[c0]) return fail("chains of the range are at different generations");
+    return one_generation(e, c0, nc, (uint32_t)e->gen_c[c0], false);
+}
+
+int dz_set_chain_state(dz_engine* e, int32_t c, const double* x, const double* prior, const double* like)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    if (c < 0 || c >= e->p.nl) return fail("bad chain index");
+    if (!e->have_logp) { DZCK(eval_logp(e, e->p.X, e->p.nl, e->p.lprior, e->p.llike)); e->have_logp = true; }
+    DZCK(upload_padded(e, e->p.X + (size_t)c * e->p.ld, x, 1, 0.0));
+    if (prior && like) {
+        HIPCK(hipMemcpy(e->p.lprior + c, prior, sizeof(double), hipMemcpyHostToDevice));
+        HIPCK(hipMemcpy(e->p.llike + c, like, sizeof(double), hipMemcpyHostToDevice));
+    } else DZCK(eval_logp(e, e->p.X + (size_t)c * e->p.ld, 1, e->p.lprior + c, e->p.llike + c));   // Dream.py:266-268
+    return 0;
+}
+
+int dz_get_chain_state(dz_engine* e, int32_t c, double* x, double* prior, double* like)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    if (c < 0 || c >= e->p.nl) return fail("bad chain index");
+    if (x) DZCK(download_rows(e, x, e->p.X + (size_t)c * e->p.ld, 1));
+    HIPCK(hipStreamSynchronize(e->stream));
+    if (prior) HIPCK(hipMemcpy(prior, e->p.lprior + c, sizeof(double), hipMemcpyDeviceToHost));
+    if (like) HIPCK(hipMemcpy(like, e->p.llike + c, sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }
 

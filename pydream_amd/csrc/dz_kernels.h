@@ -14,6 +14,9 @@ namespace dz {
 constexpr int MAXK = 16;      // multitry limit
 constexpr int MAXPAIR = 8;    // DEpairs limit
 
+// per-chain control decisions of one generation, computed once (lane-parallel) instead of by every wave
+struct ChainCtl { int snk, cr_idx, delta, glev; double u_sel, u_acc; };
+
 struct Params {
     int N, nl, off, d, ld, k, depairs, ncr, ngamma, thin, burnin, adapt_cr, adapt_g, hard;
     uint32_t k0, k1;
@@ -33,6 +36,7 @@ struct Params {
     // wave-uniform Philox outputs of one generation, precomputed lane-parallel (k_draws / k_accept):
     // [nl][nslots] uint4; slot 0..2 = control stream idx 0..2, then npt slots per (phase, try)
     const uint4* draws; uint4* draws_next; int nslots, npt;
+    const ChainCtl* ctl; ChainCtl* ctl_next;
 };
 
 struct StepFlags { bool snk; int cr_idx, delta, glev; };
@@ -62,8 +66,9 @@ DZ_DEV int mt_select(const Params& p, int c, double u_sel, int lane, bool* anyfi
     const double w = dexp(lp - mx);
     double S = 0.0;
     for (int i = 0; i < k; ++i) S = S + __shfl(w, i, 64);
+    const double pr = w / S;                          // lane i: probability of try i (:907)
     double cum = 0.0; int sel = k - 1;
-    for (int i = 0; i < k; ++i) { cum = cum + __shfl(w, i, 64) / S; if (u_sel < cum) { sel = i; break; } }
+    for (int i = 0; i < k; ++i) { cum = cum + __shfl(pr, i, 64); if (u_sel < cum) { sel = i; break; } }
     return sel;
 }
 
@@ -268,12 +273,12 @@ __global__ __launch_bounds__(256) void k_propose(Params p, int phase, uint32_t g
     const int lane = threadIdx.x & 63;
     const int c = c0 + wave / n, i = wave % n;
     const uint4* dr = p.draws + (size_t)c * p.nslots;
-    const Ctrl u = ctrl_from(p, dr, (uint32_t)(p.off + c), g);
-    const StepFlags f = step_flags(p, u);
+    const ChainCtl ct = p.ctl[c];
+    StepFlags f; f.snk = ct.snk != 0; f.cr_idx = ct.cr_idx; f.delta = ct.delta; f.glev = ct.glev;
     const double* base; double* out; double* sl;
     if (phase == 0) { base = p.X + (size_t)c * p.ld; out = p.P + ((size_t)c * p.k + i) * p.ld; sl = p.p_slogp + (size_t)c * p.k + i; }
     else {
-        bool fin; const int sel = mt_select(p, c, u.u_sel, lane, &fin);
+        bool fin; const int sel = mt_select(p, c, ct.u_sel, lane, &fin);
         base = p.P + ((size_t)c * p.k + sel) * p.ld; out = p.R + ((size_t)c * (p.k - 1) + i) * p.ld; sl = p.r_slogp + (size_t)c * (p.k - 1) + i;
     }
     propose_point<NCH>(p, phase, g, M, c, i, n, lane, base, out, sl, (phase == 0 && p.k == 1) ? p.cur_snk + c : nullptr,
@@ -576,19 +581,29 @@ __global__ __launch_bounds__(256) void k_prior_add(Params p, const double* __res
 // (:424-449).  One wave per chain.
 // ------------------------------------------------------------------------------------------
 template <int NCH>
-__global__ __launch_bounds__(256) void k_accept(Params p, uint32_t g, int64_t M, int c0, int nc, int64_t trace_slot, int append, int publish)
+__global__ __launch_bounds__(256) void k_accept(Params p, uint32_t g, int64_t zbase, int c0, int nc, int64_t trace_slot, int append, int publish, int prep_next)
 {
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (wave >= nc) return;
     const int lane = threadIdx.x & 63;
     const int c = c0 + wave, k = p.k, ld = p.ld;
     const uint32_t gc = (uint32_t)(p.off + c);
-    const Ctrl u = ctrl_from(p, p.draws + (size_t)c * p.nslots, gc, g);
-    const StepFlags f = step_flags(p, u);
-    // lane-parallel: the wave-uniform Philox outputs this chain needs in generation g+1
-    for (int slot = lane; slot < p.nslots; slot += 64) {
-        const u32x4 w = slot_counter_draw(p, slot, gc, g + 1);
-        p.draws_next[(size_t)c * p.nslots + slot] = make_uint4(w.x, w.y, w.z, w.w);
+    const ChainCtl ct = p.ctl[c];
+    StepFlags f; f.snk = ct.snk != 0; f.cr_idx = ct.cr_idx; f.delta = ct.delta; f.glev = ct.glev;
+    Ctrl u; u.u_sel = ct.u_sel; u.u_acc = ct.u_acc;
+    if (prep_next) {   // lane-parallel: the wave-uniform Philox outputs and control decisions of generation g+1
+        u32x4 w0 = u32x4{0, 0, 0, 0};
+        for (int slot = lane; slot < p.nslots; slot += 64) {
+            const u32x4 w = slot_counter_draw(p, slot, gc, g + 1);
+            if (slot == lane) w0 = w;
+            p.draws_next[(size_t)c * p.nslots + slot] = make_uint4(w.x, w.y, w.z, w.w);
+        }
+        Ctrl un;
+        un.u_snk = u53(__shfl(w0.x, 0, 64), __shfl(w0.y, 0, 64)); un.u_cr = u53(__shfl(w0.z, 0, 64), __shfl(w0.w, 0, 64));
+        un.u_de = u53(__shfl(w0.x, 1, 64), __shfl(w0.y, 1, 64)); un.u_glev = u53(__shfl(w0.z, 1, 64), __shfl(w0.w, 1, 64));
+        un.u_sel = u53(__shfl(w0.x, 2, 64), __shfl(w0.y, 2, 64)); un.u_acc = u53(__shfl(w0.z, 2, 64), __shfl(w0.w, 2, 64));
+        const StepFlags fn = step_flags(p, un);
+        if (lane == 0) { ChainCtl o; o.snk = fn.snk ? 1 : 0; o.cr_idx = fn.cr_idx; o.delta = fn.delta; o.glev = fn.glev; o.u_sel = un.u_sel; o.u_acc = un.u_acc; p.ctl_next[c] = o; }
     }
     const double last_prior = p.lprior[c], last_like = p.llike[c];
     const double last_logp = p.T * last_like + last_prior;                     // :243, :268
@@ -647,7 +662,7 @@ __global__ __launch_bounds__(256) void k_accept(Params p, uint32_t g, int64_t M,
             const double2 t = {xn[it][0], xn[it][1]};
             if (accept) *reinterpret_cast<double2*>(xrow + jj) = t;
             if (trace_slot >= 0) *reinterpret_cast<double2*>(p.tX + ((size_t)trace_slot * p.nl + c) * ld + jj) = t;
-            if (append) *reinterpret_cast<double2*>(p.Z + ((size_t)M + gc) * ld + jj) = t;       // :933-936
+            if (append) *reinterpret_cast<double2*>(p.Z + (size_t)(zbase + (int64_t)gc) * ld + jj) = t;   // :933-936
             if (publish) *reinterpret_cast<double2*>(p.cp_new + (size_t)gc * ld + jj) = t;       // :447-449
         }
     }
@@ -661,14 +676,22 @@ __global__ __launch_bounds__(256) void k_accept(Params p, uint32_t g, int64_t M,
     }
 }
 
-// uniform draws of generation g for local chains [c0, c0+nc): one lane per (chain, slot)
-__global__ void k_draws(Params p, uint32_t g, int c0, int nc, uint4* __restrict__ out)
+// uniform draws of generation g for local chains [c0, c0+nc): one lane per (chain, slot); the lanes of
+// slot 0 also derive the chain's control decisions (needs the CURRENT crossover / gamma-level probabilities)
+__global__ void k_draws(Params p, uint32_t g, int c0, int nc, uint4* __restrict__ out, ChainCtl* __restrict__ ctl)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nc * p.nslots) return;
     const int c = c0 + t / p.nslots, slot = t % p.nslots;
-    const u32x4 w = slot_counter_draw(p, slot, (uint32_t)(p.off + c), g);
+    const uint32_t gc = (uint32_t)(p.off + c);
+    const u32x4 w = slot_counter_draw(p, slot, gc, g);
     out[(size_t)c * p.nslots + slot] = make_uint4(w.x, w.y, w.z, w.w);
+    if (slot == 0) {
+        const Ctrl u = draw_ctrl(p.k0, p.k1, gc, g);
+        const StepFlags f = step_flags(p, u);
+        ChainCtl o; o.snk = f.snk ? 1 : 0; o.cr_idx = f.cr_idx; o.delta = f.delta; o.glev = f.glev; o.u_sel = u.u_sel; o.u_acc = u.u_acc;
+        ctl[c] = o;
+    }
 }
 
 // copy rows [nl,ld] (used for publishing start positions and the sharded exchange staging)
@@ -708,11 +731,12 @@ __global__ void k_strip_finish(const double* __restrict__ partial, int nstrips, 
 
 // one wave per GLOBAL chain: bins and normalised squared jumps (:481, :527)
 template <int NCH>
-__global__ __launch_bounds__(256) void k_jump(Params p, uint32_t g, const double* __restrict__ sdc, const double* __restrict__ sdg,
+__global__ __launch_bounds__(256) void k_jump(Params p, uint32_t g, int gc0, int ngc, const double* __restrict__ sdc, const double* __restrict__ sdg,
                                               double* __restrict__ dl, double* __restrict__ dlg, int* __restrict__ binc, int* __restrict__ bing)
 {
-    const int gcn = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (gcn >= p.N) return;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= ngc) return;
+    const int gcn = gc0 + w;
     const int lane = threadIdx.x & 63;
     const Ctrl u = draw_ctrl(p.k0, p.k1, (uint32_t)gcn, g);
     const StepFlags f = step_flags(p, u);

@@ -1,0 +1,120 @@
+"""Host-side mirror of the reference's Python API (no GPU needed): priors, Model, Gelman_Rubin, the
+Dream constructor's option handling and run_dream's validation errors -- written after the
+reference's own tests (pydream/tests/test_dream.py)."""
+import numpy as np
+import pytest
+from scipy.stats import norm, uniform, gamma as gamma_dist
+
+from pydream_amd.Dream import Dream
+from pydream_amd.convergence import Gelman_Rubin
+from pydream_amd.core import run_dream
+from pydream_amd.likelihoods import GaussianMixtureLogLike, MVNormalLogLike
+from pydream_amd.model import Model
+from pydream_amd.parameters import FlatParam, SampledParam
+from tests import helpers as H
+
+
+def simple_likelihood(param):      # pydream/tests/test_models.py:47-50
+    return np.sum(param + 3)
+
+
+def onedmodel():                   # test_models.py:14-22
+    return [SampledParam(norm, loc=-2, scale=3)], simple_likelihood
+
+
+def multidmodel():                 # test_models.py:24-33
+    return [SampledParam(norm, loc=np.array([-6.6, 3, 1.0, -.12]), scale=np.array([.13, 5, .9, 1.0]))], simple_likelihood
+
+
+def multidmodel_uniform():         # test_models.py:35-45
+    lower = np.array([-5, -9, 5, 3]); upper = np.array([10, 2, 7, 8])
+    return [SampledParam(uniform, loc=lower, scale=upper - lower)], simple_likelihood
+
+
+def test_check_dimension_and_boundaries():
+    """test_dream.py:30-50: dimensions 1 and 4; bounds from interval(1)."""
+    p, l = onedmodel()
+    assert Dream(model=Model(l, p)).total_var_dimension == 1
+    p, l = multidmodel_uniform()
+    step = Dream(model=Model(l, p))
+    assert step.total_var_dimension == 4
+    np.testing.assert_array_equal(step.mins, [-5, -9, 5, 3])
+    np.testing.assert_array_equal(step.maxs, [10, 2, 7, 8])
+    f = Dream(model=Model(l, [FlatParam(np.zeros(3))]))
+    assert np.all(np.isinf(f.mins)) and np.all(np.isinf(f.maxs))
+
+
+def test_gamma_array_known_values():
+    """test_dream.py:68-76"""
+    p, l = onedmodel()
+    dream = Dream(model=Model(l, p), DEpairs=5, p_gamma_unity=0)
+    np.testing.assert_allclose(dream.gamma_arr[0, :, 0], [1.683, 1.19, .972, .841, .753], atol=5e-4)
+    fx = H.load("densities")
+    np.testing.assert_array_equal(Dream(model=Model(l, [FlatParam(np.zeros(7))]), DEpairs=5, gamma_levels=4).gamma_arr, fx["gamma_arr_7_5_4"])
+
+
+def test_option_handling():
+    """multitry False/True/int (Dream.py:155-161), nCR clipped to d (:110-113), adapt off at d=1 (:115-118),
+    nseedchains default 10 d (:168-170), unknown kwargs swallowed (:67), multitry=2 rejected."""
+    p, l = multidmodel()
+    m = Model(l, p)
+    assert Dream(model=m).multitry == 1
+    assert Dream(model=m, multitry=True).multitry == 5
+    assert Dream(model=m, multitry=3).multitry == 3
+    assert Dream(model=m, nCR=9).nCR == 4
+    assert Dream(model=m).nseedchains == 40
+    assert Dream(model=m, nverbose=3).total_var_dimension == 4
+    p1, l1 = onedmodel()
+    assert Dream(model=Model(l1, p1), adapt_crossover=True).adapt_crossover is False
+    np.testing.assert_allclose(Dream(model=m).CR_values, [1 / 3., 2 / 3., 1.0])
+    with pytest.raises(Exception, match="multitry=2"):
+        Dream(model=m, multitry=2)
+
+
+def test_priors_and_model():
+    """parameters.py:37-47, 62-63; model.py:17-32"""
+    p, l = multidmodel()
+    q = np.array([-6.5, 2.0, 1.1, 0.3])
+    m = Model(l, p)
+    pr, lk = m.total_logp(q)
+    assert pr == pytest.approx(np.sum(norm(loc=[-6.6, 3, 1.0, -.12], scale=[.13, 5, .9, 1.0]).logpdf(q)))
+    assert lk == pytest.approx(np.sum(q + 3))
+    kind, a, b = m.device_prior()
+    np.testing.assert_array_equal(kind, [1, 1, 1, 1]); np.testing.assert_allclose(a, [-6.6, 3, 1.0, -.12]); np.testing.assert_allclose(b, [.13, 5, .9, 1.0])
+    pu, _ = multidmodel_uniform()
+    kind, a, b = Model(l, pu).device_prior()
+    np.testing.assert_array_equal(kind, [2, 2, 2, 2]); np.testing.assert_allclose(a, [-5, -9, 5, 3]); np.testing.assert_allclose(b, [15, 11, 2, 5])
+    assert Model(l, [SampledParam(gamma_dist, 2.0)]).device_prior() is None          # host prior for anything else
+    f = FlatParam(np.zeros(5))
+    assert f.prior(np.ones(5)) == 0 and f.dsize == 5
+    pr_b, lk_b = Model(l, [f, SampledParam(gamma_dist, 2.0)]).batch_logp(np.ones((3, 6)), with_prior=True)
+    assert pr_b[0] == pytest.approx(gamma_dist(2.0).logpdf(1.0)) and lk_b[0] == 24
+
+
+def test_device_likelihood_objects_are_plain_callables():
+    fx = H.load("densities")
+    ll = MVNormalLogLike(fx["mvn10_invC"], log_F=float(fx["mvn10_logF"]))
+    np.testing.assert_allclose([ll(x) for x in fx["mvn10_X"]], fx["mvn10_logp"], atol=1e-10)
+    mix = GaussianMixtureLogLike(fx["mix2_mu"], fx["mix2_logF"])
+    np.testing.assert_allclose([mix(x) for x in fx["mix2_X"]], fx["mix2_logp"], atol=1e-10)
+
+
+def test_gelman_rubin_matches_reference():
+    fx = H.load("densities")
+    tr = fx["gr_traces"]
+    np.testing.assert_allclose(Gelman_Rubin([tr[c] for c in range(len(tr))]), fx["gr_rhat"], rtol=1e-12)
+
+
+def test_run_dream_validation_errors():
+    """core.py:46-50, 252-254, 270-273 -- raised before any device work."""
+    p, l = multidmodel()
+    with pytest.raises(Exception, match="no start positions"):
+        run_dream(p, l, restart=True)
+    with pytest.raises(Exception, match="no model name"):
+        run_dream(p, l, restart=True, start=[np.zeros(4)] * 5)
+    with pytest.raises(Exception, match=r"at least \(2\*DEpairs\)\+1"):
+        run_dream(p, l, nchains=2, niterations=10, verbose=False)
+    with pytest.raises(Exception, match="seeded starting history is insufficient"):
+        run_dream(p, l, nchains=30, niterations=10, verbose=False)          # default nseedchains = 40 < 2*30
+    with pytest.raises(NotImplementedError):
+        run_dream(p, l, nchains=5, niterations=10, verbose=False, tempering=True)

@@ -1,0 +1,139 @@
+"""End-to-end through the reference-shaped Python API on the GPU -- after the reference's
+Test_Dream_Algorithm_Components / Test_Dream_Full_Algorithm (pydream/tests/test_dream.py:499-705)."""
+import os
+
+import numpy as np
+import pytest
+from scipy.stats import uniform
+
+from pydream_amd import Dream_shared_vars
+from pydream_amd.Dream import Dream
+from pydream_amd.convergence import Gelman_Rubin
+from pydream_amd.core import _setup_mp_dream_pool, run_dream
+from pydream_amd.likelihoods import MVNormalLogLike
+from pydream_amd.model import Model
+from pydream_amd.parameters import FlatParam, SampledParam
+from tests import helpers as H
+from tests.test_api_cpu import multidmodel, multidmodel_uniform, onedmodel
+
+pytestmark = pytest.mark.gpu
+
+
+def test_astep_round_robin_equals_reference_s1(tmp_path):
+    """Dream.astep driven round-robin in one process, the reference's own idiom (test_dream.py:507-518):
+    identical to the UNMODIFIED reference's trace (golden trace_s1_c1: 3 chains, 10-D MVN, multitry 5)
+    and bit-identical to the oracle's schedule S1."""
+    import copy
+    from oracle import oracle as O
+    fx = H.load("trace_s1_c1")
+    d, N, G = int(fx["cfg_d"]), int(fx["cfg_N"]), int(fx["cfg_G"])
+    hist = tmp_path / "seed.npy"
+    np.save(hist, fx["Z0"])
+    like = MVNormalLogLike(fx["invC"], log_F=float(fx["log_F"]), factorize=False)
+    step = Dream(model=Model(like, [FlatParam(np.zeros(d))]), history_file=str(hist), start_random=False, save_history=False,
+                 multitry=5, adapt_crossover=False, crossover_burnin=10 ** 9)
+    pool = _setup_mp_dream_pool(N, G, step, start_pt=[fx["starts"][i] for i in range(N)], seed=int(fx["cfg_seed"]))
+    pool._initializer(*pool._initargs)
+    try:
+        # the k-th Dream instance claims chain N-1-k (Dream.py:198-200); drive them so that chain 0 goes first
+        chains = [copy.copy(step) for _ in range(N)]
+        order = list(range(N - 1, -1, -1))
+        for k in range(N):
+            chains[k].chain_n = None
+        x = {c: fx["starts"][c].copy() for c in range(N)}
+        X = np.zeros((G, N, d)); lp = np.zeros((G, N))
+        claimed = {}
+        for g in range(G):
+            for c in range(N):
+                inst = chains[order[c]] if g == 0 else claimed[c]
+                if g == 0:
+                    # make instance -> chain mapping explicit
+                    Dream_shared_vars.nchains_counter = c + 1
+                    claimed[c] = inst
+                q, pr, lk = inst.astep(x[c])
+                assert isinstance(q, np.ndarray) and isinstance(pr, float) and isinstance(lk, float)
+                x[c] = q; X[g, c] = q; lp[g, c] = pr + lk
+        np.testing.assert_allclose(X, fx["X"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(lp, fx["logp"], rtol=0, atol=1e-10)
+        o = H.engine_from_trace_fixture(O.Engine, fx)      # schedule S1
+        o.step(G)
+        np.testing.assert_array_equal(X, o.get_trace(0, G)["X"])
+        np.testing.assert_array_equal(pool.engine.get_history(), o.get_history())
+    finally:
+        pool.close(); pool.join()
+
+
+def test_run_dream_shapes_and_types():
+    """test_dream.py:564-584, 708-806: list of nchains arrays (niterations, d) and (niterations, 1)."""
+    for params, like in (onedmodel(), multidmodel(), multidmodel_uniform()):
+        sampled, log_ps = run_dream(params, like, nchains=5, niterations=30, verbose=False, save_history=False, seed=1)
+        assert len(sampled) == 5 and len(log_ps) == 5
+        d = sum(p.dsize for p in params)
+        for s, l in zip(sampled, log_ps):
+            assert s.shape == (30, d) and l.shape == (30, 1) and np.all(np.isfinite(l))
+    sampled, _ = run_dream(*multidmodel(), nchains=5, niterations=20, verbose=False, save_history=False, multitry=5, seed=2,
+                           DEpairs=2, gamma_levels=3, adapt_gamma=True, snooker=.2)
+    assert sampled[0].shape == (20, 4)
+
+
+def test_history_file_matches_samples(tmp_path):
+    """test_dream.py:629-668: every appended history row is one of the returned samples (thin=1: all of them)."""
+    os.chdir(tmp_path)
+    params, like = multidmodel()
+    sampled, _ = run_dream(params, like, nchains=5, niterations=20, verbose=False, history_thin=1, model_name="t_hist",
+                           save_history=True, adapt_crossover=False, seed=3)
+    hist = np.load("t_hist_DREAM_chain_history.npy").reshape(-1, 4)
+    nseed = 40
+    assert len(hist) == nseed + 5 * 20
+    appended = hist[nseed:].reshape(20, 5, 4)
+    np.testing.assert_array_equal(appended, np.stack(sampled, axis=1))
+    assert os.path.exists("t_hist_DREAM_chain_adapted_crossoverprob.npy") and os.path.exists("t_hist_DREAM_chain_adapted_gammalevelprob.npy")
+    # restart from the files (core.py:46-62, 255-263)
+    s2, _ = run_dream(params, like, nchains=5, niterations=10, verbose=False, restart=True, model_name="t_hist",
+                      start=[s[-1] for s in sampled], save_history=False, seed=4)
+    assert s2[0].shape == (10, 4)
+
+
+def test_hard_boundaries_never_violated():
+    """test_dream.py:670-705: uniform prior on [-5,10]x[-9,2]x[5,7]x[3,8], 1000 iterations, 5 chains."""
+    params, like = multidmodel_uniform()
+    lower = np.array([-5, -9, 5, 3]); upper = np.array([10, 2, 7, 8])
+    sampled, _ = run_dream(params, like, nchains=5, niterations=1000, verbose=False, save_history=False, hardboundaries=True,
+                           multitry=3, seed=5, lamb=0.5)
+    S = np.concatenate(sampled)
+    assert np.all(S >= lower) and np.all(S <= upper)
+    assert len(np.unique(S[:, 0])) > 50           # the chains do move
+
+
+def test_host_likelihood_equals_device_likelihood():
+    """The same model through the host callback (arbitrary Python likelihood) and through the device
+    descriptor gives the same chain decisions; logp agree to 1e-10."""
+    d, N, n = 10, 6, 40
+    P = H.mvn_precision(d)
+    dev = MVNormalLogLike(P, factorize=False)
+    host = lambda x: -.5 * np.sum(x * np.dot(P, x))          # dream_ex_ndim_gaussian.py:49-52
+    hist = "/tmp/_dz_seed_%d.npy" % os.getpid()
+    np.save(hist, H.seed_history(100, d, 8))
+    kw = dict(nchains=N, niterations=n, verbose=False, save_history=False, history_file=hist, multitry=5, seed=6,
+              start=[H.seed_history(100, d, 8)[i] for i in range(N)])
+    s_dev, l_dev = run_dream([FlatParam(np.zeros(d))], dev, **kw)
+    s_host, l_host = run_dream([FlatParam(np.zeros(d))], host, **kw)
+    os.remove(hist)
+    np.testing.assert_allclose(np.array(l_dev), np.array(l_host), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(np.array(s_dev), np.array(s_host), rtol=1e-12)
+
+
+def test_converges_on_the_reference_example_target(tmp_path):
+    """C1 plumbing config (examples/ndim_gaussian at d=10, 3 chains, multitry 5): R-hat < 1.2 on every
+    dimension (the example's own criterion, dream_ex_ndim_gaussian.py:80) and Var(x_i) ~ i."""
+    d = 10
+    hist = tmp_path / "seed.npy"
+    Z0 = H.seed_history(1000, d, 9)
+    np.save(hist, Z0)
+    sampled, _ = run_dream([FlatParam(np.zeros(d))], MVNormalLogLike(H.mvn_precision(d)), nchains=3, niterations=6000, verbose=False,
+                           start=[Z0[i] for i in range(3)], start_random=False, save_history=False, history_file=str(hist),
+                           multitry=5, seed=10)
+    assert np.all(Gelman_Rubin(sampled) < 1.2)
+    S = np.concatenate([s[3000:] for s in sampled])
+    np.testing.assert_allclose(S.var(axis=0), np.arange(1, d + 1), rtol=0.35)
+    assert np.all(np.abs(S.mean(axis=0)) < 0.6)

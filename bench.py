@@ -128,7 +128,7 @@ def main():
 
     n_local = args.chains_per_gpu
     n_global = n_local * world
-    total = args.steps + args.warmup
+    total = 2 * args.steps + args.warmup             # warm-up + timed pass + HIP-event pass
     e = setup_engine(_capi.Engine, args, n_global, n_local, rank * n_local, total, device=local_rank)
     if world > 1:
         ids = [_capi.comm_unique_id() if rank == 0 else None]
@@ -143,10 +143,8 @@ def main():
     e.step(args.warmup)
     barrier()
     e.trace_reset()
-    if not args.no_events:
-        e.profile_enable(True, prealloc_pairs=8 * args.steps)
-        e.profile_reset()
     barrier()
+    # ---- timed region: exactly K generations, nothing else on the stream ----
     t0 = time.perf_counter()
     e.step(args.steps)
     e.sync()
@@ -158,16 +156,28 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
+    tr = e.get_trace(0, args.steps, with_X=False)
+    acc = float(tr["moved"].mean())
+    rhat = e.get_rhat() if world == 1 else None
+    if world > 1:
+        from pydream_amd.distributed import gelman_rubin_sharded
+        rhat = gelman_rubin_sharded(e, args.steps)
 
+    # ---- second pass of K generations with HIP events around every kernel launch (per-kernel durations
+    #      for the roofline; kept out of the timed region because each event record costs a few us) ----
     prof = {}
     if not args.no_events:
+        e.trace_reset()
+        e.profile_enable(True, prealloc_pairs=8 * args.steps)
+        e.profile_reset()
+        e.step(args.steps)
+        e.sync()
         e.profile_enable(False)
         for name in ("propose", "logp", "accept", "adapt", "exchange"):
             ms, n = e.profile_get(name)
             prof[name] = {"total_ms": ms, "launches": n, "avg_us": (1e3 * ms / n) if n else None}
-    tr = e.get_trace(0, args.steps, with_X=False)
-    acc = float(tr["moved"].mean())
-    rhat = e.get_rhat()
+        if dist is not None:
+            dist.barrier()
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()

@@ -56,17 +56,18 @@ def run_dream(parameters, likelihood, nchains=5, niterations=50000, start=None, 
                                 seed=kwargs.get('seed'), device=kwargs.get('device', 0))
     try:
         pool._initializer(*pool._initargs)
-        sampled_params, log_ps = _sample_dream_batched(pool.engine, step_instance, nchains, niterations, verbose, nverbose)
+        sampled_params, log_ps = _sample_dream_batched(pool.engine, step_instance, niterations, verbose, nverbose)
     finally:
         pool.close()
         pool.join()
     return sampled_params, log_ps
 
 
-def _sample_dream_batched(eng, step, nchains, niterations, verbose, nverbose):
+def _sample_dream_batched(eng, step, niterations, verbose, nverbose):
     """The per-chain loop of core._sample_dream (core.py:89-129) for all chains at once: advance the
     engine in chunks that fit the device trace buffer and collect trace / log_ps per chain."""
     d = step.total_var_dimension
+    nchains = eng.nl                                  # the chains this engine owns (all of them on one GPU)
     sampled = [np.empty((niterations, d)) for _ in range(nchains)]
     log_ps = [np.empty((niterations, 1)) for _ in range(nchains)]
     chunk = eng.cfg.trace_capacity
@@ -140,7 +141,7 @@ def _mp_dream_init(engine, nchains):
 
 
 def _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=None, mp_context=None, seed=None, device=0,
-                         chain_offset=0, nchains_local=None):
+                         chain_offset=0, nchains_local=None, engine_cls=None):
     """Validate, size and allocate the shared sampler state (core.py:250-314) -- in HBM."""
     min_njobs = (2 * len(step_instance.DEpairs)) + 1
     if nchains < min_njobs:
@@ -173,7 +174,7 @@ def _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=None, mp_
     n_appends = (niterations + thin - 1) // thin + 1
     ld = (d + 15) // 16 * 16
     trace_cap = int(max(1, min(niterations, (2 << 30) // (nl * ld * 8))))
-    eng = _capi.Engine(nchains=nchains, nchains_local=nl, chain_offset=chain_offset, ndim=d, multitry=int(step_instance.multitry),
+    eng = (engine_cls or _capi.Engine)(nchains=nchains, nchains_local=nl, chain_offset=chain_offset, ndim=d, multitry=int(step_instance.multitry),
                        depairs=len(step_instance.DEpairs), ncr=int(step_instance.nCR), ngamma=int(step_instance.ngamma),
                        history_thin=int(thin), crossover_burnin=int(min(step_instance.crossover_burnin, 2 ** 31 - 1)),
                        adapt_crossover=int(bool(step_instance.adapt_crossover)), adapt_gamma=int(bool(step_instance.adapt_gamma)),

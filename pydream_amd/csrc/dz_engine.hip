@@ -205,7 +205,7 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
 // in-place all-gather of `rows_local` rows per rank inside buf (global layout [N,ld])
 int allgather_rows(dz_engine* e, double* buf)
 {
-    if (e->world == 1 && e->p.nl == e->p.N) return 0;
+    if (!e->comm && e->p.nl == e->p.N) return 0;     // single GPU, no communicator: the kernels wrote the rows in place
     ProfScope ps(e, PR_EXCHANGE);
     const size_t cnt = (size_t)e->p.nl * e->p.ld;
     double* mine = buf + (size_t)e->p.off * e->p.ld;

@@ -1,0 +1,68 @@
+"""The written contracts the oracle and the GPU both implement (DESIGN.md sections 4-6): Philox4x32-10
+known answers, uniform/normal conversions, the elementary functions, index sampling, the reduction
+order.  CPU only; exercised on the GPU through the bit-exact trace comparisons."""
+import math
+
+import numpy as np
+
+from oracle import oracle as O
+
+
+def test_philox4x32_10_known_answers():
+    """Random123 kat_vectors (philox4x32, 10 rounds)."""
+    assert [hex(x) for x in O.philox(0, 0, 0, 0, 0)] == ['0x6627e8d5', '0xe169c58d', '0xbc57ac4c', '0x9b00dbd8']
+    assert [hex(x) for x in O.philox(0xffffffffffffffff, *[0xffffffff] * 4)] == ['0x408f276d', '0x41c83b0e', '0xa20bc7c6', '0x6d5451fd']
+    assert [hex(x) for x in O.philox(0x299f31d0a4093822, 0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344)] == \
+        ['0xd16cfe09', '0x94fdcceb', '0x5001e420', '0x24126ea1']
+
+
+def test_uniform_conversions():
+    assert O.u53(0, 0) == 0.0 and O.u53(0xffffffff, 0xffffffff) == 1.0 - 2.0 ** -53
+    assert O.u32(0) == 2.0 ** -33 and O.u32(0xffffffff) == 1.0 - 2.0 ** -33
+    assert O.stream_id(O.K_DIM, 3, 1) == (2 | 3 << 4 | 1 << 12)
+
+
+def test_exp_log_accuracy_and_special_values():
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([rng.uniform(-700, 700, 20000), rng.uniform(-3, 3, 20000)])
+    ulp = max(abs(O.exp(x) - math.exp(x)) / (math.ulp(math.exp(x))) for x in xs)
+    assert ulp <= 1.5
+    xs = np.concatenate([np.exp(rng.uniform(-700, 700, 20000)), rng.uniform(0.5, 2, 20000), [5e-324, 1e-310]])
+    ulp = max(abs(O.log(x) - math.log(x)) / math.ulp(math.log(x)) for x in xs if x != 1.0)
+    assert ulp <= 2.0
+    assert O.exp(-np.inf) == 0.0 and O.exp(1000.0) == np.inf and np.isnan(O.exp(np.nan)) and O.exp(0.0) == 1.0
+    assert O.log(0.0) == -np.inf and O.log(1.0) == 0.0 and np.isnan(O.log(-1.0)) and O.log(np.inf) == np.inf
+
+
+def test_normal32_is_a_standard_normal():
+    rng = np.random.default_rng(2)
+    w = rng.integers(0, 2 ** 32, size=(100000, 2), dtype=np.uint64)
+    z = np.array([O.normal32(a, b) for a, b in w])
+    u1 = ((w[:, 0] >> 9) + 0.5) * 2.0 ** -23
+    u2 = ((w[:, 1] >> 9) + 0.5) * 2.0 ** -23
+    np.testing.assert_allclose(z, np.sqrt(-2 * np.log(u1)) * np.cos(2 * np.pi * u2), atol=2e-6)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01 and abs(((z - z.mean()) ** 4).mean() / z.var() ** 2 - 3) < 0.1
+
+
+def test_sample_distinct_is_uniform_without_replacement():
+    """stands in for random.sample(range(M), n) (Dream.py:662); the reference's own test of this
+    property is test_dream.py:160-200 (M=2 returns both rows)."""
+    rng = np.random.default_rng(3)
+    assert sorted(O.sample_distinct(rng.integers(0, 2 ** 32, 2, dtype=np.uint64), 2)) == [0, 1]
+    counts = np.zeros((5, 5))
+    for _ in range(20000):
+        a, b = O.sample_distinct(rng.integers(0, 2 ** 32, 2, dtype=np.uint64), 5)
+        assert a != b
+        counts[a, b] += 1
+    off = counts[~np.eye(5, dtype=bool)]
+    assert np.all(np.abs(off / 20000 - 1 / 20.) < 0.01)
+    s = O.sample_distinct(rng.integers(0, 2 ** 32, 6, dtype=np.uint64), 6)
+    assert sorted(s) == list(range(6))
+
+
+def test_invcdf_and_wave_dot():
+    assert O.invcdf([0.1, 0.9], 0.05) == 0 and O.invcdf([0.1, 0.9], 0.5) == 1 and O.invcdf([0.3, 0.3, 0.4], 0.999999) == 2
+    rng = np.random.default_rng(4)
+    for d in (1, 7, 100, 129, 1000):
+        a, b = rng.normal(size=d), rng.normal(size=d)
+        assert abs(O.wave_dot(a, b) - float(np.dot(a, b))) <= 1e-12 * max(1.0, abs(np.dot(a, b))) + 1e-13 * d

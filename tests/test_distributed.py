@@ -1,0 +1,130 @@
+"""The N>1 path: chains sharded over ranks, Z replicated by all-gather.
+
+CPU (gloo, world_size 2): the host logic (shard arithmetic, seed agreement, exchange hook, per-rank
+assembly) with the ORACLE standing in for the device engine -- sharded == unsharded, bit for bit.
+GPU (marked gpu): the same with the HIP engine, two ranks sharing the one GPU of the test box
+through the host-staged transport.  The RCCL transport itself needs >= 2 GPUs (driver's 8-GPU run).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model(d):
+    from tests import helpers as H
+    from pydream_amd.likelihoods import MVNormalLogLike
+    from pydream_amd.parameters import FlatParam
+    return [FlatParam(np.zeros(d))], MVNormalLogLike(H.mvn_precision(d), factorize=False)
+
+
+KW = dict(nchains=8, niterations=45, multitry=5, adapt_crossover=True, crossover_burnin=20, save_history=False, seed=77,
+          nseedchains=40, history_thin=5)
+
+
+def _worker(rank, world, port, backend_engine, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from pydream_amd.distributed import run_dream_sharded
+    from tests import helpers as H
+    d = 12
+    params, like = _model(d)
+    if backend_engine == "oracle":
+        from oracle import oracle as O
+        cls = O.Engine
+    else:
+        cls = None
+    Z0 = H.seed_history(40, d, 3)
+    hist = os.path.join(outdir, "seed_%d.npy" % rank)
+    np.save(hist, Z0)
+    sampled, log_ps = run_dream_sharded(params, like, start=[Z0[i] for i in range(8)], history_file=hist, transport="host",
+                                        engine_cls=cls, device=0, **KW)
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), X=np.array(sampled), lp=np.array(log_ps))
+    dist.destroy_process_group()
+
+
+def _single(backend_engine, outdir):
+    from pydream_amd import core
+    from pydream_amd.Dream import Dream
+    from pydream_amd.model import Model
+    from tests import helpers as H
+    d = 12
+    params, like = _model(d)
+    Z0 = H.seed_history(40, d, 3)
+    hist = os.path.join(outdir, "seed_single.npy")
+    np.save(hist, Z0)
+    kw = dict(KW)
+    n, it, seed = kw.pop("nchains"), kw.pop("niterations"), kw.pop("seed")
+    step = Dream(model=Model(like, params), history_file=hist, **kw)
+    cls = None
+    if backend_engine == "oracle":
+        from oracle import oracle as O
+        cls = O.Engine
+    pool = core._setup_mp_dream_pool(n, it, step, start_pt=[Z0[i] for i in range(8)], seed=seed, engine_cls=cls)
+    try:
+        s, l = core._sample_dream_batched(pool.engine, step, it, False, 10)
+        Z = pool.engine.get_history()
+        cr = pool.engine.get_cr_state()[0]
+    finally:
+        pool.close(); pool.join()
+    return np.array(s), np.array(l), Z, cr
+
+
+def _run_two_ranks(backend_engine, tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, backend_engine, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "rank0.npz"); r1 = np.load(tmp_path / "rank1.npz")
+    X = np.concatenate([r0["X"], r1["X"]]); lp = np.concatenate([r0["lp"], r1["lp"]])
+    Xs, lps, _, cr = _single(backend_engine, str(tmp_path))
+    np.testing.assert_array_equal(X, Xs)
+    np.testing.assert_array_equal(lp, lps)
+    assert not np.allclose(cr, 1 / 3.)            # adaptation ran (and was identical on both ranks, or the traces would differ)
+
+
+def test_shard_arithmetic():
+    from pydream_amd.distributed import shard
+    assert shard(32768, 3, 8) == (12288, 4096)
+    with pytest.raises(Exception):
+        shard(10, 0, 4)
+
+
+def test_two_ranks_gloo_oracle_backend(tmp_path):
+    _run_two_ranks("oracle", tmp_path)
+
+
+@pytest.mark.gpu
+def test_two_ranks_one_gpu_hip_engine(tmp_path):
+    _run_two_ranks("hip", tmp_path)
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_comm(tmp_path):
+    """RCCL bootstrap + in-place ncclAllGather with world size 1 (all the 1-GPU box can run)."""
+    from pydream_amd import _capi
+    from tests import helpers as H
+    d, N, n = 16, 8, 25
+    P = H.mvn_precision(d); Z0 = H.seed_history(40, d, 4)
+    res = []
+    for use_comm in (False, True):
+        e = _capi.Engine(nchains=N, ndim=d, multitry=5, history_capacity=40 + N * 8, trace_capacity=n, seed=5, history_thin=5)
+        if use_comm:
+            e.comm_init_rccl(0, 1, _capi.comm_unique_id())
+        e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), P, 0, 0.0)
+        e.step(n)
+        res.append((e.get_trace(0, n)["X"], e.get_history()))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])

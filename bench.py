@@ -105,8 +105,8 @@ def main():
     ap.add_argument("--seed", type=int, default=20260929)
     ap.add_argument("--target", choices=["mvn", "mix3"], default="mvn")
     ap.add_argument("--mvn-kind", choices=["dense", "tri"], default="dense")
-    ap.add_argument("--cpu-chains", type=int, default=256)
-    ap.add_argument("--cpu-steps", type=int, default=150)
+    ap.add_argument("--cpu-chains", type=int, default=512)
+    ap.add_argument("--cpu-steps", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not time individual kernels with HIP events")
     args = ap.parse_args()

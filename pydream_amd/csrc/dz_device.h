@@ -159,11 +159,30 @@ DZ_DEV bool is_finite(double x) { return (x == x) && (x != __builtin_huge_val())
 // ---------------------------------------------------------------- wave-64 reductions
 // lane(j) = (j >> 1) & 63; a lane adds its own dimensions in increasing j; the 64 lane
 // partials are combined by an xor butterfly (32,16,...,1).  Every lane ends with the total.
+// One DPP row rotation (lanes rotate right by ROR inside each row of 16); no LDS crossbar involved.
+template <int ROR>
+DZ_DEV double row_ror(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x120 + ROR, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x120 + ROR, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// p[i] + p[i ^ off] for off = 8,4,2,1 inside rows of 16 lanes.  After the step with offset 2m the values have
+// period 2m within the row, so rotating by m fetches a lane that holds exactly the bits of lane i ^ m.
+DZ_DEV double bfly16(double v)
+{
+    v = v + row_ror<8>(v);
+    v = v + row_ror<4>(v);
+    v = v + row_ror<2>(v);
+    v = v + row_ror<1>(v);
+    return v;
+}
 DZ_DEV double wave_bfly(double v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
-    return v;
+    v = v + __shfl_xor(v, 32, 64);
+    v = v + __shfl_xor(v, 16, 64);
+    return bfly16(v);       // all four rows now hold the same 16 values
 }
 DZ_DEV int wave_isum(int v)
 {

@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -70,6 +71,10 @@ struct dz_engine {
     dz_config c{};
     dz::Params p{};
     hipStream_t stream = nullptr;
+    // independent chain groups ("lanes") run their propose/logp/accept kernels on separate streams: between two
+    // history appends the groups share nothing, so one group's likelihood (matrix pipe) overlaps another's
+    // proposal generation (VALU) -- lane 0 is `stream`
+    int nlanes = 1; hipStream_t lane_stream[8] = {nullptr}; hipEvent_t lane_ev[8] = {nullptr}; bool need_join = true;
     int nch = 1;
     int64_t M = 0, gen = 0, ntrace = 0, draws_gen = -1;
     std::vector<int64_t> gen_c;     // per-chain generation counters (differ only under single-chain stepping)
@@ -90,7 +95,10 @@ struct dz_engine {
     double *d_cmean = nullptr, *d_cvar = nullptr, *d_rhat = nullptr;
     std::vector<double> h_stage;     // host staging (callback likelihood / exchange)
     bool prof = false;
-    bool mvn_wave_kernel = false;
+    int num_cu = 256;
+    int waves_per_block = 0;        // DZ_WPB
+    int propose_split = 1;          // waves per chain in k_propose (DZ_PROPOSE_SPLIT)
+    int force_pt = 0;               // measurement switch: DZ_MFMA_PT=1|2 forces the point tiles per wave
     std::vector<hipEvent_t> ev_pool;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[PR_COUNT];
     std::vector<void*> to_free;
@@ -99,19 +107,25 @@ struct dz_engine {
 namespace {
 
 struct ProfScope {
-    dz_engine* e; int which; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(dz_engine* e_, int w) : e(e_), which(w)
+    dz_engine* e; int which; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(dz_engine* e_, int w, hipStream_t st_ = nullptr) : e(e_), which(w), st(st_ ? st_ : e_->stream)
     {
         if (e->prof) {
             for (hipEvent_t* x : {&a, &b}) {
                 if (!e->ev_pool.empty()) { *x = e->ev_pool.back(); e->ev_pool.pop_back(); }
                 else hipEventCreate(x);
             }
-            hipEventRecord(a, e->stream);
+            hipEventRecord(a, st);
         }
     }
-    ~ProfScope() { if (e->prof) { hipEventRecord(b, e->stream); e->ev[which].emplace_back(a, b); } }
+    ~ProfScope() { if (e->prof) { hipEventRecord(b, st); e->ev[which].emplace_back(a, b); } }
 };
+
+int sync_all(dz_engine* e)
+{
+    for (int s = 0; s < e->nlanes; ++s) HIPCK(hipStreamSynchronize(e->lane_stream[s]));
+    return 0;
+}
 
 template <class T> int ealloc(dz_engine* e, T** p, size_t n)
 {
@@ -126,14 +140,14 @@ int upload_padded(dz_engine* e, double* dst, const double* src, int rows, double
     std::vector<double> h((size_t)rows * ld, padval);
     for (int r = 0; r < rows; ++r) memcpy(&h[(size_t)r * ld], src + (size_t)r * d, sizeof(double) * d);
     HIPCK(hipMemcpyAsync(dst, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, e->stream));
-    HIPCK(hipStreamSynchronize(e->stream));
+    DZCK(sync_all(e));
     return 0;
 }
 int download_rows(dz_engine* e, double* dst, const double* src, size_t rows)
 {   // src [rows,ld] device -> dst [rows,d] host
     HIPCK(hipMemcpy2DAsync(dst, sizeof(double) * e->p.d, src, sizeof(double) * e->p.ld, sizeof(double) * e->p.d, rows,
                            hipMemcpyDeviceToHost, e->stream));
-    HIPCK(hipStreamSynchronize(e->stream));
+    DZCK(sync_all(e));
     return 0;
 }
 
@@ -153,40 +167,48 @@ int launch_check(const char* what)
 }
 
 // Model.total_logp for n points stored [n,ld] on the device
-int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* like)
+int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* like, hipStream_t st = nullptr)
 {
     if (n <= 0) return 0;
-    ProfScope ps(e, PR_LOGP);
+    if (!st) st = e->stream;
+    ProfScope ps(e, PR_LOGP, st);
     const dim3 grid((n + 3) / 4), block(256);
     if (e->lk == LK_MVN) {
-        if (e->mvn_wave_kernel) {      // v1 kernel (one wave per point), kept for A/B measurements
-            const size_t lds = sizeof(double) * 4 * 2 * e->p.ld;
-            NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_logp_mvn<NCH>, grid, block, lds, e->stream, e->p, pts, n, prior, like));
-        } else {
+        {
             const int nrt = e->p.ld / 16;
-            if (nrt <= 8) {
+            if (nrt <= 8 && !e->force_pt) {
                 const int ntiles = (n + 15) / 16;
-                const int pt = ntiles > 1024 ? 2 : 1;       // 1024 SIMDs: share B operands between two point tiles once every SIMD has work
+                const int ks4 = 4 * ((e->p.d + 3) / 4);
+                const size_t lds = sizeof(double) * ((size_t)ks4 * e->p.ld + e->p.ld + (size_t)4 * 16 * (e->p.ld + 1));
+                const dim3 gl((unsigned)std::min(e->num_cu, (ntiles + 3) / 4)), bl(256);
+#define DZ_LDS_CASE(NRT_)                                                                                                      \
+    case NRT_:                                                                                                                 \
+        if (e->p.tri) hipLaunchKernelGGL((dz::k_logp_mvn_lds<NRT_, true>), gl, bl, lds, st, e->p, pts, n, prior, like);  \
+        else hipLaunchKernelGGL((dz::k_logp_mvn_lds<NRT_, false>), gl, bl, lds, st, e->p, pts, n, prior, like);          \
+        break;
+                switch (nrt) { DZ_LDS_CASE(1) DZ_LDS_CASE(2) DZ_LDS_CASE(3) DZ_LDS_CASE(4) DZ_LDS_CASE(5) DZ_LDS_CASE(6) DZ_LDS_CASE(7) DZ_LDS_CASE(8) }
+#undef DZ_LDS_CASE
+            } else if (nrt <= 8) {
+                const int ntiles = (n + 15) / 16;
+                const int pt = (e->force_pt ? e->force_pt : (ntiles > 1024 ? 2 : 1));   // 1024 SIMDs: share B operands between two point tiles once every SIMD has work
                 const dim3 g2((n + 64 * pt - 1) / (64 * pt));
-                const size_t lds = sizeof(double) * 4 * 16 * pt * (nrt * 16 + 1);
 #define DZ_MFMA_CASE(NRT_)                                                                                                                     \
     case NRT_:                                                                                                                                 \
-        if (pt == 2) { if (e->p.tri) hipLaunchKernelGGL((dz::k_logp_mvn_mfma<2, NRT_, true>), g2, block, lds, e->stream, e->p, pts, n, prior, like);   \
-                       else hipLaunchKernelGGL((dz::k_logp_mvn_mfma<2, NRT_, false>), g2, block, lds, e->stream, e->p, pts, n, prior, like); }  \
-        else { if (e->p.tri) hipLaunchKernelGGL((dz::k_logp_mvn_mfma<1, NRT_, true>), g2, block, lds, e->stream, e->p, pts, n, prior, like);           \
-               else hipLaunchKernelGGL((dz::k_logp_mvn_mfma<1, NRT_, false>), g2, block, lds, e->stream, e->p, pts, n, prior, like); }          \
+        if (pt == 2) { if (e->p.tri) hipLaunchKernelGGL((dz::k_logp_mvn_mfma<2, NRT_, true>), g2, block, 0, st, e->p, pts, n, prior, like);   \
+                       else hipLaunchKernelGGL((dz::k_logp_mvn_mfma<2, NRT_, false>), g2, block, 0, st, e->p, pts, n, prior, like); }  \
+        else { if (e->p.tri) hipLaunchKernelGGL((dz::k_logp_mvn_mfma<1, NRT_, true>), g2, block, 0, st, e->p, pts, n, prior, like);           \
+               else hipLaunchKernelGGL((dz::k_logp_mvn_mfma<1, NRT_, false>), g2, block, 0, st, e->p, pts, n, prior, like); }          \
         break;
                 switch (nrt) { DZ_MFMA_CASE(1) DZ_MFMA_CASE(2) DZ_MFMA_CASE(3) DZ_MFMA_CASE(4) DZ_MFMA_CASE(5) DZ_MFMA_CASE(6) DZ_MFMA_CASE(7) DZ_MFMA_CASE(8) }
 #undef DZ_MFMA_CASE
             } else {
                 constexpr int RTC = 8;
-                const size_t lds = sizeof(double) * 4 * 16 * (RTC * 16 + 1);
-                hipLaunchKernelGGL(dz::k_logp_mvn_mfma_big<RTC>, dim3((n + 63) / 64), block, lds, e->stream, e->p, pts, n, prior, like);
+                hipLaunchKernelGGL(dz::k_logp_mvn_mfma_big<RTC>, dim3((n + 63) / 64), block, 0, st, e->p, pts, n, prior, like);
             }
-            if (e->p.have_prior) NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_prior_only<NCH>, grid, block, 0, e->stream, e->p, pts, n, prior));
+            if (e->p.have_prior) NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_prior_only<NCH>, grid, block, 0, st, e->p, pts, n, prior));
         }
     } else if (e->lk == LK_MIX) {
-        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_logp_mix<NCH>, grid, block, 0, e->stream, e->p, pts, n, prior, like));
+        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_logp_mix<NCH>, grid, block, 0, st, e->p, pts, n, prior, like));
     } else if (e->lk == LK_HOST) {
         const int d = e->p.d;
         e->h_stage.resize((size_t)n * (d + 2));
@@ -196,8 +218,8 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
         if (e->cb(hx, n, d, hp, hl, e->cb_user)) return fail("host likelihood callback failed");
         HIPCK(hipMemcpyAsync(prior, hp, sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
         HIPCK(hipMemcpyAsync(like, hl, sizeof(double) * n, hipMemcpyHostToDevice, e->stream));
-        HIPCK(hipStreamSynchronize(e->stream));
-        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_prior_add<NCH>, grid, block, 0, e->stream, e->p, pts, n, prior, like));
+        DZCK(sync_all(e));
+        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_prior_add<NCH>, grid, block, 0, st, e->p, pts, n, prior, like));
     } else return fail("no likelihood set");
     return launch_check("logp kernel");
 }
@@ -219,10 +241,10 @@ int allgather_rows(dz_engine* e, double* buf)
     e->h_stage.resize(cnt * (nranks + 1));
     double* hs = e->h_stage.data(); double* hr = hs + cnt;
     HIPCK(hipMemcpyAsync(hs, mine, sizeof(double) * cnt, hipMemcpyDeviceToHost, e->stream));
-    HIPCK(hipStreamSynchronize(e->stream));
+    DZCK(sync_all(e));
     if (e->xcb(hs, hr, (int64_t)(sizeof(double) * cnt), e->xcb_user)) return fail("exchange callback failed");
     HIPCK(hipMemcpyAsync(buf, hr, sizeof(double) * cnt * nranks, hipMemcpyHostToDevice, e->stream));
-    HIPCK(hipStreamSynchronize(e->stream));
+    DZCK(sync_all(e));
     return 0;
 }
 
@@ -245,6 +267,15 @@ int adapt_generation(dz_engine* e, uint32_t g, int gc0, int ngc)
     return launch_check("adaptation kernels");
 }
 
+// every lane waits for everything queued so far on every other lane
+int join_all(dz_engine* e)
+{
+    if (e->nlanes <= 1) return 0;
+    for (int s = 0; s < e->nlanes; ++s) HIPCK(hipEventRecord(e->lane_ev[s], e->lane_stream[s]));
+    for (int s = 0; s < e->nlanes; ++s)
+        for (int t = 0; t < e->nlanes; ++t) if (t != s) HIPCK(hipStreamWaitEvent(e->lane_stream[s], e->lane_ev[t], 0));
+    return 0;
+}
 // one transition of local chains [c0, c0+nc) at generation g.  Full range = a lockstep generation
 // (schedule S2); a sub-range is the single-chain view used by Dream.astep: its end-of-generation
 // updates (append, publish, adaptation) take effect immediately, as when the reference is driven
@@ -255,31 +286,17 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced)
     const int k = p.k;
     const bool full = (c0 == 0 && nc == p.nl);
     if (!full && e->world > 1) return fail("single-chain stepping is not available on a sharded engine");
+    const int L = (full && e->lk != LK_HOST) ? e->nlanes : 1;     // the host-callback likelihood is synchronous anyway
+    if (e->need_join || !full) { DZCK(join_all(e)); e->need_join = false; }
     if (full && g == 0 && e->adapt) {   // publish the start positions (Dream_shared_vars.current_positions)
         const size_t n = (size_t)p.nl * p.ld;
         hipLaunchKernelGGL(dz::k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, p.X, p.cp_new + (size_t)p.off * p.ld, n);
         DZCK(allgather_rows(e, p.cp_new));
+        DZCK(join_all(e));
     }
     p.draws = e->d_draws[g & 1]; p.draws_next = e->d_draws[(g + 1) & 1];
     p.ctl = e->d_ctl[g & 1]; p.ctl_next = e->d_ctl[(g + 1) & 1];
-    if (!full || e->draws_gen != (int64_t)g) {   // not prepared by k_accept of the previous generation
-        hipLaunchKernelGGL(dz::k_draws, dim3((nc * p.nslots + 255) / 256), dim3(256), 0, e->stream, p, g, c0, nc, e->d_draws[g & 1], e->d_ctl[g & 1]);
-        e->draws_gen = full ? (int64_t)g : -1;
-    }
-    {
-        ProfScope ps(e, PR_PROPOSE);
-        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((nc * k + 3) / 4), dim3(256), 0, e->stream, p, 0, g, (uint32_t)e->M, c0, nc));
-    }
-    DZCK(launch_check("propose"));
-    DZCK(eval_logp(e, p.P + (size_t)c0 * k * p.ld, nc * k, p.p_prior + (size_t)c0 * k, p.p_like + (size_t)c0 * k));
-    if (k > 1) {
-        {
-            ProfScope ps(e, PR_PROPOSE);
-            NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((nc * (k - 1) + 3) / 4), dim3(256), 0, e->stream, p, 1, g, (uint32_t)e->M, c0, nc));
-        }
-        DZCK(launch_check("propose(ref)"));
-        DZCK(eval_logp(e, p.R + (size_t)c0 * (k - 1) * p.ld, nc * (k - 1), p.r_prior + (size_t)c0 * (k - 1), p.r_like + (size_t)c0 * (k - 1)));
-    }
+    const bool need_draws = !full || e->draws_gen != (int64_t)g;     // not prepared by k_accept of the previous generation
     const bool append = (g % (uint32_t)p.thin) == 0;                           // Dream.py:360
     const bool publish = e->adapt && (int64_t)g < (int64_t)p.burnin + 1;      // Dream.py:364
     const int nrows = full ? p.N : nc;
@@ -291,20 +308,47 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced)
             hipLaunchKernelGGL(dz::k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, p.X + (size_t)c0 * p.ld, p.cp_prev + (size_t)(p.off + c0) * p.ld, n);
         }
     }
+    // waves per block: 16 (one block fills a CU's 4 SIMDs evenly) once there is at least one such block per CU
+    const int wpb = e->waves_per_block ? e->waves_per_block : ((nc / L) >= 16 * e->num_cu ? 16 : 4);
+    const int sp0 = std::max(1, std::min(k, e->propose_split)), sp1 = std::max(1, std::min(k - 1, e->propose_split));
     const int64_t slot = (traced && e->c.trace_capacity) ? e->ntrace : -1;
     const int64_t zbase = full ? e->M : e->M - (int64_t)(p.off + c0);
-    {
-        ProfScope ps(e, PR_ACCEPT);
-        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_accept<NCH>, dim3((nc + 3) / 4), dim3(256), 0, e->stream, p, g, zbase, c0, nc, slot, append ? 1 : 0, publish ? 1 : 0, (full && !publish) ? 1 : 0));
+    for (int s = 0; s < L; ++s) {
+        const int lc0 = c0 + (int)((int64_t)nc * s / L), lc1 = c0 + (int)((int64_t)nc * (s + 1) / L), lnc = lc1 - lc0;
+        if (lnc <= 0) continue;
+        hipStream_t st = e->lane_stream[s];
+        if (need_draws)
+            hipLaunchKernelGGL(dz::k_draws, dim3((lnc * p.nslots + 255) / 256), dim3(256), 0, st, p, g, lc0, lnc, e->d_draws[g & 1], e->d_ctl[g & 1]);
+        {
+            ProfScope ps(e, PR_PROPOSE, st);
+            NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((lnc * sp0 + wpb - 1) / wpb), dim3(64 * wpb), 0, st, p, 0, g, (uint32_t)e->M, lc0, lnc, sp0));
+        }
+        DZCK(launch_check("propose"));
+        DZCK(eval_logp(e, p.P + (size_t)lc0 * k * p.ld, lnc * k, p.p_prior + (size_t)lc0 * k, p.p_like + (size_t)lc0 * k, st));
+        if (k > 1) {
+            {
+                ProfScope ps(e, PR_PROPOSE, st);
+                NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((lnc * sp1 + wpb - 1) / wpb), dim3(64 * wpb), 0, st, p, 1, g, (uint32_t)e->M, lc0, lnc, sp1));
+            }
+            DZCK(launch_check("propose(ref)"));
+            DZCK(eval_logp(e, p.R + (size_t)lc0 * (k - 1) * p.ld, lnc * (k - 1), p.r_prior + (size_t)lc0 * (k - 1), p.r_like + (size_t)lc0 * (k - 1), st));
+        }
+        {
+            ProfScope ps(e, PR_ACCEPT, st);
+            NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_accept<NCH>, dim3((lnc + wpb - 1) / wpb), dim3(64 * wpb), 0, st, p, g, zbase, lc0, lnc, slot, append ? 1 : 0, publish ? 1 : 0, (full && !publish) ? 1 : 0));
+        }
+        DZCK(launch_check("accept"));
     }
-    DZCK(launch_check("accept"));
-    if (full && !publish) e->draws_gen = (int64_t)g + 1;     // while adapting, next generation's decisions must wait for the new probabilities
-    if (publish) {
-        if (full) DZCK(allgather_rows(e, p.cp_new));
-        DZCK(adapt_generation(e, g, full ? 0 : p.off + c0, full ? p.N : nc));
-        if (!full) e->draws_gen = -1;
+    e->draws_gen = (full && !publish) ? (int64_t)g + 1 : -1;   // while adapting, next generation's decisions must wait for the new probabilities
+    if (publish || append) {         // shared state changed: the lanes meet before anything reads it
+        if (L > 1) DZCK(join_all(e));
+        if (publish) {
+            if (full) DZCK(allgather_rows(e, p.cp_new));
+            DZCK(adapt_generation(e, g, full ? 0 : p.off + c0, full ? p.N : nc));
+        }
+        if (append) { if (full) DZCK(allgather_rows(e, p.Z + (size_t)e->M * p.ld)); e->M += nrows; }
+        e->need_join = true;
     }
-    if (append) { if (full) DZCK(allgather_rows(e, p.Z + (size_t)e->M * p.ld)); e->M += nrows; }
     for (int c = c0; c < c0 + nc; ++c) e->gen_c[c] = (int64_t)g + 1;
     if (full) e->gen = (int64_t)g + 1;
     if (slot >= 0) e->ntrace++;
@@ -345,11 +389,14 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     dz_engine* e = new dz_engine();
     e->c = *cfg;
     e->gen_c.assign((size_t)cfg->nchains_local, 0);
+    if (const char* kv = getenv("DZ_WPB")) e->waves_per_block = atoi(kv);
+    if (const char* kv = getenv("DZ_PROPOSE_SPLIT")) e->propose_split = atoi(kv);
+    if (const char* kv = getenv("DZ_MFMA_PT")) e->force_pt = atoi(kv) == 2 ? 2 : atoi(kv) == 1 ? 1 : 0;
     dz::Params& p = e->p;
     p.N = cfg->nchains; p.nl = cfg->nchains_local; p.off = cfg->chain_offset; p.d = cfg->ndim;
     p.ld = (cfg->ndim + 15) / 16 * 16;
     p.k = cfg->multitry; p.depairs = cfg->depairs; p.ncr = cfg->ncr; p.ngamma = cfg->ngamma; p.thin = cfg->history_thin;
-    p.burnin = cfg->crossover_burnin; p.adapt_cr = cfg->adapt_crossover; p.adapt_g = cfg->adapt_gamma; p.hard = cfg->hardboundaries;
+    p.burnin = cfg->crossover_burnin; p.adapt_cr = cfg->adapt_crossover; p.adapt_g = cfg->adapt_gamma; p.hard = 0;   // set by dz_set_bounds
     p.k0 = (uint32_t)cfg->seed; p.k1 = (uint32_t)(cfg->seed >> 32);
     p.lamb = cfg->lamb; p.zeta = cfg->zeta; p.snooker = cfg->snooker; p.pgu = cfg->p_gamma_unity; p.T = cfg->temperature;
     const int chunks = (p.ld + 127) / 128;
@@ -357,6 +404,16 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     e->adapt = cfg->adapt_crossover || cfg->adapt_gamma;
     e->world = cfg->nchains / cfg->nchains_local; e->rank = cfg->chain_offset / cfg->nchains_local;
     HIPCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    {
+        int nl_req = 2;                                         // default: two chain groups (measured best)
+        if (const char* ev = getenv("DZ_STREAMS")) nl_req = atoi(ev);
+        e->nlanes = std::max(1, std::min(8, nl_req));
+        if (cfg->nchains_local < 64 * e->nlanes) e->nlanes = 1;
+        e->lane_stream[0] = e->stream;
+        for (int s = 1; s < e->nlanes; ++s) HIPCK(hipStreamCreateWithFlags(&e->lane_stream[s], hipStreamNonBlocking));
+        for (int s = 0; s < e->nlanes; ++s) HIPCK(hipEventCreateWithFlags(&e->lane_ev[s], hipEventDisableTiming));
+    }
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cu = prop.multiProcessorCount; }
     const size_t ld = p.ld, nl = p.nl, N = p.N, k = p.k, tc = (size_t)cfg->trace_capacity;
     int rc = 0;
     rc |= ealloc(e, &p.Z, (size_t)cfg->history_capacity * ld);
@@ -368,6 +425,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     p.npt = 1 + (2 * cfg->depairs + 3) / 4; p.nslots = 3 + (2 * cfg->multitry - 1) * p.npt;
     rc |= ealloc(e, &e->d_draws[0], nl * (size_t)p.nslots); rc |= ealloc(e, &e->d_draws[1], nl * (size_t)p.nslots);
     rc |= ealloc(e, &e->d_ctl[0], nl); rc |= ealloc(e, &e->d_ctl[1], nl);
+    rc |= ealloc(e, &p.sel, nl);
     rc |= ealloc(e, &e->d_mins, ld); rc |= ealloc(e, &e->d_maxs, ld);
     rc |= ealloc(e, &e->d_gtab, (size_t)cfg->ngamma * cfg->depairs * p.d);
     rc |= ealloc(e, &e->d_shared, (size_t)3 * (cfg->ncr + cfg->ngamma));
@@ -406,7 +464,9 @@ int dz_destroy(dz_engine* e)
 {
     if (!e) return 0;
     hipSetDevice(e->c.device);
-    if (e->stream) hipStreamSynchronize(e->stream);
+    for (int s2 = 0; s2 < e->nlanes; ++s2) if (e->lane_stream[s2]) hipStreamSynchronize(e->lane_stream[s2]);
+    for (int s2 = 1; s2 < e->nlanes; ++s2) if (e->lane_stream[s2]) hipStreamDestroy(e->lane_stream[s2]);
+    for (int s2 = 0; s2 < e->nlanes; ++s2) if (e->lane_ev[s2]) hipEventDestroy(e->lane_ev[s2]);
     for (auto& v : e->ev) for (auto& pr : v) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (hipEvent_t x : e->ev_pool) hipEventDestroy(x);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
@@ -420,6 +480,9 @@ int dz_destroy(dz_engine* e)
 int dz_set_bounds(dz_engine* e, const double* mins, const double* maxs)
 {
     HIPCK(hipSetDevice(e->c.device));
+    bool any_finite = false;
+    for (int j = 0; j < e->p.d; ++j) any_finite = any_finite || std::isfinite(mins[j]) || std::isfinite(maxs[j]);
+    e->p.hard = (e->c.hardboundaries && any_finite) ? 1 : 0;     // with all bounds infinite the reflection code can never trigger
     DZCK(upload_padded(e, e->d_mins, mins, 1, -HUGE_VAL));
     return upload_padded(e, e->d_maxs, maxs, 1, HUGE_VAL);
 }
@@ -469,7 +532,7 @@ int dz_set_cr_probs(dz_engine* e, const double* pr, int32_t n)
 {
     if (n != e->c.ncr) return fail("nCR mismatch");
     HIPCK(hipSetDevice(e->c.device));
-    HIPCK(hipStreamSynchronize(e->stream));
+    DZCK(sync_all(e));
     HIPCK(hipMemcpy(e->p.cr_probs, pr, sizeof(double) * n, hipMemcpyHostToDevice));
     e->draws_gen = -1;
     return 0;
@@ -478,7 +541,7 @@ int dz_set_gamma_probs(dz_engine* e, const double* pr, int32_t n)
 {
     if (n != e->c.ngamma) return fail("ngamma mismatch");
     HIPCK(hipSetDevice(e->c.device));
-    HIPCK(hipStreamSynchronize(e->stream));
+    DZCK(sync_all(e));
     HIPCK(hipMemcpy(e->p.g_probs, pr, sizeof(double) * n, hipMemcpyHostToDevice));
     e->draws_gen = -1;
     return 0;
@@ -605,7 +668,7 @@ int dz_get_chain_state(dz_engine* e, int32_t c, double* x, double* prior, double
     HIPCK(hipSetDevice(e->c.device));
     if (c < 0 || c >= e->p.nl) return fail("bad chain index");
     if (x) DZCK(download_rows(e, x, e->p.X + (size_t)c * e->p.ld, 1));
-    HIPCK(hipStreamSynchronize(e->stream));
+    DZCK(sync_all(e));
     if (prior) HIPCK(hipMemcpy(prior, e->p.lprior + c, sizeof(double), hipMemcpyDeviceToHost));
     if (like) HIPCK(hipMemcpy(like, e->p.llike + c, sizeof(double), hipMemcpyDeviceToHost));
     return 0;
@@ -614,7 +677,7 @@ int dz_get_chain_state(dz_engine* e, int32_t c, double* x, double* prior, double
 int dz_sync(dz_engine* e)
 {
     HIPCK(hipSetDevice(e->c.device));
-    HIPCK(hipStreamSynchronize(e->stream));
+    DZCK(sync_all(e));
     return 0;
 }
 int dz_trace_reset(dz_engine* e) { e->ntrace = 0; return 0; }
@@ -624,7 +687,7 @@ int dz_get_state(dz_engine* e, double* X, double* prior, double* like)
 {
     HIPCK(hipSetDevice(e->c.device));
     if (X) DZCK(download_rows(e, X, e->p.X, (size_t)e->p.nl));
-    HIPCK(hipStreamSynchronize(e->stream));
+    DZCK(sync_all(e));
     if (prior) HIPCK(hipMemcpy(prior, e->p.lprior, sizeof(double) * e->p.nl, hipMemcpyDeviceToHost));
     if (like) HIPCK(hipMemcpy(like, e->p.llike, sizeof(double) * e->p.nl, hipMemcpyDeviceToHost));
     return 0;
@@ -636,7 +699,7 @@ int dz_get_trace(dz_engine* e, int64_t g0, int64_t ng, double* X, double* logp, 
     if (g0 < 0 || ng < 0 || g0 + ng > e->ntrace) return fail("trace range");
     const size_t nl = e->p.nl, o = (size_t)g0 * nl, n = (size_t)ng * nl;
     if (X) DZCK(download_rows(e, X, e->p.tX + o * e->p.ld, n));
-    HIPCK(hipStreamSynchronize(e->stream));
+    DZCK(sync_all(e));
     if (logp) HIPCK(hipMemcpy(logp, e->p.tlogp + o, sizeof(double) * n, hipMemcpyDeviceToHost));
     if (moved) HIPCK(hipMemcpy(moved, e->p.tmoved + o, n, hipMemcpyDeviceToHost));
     if (try_idx) HIPCK(hipMemcpy(try_idx, e->p.ttry + o, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
@@ -656,7 +719,7 @@ int dz_get_history(dz_engine* e, double* Z, int64_t cap_rows, int64_t* rows)
 static int get_shared(dz_engine* e, const double* probs, const double* delta, const double* n, int nb, double* o_probs, double* o_delta, double* o_n)
 {
     HIPCK(hipSetDevice(e->c.device));
-    HIPCK(hipStreamSynchronize(e->stream));
+    DZCK(sync_all(e));
     if (o_probs) HIPCK(hipMemcpy(o_probs, probs, sizeof(double) * nb, hipMemcpyDeviceToHost));
     if (o_delta) HIPCK(hipMemcpy(o_delta, delta, sizeof(double) * nb, hipMemcpyDeviceToHost));
     if (o_n) HIPCK(hipMemcpy(o_n, n, sizeof(double) * nb, hipMemcpyDeviceToHost));
@@ -682,7 +745,7 @@ int dz_get_chain_moments(dz_engine* e, double* mean, double* var)
 {
     HIPCK(hipSetDevice(e->c.device));
     DZCK(chain_moments(e));
-    HIPCK(hipStreamSynchronize(e->stream));
+    DZCK(sync_all(e));
     const size_t n = (size_t)e->p.nl * e->p.d;
     HIPCK(hipMemcpy(mean, e->d_cmean, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIPCK(hipMemcpy(var, e->d_cvar, sizeof(double) * n, hipMemcpyDeviceToHost));
@@ -695,7 +758,7 @@ int dz_get_rhat(dz_engine* e, double* rhat)
     const dz::Params& p = e->p;
     hipLaunchKernelGGL(dz::k_rhat, dim3((p.d + 127) / 128), dim3(128), 0, e->stream, e->d_cmean, e->d_cvar, p.nl, p.d, (int)e->ntrace, e->d_rhat);
     DZCK(launch_check("rhat"));
-    HIPCK(hipStreamSynchronize(e->stream));
+    DZCK(sync_all(e));
     HIPCK(hipMemcpy(rhat, e->d_rhat, sizeof(double) * p.d, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -718,7 +781,7 @@ int dz_eval_logp(dz_engine* e, const double* X, int64_t n, double* prior, double
     double* pts = e->d_scratch; double* dp = pts + (size_t)n * e->p.ld; double* dl = dp + n;
     DZCK(upload_padded(e, pts, X, (int)n, 0.0));
     DZCK(eval_logp(e, pts, (int)n, dp, dl));
-    HIPCK(hipStreamSynchronize(e->stream));
+    DZCK(sync_all(e));
     HIPCK(hipMemcpy(prior, dp, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIPCK(hipMemcpy(like, dl, sizeof(double) * n, hipMemcpyDeviceToHost));
     return 0;
@@ -733,7 +796,7 @@ int dz_debug_propose(dz_engine* e, int32_t chain_local, int64_t gen, int32_t pha
     DZCK(need_scratch(e, (size_t)n + 1));
     double* dbase = e->d_scratch; double* dout = dbase + e->p.ld; double* dsl = dout + (size_t)n * e->p.ld;
     DZCK(upload_padded(e, dbase, base, 1, 0.0));
-    NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose_debug<NCH>, dim3((n + 3) / 4), dim3(256), 0, e->stream, e->p, phase, (uint32_t)gen, (uint32_t)e->M,
+    NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose_debug<NCH>, dim3(1), dim3(64), 0, e->stream, e->p, phase, (uint32_t)gen, (uint32_t)e->M,
                                        chain_local, n, dbase, dout, dsl, run_snooker, cr_idx, delta, glev));
     DZCK(launch_check("propose(debug)"));
     DZCK(download_rows(e, pts, dout, (size_t)n));
@@ -753,7 +816,7 @@ int dz_profile_enable(dz_engine* e, int32_t on)
 int dz_profile_reset(dz_engine* e)
 {
     HIPCK(hipSetDevice(e->c.device));
-    HIPCK(hipStreamSynchronize(e->stream));
+    DZCK(sync_all(e));
     for (auto& v : e->ev) { for (auto& pr : v) { e->ev_pool.push_back(pr.first); e->ev_pool.push_back(pr.second); } v.clear(); }
     return 0;
 }
@@ -761,7 +824,7 @@ int dz_profile_get(dz_engine* e, int32_t which, double* total_ms, int64_t* launc
 {
     if (which < 0 || which >= PR_COUNT) return fail("bad profile class");
     HIPCK(hipSetDevice(e->c.device));
-    HIPCK(hipStreamSynchronize(e->stream));
+    DZCK(sync_all(e));
     double tot = 0.0;
     for (auto& pr : e->ev[which]) { float ms = 0.f; HIPCK(hipEventElapsedTime(&ms, pr.first, pr.second)); tot += ms; }
     if (total_ms) *total_ms = tot;

@@ -37,6 +37,7 @@ struct Params {
     // [nl][nslots] uint4; slot 0..2 = control stream idx 0..2, then npt slots per (phase, try)
     const uint4* draws; uint4* draws_next; int nslots, npt;
     const ChainCtl* ctl; ChainCtl* ctl_next;
+    int* sel;      // [nl] selected try | anyfinite<<8, written by the reference-phase proposal wave
 };
 
 struct StepFlags { bool snk; int cr_idx, delta, glev; };
@@ -83,6 +84,26 @@ DZ_DEV u32x4 slot_counter_draw(const Params& p, int slot, uint32_t gc, uint32_t 
     const int phase = q >= p.k ? 1 : 0, tr = phase ? q - p.k : q;
     return philox(p.k0, p.k1, (uint32_t)idx, stream_id(K_PT, (uint32_t)tr, (uint32_t)phase), gc, g);
 }
+// Where a wave gets its uniform draws from: lane s of the wave holds slot s of the chain's precomputed table
+// (ONE coalesced 16-byte load per lane at wave start, then v_readlane), or nothing (evaluate Philox in place).
+struct DrawSrc { uint4 mine; bool have; };
+DZ_DEV DrawSrc load_draws(const Params& p, const uint4* dr, int lane)
+{
+    DrawSrc d; d.have = (dr != nullptr) && p.nslots <= 64; d.mine = make_uint4(0, 0, 0, 0);
+    if (d.have && lane < p.nslots) d.mine = dr[lane];
+    const unsigned zero = threadIdx.x >> 12;        // runtime 0: re-defines the registers by a VALU op, so later
+    d.mine.x += zero; d.mine.y += zero; d.mine.z += zero; d.mine.w += zero;   // v_readlane never waits on the memory counter
+    return d;
+}
+DZ_DEV u32x4 uniform_draw(const Params& p, const DrawSrc& d, int slot, uint32_t gc, uint32_t g)
+{
+    if (d.have) {
+        const int sl = __builtin_amdgcn_readfirstlane(slot);
+        return u32x4{(uint32_t)__builtin_amdgcn_readlane((int)d.mine.x, sl), (uint32_t)__builtin_amdgcn_readlane((int)d.mine.y, sl),
+                     (uint32_t)__builtin_amdgcn_readlane((int)d.mine.z, sl), (uint32_t)__builtin_amdgcn_readlane((int)d.mine.w, sl)};
+    }
+    return slot_counter_draw(p, slot, gc, g);
+}
 // uniform draw: from the precomputed table when available (dr != nullptr), else evaluated in place
 DZ_DEV u32x4 uniform_draw(const Params& p, const uint4* dr, int slot, uint32_t gc, uint32_t g)
 {
@@ -102,24 +123,36 @@ DZ_DEV Ctrl ctrl_from(const Params& p, const uint4* dr, uint32_t gc, uint32_t g)
 // generate_proposal_points :670-796 (+ snooker_update :798-837, sample_from_history :646-668,
 // set_gamma :601-626).  grid: ceil(nc*n/4) blocks of 256; one wave per (chain, try).
 // ------------------------------------------------------------------------------------------
-template <int NCH>
-DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, int c, int i, int n, int lane,
-                          const double* __restrict__ base, double* __restrict__ out, double* slogp_out,
-                          double* cur_snk_out, bool snk, int cr_idx, int delta, int glev, const uint4* dr)
+// number of 32-bit words w with (w + 1/2) 2^-32 < CR, so that `U_j < CR` (:704, :723) is the integer test
+// w < crossover_threshold(CR) -- exactly the same predicate as the double comparison
+DZ_DEV uint64_t crossover_threshold(double CR)
 {
-    const int d = p.d, ld = p.ld;
-    const uint32_t gc = (uint32_t)(p.off + c);
-    const double CR = (double)(cr_idx + 1) / (double)p.ncr;                   // :146
-    const uint32_t s_dim = stream_id(K_DIM, (uint32_t)i, (uint32_t)phase),
-                   s_bnd = stream_id(K_BND, (uint32_t)i, (uint32_t)phase);
-    double xb[NCH][2], pr[NCH][2];
+    const double t = CR * 4294967296.0 - 0.5;          // exact: CR*2^32 <= 2^32 has ulp <= 2^-21
+    const double c = ceil(t);
+    return c <= 0.0 ? 0ull : (uint64_t)c;
+}
+
+template <int NCH>
+DZ_DEV void load_row(const double* __restrict__ base, int ld, int lane, double (&xb)[NCH][2])
+{
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
         const int jj = 128 * it + 2 * lane;
         xb[it][0] = 0.0; xb[it][1] = 0.0;
         if (jj < ld) { const double2 t = *reinterpret_cast<const double2*>(base + jj); xb[it][0] = t.x; xb[it][1] = t.y; }
     }
-    double slogp = 0.0;
+}
+
+// Z rows of one try.  DE: a = sum of the first delta rows, b = sum of
+// the last delta rows (sample_from_history :646-668, chain_differences :692); snooker: a = z, b, c = the
+// projected pair (:808-810).
+template <int NCH> struct ZRows { double a[NCH][2], b[NCH][2], c[NCH][2]; };
+
+template <int NCH>
+DZ_DEV void fetch_rows(const Params& p, int phase, uint32_t g, uint32_t M, uint32_t gc, int i, int lane, bool snk, int delta,
+                       const DrawSrc& dr, ZRows<NCH>& zr)
+{
+    const int ld = p.ld;
     if (!snk) {
         uint32_t rows[2 * MAXPAIR];
         {   // random.sample(range(M), 2*delta) :662
@@ -136,58 +169,29 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
                 sorted[pos] = r; rows[t] = r;
             }
         }
-        double df[NCH][2];
 #pragma unroll
-        for (int it = 0; it < NCH; ++it) {    // chain_differences :692
+        for (int it = 0; it < NCH; ++it) {
             const int jj = 128 * it + 2 * lane;
-            df[it][0] = 0.0; df[it][1] = 0.0;
+            double2 a = {0.0, 0.0}, b = {0.0, 0.0};
             if (jj < ld) {
-                double2 a = *reinterpret_cast<const double2*>(p.Z + (size_t)rows[0] * ld + jj);
-                double2 b = *reinterpret_cast<const double2*>(p.Z + (size_t)rows[delta] * ld + jj);
-                for (int t = 1; t < delta; ++t) {
-                    const double2 a2 = *reinterpret_cast<const double2*>(p.Z + (size_t)rows[t] * ld + jj);
-                    const double2 b2 = *reinterpret_cast<const double2*>(p.Z + (size_t)rows[delta + t] * ld + jj);
-                    a.x = a.x + a2.x; a.y = a.y + a2.y; b.x = b.x + b2.x; b.y = b.y + b2.y;
+                if (delta == 1) {       // common case kept free of arithmetic on the loaded values: the loads stay in
+                    a = *reinterpret_cast<const double2*>(p.Z + (size_t)rows[0] * ld + jj);      // flight until the
+                    b = *reinterpret_cast<const double2*>(p.Z + (size_t)rows[1] * ld + jj);      // consumer needs them
+                } else {
+                    a = *reinterpret_cast<const double2*>(p.Z + (size_t)rows[0] * ld + jj);
+                    b = *reinterpret_cast<const double2*>(p.Z + (size_t)rows[delta] * ld + jj);
+                    for (int t = 1; t < delta; ++t) {
+                        const double2 a2 = *reinterpret_cast<const double2*>(p.Z + (size_t)rows[t] * ld + jj);
+                        const double2 b2 = *reinterpret_cast<const double2*>(p.Z + (size_t)rows[delta + t] * ld + jj);
+                        a.x = a.x + a2.x; a.y = a.y + a2.y; b.x = b.x + b2.x; b.y = b.y + b2.y;
+                    }
                 }
-                df[it][0] = a.x - b.x; df[it][1] = a.y - b.y;
             }
+            zr.a[it][0] = a.x; zr.a[it][1] = a.y; zr.b[it][0] = b.x; zr.b[it][1] = b.y; zr.c[it][0] = 0.0; zr.c[it][1] = 0.0;
         }
-        bool keep[NCH][2]; double e1[NCH][2], zt[NCH][2];
-        int cnt = 0;
-#pragma unroll
-        for (int it = 0; it < NCH; ++it)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {     // zeta, e, U :694-700
-                const int j = 128 * it + 2 * lane + s;
-                keep[it][s] = false; e1[it][s] = 0.0; zt[it][s] = 0.0;
-                if (j < d) {
-                    const u32x4 w = philox(p.k0, p.k1, (uint32_t)j, s_dim, gc, g);
-                    keep[it][s] = u32d(w.x) < CR;
-                    e1[it][s] = (-p.lamb + (p.lamb - (-p.lamb)) * u32d(w.y)) + 1.0;
-                    zt[it][s] = p.zeta * (double)normal32(w.z, w.w);
-                    cnt += keep[it][s] ? 1 : 0;
-                }
-            }
-        const int dprime = wave_isum(cnt);                                     // :704 / :709
-        const u32x4 wg = uniform_draw(p, dr, pt_slot(p, phase, i, 0), gc, g);  // set_gamma :615
-        double gamma = 1.0;
-        if (!(u53(wg.x, wg.y) < p.pgu))
-            gamma = p.gtab[((size_t)(glev - 1) * p.depairs + (delta - 1)) * d + ((dprime == 0 ? d : dprime) - 1)];   // :624
-#pragma unroll
-        for (int it = 0; it < NCH; ++it)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {     // :714 / :717, crossover :720-726
-                double t = e1[it][s] * gamma; t = t * df[it][s];
-                double q = xb[it][s] + t; q = q + zt[it][s];
-                pr[it][s] = keep[it][s] ? q : xb[it][s];
-            }
     } else {
-        const u32x4 wg = uniform_draw(p, dr, pt_slot(p, phase, 0, 0), gc, g);
-        const double gamma_s = 1.2 + (2.2 - 1.2) * u53(wg.z, wg.w);            // :618
         const u32x4 wi = uniform_draw(p, dr, pt_slot(p, phase, i, 1), gc, g);  // :808-810
         const uint32_t iz = mulhi_idx(wi.x, M), i1 = mulhi_idx(wi.y, M), i2 = mulhi_idx(wi.z, M);
-        double v[NCH][2], dzz[NCH][2], zz[NCH][2];
-        double accD = 0.0, accS = 0.0;
 #pragma unroll
         for (int it = 0; it < NCH; ++it) {
             const int jj = 128 * it + 2 * lane;
@@ -197,11 +201,109 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
                 r1 = *reinterpret_cast<const double2*>(p.Z + (size_t)i1 * ld + jj);
                 r2 = *reinterpret_cast<const double2*>(p.Z + (size_t)i2 * ld + jj);
             }
-            zz[it][0] = z.x; zz[it][1] = z.y;
-            v[it][0] = xb[it][0] - z.x; v[it][1] = xb[it][1] - z.y;            // :813
-            dzz[it][0] = r1.x - r2.x; dzz[it][1] = r1.y - r2.y;                // :819
+            zr.a[it][0] = z.x; zr.a[it][1] = z.y; zr.b[it][0] = r1.x; zr.b[it][1] = r1.y; zr.c[it][0] = r2.x; zr.c[it][1] = r2.y;
+        }
+    }
+}
+
+// gamma_arr[level-1][delta-1][:] (Dream.py:172-179) in the lanes' registers, same dimension->lane layout as a
+// data row: the look-up gamma_arr[..][d'-1] (:624) becomes a v_readlane instead of a dependent global load
+// at the very end of every try.
+template <int NCH>
+DZ_DEV void load_gamma_row(const Params& p, int glev, int delta, int lane, double (&gt)[NCH][2])
+{
+    const double* row = p.gtab + ((size_t)(glev - 1) * p.depairs + (delta - 1)) * p.d;
+    const double zero = (double)(threadIdx.x >> 12);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) if (jj + s < d) { accD = fma(v[it][s], v[it][s], accD); accS = fma(dzz[it][s], v[it][s], accS); }
+    for (int it = 0; it < NCH; ++it)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { const int j = 128 * it + 2 * lane + s; gt[it][s] = (j < p.d ? row[j] : 0.0) + zero; }
+}
+template <int NCH>
+DZ_DEV double gamma_lookup(const double (&gt)[NCH][2], int idx)      // idx wave-uniform
+{
+    const int u = __builtin_amdgcn_readfirstlane(idx);
+    const int it = u >> 7, ln = (u & 127) >> 1, sb = u & 1;
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) if (q == it) v = sb ? gt[q][1] : gt[q][0];
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), ln), hi = __builtin_amdgcn_readlane((int)(b >> 32), ln);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// What propose_point needs from the fetched rows, reduced to VALU-defined registers as soon as the loads land
+// (so that later instructions never wait on the memory counter for them): DE: a = Z_a - Z_b (:692);
+// snooker: a = z, b = zR1 - zR2 (:819).
+template <int NCH> struct RowTerms { double a[NCH][2], b[NCH][2]; };
+template <int NCH>
+DZ_DEV void reduce_rows(const ZRows<NCH>& zr, bool snk, RowTerms<NCH>& rt)
+{
+#pragma unroll
+    for (int it = 0; it < NCH; ++it)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            rt.a[it][s] = snk ? zr.a[it][s] : zr.a[it][s] - zr.b[it][s];
+            rt.b[it][s] = snk ? zr.b[it][s] - zr.c[it][s] : 0.0;
+        }
+}
+
+template <int NCH>
+DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, int c, int i, int n, int lane,
+                          const double (&xb)[NCH][2], const double (&gt)[NCH][2], const RowTerms<NCH>& zr, double* __restrict__ out, double* slogp_out,
+                          double* cur_snk_out, bool snk, int cr_idx, int delta, int glev, const DrawSrc& dr)
+{
+    const int d = p.d, ld = p.ld;
+    const uint32_t gc = (uint32_t)(p.off + c);
+    const uint64_t thr = crossover_threshold((double)(cr_idx + 1) / (double)p.ncr);   // CR = CR_values[m], :146
+    const uint32_t s_dim = stream_id(K_DIM, (uint32_t)i, (uint32_t)phase),
+                   s_bnd = stream_id(K_BND, (uint32_t)i, (uint32_t)phase);
+    double pr[NCH][2];
+    double slogp = 0.0;
+    if (!snk) {
+        bool keep[NCH][2]; double e1[NCH][2], zt[NCH][2];
+        int dprime = 0;
+#pragma unroll
+        for (int it = 0; it < NCH; ++it)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {     // zeta, e, U :694-700
+                const int j = 128 * it + 2 * lane + s;
+                keep[it][s] = false; e1[it][s] = 0.0; zt[it][s] = 0.0;
+                if (j < d) {
+                    const u32x4 w = philox(p.k0, p.k1, (uint32_t)j, s_dim, gc, g);
+                    keep[it][s] = (uint64_t)w.x < thr;                       // U_j < CR
+                    e1[it][s] = (-p.lamb + (p.lamb - (-p.lamb)) * u32d(w.y)) + 1.0;
+                    zt[it][s] = p.zeta * (double)normal32(w.z, w.w);
+                }
+                dprime += __popcll(__ballot(keep[it][s]));                     // d' :704 / :709
+            }
+        const u32x4 wg = uniform_draw(p, dr, pt_slot(p, phase, i, 0), gc, g);  // set_gamma :615
+        double gamma = 1.0;
+        if (!(u53(wg.x, wg.y) < p.pgu))
+            gamma = gamma_lookup<NCH>(gt, (dprime == 0 ? d : dprime) - 1);      // gamma_arr[level-1][delta-1][d'-1], :624
+#pragma unroll
+        for (int it = 0; it < NCH; ++it)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {     // :714 / :717, crossover :720-726
+                double t = e1[it][s] * gamma; t = t * zr.a[it][s];                          // chain_differences :692
+                double q = xb[it][s] + t; q = q + zt[it][s];
+                pr[it][s] = keep[it][s] ? q : xb[it][s];
+            }
+    } else {
+        const u32x4 wg = uniform_draw(p, dr, pt_slot(p, phase, 0, 0), gc, g);
+        const double gamma_s = 1.2 + (2.2 - 1.2) * u53(wg.z, wg.w);            // :618
+        double v[NCH][2], dzz[NCH][2], zz[NCH][2];
+        double accD = 0.0, accS = 0.0;
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) {
+            const int jj = 128 * it + 2 * lane;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                zz[it][s] = zr.a[it][s];
+                v[it][s] = xb[it][s] - zr.a[it][s];                            // :813
+                dzz[it][s] = zr.b[it][s];                                      // :819
+                if (jj + s < d) { accD = fma(v[it][s], v[it][s], accD); accS = fma(dzz[it][s], v[it][s], accS); }
+            }
         }
         const double D = wave_bfly(accD);                                      // :816 / :827
         if (n > 1) {
@@ -264,35 +366,135 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
     if (lane == 0) *slogp_out = slogp;
 }
 
+// split = 1: one wave per CHAIN (control decisions, crossover threshold and base row fetched once, the wave
+// loops over the tries); split = n: one wave per (chain, try).  The host picks by problem size: per-chain
+// waves do ~35% fewer instructions, per-try waves expose 5x more parallelism.
 template <int NCH>
-__global__ __launch_bounds__(256) void k_propose(Params p, int phase, uint32_t g, uint32_t M, int c0, int nc)
+__global__ __launch_bounds__(1024) void k_propose(Params p, int phase, uint32_t g, uint32_t M, int c0, int nc, int split)
 {
     const int n = phase == 0 ? p.k : p.k - 1;
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform: scalar Philox for the control draws
-    if (wave >= nc * n) return;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (wave >= nc * split) return;
     const int lane = threadIdx.x & 63;
-    const int c = c0 + wave / n, i = wave % n;
-    const uint4* dr = p.draws + (size_t)c * p.nslots;
+    const int c = c0 + wave / split;
+    const int per = (n + split - 1) / split;
+    const int i0 = (wave % split) * per, i1 = min(n, i0 + per);
+    const DrawSrc dsrc = load_draws(p, p.draws + (size_t)c * p.nslots, lane);
     const ChainCtl ct = p.ctl[c];
-    StepFlags f; f.snk = ct.snk != 0; f.cr_idx = ct.cr_idx; f.delta = ct.delta; f.glev = ct.glev;
     const double* base; double* out; double* sl;
-    if (phase == 0) { base = p.X + (size_t)c * p.ld; out = p.P + ((size_t)c * p.k + i) * p.ld; sl = p.p_slogp + (size_t)c * p.k + i; }
+    if (phase == 0) { base = p.X + (size_t)c * p.ld; out = p.P + (size_t)c * p.k * p.ld; sl = p.p_slogp + (size_t)c * p.k; }
     else {
         bool fin; const int sel = mt_select(p, c, ct.u_sel, lane, &fin);
-        base = p.P + ((size_t)c * p.k + sel) * p.ld; out = p.R + ((size_t)c * (p.k - 1) + i) * p.ld; sl = p.r_slogp + (size_t)c * (p.k - 1) + i;
+        if (lane == 0 && i0 == 0) p.sel[c] = sel | (fin ? 256 : 0);
+        base = p.P + ((size_t)c * p.k + sel) * p.ld; out = p.R + (size_t)c * (p.k - 1) * p.ld; sl = p.r_slogp + (size_t)c * (p.k - 1);
     }
-    propose_point<NCH>(p, phase, g, M, c, i, n, lane, base, out, sl, (phase == 0 && p.k == 1) ? p.cur_snk + c : nullptr,
-                       f.snk, f.cr_idx, f.delta, f.glev, dr);
+    double xb[NCH][2];
+    load_row<NCH>(base, p.ld, lane, xb);
+    {
+        const double zero = (double)(threadIdx.x >> 12);
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) { xb[it][0] = xb[it][0] + zero; xb[it][1] = xb[it][1] + zero; }   // VALU-defined (see load_draws)
+    }
+    double gt[NCH][2];
+    load_gamma_row<NCH>(p, ct.glev, ct.delta, lane, gt);
+    const uint32_t gc = (uint32_t)(p.off + c);
+    const bool snk = ct.snk != 0;
+    double* csn = (phase == 0 && p.k == 1) ? p.cur_snk + c : nullptr;
+    // software pipeline over the tries: the Z rows of try i+1 are requested before try i's arithmetic starts,
+    // and no scalar memory wait sits in between because the draws are already in registers
+    if (!snk && ct.delta == 1) {
+        // Common case (DE move, one pair): straight-line software pipeline.  The two Z rows of try i+1 are
+        // requested right after try i's difference has been formed, and stay in flight during try i's
+        // random numbers and arithmetic.  (Kept free of other control flow on purpose: any merge of paths that
+        // define the row registers makes the compiler wait for the loads at the merge.)
+        double2 ra[NCH], rb[NCH];
+        auto request = [&](int i) {
+            const u32x4 w = uniform_draw(p, dsrc, pt_slot(p, phase, i, 1), gc, g);
+            const uint32_t r0 = mulhi_idx(w.x, M);
+            uint32_t r1 = mulhi_idx(w.y, M - 1u);
+            if (r1 >= r0) r1++;                                   // random.sample(range(M), 2) :662
+#pragma unroll
+            for (int it = 0; it < NCH; ++it) {
+                const int jj = 128 * it + 2 * lane;
+                if (jj < p.ld) {
+                    ra[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)r0 * p.ld + jj);
+                    rb[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)r1 * p.ld + jj);
+                }
+            }
+        };
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) { ra[it] = double2{0.0, 0.0}; rb[it] = double2{0.0, 0.0}; }
+        request(i0);
+        for (int i = i0; i < i1; ++i) {
+            RowTerms<NCH> rt;
+#pragma unroll
+            for (int it = 0; it < NCH; ++it) {
+                rt.a[it][0] = ra[it].x - rb[it].x; rt.a[it][1] = ra[it].y - rb[it].y;   // chain_differences :692
+                rt.b[it][0] = 0.0; rt.b[it][1] = 0.0;
+            }
+            if (i + 1 < i1) request(i + 1);
+            propose_point<NCH>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * p.ld, sl + i, csn, false, ct.cr_idx, 1, ct.glev, dsrc);
+        }
+        return;
+    }
+    if (snk) {
+        // snooker move: same pipeline with three rows per try (z and the projected pair, :808-810)
+        double2 rz[NCH], r1[NCH], r2[NCH];
+        auto request = [&](int i) {
+            const u32x4 w = uniform_draw(p, dsrc, pt_slot(p, phase, i, 1), gc, g);
+            const uint32_t iz = mulhi_idx(w.x, M), i1x = mulhi_idx(w.y, M), i2x = mulhi_idx(w.z, M);
+#pragma unroll
+            for (int it = 0; it < NCH; ++it) {
+                const int jj = 128 * it + 2 * lane;
+                if (jj < p.ld) {
+                    rz[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)iz * p.ld + jj);
+                    r1[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)i1x * p.ld + jj);
+                    r2[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)i2x * p.ld + jj);
+                }
+            }
+        };
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) { rz[it] = double2{0.0, 0.0}; r1[it] = rz[it]; r2[it] = rz[it]; }
+        request(i0);
+        for (int i = i0; i < i1; ++i) {
+            RowTerms<NCH> rt;
+#pragma unroll
+            for (int it = 0; it < NCH; ++it) {
+                rt.a[it][0] = rz[it].x; rt.a[it][1] = rz[it].y;
+                rt.b[it][0] = r1[it].x - r2[it].x; rt.b[it][1] = r1[it].y - r2[it].y;          // :819
+            }
+            if (i + 1 < i1) request(i + 1);
+            propose_point<NCH>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * p.ld, sl + i, csn, true, ct.cr_idx, ct.delta, ct.glev, dsrc);
+        }
+        return;
+    }
+    for (int i = i0; i < i1; ++i) {     // DEpairs > 1
+        ZRows<NCH> raw;
+        RowTerms<NCH> rt;
+        fetch_rows<NCH>(p, phase, g, M, gc, i, lane, false, ct.delta, dsrc, raw);
+        reduce_rows<NCH>(raw, false, rt);
+        propose_point<NCH>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * p.ld, sl + i, csn, false, ct.cr_idx, ct.delta, ct.glev, dsrc);
+    }
 }
 
-// debug entry: flags supplied by the host (function-level parity tests)
+// debug entry: flags supplied by the host (function-level parity tests); one wave, all tries
 template <int NCH>
-__global__ __launch_bounds__(256) void k_propose_debug(Params p, int phase, uint32_t g, uint32_t M, int c, int n,
-                                                      const double* base, double* out, double* sl, int snk, int cr_idx, int delta, int glev)
+__global__ __launch_bounds__(64) void k_propose_debug(Params p, int phase, uint32_t g, uint32_t M, int c, int n,
+                                                     const double* base, double* out, double* sl, int snk, int cr_idx, int delta, int glev)
 {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n) return;
-    propose_point<NCH>(p, phase, g, M, c, i, n, threadIdx.x & 63, base, out + (size_t)i * p.ld, sl + i, nullptr, snk != 0, cr_idx, delta, glev, nullptr);
+    const int lane = threadIdx.x & 63;
+    double xb[NCH][2];
+    load_row<NCH>(base, p.ld, lane, xb);
+    ZRows<NCH> zr;
+    double gt[NCH][2];
+    load_gamma_row<NCH>(p, glev, delta, lane, gt);
+    const DrawSrc none = load_draws(p, nullptr, lane);
+    for (int i = 0; i < n; ++i) {
+        fetch_rows<NCH>(p, phase, g, M, (uint32_t)(p.off + c), i, lane, snk != 0, delta, none, zr);
+        RowTerms<NCH> rt;
+        reduce_rows<NCH>(zr, snk != 0, rt);
+        propose_point<NCH>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * p.ld, sl + i, nullptr, snk != 0, cr_idx, delta, glev, none);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -321,71 +523,23 @@ DZ_DEV double prior_of_point(const Params& p, const double (&x)[NCH][2], int lan
 }
 DZ_DEV double nan_to_ninf(double x) { return x != x ? -__builtin_huge_val() : x; }
 
-// MVN (examples/ndim_gaussian/dream_ex_ndim_gaussian.py:49-52), v1: one wave per point.
-// y_r = sum_c M[r][c] v_c (ascending c, fma chain); Q = sum_r y_r s_r (ascending r, fma chain).
-// Mt is M transposed, [d][ld], so that lanes (= rows r) read consecutive addresses.
-template <int NCH>
-__global__ __launch_bounds__(256) void k_logp_mvn(Params p, const double* __restrict__ pts, int npts, double* prior_out, double* like_out)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int pt = blockIdx.x * 4 + wv;
-    const int ptc = pt < npts ? pt : npts - 1;
-    double* vs = lds + (size_t)wv * 2 * p.ld;
-    double* ys = vs + p.ld;
-    double x[NCH][2];
-#pragma unroll
-    for (int it = 0; it < NCH; ++it) {
-        const int jj = 128 * it + 2 * lane;
-        x[it][0] = 0.0; x[it][1] = 0.0;
-        if (jj < p.ld) {
-            const double2 t = *reinterpret_cast<const double2*>(pts + (size_t)ptc * p.ld + jj);
-            x[it][0] = t.x; x[it][1] = t.y;
-            vs[jj] = (jj < p.d) ? t.x - p.mu[jj] : 0.0;
-            vs[jj + 1] = (jj + 1 < p.d) ? t.y - p.mu[jj + 1] : 0.0;
-        }
-    }
-    const double prior = prior_of_point<NCH>(p, x, lane);
-    __syncthreads();
-    double y[2 * NCH];
-#pragma unroll
-    for (int rr = 0; rr < 2 * NCH; ++rr) y[rr] = 0.0;
-    for (int c = 0; c < p.d; ++c) {
-        const double vc = vs[c];
-        const double* col = p.Mt + (size_t)c * p.ld;
-#pragma unroll
-        for (int rr = 0; rr < 2 * NCH; ++rr) {
-            const int r = lane + 64 * rr;
-            if (r < p.d && (!p.tri || r <= c)) y[rr] = fma(col[r], vc, y[rr]);
-        }
-    }
-#pragma unroll
-    for (int rr = 0; rr < 2 * NCH; ++rr) { const int r = lane + 64 * rr; if (r < p.ld) ys[r] = y[rr]; }
-    __syncthreads();
-    double Q = 0.0;
-    for (int r = 0; r < p.d; ++r) { const double yr = ys[r]; Q = fma(yr, p.tri ? yr : vs[r], Q); }
-    if (pt < npts && lane == 0) { prior_out[pt] = nan_to_ninf(prior); like_out[pt] = nan_to_ninf(p.logF - 0.5 * Q); }
-}
-
-// MVN on the matrix pipe.  v_mfma_f64_16x16x4_f64 accumulates exactly like an ascending-k fma chain
-// (tools/mfma_f64_layout.hip, measured on gfx950: 0 mismatches in 51200, 77.6 TFLOP/s), so
-// Y[p][r] = sum_c M[r][c] v[p][c] comes out bit-identical to the scalar contract.  One wave = 16 points:
+// MVN likelihood (examples/ndim_gaussian/dream_ex_ndim_gaussian.py:49-52) on the FP64 matrix pipe.
+// v_mfma_f64_16x16x4_f64 accumulates exactly like an ascending-k fma chain (tools/mfma_f64_layout.hip,
+// measured on gfx950: 0 mismatches in 51200 outputs, 77.6 TFLOP/s), so y[p][r] = sum_c M[r][c] v[p][c]
+// (ascending c) comes out bit-identical to the scalar contract.  One wave = PT tiles of 16 points:
 //   A operand (16 points x 4 cols): lane l supplies v[p0 + l%16][4 ks + l/16]
-//   B operand (4 cols x 16 rows):   lane l supplies Mt[4 ks + l/16][16 rt + l%16]
-//   D: lane l, element e holds Y[p0 + l/16 + 4 e][16 rt + l%16]
-// Row tiles are produced RTC at a time, spilled to LDS and folded into the per-point chain
-// Q = fma(y_r, s_r, Q) (ascending r) by lanes 0..15.  For the triangular factor the k-steps left of the
-// diagonal tile are skipped (their entries are structural zeros).
+//   B operand (4 cols x 16 rows):   lane l supplies Mt[4 ks + l/16][16 t + l%16]   (shared by the PT tiles)
+//   D: lane l, element e holds y[p0 + l/16 + 4 e][16 t + l%16]
+// Q contract: row r = 16 t + i adds fma(y_r, s_r, acc_i) to partial i = r mod 16 in ascending t; the 16
+// partials are combined by an xor butterfly (8,4,2,1) -- which is exactly the D layout, so the quadratic
+// form never leaves the registers.  s = v (dense precision) or y (triangular factor; the k-steps left of
+// a diagonal tile are structural zeros and are skipped).
 typedef double dz_double4 __attribute__((ext_vector_type(4)));
 
-// Specialisation for ld <= 128 (NRT = ld/16 row tiles, all accumulators live in registers):
-// PT point tiles (16 points each) per wave share every B operand; the A operands of all k-steps are
-// loaded up front; the k loop is fully unrolled so the B loads are hoisted ahead of the MFMAs.
+// ld <= 128: NRT = ld/16 row tiles, everything in registers, k loop fully unrolled
 template <int PT, int NRT, bool TRI>
 __global__ __launch_bounds__(256) void k_logp_mvn_mfma(Params p, const double* __restrict__ pts, int npts, double* prior_out, double* like_out)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int YS = NRT * 16 + 1;
     constexpr int KSP = NRT * 4;
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int p0 = (blockIdx.x * 4 + wv) * 16 * PT;
@@ -393,7 +547,6 @@ __global__ __launch_bounds__(256) void k_logp_mvn_mfma(Params p, const double* _
     const int pi = l & 15, kq = l >> 4;
     const int ld = p.ld, d = p.d;
     const int KS = (d + 3) >> 2;
-    double* Ys = lds + (size_t)wv * 16 * PT * YS;
     double A[PT][KSP];
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
@@ -424,38 +577,153 @@ __global__ __launch_bounds__(256) void k_logp_mvn_mfma(Params p, const double* _
 #pragma unroll
     for (int u = 0; u < PT; ++u)
 #pragma unroll
-        for (int t = 0; t < NRT; ++t)
+        for (int e = 0; e < 4; ++e) {
+            const int pt = p0 + 16 * u + kq + 4 * e;
+            const double* xs = pts + (size_t)min(pt, npts - 1) * ld;
+            double q = 0.0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) Ys[(16 * u + kq + 4 * e) * YS + 16 * t + pi] = acc[u][t][e];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (l < 16 * PT && p0 + l < npts) {
-        const double* xr = pts + (size_t)(p0 + l) * ld;
-        double Q = 0.0;
-        for (int r = 0; r < d; ++r) {
-            const double y = Ys[l * YS + r];
-            Q = fma(y, TRI ? y : xr[r] - p.mu[r], Q);
+            for (int t = 0; t < NRT; ++t) {
+                const int r = 16 * t + pi;
+                const double y = acc[u][t][e];
+                const double sv = TRI ? y : xs[r] - p.mu[r];
+                if (r < d) q = fma(y, sv, q);
+            }
+            q = bfly16(q);
+            if (pi == 0 && pt < npts) {
+                like_out[pt] = nan_to_ninf(p.logF - 0.5 * q);
+                if (!p.have_prior) prior_out[pt] = 0.0;
+            }
         }
-        like_out[p0 + l] = nan_to_ninf(p.logF - 0.5 * Q);
-        if (!p.have_prior) prior_out[p0 + l] = 0.0;
+}
+
+// Persistent variant (ld <= 128): operands through LDS.
+//  * The 16 points of a tile are 16*ld contiguous doubles: the wave streams them with full-width coalesced
+//    loads (16 B per lane) into a private LDS tile and only then picks the A operands out of it in the
+//    MFMA layout.  (Fetching the A layout straight from global memory -- 16 rows x 32 B per instruction,
+//    each line revisited four times -- measured 3-7x the footprint in L2 misses and 21-32% matrix-pipe
+//    utilisation.)
+//  * The matrix (the same for every point) is staged once per block; each block starts its copy at a
+//    different offset so the CUs do not sweep the L2 channels in lockstep.  B reads are conflict-free
+//    (16 consecutive doubles per k-row, k-rows 896 B apart = bank offset 32).
+// One block (4 waves, one per SIMD) per CU loops over the point tiles; the next tile's rows are fetched
+// into registers while the current tile's MFMAs run.
+template <int NRT, bool TRI>
+__global__ __launch_bounds__(256) void k_logp_mvn_lds(Params p, const double* __restrict__ pts, int npts, double* prior_out, double* like_out)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int KSP = NRT * 4;
+    constexpr int LD = NRT * 16;          // == p.ld
+    constexpr int LDT = LD + 1;           // padded tile row: the A-layout reads hit distinct banks
+    constexpr int NV = LD / 8;            // double2 loads per lane for one tile (16*LD/2/64)
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int d = p.d;
+    const int KS = (d + 3) >> 2;
+    double* Ms = smem;                                    // [4*KS][LD]
+    double* mus = Ms + (size_t)4 * KS * LD;               // [LD]
+    double* Vt = mus + LD + (size_t)wv * 16 * LDT;        // [16][LDT] per wave
+    const int pi = l & 15, kq = l >> 4;
+    const int ntiles = (npts + 15) >> 4;
+    const double* mbase = Ms + (size_t)kq * LD + pi;
+    int tile = blockIdx.x * 4 + wv;
+    double2 nx[NV];
+    auto fetch = [&](int tl) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int i2 = 2 * (l + 64 * q);                      // element index inside the 16 x LD tile
+            const int row = i2 / LD, col = i2 - row * LD;
+            const int pt = min(tl * 16 + row, npts - 1);
+            nx[q] = *reinterpret_cast<const double2*>(pts + (size_t)pt * LD + col);
+        }
+    };
+    if (tile < ntiles) fetch(tile);                // the first tile's rows are requested before the matrix
+    {   // stage the matrix: all loads of a batch are issued before the first LDS store, so the copy costs
+        // one memory latency per batch, not one per element
+        const int nvec = (4 * KS * LD) >> 1;
+        const double2* src = reinterpret_cast<const double2*>(p.Mt);
+        double2* dst = reinterpret_cast<double2*>(Ms);
+        const int start = (int)(((size_t)blockIdx.x * 1024) % (size_t)nvec);
+        constexpr int NIT = (4 * KSP * LD / 2 + 255) / 256;       // upper bound on elements per thread
+        constexpr int BATCH = NIT;
+#pragma unroll
+        for (int b0 = 0; b0 < NIT; b0 += BATCH) {
+            double2 tmp[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int i = threadIdx.x + 256 * (b0 + u);
+                int j = i + start; if (j >= nvec) j -= nvec;
+                tmp[u] = (b0 + u < NIT && i < nvec) ? src[j] : double2{0.0, 0.0};
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int i = threadIdx.x + 256 * (b0 + u);
+                int j = i + start; if (j >= nvec) j -= nvec;
+                if (b0 + u < NIT && i < nvec) dst[j] = tmp[u];
+            }
+        }
+        if (threadIdx.x < LD) mus[threadIdx.x] = p.mu[threadIdx.x];
+    }
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x * 4) {
+        const int p0 = tile * 16;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int i2 = 2 * (l + 64 * q);
+            const int row = i2 / LD, col = i2 - row * LD;
+            Vt[row * LDT + col] = nx[q].x - mus[col];
+            Vt[row * LDT + col + 1] = nx[q].y - mus[col + 1];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (tile + (int)gridDim.x * 4 < ntiles) fetch(tile + gridDim.x * 4);
+        double A[KSP];
+#pragma unroll
+        for (int ks = 0; ks < KSP; ++ks) A[ks] = Vt[pi * LDT + 4 * ks + kq];
+        dz_double4 acc[NRT];
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) acc[t] = dz_double4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KSP; ++ks) {
+            if (ks < KSP - 4 || ks < KS) {
+                const double* mrow = mbase + (size_t)(4 * ks) * LD;
+#pragma unroll
+                for (int t = 0; t < NRT; ++t)
+                    if (!TRI || ks >= 4 * t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ks], mrow[16 * t], acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int pt = p0 + kq + 4 * e;
+            double q = 0.0;
+#pragma unroll
+            for (int t = 0; t < NRT; ++t) {
+                const int r = 16 * t + pi;
+                const double y = acc[t][e];
+                const double sv = TRI ? y : Vt[(kq + 4 * e) * LDT + r];
+                if (r < d) q = fma(y, sv, q);
+            }
+            q = bfly16(q);
+            if (pi == 0 && pt < npts) {
+                like_out[pt] = nan_to_ninf(p.logF - 0.5 * q);
+                if (!p.have_prior) prior_out[pt] = 0.0;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
-// Generic variant (any ld <= 1024): row tiles RTC at a time, operands fetched one k-step ahead.
+// any ld <= 1024: row tiles RTC at a time, operands fetched one k-step ahead
 template <int RTC>
 __global__ __launch_bounds__(256) void k_logp_mvn_mfma_big(Params p, const double* __restrict__ pts, int npts, double* prior_out, double* like_out)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int YS = RTC * 16 + 1;
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int p0 = (blockIdx.x * 4 + wv) * 16;
     if (p0 >= npts) return;
     const int pi = l & 15, kq = l >> 4;
     const int ld = p.ld, d = p.d;
     const double* xrow = pts + (size_t)min(p0 + pi, npts - 1) * ld;
-    double* Ys = lds + (size_t)wv * 16 * YS;
     const int KS = (d + 3) >> 2, NRT = (d + 15) >> 4;
-    double Q = 0.0;
+    double q[4] = {0.0, 0.0, 0.0, 0.0};
     for (int rt0 = 0; rt0 < NRT; rt0 += RTC) {
         dz_double4 acc[RTC];
 #pragma unroll
@@ -483,25 +751,23 @@ __global__ __launch_bounds__(256) void k_logp_mvn_mfma_big(Params p, const doubl
             }
         }
 #pragma unroll
-        for (int t = 0; t < RTC; ++t)
+        for (int e = 0; e < 4; ++e) {
+            const double* xs = pts + (size_t)min(p0 + kq + 4 * e, npts - 1) * ld;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) Ys[(kq + 4 * e) * YS + 16 * t + pi] = acc[t][e];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        if (l < 16) {
-            const int nr = min(16 * RTC, d - 16 * rt0);
-            for (int rr = 0; rr < nr; ++rr) {
-                const double y = Ys[l * YS + rr];
-                const int r = 16 * rt0 + rr;
-                Q = fma(y, p.tri ? y : xrow[r] - p.mu[r], Q);
+            for (int t = 0; t < RTC; ++t) {
+                const int r = 16 * (rt0 + t) + pi;
+                if (rt0 + t < NRT && r < d) { const double y = acc[t][e]; q[e] = fma(y, p.tri ? y : xs[r] - p.mu[r], q[e]); }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
     }
-    if (l < 16 && p0 + l < npts) {
-        like_out[p0 + l] = nan_to_ninf(p.logF - 0.5 * Q);
-        if (!p.have_prior) prior_out[p0 + l] = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int pt = p0 + kq + 4 * e;
+        const double Q = bfly16(q[e]);
+        if (pi == 0 && pt < npts) {
+            like_out[pt] = nan_to_ninf(p.logF - 0.5 * Q);
+            if (!p.have_prior) prior_out[pt] = 0.0;
+        }
     }
 }
 
@@ -581,9 +847,9 @@ __global__ __launch_bounds__(256) void k_prior_add(Params p, const double* __res
 // (:424-449).  One wave per chain.
 // ------------------------------------------------------------------------------------------
 template <int NCH>
-__global__ __launch_bounds__(256) void k_accept(Params p, uint32_t g, int64_t zbase, int c0, int nc, int64_t trace_slot, int append, int publish, int prep_next)
+__global__ __launch_bounds__(1024) void k_accept(Params p, uint32_t g, int64_t zbase, int c0, int nc, int64_t trace_slot, int append, int publish, int prep_next)
 {
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (wave >= nc) return;
     const int lane = threadIdx.x & 63;
     const int c = c0 + wave, k = p.k, ld = p.ld;
@@ -613,7 +879,7 @@ __global__ __launch_bounds__(256) void k_accept(Params p, uint32_t g, int64_t zb
         if (f.snk) ratio = nan_to_num((q_logp + p.p_slogp[c]) - (last_logp + p.cur_snk[c]));   // :326-332
         else ratio = nan_to_num(q_logp) - nan_to_num(last_logp);               // :334
     } else {
-        bool fin; sel = mt_select(p, c, u.u_sel, lane, &fin);
+        const int sf = p.sel[c]; sel = sf & 255; const bool fin = (sf & 256) != 0;      // mt_choose_proposal_pt result of this chain (:291)
         // lane i < k holds proposal term A_i, lane 16+i holds reference term B_i (:306-317)
         double val = -__builtin_huge_val();
         if (lane < k) {

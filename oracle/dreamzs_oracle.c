@@ -407,9 +407,9 @@ int64_t orc_generation(orc_engine* e) { return e->gen; }
  * MVN: examples/ndim_gaussian/dream_ex_ndim_gaussian.py:49-52
  *      logp = log_F - .5 * sum(x * dot(invC, x));  kind 0 takes invC itself,
  *      kind 1 an upper-triangular U with invC = U^T U (Q = |U v|^2).
- *      Order: y_r = sum_c M[r][c] v_c ascending c (fma chain); Q: row r adds
- *      fma(y_r, s_r, .) to partial r mod 16 in ascending r, the 16 partials are combined
- *      by an xor butterfly (8,4,2,1); s = v (dense) or y (triangular).
+ *      Order: y_r = sum_c M[r][c] v_c ascending c (fma chain); Q = q_0 + q_1 + ... over row
+ *      tiles of 16 in ascending order, q_t = xor butterfly (8,4,2,1) of the 16 products y_r s_r;
+ *      s = v (dense) or y (triangular).
  * Mixture: examples/mixturemodel/mixturemodel.py:37-48; the squared distances are
  *      summed in the lane/butterfly order of the reduction contract. */
 HOT double orc_loglike(orc_engine* e, const double* x)
@@ -419,20 +419,26 @@ HOT double orc_loglike(orc_engine* e, const double* x)
         int tri = e->lk == LK_MVN_TRI;
         double* v = e->work + 6 * (size_t)d;
         for (int j = 0; j < d; ++j) v[j] = x[j] - e->mu[j];
-        double acc[16];
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0;
-        for (int r = 0; r < d; ++r) {
-            const double* row = e->Mx + (size_t)r * d;
-            double y = 0.0;
-            for (int c = tri ? r : 0; c < d; ++c) y = fma(row[c], v[c], y);
-            acc[r & 15] = fma(y, tri ? y : v[r], acc[r & 15]);     /* partial r mod 16, ascending r */
+        double Q = 0.0;
+        for (int t0 = 0; t0 < d; t0 += 16) {                       /* row tiles of 16, ascending */
+            double acc[16];
+            for (int i = 0; i < 16; ++i) {
+                const int r = t0 + i;
+                acc[i] = 0.0;
+                if (r < d) {
+                    const double* row = e->Mx + (size_t)r * d;
+                    double y = 0.0;
+                    for (int c = tri ? r : 0; c < d; ++c) y = fma(row[c], v[c], y);
+                    acc[i] = y * (tri ? y : v[r]);
+                }
+            }
+            for (int off = 8; off >= 1; off >>= 1) {               /* xor butterfly over the tile's 16 products */
+                double t[16];
+                for (int i = 0; i < 16; ++i) t[i] = acc[i] + acc[i ^ off];
+                memcpy(acc, t, sizeof t);
+            }
+            Q = Q + acc[0];
         }
-        for (int off = 8; off >= 1; off >>= 1) {                   /* xor butterfly over the 16 partials */
-            double t[16];
-            for (int i = 0; i < 16; ++i) t[i] = acc[i] + acc[i ^ off];
-            memcpy(acc, t, sizeof t);
-        }
-        double Q = acc[0];
         return e->logF - 0.5 * Q;
     }
     if (e->lk == LK_MIX) {

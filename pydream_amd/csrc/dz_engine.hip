@@ -97,6 +97,9 @@ struct dz_engine {
     bool prof = false;
     int num_cu = 256;
     int waves_per_block = 0;        // DZ_WPB
+    bool fuse = true;               // DZ_FUSE=0 disables the accept+propose fusion
+    bool pending_accept = false;    // generation gen-1's Metropolis step has been deferred into the next proposal kernel
+    int64_t pending_slot = -1;
     int propose_split = 1;          // waves per chain in k_propose (DZ_PROPOSE_SPLIT)
     int force_pt = 0;               // measurement switch: DZ_MFMA_PT=1|2 forces the point tiles per wave
     std::vector<hipEvent_t> ev_pool;
@@ -280,7 +283,7 @@ int join_all(dz_engine* e)
 // (schedule S2); a sub-range is the single-chain view used by Dream.astep: its end-of-generation
 // updates (append, publish, adaptation) take effect immediately, as when the reference is driven
 // round-robin in one process.
-int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced)
+int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool more_follow)
 {
     dz::Params& p = e->p;
     const int k = p.k;
@@ -296,7 +299,8 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced)
     }
     p.draws = e->d_draws[g & 1]; p.draws_next = e->d_draws[(g + 1) & 1];
     p.ctl = e->d_ctl[g & 1]; p.ctl_next = e->d_ctl[(g + 1) & 1];
-    const bool need_draws = !full || e->draws_gen != (int64_t)g;     // not prepared by k_accept of the previous generation
+    const bool fused_in = full && e->pending_accept;                  // generation g-1's accept rides in front of this phase-0 kernel
+    const bool need_draws = !fused_in && (!full || e->draws_gen != (int64_t)g);     // not prepared by the accept of the previous generation
     const bool append = (g % (uint32_t)p.thin) == 0;                           // Dream.py:360
     const bool publish = e->adapt && (int64_t)g < (int64_t)p.burnin + 1;      // Dream.py:364
     const int nrows = full ? p.N : nc;
@@ -312,6 +316,9 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced)
     const int wpb = e->waves_per_block ? e->waves_per_block : ((nc / L) >= 16 * e->num_cu ? 16 : 4);
     const int sp0 = std::max(1, std::min(k, e->propose_split)), sp1 = std::max(1, std::min(k - 1, e->propose_split));
     const int64_t slot = (traced && e->c.trace_capacity) ? e->ntrace : -1;
+    // the Metropolis step of this generation can ride in front of the next generation's proposal kernel when
+    // nothing shared changes in between (no history append, no published positions) and a generation follows
+    const bool defer = full && e->fuse && more_follow && !append && !publish && e->propose_split == 1 && e->lk != LK_HOST;
     const int64_t zbase = full ? e->M : e->M - (int64_t)(p.off + c0);
     for (int s = 0; s < L; ++s) {
         const int lc0 = c0 + (int)((int64_t)nc * s / L), lc1 = c0 + (int)((int64_t)nc * (s + 1) / L), lnc = lc1 - lc0;
@@ -321,24 +328,26 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced)
             hipLaunchKernelGGL(dz::k_draws, dim3((lnc * p.nslots + 255) / 256), dim3(256), 0, st, p, g, lc0, lnc, e->d_draws[g & 1], e->d_ctl[g & 1]);
         {
             ProfScope ps(e, PR_PROPOSE, st);
-            NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((lnc * sp0 + wpb - 1) / wpb), dim3(64 * wpb), 0, st, p, 0, g, (uint32_t)e->M, lc0, lnc, sp0));
+            if (fused_in) { NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((lnc + wpb - 1) / wpb), dim3(64 * wpb), 0, st, p, 0, g, (uint32_t)e->M, lc0, lnc, 1, 1, e->pending_slot)); }
+            else { NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((lnc * sp0 + wpb - 1) / wpb), dim3(64 * wpb), 0, st, p, 0, g, (uint32_t)e->M, lc0, lnc, sp0, 0, (int64_t)-1)); }
         }
         DZCK(launch_check("propose"));
         DZCK(eval_logp(e, p.P + (size_t)lc0 * k * p.ld, lnc * k, p.p_prior + (size_t)lc0 * k, p.p_like + (size_t)lc0 * k, st));
         if (k > 1) {
             {
                 ProfScope ps(e, PR_PROPOSE, st);
-                NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((lnc * sp1 + wpb - 1) / wpb), dim3(64 * wpb), 0, st, p, 1, g, (uint32_t)e->M, lc0, lnc, sp1));
+                NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((lnc * sp1 + wpb - 1) / wpb), dim3(64 * wpb), 0, st, p, 1, g, (uint32_t)e->M, lc0, lnc, sp1, 0, (int64_t)-1));
             }
             DZCK(launch_check("propose(ref)"));
             DZCK(eval_logp(e, p.R + (size_t)lc0 * (k - 1) * p.ld, lnc * (k - 1), p.r_prior + (size_t)lc0 * (k - 1), p.r_like + (size_t)lc0 * (k - 1), st));
         }
-        {
+        if (!defer) {
             ProfScope ps(e, PR_ACCEPT, st);
             NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_accept<NCH>, dim3((lnc + wpb - 1) / wpb), dim3(64 * wpb), 0, st, p, g, zbase, lc0, lnc, slot, append ? 1 : 0, publish ? 1 : 0, (full && !publish) ? 1 : 0));
+            DZCK(launch_check("accept"));
         }
-        DZCK(launch_check("accept"));
     }
+    e->pending_accept = defer; e->pending_slot = defer ? slot : -1;
     e->draws_gen = (full && !publish) ? (int64_t)g + 1 : -1;   // while adapting, next generation's decisions must wait for the new probabilities
     if (publish || append) {         // shared state changed: the lanes meet before anything reads it
         if (L > 1) DZCK(join_all(e));
@@ -389,6 +398,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     dz_engine* e = new dz_engine();
     e->c = *cfg;
     e->gen_c.assign((size_t)cfg->nchains_local, 0);
+    if (const char* kv = getenv("DZ_FUSE")) e->fuse = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_WPB")) e->waves_per_block = atoi(kv);
     if (const char* kv = getenv("DZ_PROPOSE_SPLIT")) e->propose_split = atoi(kv);
     if (const char* kv = getenv("DZ_MFMA_PT")) e->force_pt = atoi(kv) == 2 ? 2 : atoi(kv) == 1 ? 1 : 0;
@@ -634,7 +644,7 @@ int dz_step(dz_engine* e, int64_t generations)
     }
     for (int c = 1; c < e->p.nl; ++c) if (e->gen_c[c] != e->gen_c[0]) return fail("chains are out of lockstep (single-chain stepping in progress)");
     e->gen = e->gen_c[0];
-    for (int64_t i = 0; i < generations; ++i) DZCK(one_generation(e, 0, e->p.nl, (uint32_t)e->gen, true));
+    for (int64_t i = 0; i < generations; ++i) DZCK(one_generation(e, 0, e->p.nl, (uint32_t)e->gen, true, i + 1 < generations));
     return 0;
 }
 
@@ -647,7 +657,7 @@ int dz_step_range(dz_engine* e, int32_t c0, int32_t nc)
     if (e->M < 2 * e->c.depairs) return fail("history not seeded");
     if (!e->have_logp) { DZCK(eval_logp(e, e->p.X, e->p.nl, e->p.lprior, e->p.llike)); e->have_logp = true; }
     for (int c = c0 + 1; c < c0 + nc; ++c) if (e->gen_c[c] != e->gen_c[c0]) return fail("chains of the range are at different generations");
-    return one_generation(e, c0, nc, (uint32_t)e->gen_c[c0], false);
+    return one_generation(e, c0, nc, (uint32_t)e->gen_c[c0], false, false);
 }
 
 int dz_set_chain_state(dz_engine* e, int32_t c, const double* x, const double* prior, const double* like)

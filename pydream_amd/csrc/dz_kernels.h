@@ -366,11 +366,113 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
     if (lane == 0) *slogp_out = slogp;
 }
 
+// The transition of chain c at generation g (one wave).  Leaves the new state in xn, and -- when prep_next --
+// the wave-uniform draws and control decisions of generation g+1 in registers (dnext: lane s holds slot s;
+// cnext) as well as in memory (draws_out / ctl_out) for the kernels that follow.
+template <int NCH>
+DZ_DEV void accept_chain(const Params& p, uint32_t g, int64_t zbase, int c, int lane, int64_t trace_slot, int append, int publish, int prep_next,
+                         const ChainCtl* ctl_cur, ChainCtl* ctl_out, uint4* draws_out,
+                         double (&xn)[NCH][2], DrawSrc& dnext, ChainCtl& cnext)
+{
+    const int k = p.k, ld = p.ld;
+    const uint32_t gc = (uint32_t)(p.off + c);
+    const ChainCtl ct = ctl_cur[c];
+    StepFlags f; f.snk = ct.snk != 0; f.cr_idx = ct.cr_idx; f.delta = ct.delta; f.glev = ct.glev;
+    Ctrl u; u.u_sel = ct.u_sel; u.u_acc = ct.u_acc;
+    dnext.have = false; dnext.mine = make_uint4(0, 0, 0, 0);
+    cnext = ct;
+    if (prep_next) {   // lane-parallel: the wave-uniform Philox outputs and control decisions of generation g+1
+        u32x4 w0 = u32x4{0, 0, 0, 0};
+        for (int slot = lane; slot < p.nslots; slot += 64) {
+            const u32x4 w = slot_counter_draw(p, slot, gc, g + 1);
+            if (slot == lane) w0 = w;
+            draws_out[(size_t)c * p.nslots + slot] = make_uint4(w.x, w.y, w.z, w.w);
+        }
+        Ctrl un;
+        un.u_snk = u53(__shfl(w0.x, 0, 64), __shfl(w0.y, 0, 64)); un.u_cr = u53(__shfl(w0.z, 0, 64), __shfl(w0.w, 0, 64));
+        un.u_de = u53(__shfl(w0.x, 1, 64), __shfl(w0.y, 1, 64)); un.u_glev = u53(__shfl(w0.z, 1, 64), __shfl(w0.w, 1, 64));
+        un.u_sel = u53(__shfl(w0.x, 2, 64), __shfl(w0.y, 2, 64)); un.u_acc = u53(__shfl(w0.z, 2, 64), __shfl(w0.w, 2, 64));
+        const StepFlags fn = step_flags(p, un);
+        cnext.snk = fn.snk ? 1 : 0; cnext.cr_idx = fn.cr_idx; cnext.delta = fn.delta; cnext.glev = fn.glev; cnext.u_sel = un.u_sel; cnext.u_acc = un.u_acc;
+        if (lane == 0) ctl_out[c] = cnext;
+        dnext.have = p.nslots <= 64; dnext.mine = make_uint4(w0.x, w0.y, w0.z, w0.w);
+    }
+    const double last_prior = p.lprior[c], last_like = p.llike[c];
+    const double last_logp = p.T * last_like + last_prior;                     // :243, :268
+    double ratio; int sel = 0;
+    if (k == 1) {
+        const double q_logp = p.T * p.p_like[c] + p.p_prior[c];                // :274
+        if (f.snk) ratio = nan_to_num((q_logp + p.p_slogp[c]) - (last_logp + p.cur_snk[c]));   // :326-332
+        else ratio = nan_to_num(q_logp) - nan_to_num(last_logp);               // :334
+    } else {
+        const int sf = p.sel[c]; sel = sf & 255; const bool fin = (sf & 256) != 0;      // mt_choose_proposal_pt result of this chain (:291)
+        // lane i < k holds proposal term A_i, lane 16+i holds reference term B_i (:306-317)
+        double val = -__builtin_huge_val();
+        if (lane < k) {
+            val = p.p_prior[c * k + lane] + p.T * p.p_like[c * k + lane];                                  // :279
+            if (f.snk) val = val + p.p_slogp[c * k + lane];                                              // :307
+        } else if (lane >= 16 && lane < 16 + k) {
+            const int i = lane - 16;
+            val = i < k - 1 ? p.T * p.r_like[c * (k - 1) + i] + p.r_prior[c * (k - 1) + i]              // :303
+                            : p.T * last_like + last_prior;                                              // :877-879
+            if (f.snk) { const double sr = i < k - 1 ? p.r_slogp[c * (k - 1) + i] : 0.0; val = (val + sr) + p.p_slogp[c * k + i]; }   // :312-313
+        }
+        double m2 = val;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) m2 = fmax(m2, __shfl_xor(m2, off, 64));                    // :320
+        m2 = __shfl(m2, 0, 64);
+        const double ev = dexp(val - m2);                                                                // :321-322
+        double SA = 0.0, SB = 0.0;
+        for (int i = 0; i < k; ++i) SA = SA + __shfl(ev, i, 64);
+        for (int i = 0; i < k; ++i) SB = SB + __shfl(ev, 16 + i, 64);
+        ratio = nan_to_num(dlog(SA / SB));                                     // :323
+        if (!fin) ratio = -__builtin_huge_val();                               // DESIGN.md deviation D1 (:282-289)
+    }
+    const bool accept = is_finite(ratio) && (dlog(u.u_acc) < ratio);           // :993
+    const double* src = p.P + ((size_t)c * k + sel) * ld;
+    double* xrow = p.X + (size_t)c * ld;
+    bool diff = false;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int jj = 128 * it + 2 * lane;
+        xn[it][0] = 0.0; xn[it][1] = 0.0;
+        if (jj < ld) {
+            const double2 xo = *reinterpret_cast<const double2*>(xrow + jj);
+            double2 t = xo;
+            if (accept) { t = *reinterpret_cast<const double2*>(src + jj); diff = diff || (t.x != xo.x) || (t.y != xo.y); }
+            xn[it][0] = t.x; xn[it][1] = t.y;
+        }
+    }
+    const bool moved = __any(diff);                                            // core.py:120
+    const double npri = accept ? p.p_prior[c * k + sel] : last_prior;          // :345-347
+    const double nlik = accept ? p.p_like[c * k + sel] : last_like;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int jj = 128 * it + 2 * lane;
+        if (jj < ld) {
+            const double2 t = {xn[it][0], xn[it][1]};
+            if (accept) *reinterpret_cast<double2*>(xrow + jj) = t;
+            if (trace_slot >= 0) *reinterpret_cast<double2*>(p.tX + ((size_t)trace_slot * p.nl + c) * ld + jj) = t;
+            if (append) *reinterpret_cast<double2*>(p.Z + (size_t)(zbase + (int64_t)gc) * ld + jj) = t;   // :933-936
+            if (publish) *reinterpret_cast<double2*>(p.cp_new + (size_t)gc * ld + jj) = t;       // :447-449
+        }
+    }
+    if (lane == 0) {
+        p.lprior[c] = npri; p.llike[c] = nlik;
+        if (trace_slot >= 0) {
+            const size_t o = (size_t)trace_slot * p.nl + c;
+            p.tlogp[o] = nlik + npri;                                          // core.py:115
+            p.tmoved[o] = moved ? 1 : 0; p.ttry[o] = sel; p.tcr[o] = f.cr_idx; p.tsnk[o] = f.snk ? 1 : 0;
+        }
+    }
+}
+
+
 // split = 1: one wave per CHAIN (control decisions, crossover threshold and base row fetched once, the wave
 // loops over the tries); split = n: one wave per (chain, try).  The host picks by problem size: per-chain
 // waves do ~35% fewer instructions, per-try waves expose 5x more parallelism.
 template <int NCH>
-__global__ __launch_bounds__(1024) void k_propose(Params p, int phase, uint32_t g, uint32_t M, int c0, int nc, int split)
+__global__ __launch_bounds__(1024) void k_propose(Params p, int phase, uint32_t g, uint32_t M, int c0, int nc, int split, int fuse_accept, int64_t fuse_slot)
 {
     const int n = phase == 0 ? p.k : p.k - 1;
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -379,17 +481,28 @@ __global__ __launch_bounds__(1024) void k_propose(Params p, int phase, uint32_t 
     const int c = c0 + wave / split;
     const int per = (n + split - 1) / split;
     const int i0 = (wave % split) * per, i1 = min(n, i0 + per);
-    const DrawSrc dsrc = load_draws(p, p.draws + (size_t)c * p.nslots, lane);
-    const ChainCtl ct = p.ctl[c];
-    const double* base; double* out; double* sl;
-    if (phase == 0) { base = p.X + (size_t)c * p.ld; out = p.P + (size_t)c * p.k * p.ld; sl = p.p_slogp + (size_t)c * p.k; }
-    else {
-        bool fin; const int sel = mt_select(p, c, ct.u_sel, lane, &fin);
-        if (lane == 0 && i0 == 0) p.sel[c] = sel | (fin ? 256 : 0);
-        base = p.P + ((size_t)c * p.k + sel) * p.ld; out = p.R + (size_t)c * (p.k - 1) * p.ld; sl = p.r_slogp + (size_t)c * (p.k - 1);
-    }
+    DrawSrc dsrc; ChainCtl ct;
     double xb[NCH][2];
-    load_row<NCH>(base, p.ld, lane, xb);
+    double* out; double* sl;
+    if (fuse_accept) {
+        // phase 0 of generation g with the Metropolis step of generation g-1 in front (same wave, same chain):
+        // the new state, the draws and the control decisions of generation g never leave the registers.
+        // Params are those of generation g: generation g-1's decisions sit in ctl_next, generation g's go to ctl/draws.
+        accept_chain<NCH>(p, g - 1, 0, c, lane, fuse_slot, 0, 0, 1, p.ctl_next, const_cast<ChainCtl*>(p.ctl), const_cast<uint4*>(p.draws), xb, dsrc, ct);
+        if (!dsrc.have) dsrc = load_draws(p, nullptr, lane);
+        out = p.P + (size_t)c * p.k * p.ld; sl = p.p_slogp + (size_t)c * p.k;
+    } else {
+        dsrc = load_draws(p, p.draws + (size_t)c * p.nslots, lane);
+        ct = p.ctl[c];
+        const double* base;
+        if (phase == 0) { base = p.X + (size_t)c * p.ld; out = p.P + (size_t)c * p.k * p.ld; sl = p.p_slogp + (size_t)c * p.k; }
+        else {
+            bool fin; const int sel = mt_select(p, c, ct.u_sel, lane, &fin);
+            if (lane == 0 && i0 == 0) p.sel[c] = sel | (fin ? 256 : 0);
+            base = p.P + ((size_t)c * p.k + sel) * p.ld; out = p.R + (size_t)c * (p.k - 1) * p.ld; sl = p.r_slogp + (size_t)c * (p.k - 1);
+        }
+        load_row<NCH>(base, p.ld, lane, xb);
+    }
     {
         const double zero = (double)(threadIdx.x >> 12);
 #pragma unroll
@@ -530,9 +643,9 @@ DZ_DEV double nan_to_ninf(double x) { return x != x ? -__builtin_huge_val() : x;
 //   A operand (16 points x 4 cols): lane l supplies v[p0 + l%16][4 ks + l/16]
 //   B operand (4 cols x 16 rows):   lane l supplies Mt[4 ks + l/16][16 t + l%16]   (shared by the PT tiles)
 //   D: lane l, element e holds y[p0 + l/16 + 4 e][16 t + l%16]
-// Q contract: row r = 16 t + i adds fma(y_r, s_r, acc_i) to partial i = r mod 16 in ascending t; the 16
-// partials are combined by an xor butterfly (8,4,2,1) -- which is exactly the D layout, so the quadratic
-// form never leaves the registers.  s = v (dense precision) or y (triangular factor; the k-steps left of
+// Q contract: Q = q_0 + q_1 + ... in ascending row tile t, where q_t is the xor butterfly (8,4,2,1) over
+// i = 0..15 of the products y_r * s_r, r = 16 t + i -- exactly the D layout, so the quadratic form never leaves
+// the registers, and row tiles can be produced by different waves.  s = v (dense precision) or y (triangular factor; the k-steps left of
 // a diagonal tile are structural zeros and are skipped).
 typedef double dz_double4 __attribute__((ext_vector_type(4)));
 
@@ -582,13 +695,12 @@ __global__ __launch_bounds__(256) void k_logp_mvn_mfma(Params p, const double* _
             const double* xs = pts + (size_t)min(pt, npts - 1) * ld;
             double q = 0.0;
 #pragma unroll
-            for (int t = 0; t < NRT; ++t) {
+            for (int t = 0; t < NRT; ++t) {      // Q = q_0 + q_1 + ... (ascending t), q_t = butterfly16 of the tile's products
                 const int r = 16 * t + pi;
                 const double y = acc[u][t][e];
                 const double sv = TRI ? y : xs[r] - p.mu[r];
-                if (r < d) q = fma(y, sv, q);
+                q = q + bfly16(r < d ? y * sv : 0.0);
             }
-            q = bfly16(q);
             if (pi == 0 && pt < npts) {
                 like_out[pt] = nan_to_ninf(p.logF - 0.5 * q);
                 if (!p.have_prior) prior_out[pt] = 0.0;
@@ -695,13 +807,12 @@ __global__ __launch_bounds__(256) void k_logp_mvn_lds(Params p, const double* __
             const int pt = p0 + kq + 4 * e;
             double q = 0.0;
 #pragma unroll
-            for (int t = 0; t < NRT; ++t) {
+            for (int t = 0; t < NRT; ++t) {      // Q = q_0 + q_1 + ... (ascending t), q_t = butterfly16 of the tile's products
                 const int r = 16 * t + pi;
                 const double y = acc[t][e];
                 const double sv = TRI ? y : Vt[(kq + 4 * e) * LDT + r];
-                if (r < d) q = fma(y, sv, q);
+                q = q + bfly16(r < d ? y * sv : 0.0);
             }
-            q = bfly16(q);
             if (pi == 0 && pt < npts) {
                 like_out[pt] = nan_to_ninf(p.logF - 0.5 * q);
                 if (!p.have_prior) prior_out[pt] = 0.0;
@@ -756,14 +867,14 @@ __global__ __launch_bounds__(256) void k_logp_mvn_mfma_big(Params p, const doubl
 #pragma unroll
             for (int t = 0; t < RTC; ++t) {
                 const int r = 16 * (rt0 + t) + pi;
-                if (rt0 + t < NRT && r < d) { const double y = acc[t][e]; q[e] = fma(y, p.tri ? y : xs[r] - p.mu[r], q[e]); }
+                if (rt0 + t < NRT) { const double y = acc[t][e]; q[e] = q[e] + bfly16(r < d ? y * (p.tri ? y : xs[r] - p.mu[r]) : 0.0); }
             }
         }
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int pt = p0 + kq + 4 * e;
-        const double Q = bfly16(q[e]);
+        const double Q = q[e];
         if (pi == 0 && pt < npts) {
             like_out[pt] = nan_to_ninf(p.logF - 0.5 * Q);
             if (!p.have_prior) prior_out[pt] = 0.0;
@@ -851,95 +962,8 @@ __global__ __launch_bounds__(1024) void k_accept(Params p, uint32_t g, int64_t z
 {
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (wave >= nc) return;
-    const int lane = threadIdx.x & 63;
-    const int c = c0 + wave, k = p.k, ld = p.ld;
-    const uint32_t gc = (uint32_t)(p.off + c);
-    const ChainCtl ct = p.ctl[c];
-    StepFlags f; f.snk = ct.snk != 0; f.cr_idx = ct.cr_idx; f.delta = ct.delta; f.glev = ct.glev;
-    Ctrl u; u.u_sel = ct.u_sel; u.u_acc = ct.u_acc;
-    if (prep_next) {   // lane-parallel: the wave-uniform Philox outputs and control decisions of generation g+1
-        u32x4 w0 = u32x4{0, 0, 0, 0};
-        for (int slot = lane; slot < p.nslots; slot += 64) {
-            const u32x4 w = slot_counter_draw(p, slot, gc, g + 1);
-            if (slot == lane) w0 = w;
-            p.draws_next[(size_t)c * p.nslots + slot] = make_uint4(w.x, w.y, w.z, w.w);
-        }
-        Ctrl un;
-        un.u_snk = u53(__shfl(w0.x, 0, 64), __shfl(w0.y, 0, 64)); un.u_cr = u53(__shfl(w0.z, 0, 64), __shfl(w0.w, 0, 64));
-        un.u_de = u53(__shfl(w0.x, 1, 64), __shfl(w0.y, 1, 64)); un.u_glev = u53(__shfl(w0.z, 1, 64), __shfl(w0.w, 1, 64));
-        un.u_sel = u53(__shfl(w0.x, 2, 64), __shfl(w0.y, 2, 64)); un.u_acc = u53(__shfl(w0.z, 2, 64), __shfl(w0.w, 2, 64));
-        const StepFlags fn = step_flags(p, un);
-        if (lane == 0) { ChainCtl o; o.snk = fn.snk ? 1 : 0; o.cr_idx = fn.cr_idx; o.delta = fn.delta; o.glev = fn.glev; o.u_sel = un.u_sel; o.u_acc = un.u_acc; p.ctl_next[c] = o; }
-    }
-    const double last_prior = p.lprior[c], last_like = p.llike[c];
-    const double last_logp = p.T * last_like + last_prior;                     // :243, :268
-    double ratio; int sel = 0;
-    if (k == 1) {
-        const double q_logp = p.T * p.p_like[c] + p.p_prior[c];                // :274
-        if (f.snk) ratio = nan_to_num((q_logp + p.p_slogp[c]) - (last_logp + p.cur_snk[c]));   // :326-332
-        else ratio = nan_to_num(q_logp) - nan_to_num(last_logp);               // :334
-    } else {
-        const int sf = p.sel[c]; sel = sf & 255; const bool fin = (sf & 256) != 0;      // mt_choose_proposal_pt result of this chain (:291)
-        // lane i < k holds proposal term A_i, lane 16+i holds reference term B_i (:306-317)
-        double val = -__builtin_huge_val();
-        if (lane < k) {
-            val = p.p_prior[c * k + lane] + p.T * p.p_like[c * k + lane];                                  // :279
-            if (f.snk) val = val + p.p_slogp[c * k + lane];                                              // :307
-        } else if (lane >= 16 && lane < 16 + k) {
-            const int i = lane - 16;
-            val = i < k - 1 ? p.T * p.r_like[c * (k - 1) + i] + p.r_prior[c * (k - 1) + i]              // :303
-                            : p.T * last_like + last_prior;                                              // :877-879
-            if (f.snk) { const double sr = i < k - 1 ? p.r_slogp[c * (k - 1) + i] : 0.0; val = (val + sr) + p.p_slogp[c * k + i]; }   // :312-313
-        }
-        double m2 = val;
-#pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) m2 = fmax(m2, __shfl_xor(m2, off, 64));                    // :320
-        m2 = __shfl(m2, 0, 64);
-        const double ev = dexp(val - m2);                                                                // :321-322
-        double SA = 0.0, SB = 0.0;
-        for (int i = 0; i < k; ++i) SA = SA + __shfl(ev, i, 64);
-        for (int i = 0; i < k; ++i) SB = SB + __shfl(ev, 16 + i, 64);
-        ratio = nan_to_num(dlog(SA / SB));                                     // :323
-        if (!fin) ratio = -__builtin_huge_val();                               // DESIGN.md deviation D1 (:282-289)
-    }
-    const bool accept = is_finite(ratio) && (dlog(u.u_acc) < ratio);           // :993
-    const double* src = p.P + ((size_t)c * k + sel) * ld;
-    double* xrow = p.X + (size_t)c * ld;
-    bool diff = false;
-    double xn[NCH][2];
-#pragma unroll
-    for (int it = 0; it < NCH; ++it) {
-        const int jj = 128 * it + 2 * lane;
-        xn[it][0] = 0.0; xn[it][1] = 0.0;
-        if (jj < ld) {
-            const double2 xo = *reinterpret_cast<const double2*>(xrow + jj);
-            double2 t = xo;
-            if (accept) { t = *reinterpret_cast<const double2*>(src + jj); diff = diff || (t.x != xo.x) || (t.y != xo.y); }
-            xn[it][0] = t.x; xn[it][1] = t.y;
-        }
-    }
-    const bool moved = __any(diff);                                            // core.py:120
-    const double npri = accept ? p.p_prior[c * k + sel] : last_prior;          // :345-347
-    const double nlik = accept ? p.p_like[c * k + sel] : last_like;
-#pragma unroll
-    for (int it = 0; it < NCH; ++it) {
-        const int jj = 128 * it + 2 * lane;
-        if (jj < ld) {
-            const double2 t = {xn[it][0], xn[it][1]};
-            if (accept) *reinterpret_cast<double2*>(xrow + jj) = t;
-            if (trace_slot >= 0) *reinterpret_cast<double2*>(p.tX + ((size_t)trace_slot * p.nl + c) * ld + jj) = t;
-            if (append) *reinterpret_cast<double2*>(p.Z + (size_t)(zbase + (int64_t)gc) * ld + jj) = t;   // :933-936
-            if (publish) *reinterpret_cast<double2*>(p.cp_new + (size_t)gc * ld + jj) = t;       // :447-449
-        }
-    }
-    if (lane == 0) {
-        p.lprior[c] = npri; p.llike[c] = nlik;
-        if (trace_slot >= 0) {
-            const size_t o = (size_t)trace_slot * p.nl + c;
-            p.tlogp[o] = nlik + npri;                                          // core.py:115
-            p.tmoved[o] = moved ? 1 : 0; p.ttry[o] = sel; p.tcr[o] = f.cr_idx; p.tsnk[o] = f.snk ? 1 : 0;
-        }
-    }
+    double xn[NCH][2]; DrawSrc dn; ChainCtl cn;
+    accept_chain<NCH>(p, g, zbase, c0 + wave, threadIdx.x & 63, trace_slot, append, publish, prep_next, p.ctl, p.ctl_next, p.draws_next, xn, dn, cn);
 }
 
 // uniform draws of generation g for local chains [c0, c0+nc): one lane per (chain, slot); the lanes of

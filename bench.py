@@ -173,7 +173,7 @@ def main():
         e.step(args.steps)
         e.sync()
         e.profile_enable(False)
-        for name in ("propose", "logp", "accept", "adapt", "exchange"):
+        for name in ("generations", "propose", "logp", "accept", "adapt", "exchange"):
             ms, n = e.profile_get(name)
             prof[name] = {"total_ms": ms, "launches": n, "avg_us": (1e3 * ms / n) if n else None}
         if dist is not None:
@@ -200,6 +200,9 @@ def main():
     }
     if prof:
         ab = algorithmic_bytes(args, n_local)
+        if prof.get("generations", {}).get("launches"):
+            # the persistent kernel covers whole generations: SURVEY.md section 8(d) B = 176 d + 152 bytes per chain-generation
+            ab["generations"] = n_local * (176.0 * args.dim + 152.0) * args.steps / prof["generations"]["launches"]
         cand = {k: v for k, v in prof.items() if k in ab and v["launches"]}
         dom = max(cand, key=lambda k: cand[k]["total_ms"])
         avg_s = cand[dom]["total_ms"] / cand[dom]["launches"] * 1e-3

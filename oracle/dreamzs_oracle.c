@@ -73,9 +73,9 @@ static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint64_t d2u(double f) { uint64_t u; memcpy(&u, &f, 8); return u; }
 static inline double u2d(uint64_t u) { double f; memcpy(&f, &u, 8); return f; }
 
-/* Standard normal in binary32 from two words: Box-Muller, cosine branch, with
- * the polynomial log / cos(2 pi u) of DESIGN.md "Elementary functions". */
-HOT float orc_normal32(uint32_t w1, uint32_t w2)
+/* Two independent standard normals in binary32 from two words: Box-Muller (z0 = r cos, z1 = r sin), with
+ * the polynomial log / sin,cos(2 pi u) of DESIGN.md "Elementary functions". */
+HOT void orc_normal32_pair(uint32_t w1, uint32_t w2, float* z0, float* z1)
 {
     float u1 = ((float)(w1 >> 9) + 0.5f) * 1.1920928955078125e-07f; /* 2^-23 */
     float u2 = ((float)(w2 >> 9) + 0.5f) * 1.1920928955078125e-07f;
@@ -97,7 +97,7 @@ HOT float orc_normal32(uint32_t w1, uint32_t w2)
     float ef = (float)e;
     float lg = fmaf(ef, 0.693145751953125f, fmaf(ef, 1.42860682030941723e-06f, lm));
     float rad = sqrtf(-2.0f * lg);
-    /* cos(2 pi u2) by octants */
+    /* cos, sin(2 pi u2) by octants: angle = (pi/4)(o + r) */
     float t8 = u2 * 8.0f;
     float fo = floorf(t8);
     int o = (int)fo;
@@ -116,10 +116,17 @@ HOT float orc_normal32(uint32_t w1, uint32_t w2)
     cp = fmaf(cp, y2, 1.0f / 24.0f);
     cp = fmaf(cp, y2, -0.5f);
     float cs = fmaf(y2, cp, 1.0f);
-    float c = (((o + 1) >> 1) & 1) ? sn : cs;
-    if (((o + 2) >> 2) & 1) c = -c;
-    return rad * c;
+    const int swap = ((o + 1) >> 1) & 1;          /* octants 1,2,5,6: cos <-> sin of the reduced angle */
+    float c = swap ? sn : cs;
+    float sv = swap ? cs : sn;
+    if (((o + 2) >> 2) & 1) c = -c;               /* cos < 0 in octants 2..5 */
+    if ((o >> 2) & 1) sv = -sv;                   /* sin < 0 in octants 4..7 */
+    *z0 = rad * c; *z1 = rad * sv;
 }
+float orc_normal32(uint32_t w1, uint32_t w2) { float a, b; orc_normal32_pair(w1, w2, &a, &b); return a; }
+float orc_normal32_sin(uint32_t w1, uint32_t w2) { float a, b; orc_normal32_pair(w1, w2, &a, &b); return b; }
+/* 16-bit uniform in (0,1): (h + 1/2) 2^-16 */
+double orc_u16(uint32_t h) { return ((double)(h & 0xffffu) + 0.5) * (1.0 / 65536.0); }
 
 /* ------------------------------------------------------------------ */
 /* Elementary functions (binary64), DESIGN.md "Elementary functions"   */
@@ -540,10 +547,15 @@ static int gen_points(orc_engine* e, uint32_t gc, uint32_t g, int phase, int n, 
             /* zeta, e, U: Dream.py:694-700 */
             int dprime = 0;
             for (int j = 0; j < d; ++j) {
-                orc_philox4x32_10(seed, (uint32_t)j, s_dim, gc, g, w);
-                U[j] = orc_u32(w[0]);
-                e1[j] = (-e->c.lamb + (e->c.lamb - (-e->c.lamb)) * orc_u32(w[1])) + 1.0;      /* :696-697 */
-                zt[j] = e->c.zeta * (double)orc_normal32(w[2], w[3]);                           /* :694 */
+                /* one Philox call per PAIR of dimensions (2q, 2q+1): w0 = the two 16-bit crossover uniforms,
+                 * w1 = the two 16-bit e uniforms, (w2,w3) = one Box-Muller pair (cos -> even, sin -> odd dim) */
+                const int h = j & 1;
+                float z0, z1;
+                orc_philox4x32_10(seed, (uint32_t)(j >> 1), s_dim, gc, g, w);
+                orc_normal32_pair(w[2], w[3], &z0, &z1);
+                U[j] = orc_u16(w[0] >> (16 * h));
+                e1[j] = (-e->c.lamb + (e->c.lamb - (-e->c.lamb)) * orc_u16(w[1] >> (16 * h))) + 1.0;      /* :696-697 */
+                zt[j] = e->c.zeta * (double)(h ? z1 : z0);                                     /* :694 */
                 if (U[j] < CR) dprime++;                                                       /* :704, :709 */
             }
             /* set_gamma, Dream.py:601-626 */

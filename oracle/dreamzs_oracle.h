@@ -98,7 +98,9 @@ int64_t orc_generation(orc_engine* e);
 void     orc_philox4x32_10(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]);
 double   orc_u53(uint32_t hi, uint32_t lo);
 double   orc_u32(uint32_t w);
-float    orc_normal32(uint32_t w1, uint32_t w2);
+float    orc_normal32(uint32_t w1, uint32_t w2);      /* cosine branch of the Box-Muller pair */
+float    orc_normal32_sin(uint32_t w1, uint32_t w2);  /* sine branch */
+double   orc_u16(uint32_t h);
 double   orc_exp(double x);
 double   orc_log(double x);
 uint32_t orc_stream_id(int kind, int tr, int phase, int round);

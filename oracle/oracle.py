@@ -53,6 +53,10 @@ def lib():
         L.orc_u32.argtypes = [C.c_uint32]
         L.orc_normal32.restype = C.c_float
         L.orc_normal32.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_normal32_sin.restype = C.c_float
+        L.orc_normal32_sin.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_u16.restype = C.c_double
+        L.orc_u16.argtypes = [C.c_uint32]
         L.orc_exp.restype = C.c_double
         L.orc_exp.argtypes = [C.c_double]
         L.orc_log.restype = C.c_double
@@ -103,6 +107,14 @@ def u32(w):
 
 def normal32(w1, w2):
     return float(lib().orc_normal32(int(w1), int(w2)))
+
+
+def normal32_sin(w1, w2):
+    return float(lib().orc_normal32_sin(int(w1), int(w2)))
+
+
+def u16(h):
+    return float(lib().orc_u16(int(h) & 0xffff))
 
 
 def exp(x):

@@ -121,7 +121,7 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
-PROFILE_CLASSES = {"propose": 0, "logp": 1, "accept": 2, "adapt": 3, "exchange": 4}
+PROFILE_CLASSES = {"propose": 0, "logp": 1, "accept": 2, "adapt": 3, "exchange": 4, "generations": 5}
 
 
 class Engine:

@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "dz_engine.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "dz_kernels.h"), os.path.join(HERE, "csrc", "dz_device.h"),
+        os.path.join(HERE, "csrc", "dz_megakernel.h"),
         os.path.join(ROOT, "include", "dreamzs.h")]
 LIB = os.path.join(HERE, "libdreamzs.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",

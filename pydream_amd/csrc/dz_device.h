@@ -38,8 +38,10 @@ DZ_DEV double u53(uint32_t hi, uint32_t lo)
 }
 DZ_DEV double u32d(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0); }
 
-// standard normal (binary32): Box-Muller cosine branch on two 23-bit uniforms
-DZ_DEV float normal32(uint32_t w1, uint32_t w2)
+DZ_DEV double u16d(uint32_t h) { return ((double)(h & 0xffffu) + 0.5) * (1.0 / 65536.0); }
+
+// two independent standard normals (binary32): Box-Muller on two 23-bit uniforms, z0 = r cos, z1 = r sin
+DZ_DEV void normal32_pair(uint32_t w1, uint32_t w2, float& z0, float& z1)
 {
     const float u1 = ((float)(w1 >> 9) + 0.5f) * 1.1920928955078125e-07f;
     const float u2 = ((float)(w2 >> 9) + 0.5f) * 1.1920928955078125e-07f;
@@ -78,9 +80,12 @@ DZ_DEV float normal32(uint32_t w1, uint32_t w2)
     cp = fmaf(cp, y2, 1.0f / 24.0f);
     cp = fmaf(cp, y2, -0.5f);
     const float cs = fmaf(y2, cp, 1.0f);
-    float c = (((o + 1) >> 1) & 1) ? sn : cs;
+    const bool swap = (((o + 1) >> 1) & 1) != 0;
+    float c = swap ? sn : cs;
+    float sv = swap ? cs : sn;
     if (((o + 2) >> 2) & 1) c = -c;
-    return rad * c;
+    if ((o >> 2) & 1) sv = -sv;
+    z0 = rad * c; z1 = rad * sv;
 }
 
 // ---------------------------------------------------------------- elementary functions

@@ -7,6 +7,7 @@
 // pydream/Dream.py:193-422 (astep -> the kernels of dz_kernels.h).
 #include "../../include/dreamzs.h"
 #include "dz_kernels.h"
+#include "dz_megakernel.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -32,7 +33,7 @@ int fail(const std::string& m) { g_err = m; return -1; }
 #define DZCK(expr) do { int _r = (expr); if (_r) return _r; } while (0)
 
 enum { LK_NONE = 0, LK_MVN = 1, LK_MIX = 2, LK_HOST = 3 };
-enum { PR_PROPOSE = 0, PR_LOGP = 1, PR_ACCEPT = 2, PR_ADAPT = 3, PR_EXCHANGE = 4, PR_COUNT = 5 };
+enum { PR_PROPOSE = 0, PR_LOGP = 1, PR_ACCEPT = 2, PR_ADAPT = 3, PR_EXCHANGE = 4, PR_GENERATIONS = 5, PR_COUNT = 6 };
 
 struct Rccl {
     void* lib = nullptr;
@@ -91,6 +92,7 @@ struct dz_engine {
     double *d_shared = nullptr;      // cr_probs|cr_delta|cr_n|g_probs|g_delta|g_n
     double *d_partial = nullptr, *d_mean = nullptr, *d_sd = nullptr, *d_sdc = nullptr, *d_dl = nullptr, *d_dlg = nullptr;
     int *d_binc = nullptr, *d_bing = nullptr;
+    dz::Params* d_params = nullptr;  // device copy of `p` for kernels that take it by pointer
     double *d_scratch = nullptr; size_t scratch_rows = 0;   // debug / eval staging [rows, ld]
     double *d_cmean = nullptr, *d_cvar = nullptr, *d_rhat = nullptr;
     std::vector<double> h_stage;     // host staging (callback likelihood / exchange)
@@ -98,6 +100,8 @@ struct dz_engine {
     int num_cu = 256;
     int waves_per_block = 0;        // DZ_WPB
     bool fuse = true;               // DZ_FUSE=0 disables the accept+propose fusion
+    bool mega = false;              // DZ_MEGA=1 enables the persistent generation kernel (experimental: at parity)
+    int mega_max_gen = 1 << 20;     // DZ_MEGA_MAXGEN: generations per launch cap (measurement)
     bool pending_accept = false;    // generation gen-1's Metropolis step has been deferred into the next proposal kernel
     int64_t pending_slot = -1;
     int propose_split = 1;          // waves per chain in k_propose (DZ_PROPOSE_SPLIT)
@@ -364,6 +368,60 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
     return 0;
 }
 
+// ---- persistent generation kernel (dz_megakernel.h) -------------------------------------------------
+size_t mega_lds_bytes(const dz_engine* e)
+{
+    return sizeof(double) * (size_t)dz::mega_layout(e->p.d, e->p.k, e->p.ld / 16, e->p.ncr, e->p.ngamma).total;
+}
+bool mega_eligible(const dz_engine* e)
+{
+    const dz::Params& p = e->p;
+    return e->mega && e->lk == LK_MVN && !p.hard && !p.have_prior && p.ld <= 128 && p.k >= 3 && p.k <= dz::MAXK && p.depairs == 1 &&
+           p.nslots <= 64 && mega_lds_bytes(e) <= 160 * 1024;
+}
+// number of generations, starting at g, that one launch may cover: none of them publishes positions
+// (crossover burn-in), and only the last one may append to the history
+int mega_segment(const dz_engine* e, uint32_t g, int64_t remaining)
+{
+    int n = 0;
+    for (uint32_t gg = g; n < remaining && n < e->mega_max_gen; ++gg) {
+        if (e->adapt && (int64_t)gg < (int64_t)e->p.burnin + 1) break;
+        ++n;
+        if (gg % (uint32_t)e->p.thin == 0) break;
+    }
+    return n;
+}
+int run_mega_segment(dz_engine* e, uint32_t g, int n)
+{
+    dz::Params& p = e->p;
+    const bool append_last = ((g + (uint32_t)n - 1) % (uint32_t)p.thin) == 0;
+    if (append_last && e->M + p.N > e->c.history_capacity) return fail("history capacity exceeded");
+    DZCK(join_all(e));
+    const int64_t slot0 = e->c.trace_capacity ? e->ntrace : -1;
+    const int nrt = p.ld / 16;
+    const dim3 grid((p.nl + dz::MEGA_CHAINS - 1) / dz::MEGA_CHAINS), block(64 * dz::MEGA_WAVES);
+    const size_t lds = mega_lds_bytes(e);
+    HIPCK(hipMemcpyAsync(e->d_params, &p, sizeof(dz::Params), hipMemcpyHostToDevice, e->stream));
+    {
+        ProfScope ps(e, PR_GENERATIONS);
+#define DZ_MEGA_CASE(NRT_)                                                                                                                        \
+    case NRT_:                                                                                                                                    \
+        if (p.tri) hipLaunchKernelGGL((dz::k_generations<NRT_, true>), grid, block, lds, e->stream, e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0);   \
+        else hipLaunchKernelGGL((dz::k_generations<NRT_, false>), grid, block, lds, e->stream, e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0);         \
+        break;
+        switch (nrt) { DZ_MEGA_CASE(1) DZ_MEGA_CASE(2) DZ_MEGA_CASE(3) DZ_MEGA_CASE(4) DZ_MEGA_CASE(5) DZ_MEGA_CASE(6) DZ_MEGA_CASE(7) DZ_MEGA_CASE(8) }
+#undef DZ_MEGA_CASE
+    }
+    DZCK(launch_check("k_generations"));
+    if (append_last) { DZCK(allgather_rows(e, p.Z + (size_t)e->M * p.ld)); e->M += p.N; }
+    e->need_join = true;
+    e->draws_gen = -1;
+    e->gen = (int64_t)g + n;
+    for (auto& gcv : e->gen_c) gcv = e->gen;
+    if (slot0 >= 0) e->ntrace += n;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -399,6 +457,8 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     e->c = *cfg;
     e->gen_c.assign((size_t)cfg->nchains_local, 0);
     if (const char* kv = getenv("DZ_FUSE")) e->fuse = atoi(kv) != 0;
+    if (const char* kv = getenv("DZ_MEGA")) e->mega = atoi(kv) != 0;
+    if (const char* kv = getenv("DZ_MEGA_MAXGEN")) e->mega_max_gen = std::max(1, atoi(kv));
     if (const char* kv = getenv("DZ_WPB")) e->waves_per_block = atoi(kv);
     if (const char* kv = getenv("DZ_PROPOSE_SPLIT")) e->propose_split = atoi(kv);
     if (const char* kv = getenv("DZ_MFMA_PT")) e->force_pt = atoi(kv) == 2 ? 2 : atoi(kv) == 1 ? 1 : 0;
@@ -436,6 +496,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     rc |= ealloc(e, &e->d_draws[0], nl * (size_t)p.nslots); rc |= ealloc(e, &e->d_draws[1], nl * (size_t)p.nslots);
     rc |= ealloc(e, &e->d_ctl[0], nl); rc |= ealloc(e, &e->d_ctl[1], nl);
     rc |= ealloc(e, &p.sel, nl);
+    rc |= ealloc(e, &e->d_params, 1);
     rc |= ealloc(e, &e->d_mins, ld); rc |= ealloc(e, &e->d_maxs, ld);
     rc |= ealloc(e, &e->d_gtab, (size_t)cfg->ngamma * cfg->depairs * p.d);
     rc |= ealloc(e, &e->d_shared, (size_t)3 * (cfg->ncr + cfg->ngamma));
@@ -644,7 +705,12 @@ int dz_step(dz_engine* e, int64_t generations)
     }
     for (int c = 1; c < e->p.nl; ++c) if (e->gen_c[c] != e->gen_c[0]) return fail("chains are out of lockstep (single-chain stepping in progress)");
     e->gen = e->gen_c[0];
-    for (int64_t i = 0; i < generations; ++i) DZCK(one_generation(e, 0, e->p.nl, (uint32_t)e->gen, true, i + 1 < generations));
+    const bool mega = mega_eligible(e);
+    for (int64_t i = 0; i < generations;) {
+        const int n = mega ? mega_segment(e, (uint32_t)e->gen, generations - i) : 0;
+        if (n > 0) { DZCK(run_mega_segment(e, (uint32_t)e->gen, n)); i += n; }
+        else { DZCK(one_generation(e, 0, e->p.nl, (uint32_t)e->gen, true, i + 1 < generations && !(mega && mega_segment(e, (uint32_t)e->gen + 1, 1) > 0))); i += 1; }
+    }
     return 0;
 }
 

@@ -42,23 +42,21 @@ struct Params {
 
 struct StepFlags { bool snk; int cr_idx, delta, glev; };
 
-DZ_DEV StepFlags step_flags(const Params& p, const Ctrl& u)
+DZ_DEV StepFlags step_flags_from(const Params& p, const Ctrl& u, const double* cr_probs, const double* g_probs)
 {
     StepFlags f;
     f.snk = (p.snooker != 0.0) && (u.u_snk < p.snooker);                      // set_snooker :542-554
-    f.cr_idx = invcdf(p.cr_probs, p.ncr, u.u_cr);                              // set_CR :556-569
+    f.cr_idx = invcdf(cr_probs, p.ncr, u.u_cr);                                // set_CR :556-569
     f.delta = p.depairs > 1 ? 1 + (int)floor(u.u_de * (double)p.depairs) : 1;  // set_DEpair :571-583
-    f.glev = 1 + invcdf(p.g_probs, p.ngamma, u.u_glev);                        // set_gamma_level :585-599
+    f.glev = 1 + invcdf(g_probs, p.ngamma, u.u_glev);                          // set_gamma_level :585-599
     return f;
 }
+DZ_DEV StepFlags step_flags(const Params& p, const Ctrl& u) { return step_flags_from(p, u, p.cr_probs, p.g_probs); }
 
 // mt_choose_proposal_pt :883-917.  Lane i < k evaluates try i's weight (one dexp per wave instead of
 // k); the sums run over the tries in order, so every lane ends with the same scalars.
-DZ_DEV int mt_select(const Params& p, int c, double u_sel, int lane, bool* anyfinite)
-{
-    const int k = p.k;
-    double lp = -__builtin_huge_val();
-    if (lane < k) lp = p.p_prior[c * k + lane] + p.T * p.p_like[c * k + lane];
+DZ_DEV int mt_select_vals(int k, double lp, double u_sel, int lane, bool* anyfinite)
+{   // lp: lane i < k holds prior_i + T like_i (:900), other lanes -inf
     double mx = lp;
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));   // MAXK = 16 lanes
@@ -71,6 +69,28 @@ DZ_DEV int mt_select(const Params& p, int c, double u_sel, int lane, bool* anyfi
     double cum = 0.0; int sel = k - 1;
     for (int i = 0; i < k; ++i) { cum = cum + __shfl(pr, i, 64); if (u_sel < cum) { sel = i; break; } }
     return sel;
+}
+DZ_DEV int mt_select(const Params& p, int c, double u_sel, int lane, bool* anyfinite)
+{
+    const int k = p.k;
+    double lp = -__builtin_huge_val();
+    if (lane < k) lp = p.p_prior[c * k + lane] + p.T * p.p_like[c * k + lane];
+    return mt_select_vals(k, lp, u_sel, lane, anyfinite);
+}
+
+// log of the multi-try ratio (:305-323).  val: lane i < k holds proposal term A_i, lane 16+i reference term B_i,
+// every other lane -inf.
+DZ_DEV double mt_log_ratio(int k, double val)
+{
+    double m2 = val;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) m2 = fmax(m2, __shfl_xor(m2, off, 64));                    // :320
+    m2 = __shfl(m2, 0, 64);
+    const double ev = dexp(val - m2);                                                                // :321-322
+    double SA = 0.0, SB = 0.0;
+    for (int i = 0; i < k; ++i) SA = SA + __shfl(ev, i, 64);
+    for (int i = 0; i < k; ++i) SB = SB + __shfl(ev, 16 + i, 64);
+    return nan_to_num(dlog(SA / SB));                                                                // :323
 }
 
 DZ_DEV uint32_t mulhi_idx(uint32_t w, uint32_t M) { return (uint32_t)(((uint64_t)w * (uint64_t)M) >> 32); }
@@ -123,11 +143,11 @@ DZ_DEV Ctrl ctrl_from(const Params& p, const uint4* dr, uint32_t gc, uint32_t g)
 // generate_proposal_points :670-796 (+ snooker_update :798-837, sample_from_history :646-668,
 // set_gamma :601-626).  grid: ceil(nc*n/4) blocks of 256; one wave per (chain, try).
 // ------------------------------------------------------------------------------------------
-// number of 32-bit words w with (w + 1/2) 2^-32 < CR, so that `U_j < CR` (:704, :723) is the integer test
-// w < crossover_threshold(CR) -- exactly the same predicate as the double comparison
+// number of 16-bit values h with (h + 1/2) 2^-16 < CR, so that `U_j < CR` (:704, :723) is the integer test
+// h < crossover_threshold(CR) -- exactly the same predicate as the double comparison
 DZ_DEV uint64_t crossover_threshold(double CR)
 {
-    const double t = CR * 4294967296.0 - 0.5;          // exact: CR*2^32 <= 2^32 has ulp <= 2^-21
+    const double t = CR * 65536.0 - 0.5;               // exact
     const double c = ceil(t);
     return c <= 0.0 ? 0ull : (uint64_t)c;
 }
@@ -248,7 +268,9 @@ DZ_DEV void reduce_rows(const ZRows<NCH>& zr, bool snk, RowTerms<NCH>& rt)
         }
 }
 
-template <int NCH>
+// LEAN drops what the persistent kernel's fast path never needs (hard-boundary handling, the single-try snooker
+// variant) so that the whole generation fits the register budget of a 16-wave block.
+template <int NCH, bool AL16 = true, bool LEAN = false>
 DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, int c, int i, int n, int lane,
                           const double (&xb)[NCH][2], const double (&gt)[NCH][2], const RowTerms<NCH>& zr, double* __restrict__ out, double* slogp_out,
                           double* cur_snk_out, bool snk, int cr_idx, int delta, int glev, const DrawSrc& dr)
@@ -264,19 +286,24 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
         bool keep[NCH][2]; double e1[NCH][2], zt[NCH][2];
         int dprime = 0;
 #pragma unroll
-        for (int it = 0; it < NCH; ++it)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {     // zeta, e, U :694-700
-                const int j = 128 * it + 2 * lane + s;
-                keep[it][s] = false; e1[it][s] = 0.0; zt[it][s] = 0.0;
-                if (j < d) {
-                    const u32x4 w = philox(p.k0, p.k1, (uint32_t)j, s_dim, gc, g);
-                    keep[it][s] = (uint64_t)w.x < thr;                       // U_j < CR
-                    e1[it][s] = (-p.lamb + (p.lamb - (-p.lamb)) * u32d(w.y)) + 1.0;
-                    zt[it][s] = p.zeta * (double)normal32(w.z, w.w);
+        for (int it = 0; it < NCH; ++it) {        // zeta, e, U :694-700 -- one Philox call and one Box-Muller pair per lane
+            const int j0 = 128 * it + 2 * lane;    // the lane's two dimensions j0, j0+1 = pair j0/2
+            keep[it][0] = false; keep[it][1] = false; e1[it][0] = 0.0; e1[it][1] = 0.0; zt[it][0] = 0.0; zt[it][1] = 0.0;
+            if (j0 < d) {
+                const u32x4 w = philox(p.k0, p.k1, (uint32_t)(j0 >> 1), s_dim, gc, g);
+                float z0, z1;
+                normal32_pair(w.z, w.w, z0, z1);
+                keep[it][0] = (uint64_t)(w.x & 0xffffu) < thr;               // U_j < CR
+                e1[it][0] = (-p.lamb + (p.lamb - (-p.lamb)) * u16d(w.y)) + 1.0;
+                zt[it][0] = p.zeta * (double)z0;
+                if (j0 + 1 < d) {
+                    keep[it][1] = (uint64_t)(w.x >> 16) < thr;
+                    e1[it][1] = (-p.lamb + (p.lamb - (-p.lamb)) * u16d(w.y >> 16)) + 1.0;
+                    zt[it][1] = p.zeta * (double)z1;
                 }
-                dprime += __popcll(__ballot(keep[it][s]));                     // d' :704 / :709
             }
+            dprime += __popcll(__ballot(keep[it][0])) + __popcll(__ballot(keep[it][1]));   // d' :704 / :709
+        }
         const u32x4 wg = uniform_draw(p, dr, pt_slot(p, phase, i, 0), gc, g);  // set_gamma :615
         double gamma = 1.0;
         if (!(u53(wg.x, wg.y) < p.pgu))
@@ -306,7 +333,7 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
             }
         }
         const double D = wave_bfly(accD);                                      // :816 / :827
-        if (n > 1) {
+        if (LEAN || n > 1) {
             const double cc = wave_bfly(accS) / D;                             // :820
 #pragma unroll
             for (int it = 0; it < NCH; ++it)
@@ -342,7 +369,7 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
     for (int it = 0; it < NCH; ++it) {
         const int jj = 128 * it + 2 * lane;
         if (jj < ld) {
-            if (p.hard) {
+            if (!LEAN && p.hard) {
                 const double2 mn = *reinterpret_cast<const double2*>(p.mins + jj);
                 const double2 mxx = *reinterpret_cast<const double2*>(p.maxs + jj);
 #pragma unroll
@@ -360,11 +387,35 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
                 }
             }
             double2 o; o.x = (jj < d) ? pr[it][0] : 0.0; o.y = (jj + 1 < d) ? pr[it][1] : 0.0;
-            *reinterpret_cast<double2*>(out + jj) = o;
+            if (AL16) *reinterpret_cast<double2*>(out + jj) = o;
+            else { if (jj < d) out[jj] = o.x; if (jj + 1 < d) out[jj + 1] = o.y; }     // unpadded, 8-byte aligned row (LDS tile)
         }
     }
     if (lane == 0) *slogp_out = slogp;
 }
+
+// sum over dims of the per-dimension prior log densities (parameters.py:37-47), lane/butterfly order
+template <int NCH>
+DZ_DEV double prior_of_point(const Params& p, const double (&x)[NCH][2], int lane)
+{
+    if (!p.have_prior) return 0.0;
+    double acc = 0.0;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int j = 128 * it + 2 * lane + s;
+            if (j < p.d) {
+                const int kd = p.pkind[j];
+                double t = 0.0;
+                if (kd == 1) { const double z = (x[it][s] - p.pa[j]) / p.pb[j]; t = (-(z * z) / 2.0 - 0.91893853320467274178) - dlog(p.pb[j]); }
+                else if (kd == 2) t = (x[it][s] >= p.pa[j] && x[it][s] <= p.pa[j] + p.pb[j]) ? -dlog(p.pb[j]) : -__builtin_huge_val();
+                acc = acc + t;
+            }
+        }
+    return wave_bfly(acc);
+}
+DZ_DEV double nan_to_ninf(double x) { return x != x ? -__builtin_huge_val() : x; }
 
 // The transition of chain c at generation g (one wave).  Leaves the new state in xn, and -- when prep_next --
 // the wave-uniform draws and control decisions of generation g+1 in registers (dnext: lane s holds slot s;
@@ -417,15 +468,7 @@ DZ_DEV void accept_chain(const Params& p, uint32_t g, int64_t zbase, int c, int 
                             : p.T * last_like + last_prior;                                              // :877-879
             if (f.snk) { const double sr = i < k - 1 ? p.r_slogp[c * (k - 1) + i] : 0.0; val = (val + sr) + p.p_slogp[c * k + i]; }   // :312-313
         }
-        double m2 = val;
-#pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) m2 = fmax(m2, __shfl_xor(m2, off, 64));                    // :320
-        m2 = __shfl(m2, 0, 64);
-        const double ev = dexp(val - m2);                                                                // :321-322
-        double SA = 0.0, SB = 0.0;
-        for (int i = 0; i < k; ++i) SA = SA + __shfl(ev, i, 64);
-        for (int i = 0; i < k; ++i) SB = SB + __shfl(ev, 16 + i, 64);
-        ratio = nan_to_num(dlog(SA / SB));                                     // :323
+        ratio = mt_log_ratio(k, val);
         if (!fin) ratio = -__builtin_huge_val();                               // DESIGN.md deviation D1 (:282-289)
     }
     const bool accept = is_finite(ratio) && (dlog(u.u_acc) < ratio);           // :993
@@ -467,6 +510,111 @@ DZ_DEV void accept_chain(const Params& p, uint32_t g, int64_t zbase, int c, int 
     }
 }
 
+
+// prior of a point that was just written to `row` (lane l reads back the dimensions it wrote)
+template <int NCH>
+DZ_DEV void point_prior(const Params& p, const double* row, int lane, double* prior_out)
+{
+    double pr = 0.0;
+    if (p.have_prior) {
+        double pt[NCH][2];
+#pragma unroll
+        for (int it = 0; it < NCH; ++it)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) { const int j = 128 * it + 2 * lane + s2; pt[it][s2] = j < p.d ? row[j] : 0.0; }
+        pr = nan_to_ninf(prior_of_point<NCH>(p, pt, lane));
+    }
+    if (lane == 0) *prior_out = pr;
+}
+
+// Tries i0..i1-1 of one chain's proposal set (phase 0: around the current state; phase 1: the reference set
+// around the selected proposal).  out / sl / prior_out address try 0's row and scalars.
+template <int NCH, bool AL16, bool GENERIC = true, bool LEAN = false>
+DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int c, uint32_t gc, int i0, int i1, int n, int lane,
+                        const double (&xb)[NCH][2], const double (&gt)[NCH][2], bool snk, int cr_idx, int delta, int glev, const DrawSrc& dsrc,
+                        double* out, int out_stride, double* sl, double* csn, double* prior_out)
+{
+    // software pipeline over the tries: the Z rows of try i+1 are requested before try i's arithmetic starts,
+    // and no scalar memory wait sits in between because the draws are already in registers
+    if (!snk && delta == 1) {
+        // Common case (DE move, one pair): straight-line software pipeline.  The two Z rows of try i+1 are
+        // requested right after try i's difference has been formed, and stay in flight during try i's
+        // random numbers and arithmetic.  (Kept free of other control flow on purpose: any merge of paths that
+        // define the row registers makes the compiler wait for the loads at the merge.)
+        double2 ra[NCH], rb[NCH];
+        auto request = [&](int i) {
+            const u32x4 w = uniform_draw(p, dsrc, pt_slot(p, phase, i, 1), gc, g);
+            const uint32_t r0 = mulhi_idx(w.x, M);
+            uint32_t r1 = mulhi_idx(w.y, M - 1u);
+            if (r1 >= r0) r1++;                                   // random.sample(range(M), 2) :662
+#pragma unroll
+            for (int it = 0; it < NCH; ++it) {
+                const int jj = 128 * it + 2 * lane;
+                if (jj < p.ld) {
+                    ra[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)r0 * p.ld + jj);
+                    rb[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)r1 * p.ld + jj);
+                }
+            }
+        };
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) { ra[it] = double2{0.0, 0.0}; rb[it] = double2{0.0, 0.0}; }
+        request(i0);
+        for (int i = i0; i < i1; ++i) {
+            RowTerms<NCH> rt;
+#pragma unroll
+            for (int it = 0; it < NCH; ++it) {
+                rt.a[it][0] = ra[it].x - rb[it].x; rt.a[it][1] = ra[it].y - rb[it].y;   // chain_differences :692
+                rt.b[it][0] = 0.0; rt.b[it][1] = 0.0;
+            }
+            if (i + 1 < i1) request(i + 1);
+            propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * out_stride, sl + i, csn, false, cr_idx, 1, glev, dsrc);
+        if (prior_out) point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i);
+            if (prior_out) point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i);
+        }
+        return;
+    }
+    if (snk) {
+        // snooker move: same pipeline with three rows per try (z and the projected pair, :808-810)
+        double2 rz[NCH], r1[NCH], r2[NCH];
+        auto request = [&](int i) {
+            const u32x4 w = uniform_draw(p, dsrc, pt_slot(p, phase, i, 1), gc, g);
+            const uint32_t iz = mulhi_idx(w.x, M), i1x = mulhi_idx(w.y, M), i2x = mulhi_idx(w.z, M);
+#pragma unroll
+            for (int it = 0; it < NCH; ++it) {
+                const int jj = 128 * it + 2 * lane;
+                if (jj < p.ld) {
+                    rz[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)iz * p.ld + jj);
+                    r1[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)i1x * p.ld + jj);
+                    r2[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)i2x * p.ld + jj);
+                }
+            }
+        };
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) { rz[it] = double2{0.0, 0.0}; r1[it] = rz[it]; r2[it] = rz[it]; }
+        request(i0);
+        for (int i = i0; i < i1; ++i) {
+            RowTerms<NCH> rt;
+#pragma unroll
+            for (int it = 0; it < NCH; ++it) {
+                rt.a[it][0] = rz[it].x; rt.a[it][1] = rz[it].y;
+                rt.b[it][0] = r1[it].x - r2[it].x; rt.b[it][1] = r1[it].y - r2[it].y;          // :819
+            }
+            if (i + 1 < i1) request(i + 1);
+            propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * out_stride, sl + i, csn, true, cr_idx, delta, glev, dsrc);
+        if (prior_out) point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i);
+            if (prior_out) point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i);
+        }
+        return;
+    }
+    if (GENERIC) for (int i = i0; i < i1; ++i) {     // DEpairs > 1
+        ZRows<NCH> raw;
+        RowTerms<NCH> rt;
+        fetch_rows<NCH>(p, phase, g, M, gc, i, lane, false, delta, dsrc, raw);
+        reduce_rows<NCH>(raw, false, rt);
+        propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * out_stride, sl + i, csn, false, cr_idx, delta, glev, dsrc);
+        if (prior_out) point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i);
+    }
+}
 
 // split = 1: one wave per CHAIN (control decisions, crossover threshold and base row fetched once, the wave
 // loops over the tries); split = n: one wave per (chain, try).  The host picks by problem size: per-chain
@@ -513,81 +661,7 @@ __global__ __launch_bounds__(1024) void k_propose(Params p, int phase, uint32_t 
     const uint32_t gc = (uint32_t)(p.off + c);
     const bool snk = ct.snk != 0;
     double* csn = (phase == 0 && p.k == 1) ? p.cur_snk + c : nullptr;
-    // software pipeline over the tries: the Z rows of try i+1 are requested before try i's arithmetic starts,
-    // and no scalar memory wait sits in between because the draws are already in registers
-    if (!snk && ct.delta == 1) {
-        // Common case (DE move, one pair): straight-line software pipeline.  The two Z rows of try i+1 are
-        // requested right after try i's difference has been formed, and stay in flight during try i's
-        // random numbers and arithmetic.  (Kept free of other control flow on purpose: any merge of paths that
-        // define the row registers makes the compiler wait for the loads at the merge.)
-        double2 ra[NCH], rb[NCH];
-        auto request = [&](int i) {
-            const u32x4 w = uniform_draw(p, dsrc, pt_slot(p, phase, i, 1), gc, g);
-            const uint32_t r0 = mulhi_idx(w.x, M);
-            uint32_t r1 = mulhi_idx(w.y, M - 1u);
-            if (r1 >= r0) r1++;                                   // random.sample(range(M), 2) :662
-#pragma unroll
-            for (int it = 0; it < NCH; ++it) {
-                const int jj = 128 * it + 2 * lane;
-                if (jj < p.ld) {
-                    ra[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)r0 * p.ld + jj);
-                    rb[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)r1 * p.ld + jj);
-                }
-            }
-        };
-#pragma unroll
-        for (int it = 0; it < NCH; ++it) { ra[it] = double2{0.0, 0.0}; rb[it] = double2{0.0, 0.0}; }
-        request(i0);
-        for (int i = i0; i < i1; ++i) {
-            RowTerms<NCH> rt;
-#pragma unroll
-            for (int it = 0; it < NCH; ++it) {
-                rt.a[it][0] = ra[it].x - rb[it].x; rt.a[it][1] = ra[it].y - rb[it].y;   // chain_differences :692
-                rt.b[it][0] = 0.0; rt.b[it][1] = 0.0;
-            }
-            if (i + 1 < i1) request(i + 1);
-            propose_point<NCH>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * p.ld, sl + i, csn, false, ct.cr_idx, 1, ct.glev, dsrc);
-        }
-        return;
-    }
-    if (snk) {
-        // snooker move: same pipeline with three rows per try (z and the projected pair, :808-810)
-        double2 rz[NCH], r1[NCH], r2[NCH];
-        auto request = [&](int i) {
-            const u32x4 w = uniform_draw(p, dsrc, pt_slot(p, phase, i, 1), gc, g);
-            const uint32_t iz = mulhi_idx(w.x, M), i1x = mulhi_idx(w.y, M), i2x = mulhi_idx(w.z, M);
-#pragma unroll
-            for (int it = 0; it < NCH; ++it) {
-                const int jj = 128 * it + 2 * lane;
-                if (jj < p.ld) {
-                    rz[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)iz * p.ld + jj);
-                    r1[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)i1x * p.ld + jj);
-                    r2[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)i2x * p.ld + jj);
-                }
-            }
-        };
-#pragma unroll
-        for (int it = 0; it < NCH; ++it) { rz[it] = double2{0.0, 0.0}; r1[it] = rz[it]; r2[it] = rz[it]; }
-        request(i0);
-        for (int i = i0; i < i1; ++i) {
-            RowTerms<NCH> rt;
-#pragma unroll
-            for (int it = 0; it < NCH; ++it) {
-                rt.a[it][0] = rz[it].x; rt.a[it][1] = rz[it].y;
-                rt.b[it][0] = r1[it].x - r2[it].x; rt.b[it][1] = r1[it].y - r2[it].y;          // :819
-            }
-            if (i + 1 < i1) request(i + 1);
-            propose_point<NCH>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * p.ld, sl + i, csn, true, ct.cr_idx, ct.delta, ct.glev, dsrc);
-        }
-        return;
-    }
-    for (int i = i0; i < i1; ++i) {     // DEpairs > 1
-        ZRows<NCH> raw;
-        RowTerms<NCH> rt;
-        fetch_rows<NCH>(p, phase, g, M, gc, i, lane, false, ct.delta, dsrc, raw);
-        reduce_rows<NCH>(raw, false, rt);
-        propose_point<NCH>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * p.ld, sl + i, csn, false, ct.cr_idx, ct.delta, ct.glev, dsrc);
-    }
+    propose_set<NCH, true>(p, phase, g, M, c, gc, i0, i1, n, lane, xb, gt, snk, ct.cr_idx, ct.delta, ct.glev, dsrc, out, p.ld, sl, csn, nullptr);
 }
 
 // debug entry: flags supplied by the host (function-level parity tests); one wave, all tries
@@ -613,28 +687,6 @@ __global__ __launch_bounds__(64) void k_propose_debug(Params p, int phase, uint3
 // ------------------------------------------------------------------------------------------
 // Model.total_logp (model.py:17-32) on the device.
 // ------------------------------------------------------------------------------------------
-// sum over dims of the per-dimension prior log densities (parameters.py:37-47), lane/butterfly order
-template <int NCH>
-DZ_DEV double prior_of_point(const Params& p, const double (&x)[NCH][2], int lane)
-{
-    if (!p.have_prior) return 0.0;
-    double acc = 0.0;
-#pragma unroll
-    for (int it = 0; it < NCH; ++it)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int j = 128 * it + 2 * lane + s;
-            if (j < p.d) {
-                const int kd = p.pkind[j];
-                double t = 0.0;
-                if (kd == 1) { const double z = (x[it][s] - p.pa[j]) / p.pb[j]; t = (-(z * z) / 2.0 - 0.91893853320467274178) - dlog(p.pb[j]); }
-                else if (kd == 2) t = (x[it][s] >= p.pa[j] && x[it][s] <= p.pa[j] + p.pb[j]) ? -dlog(p.pb[j]) : -__builtin_huge_val();
-                acc = acc + t;
-            }
-        }
-    return wave_bfly(acc);
-}
-DZ_DEV double nan_to_ninf(double x) { return x != x ? -__builtin_huge_val() : x; }
 
 // MVN likelihood (examples/ndim_gaussian/dream_ex_ndim_gaussian.py:49-52) on the FP64 matrix pipe.
 // v_mfma_f64_16x16x4_f64 accumulates exactly like an ascending-k fma chain (tools/mfma_f64_layout.hip,

@@ -85,8 +85,17 @@ class ContractRandom:
         return O.philox(self.seed, idx, O.stream_id(O.K_PT, tr, self.phase), self.gc, self.g)
 
     def _dim(self, tr, d):
+        """per-dimension draws of one try: arrays (U, u_e, z); one Philox call per PAIR of dimensions."""
         s = O.stream_id(O.K_DIM, tr, self.phase)
-        return np.array([O.philox(self.seed, j, s, self.gc, self.g) for j in range(d)], dtype=np.uint32)
+        U, ue, z = np.zeros(d), np.zeros(d), np.zeros(d)
+        for q in range((d + 1) // 2):
+            w = O.philox(self.seed, q, s, self.gc, self.g)
+            zz = (O.normal32(w[2], w[3]), O.normal32_sin(w[2], w[3]))
+            for h in (0, 1):
+                j = 2 * q + h
+                if j < d:
+                    U[j] = O.u16(int(w[0]) >> (16 * h)); ue[j] = O.u16(int(w[1]) >> (16 * h)); z[j] = zz[h]
+        return U, ue, z
 
     @staticmethod
     def _onehot(n, m):
@@ -129,8 +138,7 @@ class ContractRandom:
 
     def normal(self, loc, scale, size):                                      # Dream.py:694
         tr = self._next("normal")
-        w = self._dim(tr, size)
-        return np.array([loc + scale * float(np.float32(O.normal32(a[2], a[3]))) for a in w])
+        return loc + scale * self._dim(tr, size)[2]
 
     def uniform(self, low=None, high=None, size=None):
         if low is None:                                                      # metrop_select, Dream.py:993
@@ -140,10 +148,9 @@ class ContractRandom:
             return low + (high - low) * O.u53(w[2], w[3])
         if isinstance(size, tuple):                                          # U, Dream.py:700
             n, d = size
-            return np.array([[O.u32(a[0]) for a in self._dim(tr, d)] for tr in range(n)])
+            return np.array([self._dim(tr, d)[0] for tr in range(n)])
         tr = self._next("e")                                                 # e, Dream.py:696
-        w = self._dim(tr, size)
-        return np.array([low + (high - low) * O.u32(a[1]) for a in w])
+        return low + (high - low) * self._dim(tr, size)[1]
 
     def rand(self, n):                                                       # bounds redraw, Dream.py:749-751, 773-775
         fr = sys._getframe(1).f_locals

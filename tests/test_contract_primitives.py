@@ -42,6 +42,23 @@ def test_normal32_is_a_standard_normal():
     u2 = ((w[:, 1] >> 9) + 0.5) * 2.0 ** -23
     np.testing.assert_allclose(z, np.sqrt(-2 * np.log(u1)) * np.cos(2 * np.pi * u2), atol=2e-6)
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01 and abs(((z - z.mean()) ** 4).mean() / z.var() ** 2 - 3) < 0.1
+    # the sine branch serves the odd dimension of a pair: same law, uncorrelated with the cosine branch
+    zs = np.array([O.normal32_sin(a, b) for a, b in w])
+    np.testing.assert_allclose(zs, np.sqrt(-2 * np.log(u1)) * np.sin(2 * np.pi * u2), atol=2e-6)
+    assert abs(zs.mean()) < 0.01 and abs(zs.std() - 1) < 0.01 and abs(np.corrcoef(z, zs)[0, 1]) < 0.01
+    assert abs(np.corrcoef(z ** 2, zs ** 2)[0, 1]) < 0.01
+
+
+def test_u16_is_a_centred_16_bit_uniform():
+    """the crossover uniforms U_j and the e_j of Dream.py:696-700 take 16 bits each; P(U_j < CR) must equal CR
+    exactly for the CR values the sampler uses (m/nCR with the centred grid, for any nCR dividing 2^16 or not
+    the error is < 2^-16)."""
+    h = np.arange(65536)
+    u = np.array([O.u16(x) for x in h])
+    np.testing.assert_array_equal(u, (h + 0.5) / 65536.0)
+    for ncr in (1, 2, 3, 4, 5, 7):
+        for m in range(1, ncr + 1):
+            assert abs((u < m / ncr).mean() - m / ncr) < 2.0 ** -16
 
 
 def test_sample_distinct_is_uniform_without_replacement():

@@ -44,7 +44,7 @@ def setup_engine(Cls, args, n_global, n_local, offset, steps_total, device=0, **
     cap = m0 + n_global * (steps_total // args.thin + 2)
     kw = dict(nchains=n_global, nchains_local=n_local, chain_offset=offset, ndim=d, multitry=k,
               history_thin=args.thin, history_capacity=cap, trace_capacity=max(args.steps, args.warmup, 2),
-              seed=args.seed, device=device, adapt_crossover=0, crossover_burnin=0)
+              seed=args.seed, device=device, adapt_crossover=0, crossover_burnin=0, snooker=args.snooker)
     kw.update(extra)
     e = Cls(**kw)
     e.set_history(Z0)
@@ -65,7 +65,7 @@ def setup_engine(Cls, args, n_global, n_local, offset, steps_total, device=0, **
 def algorithmic_bytes(args, n_local):
     """Per-launch algorithmic HBM bytes of each kernel class (DESIGN.md "Roofline accounting",
     from SURVEY.md section 8(d)'s per-unit figures; rows unpadded, snooker fraction s)."""
-    d, k, s = args.dim, args.multitry, 0.1
+    d, k, s = args.dim, args.multitry, args.snooker
     row = 8.0 * d
     rows_z = 2 * (1 - s) + 3 * s
     pts = n_local * (2 * k - 1)
@@ -96,15 +96,21 @@ def cpu_baseline(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--spinup", type=int, default=2000,
+                    help="untimed generations run before the W warm-up steps so that the GPU leaves its idle clock "
+                         "state (a cold MI355X needs ~0.1 s of load; without it short runs vary 3x)")
     ap.add_argument("--chains-per-gpu", type=int, default=4096)
     ap.add_argument("--dim", type=int, default=100)
     ap.add_argument("--multitry", type=int, default=5)
     ap.add_argument("--thin", type=int, default=10)
     ap.add_argument("--seed", type=int, default=20260929)
     ap.add_argument("--target", choices=["mvn", "mix3"], default="mvn")
-    ap.add_argument("--mvn-kind", choices=["dense", "tri"], default="dense")
+    ap.add_argument("--mvn-kind", choices=["dense", "tri"], default="tri",
+                    help="form of the MVN whitening matrix: tri = Cholesky factor of the precision (what "
+                         "pydream_amd.likelihoods.MVNormalLogLike builds), dense = full precision matrix")
+    ap.add_argument("--snooker", type=float, default=0.1, help="snooker probability (reference default 0.1)")
     ap.add_argument("--cpu-chains", type=int, default=512)
     ap.add_argument("--cpu-steps", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -128,7 +134,7 @@ def main():
 
     n_local = args.chains_per_gpu
     n_global = n_local * world
-    total = 2 * args.steps + args.warmup             # warm-up + timed pass + HIP-event pass
+    total = args.spinup + 2 * args.steps + args.warmup      # spin-up + warm-up + timed pass + HIP-event pass
     e = setup_engine(_capi.Engine, args, n_global, n_local, rank * n_local, total, device=local_rank)
     if world > 1:
         ids = [_capi.comm_unique_id() if rank == 0 else None]
@@ -140,6 +146,12 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    chunk = max(1, min(args.spinup, max(args.steps, args.warmup, 2)))
+    for g0 in range(0, args.spinup, chunk):           # clock spin-up (untimed, not part of W or K)
+        e.trace_reset()
+        e.step(min(chunk, args.spinup - g0))
+    barrier()
+    e.trace_reset()
     e.step(args.warmup)
     barrier()
     e.trace_reset()
@@ -147,6 +159,7 @@ def main():
     # ---- timed region: exactly K generations, nothing else on the stream ----
     t0 = time.perf_counter()
     e.step(args.steps)
+    t_enqueued = time.perf_counter() - t0
     e.sync()
     if dist is not None:
         dist.barrier()
@@ -173,9 +186,14 @@ def main():
         e.step(args.steps)
         e.sync()
         e.profile_enable(False)
+        # propose / logp / accept launches carry their own start/stop events (hipExtLaunchKernelGGL: the dispatch's
+        # begin/end timestamps, the same figures rocprofv3's kernel trace reports); adapt / exchange / generations
+        # are bracketed by event records, which adds about `event_bracket_us` to each of those
         for name in ("generations", "propose", "logp", "accept", "adapt", "exchange"):
             ms, n = e.profile_get(name)
             prof[name] = {"total_ms": ms, "launches": n, "avg_us": (1e3 * ms / n) if n else None}
+        ms0, n0 = e.profile_get("empty")
+        prof["event_bracket_us"] = (1e3 * ms0 / n0) if n0 else None
         if dist is not None:
             dist.barrier()
     if rank != 0:
@@ -189,13 +207,14 @@ def main():
         "value": value, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%d chains/GPU x %d-D %s target (%s), multitry=%d, DE+snooker(0.1), nCR=3, history_thin=%d, "
+        "config": {"workload": "%d chains/GPU x %d-D %s target (%s), multitry=%d, DE+snooker(%g), nCR=3, history_thin=%d, "
                                "seed archive max(10d,2N) rows U(-5,15); BASELINE north_star target / configs[3] per-GPU shard"
                                % (n_local, args.dim, "correlated MVN" if args.target == "mvn" else "3-Gaussian mixture",
-                                  args.mvn_kind if args.target == "mvn" else "identity cov", args.multitry, args.thin),
+                                  args.mvn_kind if args.target == "mvn" else "identity cov", args.multitry, args.snooker, args.thin),
                    "chains_global": n_global, "chains_per_gpu": n_local, "ndim": args.dim, "multitry": args.multitry,
                    "parallelism": "chains sharded x%d, Z replicated by RCCL all-gather" % world if world > 1 else "single GPU"},
         "logp_points_per_s": n_global * (2 * args.multitry - 1) * args.steps / dt,
+        "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps, "spinup_generations": args.spinup,
         "acceptance_rate": acc, "rhat_max": float(np.max(rhat)),
     }
     if prof:
@@ -205,7 +224,7 @@ def main():
             ab["generations"] = n_local * (176.0 * args.dim + 152.0) * args.steps / prof["generations"]["launches"]
         cand = {k: v for k, v in prof.items() if k in ab and v["launches"]}
         dom = max(cand, key=lambda k: cand[k]["total_ms"])
-        avg_s = cand[dom]["total_ms"] / cand[dom]["launches"] * 1e-3
+        avg_s = cand[dom]["avg_us"] * 1e-6
         achieved = ab[dom] / avg_s / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": None,

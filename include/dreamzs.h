@@ -132,7 +132,8 @@ int dz_debug_propose(dz_engine* e, int32_t chain_local, int64_t gen, int32_t pha
 
 /* HIP-event timing of the engine's kernels over the launches since the last reset.
  * which: 0 propose, 1 logp, 2 accept, 3 adapt, 4 exchange, 5 generations (the persistent
- * multi-generation kernel).  Returns total ms and count. */
+ * multi-generation kernel), 6 empty (64 event pairs with no launch in between, recorded by
+ * dz_profile_reset: the time one bracket adds to every measured launch).  Returns total ms and count. */
 int dz_profile_enable(dz_engine* e, int32_t on);
 int dz_profile_get(dz_engine* e, int32_t which, double* total_ms, int64_t* launches);
 int dz_profile_reset(dz_engine* e);

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdreamzs.so")
+LIB_PATH = os.environ.get("DREAMZS_LIB") or os.path.join(HERE, "libdreamzs.so")   # DREAMZS_LIB: an alternative build
 
 
 class DreamZSError(RuntimeError):
@@ -121,7 +121,7 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
-PROFILE_CLASSES = {"propose": 0, "logp": 1, "accept": 2, "adapt": 3, "exchange": 4, "generations": 5}
+PROFILE_CLASSES = {"propose": 0, "logp": 1, "accept": 2, "adapt": 3, "exchange": 4, "generations": 5, "empty": 6}
 
 
 class Engine:

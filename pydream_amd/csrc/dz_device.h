@@ -17,6 +17,9 @@ struct u32x4 { uint32_t x, y, z, w; };
 // Philox4x32-10, key = 64-bit seed, counter = (idx, stream, chain, generation).
 DZ_DEV u32x4 philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3)
 {
+#ifdef DZ_EXP_NOPHILOX   // timing experiment only (tools/variants.sh): breaks the random contract
+    return u32x4{c0 * 0x9E3779B9u ^ k0, c1 * 0xBB67AE85u ^ c2, c2 * 0xD2511F53u ^ c3, (c3 + c0) * 0xCD9E8D57u ^ k1};
+#endif
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
@@ -43,6 +46,9 @@ DZ_DEV double u16d(uint32_t h) { return ((double)(h & 0xffffu) + 0.5) * (1.0 / 6
 // two independent standard normals (binary32): Box-Muller on two 23-bit uniforms, z0 = r cos, z1 = r sin
 DZ_DEV void normal32_pair(uint32_t w1, uint32_t w2, float& z0, float& z1)
 {
+#ifdef DZ_EXP_NOBM       // timing experiment only
+    z0 = (float)(int)w1 * 4.6e-10f; z1 = (float)(int)w2 * 4.6e-10f; return;
+#endif
     const float u1 = ((float)(w1 >> 9) + 0.5f) * 1.1920928955078125e-07f;
     const float u2 = ((float)(w2 >> 9) + 0.5f) * 1.1920928955078125e-07f;
     const uint32_t b = __float_as_uint(u1);

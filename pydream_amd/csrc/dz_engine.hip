@@ -9,6 +9,7 @@
 #include "dz_kernels.h"
 #include "dz_megakernel.h"
 
+#include <hip/hip_ext.h>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -33,7 +34,7 @@ int fail(const std::string& m) { g_err = m; return -1; }
 #define DZCK(expr) do { int _r = (expr); if (_r) return _r; } while (0)
 
 enum { LK_NONE = 0, LK_MVN = 1, LK_MIX = 2, LK_HOST = 3 };
-enum { PR_PROPOSE = 0, PR_LOGP = 1, PR_ACCEPT = 2, PR_ADAPT = 3, PR_EXCHANGE = 4, PR_GENERATIONS = 5, PR_COUNT = 6 };
+enum { PR_PROPOSE = 0, PR_LOGP = 1, PR_ACCEPT = 2, PR_ADAPT = 3, PR_EXCHANGE = 4, PR_GENERATIONS = 5, PR_EMPTY = 6, PR_COUNT = 7 };
 
 struct Rccl {
     void* lib = nullptr;
@@ -76,6 +77,9 @@ struct dz_engine {
     // history appends the groups share nothing, so one group's likelihood (matrix pipe) overlaps another's
     // proposal generation (VALU) -- lane 0 is `stream`
     int nlanes = 1; hipStream_t lane_stream[8] = {nullptr}; hipEvent_t lane_ev[8] = {nullptr}; bool need_join = true;
+    // bounded host run-ahead: a marker every ra_stride generations, the host never gets more than 3 markers ahead
+    int logp_waves = 0;      // DZ_LOGP_WAVES: force the block size of k_logp_mvn_lds (tuning)
+    int ra_stride = 32; hipEvent_t ra_ev[4] = {nullptr}; bool ra_used[4] = {false, false, false, false}; int64_t ra_n = 0;
     int nch = 1;
     int64_t M = 0, gen = 0, ntrace = 0, draws_gen = -1;
     std::vector<int64_t> gen_c;     // per-chain generation counters (differ only under single-chain stepping)
@@ -115,9 +119,10 @@ namespace {
 
 struct ProfScope {
     dz_engine* e; int which; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(dz_engine* e_, int w, hipStream_t st_ = nullptr) : e(e_), which(w), st(st_ ? st_ : e_->stream)
+    bool on;
+    ProfScope(dz_engine* e_, int w, hipStream_t st_ = nullptr, bool active = true) : e(e_), which(w), st(st_ ? st_ : e_->stream), on(active && e_->prof)
     {
-        if (e->prof) {
+        if (on) {
             for (hipEvent_t* x : {&a, &b}) {
                 if (!e->ev_pool.empty()) { *x = e->ev_pool.back(); e->ev_pool.pop_back(); }
                 else hipEventCreate(x);
@@ -125,8 +130,27 @@ struct ProfScope {
             hipEventRecord(a, st);
         }
     }
-    ~ProfScope() { if (e->prof) { hipEventRecord(b, st); e->ev[which].emplace_back(a, b); } }
+    ~ProfScope() { if (on) { hipEventRecord(b, st); e->ev[which].emplace_back(a, b); } }
 };
+
+hipEvent_t prof_event(dz_engine* e)
+{
+    hipEvent_t x = nullptr;
+    if (!e->ev_pool.empty()) { x = e->ev_pool.back(); e->ev_pool.pop_back(); }
+    else hipEventCreate(&x);
+    return x;
+}
+// One kernel launch of profile class CLS.  While profiling, the launch carries its own start/stop events
+// (hipExtLaunchKernelGGL): they take the dispatch's begin/end timestamps -- the figures rocprofv3's kernel trace
+// reports -- instead of bracketing the launch with two extra barrier packets that each add microseconds.
+#define DZ_KLAUNCH(E, CLS, ST, KERN, GRID, BLOCK, LDS, ...)                                               \
+    do {                                                                                                   \
+        if ((E)->prof) {                                                                                   \
+            hipEvent_t ka_ = prof_event(E), kb_ = prof_event(E);                                           \
+            hipExtLaunchKernelGGL(KERN, GRID, BLOCK, LDS, ST, ka_, kb_, 0, __VA_ARGS__);                   \
+            (E)->ev[CLS].emplace_back(ka_, kb_);                                                           \
+        } else hipLaunchKernelGGL(KERN, GRID, BLOCK, LDS, ST, __VA_ARGS__);                                \
+    } while (0)
 
 int sync_all(dz_engine* e)
 {
@@ -178,7 +202,8 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
 {
     if (n <= 0) return 0;
     if (!st) st = e->stream;
-    ProfScope ps(e, PR_LOGP, st);
+    const bool one_kernel = e->lk == LK_MVN && !e->p.have_prior && e->p.ld / 16 <= 8 && !e->force_pt;   // the LDS kernel alone: timed by the launch's own events
+    ProfScope ps(e, PR_LOGP, st, !one_kernel);
     const dim3 grid((n + 3) / 4), block(256);
     if (e->lk == LK_MVN) {
         {
@@ -186,12 +211,21 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
             if (nrt <= 8 && !e->force_pt) {
                 const int ntiles = (n + 15) / 16;
                 const int ks4 = 4 * ((e->p.d + 3) / 4);
-                const size_t lds = sizeof(double) * ((size_t)ks4 * e->p.ld + e->p.ld + (size_t)4 * 16 * (e->p.ld + 1));
-                const dim3 gl((unsigned)std::min(e->num_cu, (ntiles + 3) / 4)), bl(256);
+                // one wave per point tile of the CU's share when LDS allows (4..8 waves): 1280 tiles on 256 CUs run as
+                // 5-wave blocks instead of 4-wave blocks of which a quarter does a second tile
+                const size_t lds_fixed = sizeof(double) * ((size_t)ks4 * e->p.ld + e->p.ld), lds_wave = sizeof(double) * (size_t)16 * (e->p.ld + 1);
+                int nwv = std::max(4, std::min(8, (ntiles + e->num_cu - 1) / e->num_cu));
+                while (nwv > 4 && lds_fixed + nwv * lds_wave > (size_t)160 * 1024) --nwv;
+                if (e->logp_waves) nwv = e->logp_waves;
+                const size_t lds = lds_fixed + nwv * lds_wave;
+                const dim3 gl((unsigned)std::min(e->num_cu, (ntiles + nwv - 1) / nwv)), bl(64 * nwv);
 #define DZ_LDS_CASE(NRT_)                                                                                                      \
     case NRT_:                                                                                                                 \
-        if (e->p.tri) hipLaunchKernelGGL((dz::k_logp_mvn_lds<NRT_, true>), gl, bl, lds, st, e->p, pts, n, prior, like);  \
-        else hipLaunchKernelGGL((dz::k_logp_mvn_lds<NRT_, false>), gl, bl, lds, st, e->p, pts, n, prior, like);          \
+        if (!one_kernel) {                                                                                                     \
+            if (e->p.tri) hipLaunchKernelGGL((dz::k_logp_mvn_lds<NRT_, true>), gl, bl, lds, st, e->p, pts, n, prior, like);   \
+            else hipLaunchKernelGGL((dz::k_logp_mvn_lds<NRT_, false>), gl, bl, lds, st, e->p, pts, n, prior, like);           \
+        } else if (e->p.tri) DZ_KLAUNCH(e, PR_LOGP, st, (dz::k_logp_mvn_lds<NRT_, true>), gl, bl, lds, e->p, pts, n, prior, like); \
+        else DZ_KLAUNCH(e, PR_LOGP, st, (dz::k_logp_mvn_lds<NRT_, false>), gl, bl, lds, e->p, pts, n, prior, like);           \
         break;
                 switch (nrt) { DZ_LDS_CASE(1) DZ_LDS_CASE(2) DZ_LDS_CASE(3) DZ_LDS_CASE(4) DZ_LDS_CASE(5) DZ_LDS_CASE(6) DZ_LDS_CASE(7) DZ_LDS_CASE(8) }
 #undef DZ_LDS_CASE
@@ -331,23 +365,20 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
         if (need_draws)
             hipLaunchKernelGGL(dz::k_draws, dim3((lnc * p.nslots + 255) / 256), dim3(256), 0, st, p, g, lc0, lnc, e->d_draws[g & 1], e->d_ctl[g & 1]);
         {
-            ProfScope ps(e, PR_PROPOSE, st);
-            if (fused_in) { NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((lnc + wpb - 1) / wpb), dim3(64 * wpb), 0, st, p, 0, g, (uint32_t)e->M, lc0, lnc, 1, 1, e->pending_slot)); }
-            else { NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((lnc * sp0 + wpb - 1) / wpb), dim3(64 * wpb), 0, st, p, 0, g, (uint32_t)e->M, lc0, lnc, sp0, 0, (int64_t)-1)); }
+            if (fused_in) { NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc + wpb - 1) / wpb), dim3(64 * wpb), 0, p, 0, g, (uint32_t)e->M, lc0, lnc, 1, 1, e->pending_slot)); }
+            else { NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc * sp0 + wpb - 1) / wpb), dim3(64 * wpb), 0, p, 0, g, (uint32_t)e->M, lc0, lnc, sp0, 0, (int64_t)-1)); }
         }
         DZCK(launch_check("propose"));
         DZCK(eval_logp(e, p.P + (size_t)lc0 * k * p.ld, lnc * k, p.p_prior + (size_t)lc0 * k, p.p_like + (size_t)lc0 * k, st));
         if (k > 1) {
             {
-                ProfScope ps(e, PR_PROPOSE, st);
-                NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_propose<NCH>, dim3((lnc * sp1 + wpb - 1) / wpb), dim3(64 * wpb), 0, st, p, 1, g, (uint32_t)e->M, lc0, lnc, sp1, 0, (int64_t)-1));
+                NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc * sp1 + wpb - 1) / wpb), dim3(64 * wpb), 0, p, 1, g, (uint32_t)e->M, lc0, lnc, sp1, 0, (int64_t)-1));
             }
             DZCK(launch_check("propose(ref)"));
             DZCK(eval_logp(e, p.R + (size_t)lc0 * (k - 1) * p.ld, lnc * (k - 1), p.r_prior + (size_t)lc0 * (k - 1), p.r_like + (size_t)lc0 * (k - 1), st));
         }
         if (!defer) {
-            ProfScope ps(e, PR_ACCEPT, st);
-            NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_accept<NCH>, dim3((lnc + wpb - 1) / wpb), dim3(64 * wpb), 0, st, p, g, zbase, lc0, lnc, slot, append ? 1 : 0, publish ? 1 : 0, (full && !publish) ? 1 : 0));
+            NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_ACCEPT, st, dz::k_accept<NCH>, dim3((lnc + wpb - 1) / wpb), dim3(64 * wpb), 0, p, g, zbase, lc0, lnc, slot, append ? 1 : 0, publish ? 1 : 0, (full && !publish) ? 1 : 0));
             DZCK(launch_check("accept"));
         }
     }
@@ -475,13 +506,16 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     e->world = cfg->nchains / cfg->nchains_local; e->rank = cfg->chain_offset / cfg->nchains_local;
     HIPCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     {
-        int nl_req = 2;                                         // default: two chain groups (measured best)
+        int nl_req = 1;     // chain groups on separate streams; 2 gains ~3% at 4096 chains but shows occasional 2x-slow passes
         if (const char* ev = getenv("DZ_STREAMS")) nl_req = atoi(ev);
         e->nlanes = std::max(1, std::min(8, nl_req));
         if (cfg->nchains_local < 64 * e->nlanes) e->nlanes = 1;
         e->lane_stream[0] = e->stream;
         for (int s = 1; s < e->nlanes; ++s) HIPCK(hipStreamCreateWithFlags(&e->lane_stream[s], hipStreamNonBlocking));
         for (int s = 0; s < e->nlanes; ++s) HIPCK(hipEventCreateWithFlags(&e->lane_ev[s], hipEventDisableTiming));
+        if (const char* ra = getenv("DZ_RUNAHEAD")) e->ra_stride = std::max(0, atoi(ra));
+        if (const char* lw = getenv("DZ_LOGP_WAVES")) e->logp_waves = std::max(4, std::min(8, atoi(lw)));
+        for (int s = 0; s < 4; ++s) HIPCK(hipEventCreateWithFlags(&e->ra_ev[s], hipEventDisableTiming));
     }
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cu = prop.multiProcessorCount; }
     const size_t ld = p.ld, nl = p.nl, N = p.N, k = p.k, tc = (size_t)cfg->trace_capacity;
@@ -538,6 +572,7 @@ int dz_destroy(dz_engine* e)
     for (int s2 = 0; s2 < e->nlanes; ++s2) if (e->lane_stream[s2]) hipStreamSynchronize(e->lane_stream[s2]);
     for (int s2 = 1; s2 < e->nlanes; ++s2) if (e->lane_stream[s2]) hipStreamDestroy(e->lane_stream[s2]);
     for (int s2 = 0; s2 < e->nlanes; ++s2) if (e->lane_ev[s2]) hipEventDestroy(e->lane_ev[s2]);
+    for (int s2 = 0; s2 < 4; ++s2) if (e->ra_ev[s2]) hipEventDestroy(e->ra_ev[s2]);
     for (auto& v : e->ev) for (auto& pr : v) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (hipEvent_t x : e->ev_pool) hipEventDestroy(x);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
@@ -710,6 +745,14 @@ int dz_step(dz_engine* e, int64_t generations)
         const int n = mega ? mega_segment(e, (uint32_t)e->gen, generations - i) : 0;
         if (n > 0) { DZCK(run_mega_segment(e, (uint32_t)e->gen, n)); i += n; }
         else { DZCK(one_generation(e, 0, e->p.nl, (uint32_t)e->gen, true, i + 1 < generations && !(mega && mega_segment(e, (uint32_t)e->gen + 1, 1) > 0))); i += 1; }
+        if (e->ra_stride > 0 && (++e->ra_n % e->ra_stride) == 0) {
+            // keep the launch queue short: thousands of queued dispatches exhaust the runtime's kernarg/signal pools
+            // and the whole pass then runs several times slower (measured; DESIGN.md "Host run-ahead")
+            const int slot = (int)((e->ra_n / e->ra_stride) & 3), oldest = (slot + 1) & 3;
+            HIPCK(hipEventRecord(e->ra_ev[slot], e->lane_stream[0]));
+            e->ra_used[slot] = true;
+            if (e->ra_used[oldest]) HIPCK(hipEventSynchronize(e->ra_ev[oldest]));
+        }
     }
     return 0;
 }
@@ -894,6 +937,10 @@ int dz_profile_reset(dz_engine* e)
     HIPCK(hipSetDevice(e->c.device));
     DZCK(sync_all(e));
     for (auto& v : e->ev) { for (auto& pr : v) { e->ev_pool.push_back(pr.first); e->ev_pool.push_back(pr.second); } v.clear(); }
+    if (e->prof) {   // class 6: event pairs with nothing in between = what one bracket adds to every measured launch
+        for (int i = 0; i < 64; ++i) { ProfScope ps(e, PR_EMPTY, e->stream); }
+        DZCK(sync_all(e));
+    }
     return 0;
 }
 int dz_profile_get(dz_engine* e, int32_t which, double* total_ms, int64_t* launches)

@@ -387,7 +387,11 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
                 }
             }
             double2 o; o.x = (jj < d) ? pr[it][0] : 0.0; o.y = (jj + 1 < d) ? pr[it][1] : 0.0;
+#ifdef DZ_EXP_NOSTORE    // timing experiment only
+            if (AL16) { if (o.x == 1.2345e300) *reinterpret_cast<double2*>(out + jj) = o; }
+#else
             if (AL16) *reinterpret_cast<double2*>(out + jj) = o;
+#endif
             else { if (jj < d) out[jj] = o.x; if (jj + 1 < d) out[jj + 1] = o.y; }     // unpadded, 8-byte aligned row (LDS tile)
         }
     }
@@ -550,10 +554,14 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
 #pragma unroll
             for (int it = 0; it < NCH; ++it) {
                 const int jj = 128 * it + 2 * lane;
+#ifdef DZ_EXP_NOZ        // timing experiment only: no archive gathers
+                if (jj < p.ld) { ra[it] = double2{(double)r0, 1.0}; rb[it] = double2{(double)r1, 2.0}; }
+#else
                 if (jj < p.ld) {
                     ra[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)r0 * p.ld + jj);
                     rb[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)r1 * p.ld + jj);
                 }
+#endif
             }
         };
 #pragma unroll
@@ -566,9 +574,10 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
                 rt.a[it][0] = ra[it].x - rb[it].x; rt.a[it][1] = ra[it].y - rb[it].y;   // chain_differences :692
                 rt.b[it][0] = 0.0; rt.b[it][1] = 0.0;
             }
+            // (a deeper pipeline -- three buffers, straight-line code, rows of tries i+1..i+3 in flight -- measured
+            //  10% SLOWER: during the tries the kernel already moves ~4 TB/s, so latency is not what limits it)
             if (i + 1 < i1) request(i + 1);
             propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * out_stride, sl + i, csn, false, cr_idx, 1, glev, dsrc);
-        if (prior_out) point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i);
             if (prior_out) point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i);
         }
         return;
@@ -601,7 +610,6 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
             }
             if (i + 1 < i1) request(i + 1);
             propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * out_stride, sl + i, csn, true, cr_idx, delta, glev, dsrc);
-        if (prior_out) point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i);
             if (prior_out) point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i);
         }
         return;
@@ -628,7 +636,11 @@ __global__ __launch_bounds__(1024) void k_propose(Params p, int phase, uint32_t 
     const int lane = threadIdx.x & 63;
     const int c = c0 + wave / split;
     const int per = (n + split - 1) / split;
+#ifdef DZ_EXP_NOTRIES    // timing experiment only: the kernel without its tries
+    const int i0 = 0, i1 = (int)(threadIdx.x >> 12);
+#else
     const int i0 = (wave % split) * per, i1 = min(n, i0 + per);
+#endif
     DrawSrc dsrc; ChainCtl ct;
     double xb[NCH][2];
     double* out; double* sl;
@@ -772,14 +784,14 @@ __global__ __launch_bounds__(256) void k_logp_mvn_mfma(Params p, const double* _
 // One block (4 waves, one per SIMD) per CU loops over the point tiles; the next tile's rows are fetched
 // into registers while the current tile's MFMAs run.
 template <int NRT, bool TRI>
-__global__ __launch_bounds__(256) void k_logp_mvn_lds(Params p, const double* __restrict__ pts, int npts, double* prior_out, double* like_out)
+__global__ __launch_bounds__(512) void k_logp_mvn_lds(Params p, const double* __restrict__ pts, int npts, double* prior_out, double* like_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int KSP = NRT * 4;
     constexpr int LD = NRT * 16;          // == p.ld
     constexpr int LDT = LD + 1;           // padded tile row: the A-layout reads hit distinct banks
     constexpr int NV = LD / 8;            // double2 loads per lane for one tile (16*LD/2/64)
-    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, nwv = blockDim.x >> 6, bdim = blockDim.x;   // 4..8 waves: one per point tile of the CU's share
     const int d = p.d;
     const int KS = (d + 3) >> 2;
     double* Ms = smem;                                    // [4*KS][LD]
@@ -788,7 +800,7 @@ __global__ __launch_bounds__(256) void k_logp_mvn_lds(Params p, const double* __
     const int pi = l & 15, kq = l >> 4;
     const int ntiles = (npts + 15) >> 4;
     const double* mbase = Ms + (size_t)kq * LD + pi;
-    int tile = blockIdx.x * 4 + wv;
+    int tile = blockIdx.x * nwv + wv;
     double2 nx[NV];
     auto fetch = [&](int tl) {
 #pragma unroll
@@ -813,13 +825,13 @@ __global__ __launch_bounds__(256) void k_logp_mvn_lds(Params p, const double* __
             double2 tmp[BATCH];
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
-                const int i = threadIdx.x + 256 * (b0 + u);
+                const int i = threadIdx.x + bdim * (b0 + u);
                 int j = i + start; if (j >= nvec) j -= nvec;
                 tmp[u] = (b0 + u < NIT && i < nvec) ? src[j] : double2{0.0, 0.0};
             }
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
-                const int i = threadIdx.x + 256 * (b0 + u);
+                const int i = threadIdx.x + bdim * (b0 + u);
                 int j = i + start; if (j >= nvec) j -= nvec;
                 if (b0 + u < NIT && i < nvec) dst[j] = tmp[u];
             }
@@ -827,7 +839,7 @@ __global__ __launch_bounds__(256) void k_logp_mvn_lds(Params p, const double* __
         if (threadIdx.x < LD) mus[threadIdx.x] = p.mu[threadIdx.x];
     }
     __syncthreads();
-    for (; tile < ntiles; tile += gridDim.x * 4) {
+    for (; tile < ntiles; tile += gridDim.x * nwv) {
         const int p0 = tile * 16;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
@@ -838,7 +850,7 @@ __global__ __launch_bounds__(256) void k_logp_mvn_lds(Params p, const double* __
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        if (tile + (int)gridDim.x * 4 < ntiles) fetch(tile + gridDim.x * 4);
+        if (tile + (int)gridDim.x * nwv < ntiles) fetch(tile + gridDim.x * nwv);
         double A[KSP];
 #pragma unroll
         for (int ks = 0; ks < KSP; ++ks) A[ks] = Vt[pi * LDT + 4 * ks + kq];

@@ -20,6 +20,9 @@ DZ_DEV u32x4 philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t
 #ifdef DZ_EXP_NOPHILOX   // timing experiment only (tools/variants.sh): breaks the random contract
     return u32x4{c0 * 0x9E3779B9u ^ k0, c1 * 0xBB67AE85u ^ c2, c2 * 0xD2511F53u ^ c3, (c3 + c0) * 0xCD9E8D57u ^ k1};
 #endif
+    // The round keys are recomputed by every call (20 scalar adds).  Left to itself the compiler hoists the whole key
+    // schedule out of the callers' loops into 20 SGPRs, which then spill to VGPR lanes: ~40 v_readlane per try in k_propose.
+    asm volatile("" : "+s"(k0), "+s"(k1));
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
@@ -175,8 +178,10 @@ template <int ROR>
 DZ_DEV double row_ror(double v)
 {
     const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x120 + ROR, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x120 + ROR, 0xf, 0xf, false);
+    // every lane of a row rotation reads a live lane, so the destination needs no defined previous value
+    // (update_dpp with old = 0 costs two extra v_mov per rotation)
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), 0x120 + ROR, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), 0x120 + ROR, 0xf, 0xf, false);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 // p[i] + p[i ^ off] for off = 8,4,2,1 inside rows of 16 lanes.  After the step with offset 2m the values have

@@ -91,7 +91,7 @@ struct dz_engine {
     dz_exchange_cb xcb = nullptr; void* xcb_user = nullptr;
     ncclComm_t comm = nullptr; int rank = 0, world = 1;
     // owned device buffers (also referenced from p)
-    double *d_mins = nullptr, *d_maxs = nullptr, *d_gtab = nullptr, *d_mu = nullptr, *d_Mt = nullptr, *d_mixF = nullptr;
+    double *d_mins = nullptr, *d_maxs = nullptr, *d_gtab = nullptr, *d_mu = nullptr, *d_Mt = nullptr, *d_Mtp = nullptr, *d_mixF = nullptr;
     double *d_pa = nullptr, *d_pb = nullptr; int32_t* d_pkind = nullptr;
     double *d_shared = nullptr;      // cr_probs|cr_delta|cr_n|g_probs|g_delta|g_n
     double *d_partial = nullptr, *d_mean = nullptr, *d_sd = nullptr, *d_sdc = nullptr, *d_dl = nullptr, *d_dlg = nullptr;
@@ -213,7 +213,7 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
                 const int ks4 = 4 * ((e->p.d + 3) / 4);
                 // one wave per point tile of the CU's share when LDS allows (4..8 waves): 1280 tiles on 256 CUs run as
                 // 5-wave blocks instead of 4-wave blocks of which a quarter does a second tile
-                const size_t lds_fixed = sizeof(double) * ((size_t)ks4 * e->p.ld + e->p.ld), lds_wave = sizeof(double) * (size_t)16 * (e->p.ld + 1);
+                const size_t lds_fixed = sizeof(double) * ((e->p.tri ? (size_t)e->p.mtp_len : (size_t)ks4 * e->p.ld) + e->p.ld), lds_wave = sizeof(double) * (size_t)16 * (e->p.ld + 1);
                 int nwv = std::max(4, std::min(8, (ntiles + e->num_cu - 1) / e->num_cu));
                 while (nwv > 4 && lds_fixed + nwv * lds_wave > (size_t)160 * 1024) --nwv;
                 if (e->logp_waves) nwv = e->logp_waves;
@@ -530,6 +530,9 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     rc |= ealloc(e, &e->d_draws[0], nl * (size_t)p.nslots); rc |= ealloc(e, &e->d_draws[1], nl * (size_t)p.nslots);
     rc |= ealloc(e, &e->d_ctl[0], nl); rc |= ealloc(e, &e->d_ctl[1], nl);
     rc |= ealloc(e, &p.sel, nl);
+#ifdef DZ_EXP_STAMPS
+    { void* hp = nullptr; if (hipHostMalloc(&hp, (size_t)4 * nl * 16 * 8, hipHostMallocDefault) == hipSuccess) { memset(hp, 0, (size_t)4 * nl * 16 * 8); p.dbg = (unsigned long long*)hp; } }
+#endif
     rc |= ealloc(e, &e->d_params, 1);
     rc |= ealloc(e, &e->d_mins, ld); rc |= ealloc(e, &e->d_maxs, ld);
     rc |= ealloc(e, &e->d_gtab, (size_t)cfg->ngamma * cfg->depairs * p.d);
@@ -567,6 +570,12 @@ int dz_create(const dz_config* cfg, dz_engine** out)
 
 int dz_destroy(dz_engine* e)
 {
+#ifdef DZ_EXP_STAMPS
+    if (e && e->p.dbg) {
+        hipDeviceSynchronize();
+        if (FILE* f = fopen("gpurun_out/stamps.bin", "wb")) { fwrite(e->p.dbg, 8, (size_t)4 * e->p.nl * 16, f); fclose(f); }
+    }
+#endif
     if (!e) return 0;
     hipSetDevice(e->c.device);
     for (int s2 = 0; s2 < e->nlanes; ++s2) if (e->lane_stream[s2]) hipStreamSynchronize(e->lane_stream[s2]);
@@ -678,6 +687,16 @@ int dz_set_likelihood_mvn(dz_engine* e, const double* mu, const double* M, int32
     HIPCK(hipMemcpy(e->d_Mt, mt.data(), sizeof(double) * mt.size(), hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(e->d_mu, m.data(), sizeof(double) * ld, hipMemcpyHostToDevice));
     e->p.mu = e->d_mu; e->p.Mt = e->d_Mt; e->p.logF = log_F; e->p.tri = kind != 0; e->lk = LK_MVN;
+    e->p.Mtp = nullptr; e->p.mtp_len = 0;
+    if (kind != 0 && ld <= 128) {   // packed triangle for k_logp_mvn_lds (dz_kernels.h tri_row_offset)
+        const int rows = 4 * ((d + 3) / 4);
+        std::vector<double> pk((size_t)dz::tri_row_offset(rows), 0.0);
+        for (int r = 0; r < rows; ++r)
+            for (int c = 0; c < 16 * (r / 16 + 1); ++c) pk[(size_t)dz::tri_row_offset(r) + c] = mt[(size_t)r * ld + c];
+        if (!e->d_Mtp) DZCK(ealloc(e, &e->d_Mtp, (size_t)dz::tri_row_offset(128)));
+        HIPCK(hipMemcpy(e->d_Mtp, pk.data(), sizeof(double) * pk.size(), hipMemcpyHostToDevice));
+        e->p.Mtp = e->d_Mtp; e->p.mtp_len = (int)pk.size();
+    }
     return 0;
 }
 

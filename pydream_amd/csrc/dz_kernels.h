@@ -33,12 +33,28 @@ struct Params {
     // likelihood / prior
     const int32_t* pkind; const double *pa, *pb; int have_prior;
     const double *mu, *Mt; double logF; int tri; int J; const double* mixF;
+    // triangular factor, packed for k_logp_mvn_lds: k-row r keeps its first 16*(r/16+1) columns (the row tiles that
+    // use it), rows back to back; mtp_len doubles (even)
+    const double* Mtp; int mtp_len;
     // wave-uniform Philox outputs of one generation, precomputed lane-parallel (k_draws / k_accept):
     // [nl][nslots] uint4; slot 0..2 = control stream idx 0..2, then npt slots per (phase, try)
     const uint4* draws; uint4* draws_next; int nslots, npt;
     const ChainCtl* ctl; ChainCtl* ctl_next;
     int* sel;      // [nl] selected try | anyfinite<<8, written by the reference-phase proposal wave
+#ifdef DZ_EXP_STAMPS   // timing experiment only: per-wave cycle stamps of the latest proposal launches
+    unsigned long long* dbg;
+#endif
 };
+#ifdef DZ_EXP_STAMPS
+#define DZ_STAMP(p_, phase_, c_, i_) do { if ((threadIdx.x & 63) == 0) (p_).dbg[((size_t)(phase_) * (p_).nl + (c_)) * 16 + (i_)] = __builtin_readcyclecounter(); } while (0)
+#define DZ_LSTAMP(p_, w_, i_) do { if ((threadIdx.x & 63) == 0) (p_).dbg[((size_t)2 * (p_).nl + (w_)) * 16 + (i_)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DZ_STAMP(p_, phase_, c_, i_) do { } while (0)
+#define DZ_LSTAMP(p_, w_, i_) do { } while (0)
+#endif
+
+// offset of k-row r in the packed triangular layout: row block b = r/16 has 16*(b+1) columns
+__host__ __device__ inline int tri_row_offset(int r) { const int b = r >> 4; return 128 * b * (b + 1) + (r - 16 * b) * 16 * (b + 1); }
 
 struct StepFlags { bool snk; int cr_idx, delta, glev; };
 
@@ -536,7 +552,11 @@ DZ_DEV void point_prior(const Params& p, const double* row, int lane, double* pr
 template <int NCH, bool AL16, bool GENERIC = true, bool LEAN = false>
 DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int c, uint32_t gc, int i0, int i1, int n, int lane,
                         const double (&xb)[NCH][2], const double (&gt)[NCH][2], bool snk, int cr_idx, int delta, int glev, const DrawSrc& dsrc,
-                        double* out, int out_stride, double* sl, double* csn, double* prior_out)
+                        double* out, int out_stride, double* sl, double* csn, double* prior_out
+#ifdef DZ_EXP_PF
+                        , __attribute__((address_space(3))) void* pf_sink = nullptr
+#endif
+                        )
 {
     // software pipeline over the tries: the Z rows of try i+1 are requested before try i's arithmetic starts,
     // and no scalar memory wait sits in between because the draws are already in registers
@@ -566,6 +586,22 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
         };
 #pragma unroll
         for (int it = 0; it < NCH; ++it) { ra[it] = double2{0.0, 0.0}; rb[it] = double2{0.0, 0.0}; }
+#ifdef DZ_EXP_PF
+        if (pf_sink) {   // warm L2 with the rows of the later tries: LDS-DMA loads into a sink nobody reads (no VGPR, no wait)
+            for (int i = i0 + 1; i < i1; ++i) {
+                const u32x4 w = uniform_draw(p, dsrc, pt_slot(p, phase, i, 1), gc, g);
+                const uint32_t r0 = mulhi_idx(w.x, M);
+                uint32_t r1 = mulhi_idx(w.y, M - 1u);
+                if (r1 >= r0) r1++;
+#pragma unroll
+                for (int it = 0; it < NCH; ++it) {
+                    const int jc = min(128 * it + 2 * lane, p.ld - 2);
+                    __builtin_amdgcn_global_load_lds(p.Z + (size_t)r0 * p.ld + jc, pf_sink, 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(p.Z + (size_t)r1 * p.ld + jc, pf_sink, 16, 0, 0);
+                }
+            }
+        }
+#endif
         request(i0);
         for (int i = i0; i < i1; ++i) {
             RowTerms<NCH> rt;
@@ -576,8 +612,10 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
             }
             // (a deeper pipeline -- three buffers, straight-line code, rows of tries i+1..i+3 in flight -- measured
             //  10% SLOWER: during the tries the kernel already moves ~4 TB/s, so latency is not what limits it)
+            DZ_STAMP(p, phase, c, 2 + 2 * i);          // rows of try i have arrived
             if (i + 1 < i1) request(i + 1);
             propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * out_stride, sl + i, csn, false, cr_idx, 1, glev, dsrc);
+            DZ_STAMP(p, phase, c, 3 + 2 * i);          // try i's arithmetic issued
             if (prior_out) point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i);
         }
         return;
@@ -635,6 +673,7 @@ __global__ __launch_bounds__(1024) void k_propose(Params p, int phase, uint32_t 
     if (wave >= nc * split) return;
     const int lane = threadIdx.x & 63;
     const int c = c0 + wave / split;
+    DZ_STAMP(p, phase, c, 0);
     const int per = (n + split - 1) / split;
 #ifdef DZ_EXP_NOTRIES    // timing experiment only: the kernel without its tries
     const int i0 = 0, i1 = (int)(threadIdx.x >> 12);
@@ -673,7 +712,15 @@ __global__ __launch_bounds__(1024) void k_propose(Params p, int phase, uint32_t 
     const uint32_t gc = (uint32_t)(p.off + c);
     const bool snk = ct.snk != 0;
     double* csn = (phase == 0 && p.k == 1) ? p.cur_snk + c : nullptr;
+    DZ_STAMP(p, phase, c, 1);
+#ifdef DZ_EXP_PF
+    __shared__ __attribute__((aligned(16))) double pf_area[128];
+    propose_set<NCH, true>(p, phase, g, M, c, gc, i0, i1, n, lane, xb, gt, snk, ct.cr_idx, ct.delta, ct.glev, dsrc, out, p.ld, sl, csn, nullptr,
+                           (__attribute__((address_space(3))) void*)pf_area);
+#else
     propose_set<NCH, true>(p, phase, g, M, c, gc, i0, i1, n, lane, xb, gt, snk, ct.cr_idx, ct.delta, ct.glev, dsrc, out, p.ld, sl, csn, nullptr);
+#endif
+    DZ_STAMP(p, phase, c, 15);
 }
 
 // debug entry: flags supplied by the host (function-level parity tests); one wave, all tries
@@ -794,8 +841,8 @@ __global__ __launch_bounds__(512) void k_logp_mvn_lds(Params p, const double* __
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, nwv = blockDim.x >> 6, bdim = blockDim.x;   // 4..8 waves: one per point tile of the CU's share
     const int d = p.d;
     const int KS = (d + 3) >> 2;
-    double* Ms = smem;                                    // [4*KS][LD]
-    double* mus = Ms + (size_t)4 * KS * LD;               // [LD]
+    double* Ms = smem;                                    // [4*KS][LD], or the packed triangle
+    double* mus = Ms + (TRI ? (size_t)p.mtp_len : (size_t)4 * KS * LD);      // [LD]
     double* Vt = mus + LD + (size_t)wv * 16 * LDT;        // [16][LDT] per wave
     const int pi = l & 15, kq = l >> 4;
     const int ntiles = (npts + 15) >> 4;
@@ -811,14 +858,15 @@ __global__ __launch_bounds__(512) void k_logp_mvn_lds(Params p, const double* __
             nx[q] = *reinterpret_cast<const double2*>(pts + (size_t)pt * LD + col);
         }
     };
+    DZ_LSTAMP(p, blockIdx.x * nwv + wv, 0);
     if (tile < ntiles) fetch(tile);                // the first tile's rows are requested before the matrix
     {   // stage the matrix: all loads of a batch are issued before the first LDS store, so the copy costs
-        // one memory latency per batch, not one per element
-        const int nvec = (4 * KS * LD) >> 1;
-        const double2* src = reinterpret_cast<const double2*>(p.Mt);
+        // one memory latency per batch, not one per element.  TRI: the packed layout (52% of the square at d=100).
+        const int nvec = TRI ? (p.mtp_len >> 1) : ((4 * KS * LD) >> 1);
+        const double2* src = reinterpret_cast<const double2*>(TRI ? p.Mtp : p.Mt);
         double2* dst = reinterpret_cast<double2*>(Ms);
         const int start = (int)(((size_t)blockIdx.x * 1024) % (size_t)nvec);
-        constexpr int NIT = (4 * KSP * LD / 2 + 255) / 256;       // upper bound on elements per thread
+        constexpr int NIT = TRI ? (64 * NRT * (NRT + 1) + 255) / 256 : (4 * KSP * LD / 2 + 255) / 256;       // upper bound on elements per thread
         constexpr int BATCH = NIT;
 #pragma unroll
         for (int b0 = 0; b0 < NIT; b0 += BATCH) {
@@ -838,19 +886,32 @@ __global__ __launch_bounds__(512) void k_logp_mvn_lds(Params p, const double* __
         }
         if (threadIdx.x < LD) mus[threadIdx.x] = p.mu[threadIdx.x];
     }
+    DZ_LSTAMP(p, blockIdx.x * nwv + wv, 1);
     __syncthreads();
+    DZ_LSTAMP(p, blockIdx.x * nwv + wv, 2);
     for (; tile < ntiles; tile += gridDim.x * nwv) {
         const int p0 = tile * 16;
+        {   // two passes: the compiler cannot move an LDS read of mus across an LDS write to Vt, so reading inside the
+            // store loop costs one exposed LDS latency per element (measured ~3000 cycles per tile)
+            double2 mv[NV];
 #pragma unroll
-        for (int q = 0; q < NV; ++q) {
-            const int i2 = 2 * (l + 64 * q);
-            const int row = i2 / LD, col = i2 - row * LD;
-            Vt[row * LDT + col] = nx[q].x - mus[col];
-            Vt[row * LDT + col + 1] = nx[q].y - mus[col + 1];
+            for (int q = 0; q < NV; ++q) {
+                const int i2 = 2 * (l + 64 * q);
+                const int col = i2 - (i2 / LD) * LD;
+                mv[q] = *reinterpret_cast<const double2*>(mus + col);
+            }
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int i2 = 2 * (l + 64 * q);
+                const int row = i2 / LD, col = i2 - row * LD;
+                Vt[row * LDT + col] = nx[q].x - mv[q].x;
+                Vt[row * LDT + col + 1] = nx[q].y - mv[q].y;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         if (tile + (int)gridDim.x * nwv < ntiles) fetch(tile + gridDim.x * nwv);
+        DZ_LSTAMP(p, blockIdx.x * nwv + wv, 3);
         double A[KSP];
 #pragma unroll
         for (int ks = 0; ks < KSP; ++ks) A[ks] = Vt[pi * LDT + 4 * ks + kq];
@@ -860,12 +921,14 @@ __global__ __launch_bounds__(512) void k_logp_mvn_lds(Params p, const double* __
 #pragma unroll
         for (int ks = 0; ks < KSP; ++ks) {
             if (ks < KSP - 4 || ks < KS) {
-                const double* mrow = mbase + (size_t)(4 * ks) * LD;
+                // k-rows 4ks..4ks+3 (lane group kq), columns 16t+pi
+                const double* mrow = TRI ? Ms + tri_row_offset(4 * ks) + kq * (16 * (ks / 4 + 1)) + pi : mbase + (size_t)(4 * ks) * LD;
 #pragma unroll
                 for (int t = 0; t < NRT; ++t)
                     if (!TRI || ks >= 4 * t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ks], mrow[16 * t], acc[t], 0, 0, 0);
             }
         }
+        DZ_LSTAMP(p, blockIdx.x * nwv + wv, 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int pt = p0 + kq + 4 * e;
@@ -882,6 +945,7 @@ __global__ __launch_bounds__(512) void k_logp_mvn_lds(Params p, const double* __
                 if (!p.have_prior) prior_out[pt] = 0.0;
             }
         }
+        DZ_LSTAMP(p, blockIdx.x * nwv + wv, 5);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }

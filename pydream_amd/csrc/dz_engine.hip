@@ -104,7 +104,7 @@ struct dz_engine {
     int num_cu = 256;
     int waves_per_block = 0;        // DZ_WPB
     bool fuse = true;               // DZ_FUSE=0 disables the accept+propose fusion
-    bool mega = false;              // DZ_MEGA=1 enables the persistent generation kernel (experimental: at parity)
+    bool mega = true;               // the persistent generation kernel serves every eligible configuration (mega_eligible); DZ_MEGA=0 forces the multi-kernel path
     int mega_max_gen = 1 << 20;     // DZ_MEGA_MAXGEN: generations per launch cap (measurement)
     bool pending_accept = false;    // generation gen-1's Metropolis step has been deferred into the next proposal kernel
     int64_t pending_slot = -1;
@@ -202,15 +202,18 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
 {
     if (n <= 0) return 0;
     if (!st) st = e->stream;
-    const bool one_kernel = e->lk == LK_MVN && !e->p.have_prior && e->p.ld / 16 <= 8 && !e->force_pt;   // the LDS kernel alone: timed by the launch's own events
+    const int nrt = e->p.ld / 16;
+    const int ks4 = 4 * ((e->p.d + 3) / 4);
+    // LDS kernel: matrix (packed triangle or square) + mean + at least 4 wave tiles must fit 160 KB
+    // (the dense 128-D square does not: 131 KB + 66 KB; it runs on the register-operand MFMA kernel)
+    const bool lds_fits = sizeof(double) * ((e->p.tri ? (size_t)e->p.mtp_len : (size_t)ks4 * e->p.ld) + e->p.ld + (size_t)4 * 16 * (e->p.ld + 1)) <= (size_t)160 * 1024;
+    const bool one_kernel = e->lk == LK_MVN && !e->p.have_prior && nrt <= 8 && !e->force_pt && lds_fits;   // the LDS kernel alone: timed by the launch's own events
     ProfScope ps(e, PR_LOGP, st, !one_kernel);
     const dim3 grid((n + 3) / 4), block(256);
     if (e->lk == LK_MVN) {
         {
-            const int nrt = e->p.ld / 16;
-            if (nrt <= 8 && !e->force_pt) {
+            if (nrt <= 8 && !e->force_pt && lds_fits) {
                 const int ntiles = (n + 15) / 16;
-                const int ks4 = 4 * ((e->p.d + 3) / 4);
                 // one wave per point tile of the CU's share when LDS allows (4..8 waves): 1280 tiles on 256 CUs run as
                 // 5-wave blocks instead of 4-wave blocks of which a quarter does a second tile
                 const size_t lds_fixed = sizeof(double) * ((e->p.tri ? (size_t)e->p.mtp_len : (size_t)ks4 * e->p.ld) + e->p.ld), lds_wave = sizeof(double) * (size_t)16 * (e->p.ld + 1);

@@ -158,3 +158,39 @@ def test_d1000_stress_shape_against_oracle(G, O):
         e.step(n)
         out.append(e.get_trace(0, n))
     assert_traces_identical(out[0], out[1])
+
+
+@pytest.mark.parametrize("N,d,k,tri,burnin,eligible", [(1024, 100, 5, 0, 0, True), (1000, 100, 5, 1, 0, True), (96, 10, 3, 1, 0, True),
+                                                       (64, 64, 4, 0, 0, True), (256, 100, 5, 1, 12, True),
+                                                       (64, 128, 4, 0, 0, False), (64, 128, 4, 1, 0, False)])
+def test_persistent_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, k, tri, burnin, eligible, monkeypatch):
+    """k_generations (whole thin-cycles in one launch, the default wherever it is eligible) against the
+    multi-kernel path (DZ_MEGA=0) and the oracle: 35 generations across three history appends, chain counts that do
+    not fill the last block, dense and triangular matrix, and a crossover burn-in in front (multi-kernel during the
+    burn-in, persistent afterwards).  The 128-D cases do not fit the persistent kernel's LDS budget (and the dense one
+    not even the LDS likelihood kernel's): they must fall back silently and still agree with the oracle."""
+    n, seed = 35, 77
+    P = H.mvn_precision(d)
+    M = np.linalg.cholesky((P + P.T) / 2).T if tri else P
+    Z0 = H.seed_history(max(10 * d, 2 * N), d, seed)
+
+    def run(Cls, mega):
+        monkeypatch.setenv("DZ_MEGA", "1" if mega else "0")
+        e = Cls(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
+                adapt_crossover=1 if burnin else 0, crossover_burnin=burnin)
+        e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), M, tri, 0.0)
+        launches = None
+        if Cls is G.Engine:
+            e.profile_enable(True); e.profile_reset()
+        e.step(n)
+        if Cls is G.Engine:
+            launches = e.profile_get("generations")[1]
+            e.profile_enable(False)
+        return e.get_trace(0, n), e.get_history(), e.get_cr_state()[0], launches
+
+    a, b, o = run(G.Engine, True), run(G.Engine, False), run(O.Engine, False)
+    assert (a[3] > 0) == eligible and b[3] == 0              # the persistent kernel really ran / really did not
+    for other in (b, o):
+        assert_traces_identical(a[0], other[0])
+        np.testing.assert_array_equal(a[1], other[1])
+        np.testing.assert_array_equal(a[2], other[2])

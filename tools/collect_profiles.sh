@@ -15,7 +15,7 @@ i=0
 while read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $group -d gpurun_out/${tag}_pmc_$i -o p --output-format csv -- python bench.py --steps 20 --warmup 5 --spinup 200 --no-cpu-baseline --no-events "$@" > gpurun_out/${tag}_pmc_$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $group -d gpurun_out/${tag}_pmc_$i -o p --output-format csv -- python bench.py --steps 40 --warmup 10 --spinup 200 --no-cpu-baseline --no-events "$@" > gpurun_out/${tag}_pmc_$i.log 2>&1
   f=$(find gpurun_out/${tag}_pmc_$i -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && python tools/pmc_summary.py $f gpurun_out/${tag}_pmc_$i.json > /dev/null
 done <<'G'

@@ -403,15 +403,18 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
 }
 
 // ---- persistent generation kernel (dz_megakernel.h) -------------------------------------------------
-size_t mega_lds_bytes(const dz_engine* e)
+// chain states, gamma table and decisions ride in LDS next to the matrix whenever that fits (the packed triangle at
+// d=100 leaves room; the dense square does not)
+size_t mega_lds_bytes(const dz_engine* e, bool xlds)
 {
-    return sizeof(double) * (size_t)dz::mega_layout(e->p.d, e->p.k, e->p.ld / 16, e->p.ncr, e->p.ngamma).total;
+    return sizeof(double) * (size_t)dz::mega_layout(e->p.d, e->p.k, e->p.ld / 16, e->p.ncr, e->p.ngamma, e->p.tri != 0, xlds).total;
 }
+bool mega_xlds(const dz_engine* e) { return mega_lds_bytes(e, true) <= (size_t)160 * 1024; }
 bool mega_eligible(const dz_engine* e)
 {
     const dz::Params& p = e->p;
     return e->mega && e->lk == LK_MVN && !p.hard && !p.have_prior && p.ld <= 128 && p.k >= 3 && p.k <= dz::MAXK && p.depairs == 1 &&
-           p.nslots <= 64 && mega_lds_bytes(e) <= 160 * 1024;
+           p.nslots <= 64 && (!p.tri || p.Mtp) && mega_lds_bytes(e, false) <= (size_t)160 * 1024;
 }
 // number of generations, starting at g, that one launch may cover: none of them publishes positions
 // (crossover burn-in), and only the last one may append to the history
@@ -434,17 +437,20 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
     const int64_t slot0 = e->c.trace_capacity ? e->ntrace : -1;
     const int nrt = p.ld / 16;
     const dim3 grid((p.nl + dz::MEGA_CHAINS - 1) / dz::MEGA_CHAINS), block(64 * dz::MEGA_WAVES);
-    const size_t lds = mega_lds_bytes(e);
+    const bool xlds = mega_xlds(e);
+    const size_t lds = mega_lds_bytes(e, xlds);
     HIPCK(hipMemcpyAsync(e->d_params, &p, sizeof(dz::Params), hipMemcpyHostToDevice, e->stream));
     {
         ProfScope ps(e, PR_GENERATIONS);
-#define DZ_MEGA_CASE(NRT_)                                                                                                                        \
-    case NRT_:                                                                                                                                    \
-        if (p.tri) hipLaunchKernelGGL((dz::k_generations<NRT_, true>), grid, block, lds, e->stream, e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0);   \
-        else hipLaunchKernelGGL((dz::k_generations<NRT_, false>), grid, block, lds, e->stream, e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0);         \
+#define DZ_MEGA_LAUNCH(NRT_, TRI_, X_) hipLaunchKernelGGL((dz::k_generations<NRT_, TRI_, X_>), grid, block, lds, e->stream, e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0)
+#define DZ_MEGA_CASE(NRT_)                                                              \
+    case NRT_:                                                                          \
+        if (p.tri) { if (xlds) DZ_MEGA_LAUNCH(NRT_, true, true); else DZ_MEGA_LAUNCH(NRT_, true, false); }    \
+        else { if (xlds) DZ_MEGA_LAUNCH(NRT_, false, true); else DZ_MEGA_LAUNCH(NRT_, false, false); }        \
         break;
         switch (nrt) { DZ_MEGA_CASE(1) DZ_MEGA_CASE(2) DZ_MEGA_CASE(3) DZ_MEGA_CASE(4) DZ_MEGA_CASE(5) DZ_MEGA_CASE(6) DZ_MEGA_CASE(7) DZ_MEGA_CASE(8) }
 #undef DZ_MEGA_CASE
+#undef DZ_MEGA_LAUNCH
     }
     DZCK(launch_check("k_generations"));
     if (append_last) { DZCK(allgather_rows(e, p.Z + (size_t)e->M * p.ld)); e->M += p.N; }

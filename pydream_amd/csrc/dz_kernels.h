@@ -255,6 +255,16 @@ DZ_DEV void load_gamma_row(const Params& p, int glev, int delta, int lane, doubl
 #pragma unroll
         for (int s = 0; s < 2; ++s) { const int j = 128 * it + 2 * lane + s; gt[it][s] = (j < p.d ? row[j] : 0.0) + zero; }
 }
+// the same from any copy of the row (the persistent kernel keeps the table in LDS)
+template <int NCH>
+DZ_DEV void load_gamma_row_from(const double* row, int d, int lane, double (&gt)[NCH][2])
+{
+    const double zero = (double)(threadIdx.x >> 12);
+#pragma unroll
+    for (int it = 0; it < NCH; ++it)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { const int j = 128 * it + 2 * lane + s; gt[it][s] = (j < d ? row[j] : 0.0) + zero; }
+}
 template <int NCH>
 DZ_DEV double gamma_lookup(const double (&gt)[NCH][2], int idx)      // idx wave-uniform
 {

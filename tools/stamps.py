@@ -3,12 +3,15 @@
 import numpy as np, sys
 a = np.fromfile(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/stamps.bin", dtype=np.uint64)
 nl = a.size // 64
-L = a[2 * nl * 16:].reshape(-1, 16).astype(np.int64)
+MG = a[3 * nl * 16:].reshape(-1, 16).astype(np.int64)
+L = a[2 * nl * 16:3 * nl * 16].reshape(-1, 16).astype(np.int64)
 a = a[:2 * nl * 16].reshape(2, nl, 16).astype(np.int64)
 for ph in (0, 1):
     s = a[ph]
     ok = s[:, 0] > 0
     s = s[ok]
+    if not len(s):
+        continue
     t0 = s[:, 0].min()
     n = 5 if ph == 0 else 4
     print("phase %d" % ph)
@@ -33,3 +36,11 @@ if len(L):
         dtt = L[:, i + 1] - L[:, i]
         print("   %-46s mean %6d  p95 %6d" % (nm, dtt.mean(), np.percentile(dtt, 95)))
     print("   whole wave mean %d" % (L[:, 5] - L[:, 0]).mean())
+
+MG = MG[(MG[:, 0] > 0) & (MG[:, 9] > MG[:, 0]) & (MG[:, 9] - MG[:, 0] < 2000000)]
+if len(MG):
+    names = ["propose 0 (k tries)", "barrier", "likelihood tiles (MFMA)", "barrier", "select + propose 1 (k-1 tries)", "barrier", "likelihood tiles (MFMA)", "barrier", "Metropolis step, trace"]
+    print("persistent kernel, last generation of the last launch: %d waves; mean generation %d cycles" % (len(MG), (MG[:, 9] - MG[:, 0]).mean()))
+    for i, nm in enumerate(names):
+        dtt = MG[:, i + 1] - MG[:, i]
+        print("   %-34s mean %6d  p5 %6d  p95 %6d" % (nm, dtt.mean(), np.percentile(dtt, 5), np.percentile(dtt, 95)))

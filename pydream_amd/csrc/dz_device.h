@@ -200,6 +200,22 @@ DZ_DEV double wave_bfly(double v)
     v = v + __shfl_xor(v, 16, 64);
     return bfly16(v);       // all four rows now hold the same 16 values
 }
+// value of lane ln (wave-uniform index) -- v_readlane, no LDS crossbar round trip
+DZ_DEV double readlane_f64(double v, int ln)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), ln), hi = __builtin_amdgcn_readlane((int)(b >> 32), ln);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// maximum over each row of 16 lanes, in every lane of the row (fmax is exact, so the order is immaterial)
+DZ_DEV double rowmax16(double v)
+{
+    v = fmax(v, row_ror<8>(v));
+    v = fmax(v, row_ror<4>(v));
+    v = fmax(v, row_ror<2>(v));
+    v = fmax(v, row_ror<1>(v));
+    return v;
+}
 DZ_DEV int wave_isum(int v)
 {
 #pragma unroll

@@ -73,17 +73,14 @@ DZ_DEV StepFlags step_flags(const Params& p, const Ctrl& u) { return step_flags_
 // k); the sums run over the tries in order, so every lane ends with the same scalars.
 DZ_DEV int mt_select_vals(int k, double lp, double u_sel, int lane, bool* anyfinite)
 {   // lp: lane i < k holds prior_i + T like_i (:900), other lanes -inf
-    double mx = lp;
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));   // MAXK = 16 lanes
-    mx = __shfl(mx, 0, 64);
+    const double mx = readlane_f64(rowmax16(lp), 0);                                   // MAXK = 16 lanes
     *anyfinite = __any(lane < k && is_finite(lp)) != 0;
     const double w = dexp(lp - mx);
     double S = 0.0;
-    for (int i = 0; i < k; ++i) S = S + __shfl(w, i, 64);
+    for (int i = 0; i < k; ++i) S = S + readlane_f64(w, i);
     const double pr = w / S;                          // lane i: probability of try i (:907)
     double cum = 0.0; int sel = k - 1;
-    for (int i = 0; i < k; ++i) { cum = cum + __shfl(pr, i, 64); if (u_sel < cum) { sel = i; break; } }
+    for (int i = 0; i < k; ++i) { cum = cum + readlane_f64(pr, i); if (u_sel < cum) { sel = i; break; } }
     return sel;
 }
 DZ_DEV int mt_select(const Params& p, int c, double u_sel, int lane, bool* anyfinite)
@@ -98,14 +95,12 @@ DZ_DEV int mt_select(const Params& p, int c, double u_sel, int lane, bool* anyfi
 // every other lane -inf.
 DZ_DEV double mt_log_ratio(int k, double val)
 {
-    double m2 = val;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) m2 = fmax(m2, __shfl_xor(m2, off, 64));                    // :320
-    m2 = __shfl(m2, 0, 64);
+    const double rm = rowmax16(val);
+    const double m2 = fmax(readlane_f64(rm, 0), readlane_f64(rm, 16));                                 // :320
     const double ev = dexp(val - m2);                                                                // :321-322
     double SA = 0.0, SB = 0.0;
-    for (int i = 0; i < k; ++i) SA = SA + __shfl(ev, i, 64);
-    for (int i = 0; i < k; ++i) SB = SB + __shfl(ev, 16 + i, 64);
+    for (int i = 0; i < k; ++i) SA = SA + readlane_f64(ev, i);
+    for (int i = 0; i < k; ++i) SB = SB + readlane_f64(ev, 16 + i);
     return nan_to_num(dlog(SA / SB));                                                                // :323
 }
 

@@ -78,6 +78,7 @@ struct dz_engine {
     // proposal generation (VALU) -- lane 0 is `stream`
     int nlanes = 1; hipStream_t lane_stream[8] = {nullptr}; hipEvent_t lane_ev[8] = {nullptr}; bool need_join = true;
     // bounded host run-ahead: a marker every ra_stride generations, the host never gets more than 3 markers ahead
+    dz::Params p_shadow; bool params_uploaded = false;    // what d_params holds
     int logp_waves = 0;      // DZ_LOGP_WAVES: force the block size of k_logp_mvn_lds (tuning)
     int ra_stride = 32; hipEvent_t ra_ev[4] = {nullptr}; bool ra_used[4] = {false, false, false, false}; int64_t ra_n = 0;
     int nch = 1;
@@ -439,10 +440,13 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
     const dim3 grid((p.nl + dz::MEGA_CHAINS - 1) / dz::MEGA_CHAINS), block(64 * dz::MEGA_WAVES);
     const bool xlds = mega_xlds(e);
     const size_t lds = mega_lds_bytes(e, xlds);
-    HIPCK(hipMemcpyAsync(e->d_params, &p, sizeof(dz::Params), hipMemcpyHostToDevice, e->stream));
+    if (!e->params_uploaded || memcmp(&e->p_shadow, &p, sizeof(dz::Params)) != 0) {   // the kernel reads Params through a pointer
+        HIPCK(hipMemcpyAsync(e->d_params, &p, sizeof(dz::Params), hipMemcpyHostToDevice, e->stream));
+        memcpy(&e->p_shadow, &p, sizeof(dz::Params));
+        e->params_uploaded = true;
+    }
     {
-        ProfScope ps(e, PR_GENERATIONS);
-#define DZ_MEGA_LAUNCH(NRT_, TRI_, X_) hipLaunchKernelGGL((dz::k_generations<NRT_, TRI_, X_>), grid, block, lds, e->stream, e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0)
+#define DZ_MEGA_LAUNCH(NRT_, TRI_, X_) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations<NRT_, TRI_, X_>), grid, block, lds, (const dz::Params*)e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0)
 #define DZ_MEGA_CASE(NRT_)                                                              \
     case NRT_:                                                                          \
         if (p.tri) { if (xlds) DZ_MEGA_LAUNCH(NRT_, true, true); else DZ_MEGA_LAUNCH(NRT_, true, false); }    \

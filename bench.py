@@ -63,20 +63,35 @@ def setup_engine(Cls, args, n_global, n_local, offset, steps_total, device=0, **
 
 
 def algorithmic_bytes(args, n_local):
-    """Per-launch algorithmic HBM bytes of each kernel class (DESIGN.md "Roofline accounting",
-    from SURVEY.md section 8(d)'s per-unit figures; rows unpadded, snooker fraction s)."""
+    """Per-launch algorithmic HBM bytes of each kernel class of the multi-kernel path (from
+    SURVEY.md section 8(d)'s per-unit figures; rows unpadded, snooker fraction s).  The persistent kernel's figure
+    (whole generations, B = 176 d + 152 per chain-generation) is added in main()."""
     d, k, s = args.dim, args.multitry, args.snooker
     row = 8.0 * d
     rows_z = 2 * (1 - s) + 3 * s
     pts = n_local * (2 * k - 1)
     return {
-        # both propose launches of a generation: Z gathers + base row read + proposal write
-        "propose": pts * row * (rows_z + 2.0) / 2.0,
-        # both logp launches: proposal read + 2 scalars written
+        # average of the two propose launches of a generation: Z gathers + proposal write per point, base row per chain
+        "propose": (pts * row * (rows_z + 1.0) + 2.0 * n_local * row) / 2.0,
+        # average of the two logp launches: proposal read + 2 scalars written
         "logp": pts * (row + 16.0) / 2.0,
-        # accept: state read + (accepted) proposal read + state/trace write + append/thin + logp scalars
+        # accept: state read + write, trace row, append/thin, logp scalars (SURVEY 8(d))
         "accept": n_local * (row * (2.0 + 1.0 + 1.0 / args.thin) + 16.0 * (2 * k - 1) + 8.0),
     }
+
+
+def measured_traffic(args, n_local, kernel_class, gens_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same workload
+    (profiles/r01_traffic.json, made by tools/collect_profiles.sh + tools/traffic_from_pmc.py), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+    default = (n_local == 4096 and args.dim == 100 and args.multitry == 5 and args.target == "mvn" and args.mvn_kind == "tri"
+               and args.snooker == 0.1 and args.thin == 10)
+    if not (default and kernel_class == "generations" and os.path.exists(path)):
+        return None, None
+    t = json.load(open(path))
+    if "k_generations" not in t["kernel"]:
+        return None, None
+    return t["bytes_per_generation"] * gens_per_launch, "profiles/r01_traffic.json"
 
 
 def cpu_baseline(args):
@@ -226,8 +241,9 @@ def main():
         dom = max(cand, key=lambda k: cand[k]["total_ms"])
         avg_s = cand[dom]["avg_us"] * 1e-6
         achieved = ab[dom] / avg_s / 1e9
+        traffic, tsrc = measured_traffic(args, n_local, dom, args.steps / cand[dom]["launches"])
         out["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                            "algorithmic_bytes_per_launch": ab[dom], "avg_launch_us": avg_s * 1e6}
         out["kernel_times"] = prof
         gen_bytes = n_local * (176.0 * args.dim + 152.0)        # B = 176 d + 152 per chain-generation

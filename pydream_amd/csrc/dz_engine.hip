@@ -701,6 +701,8 @@ int dz_set_likelihood_mvn(dz_engine* e, const double* mu, const double* M, int32
     HIPCK(hipMemcpy(e->d_mu, m.data(), sizeof(double) * ld, hipMemcpyHostToDevice));
     e->p.mu = e->d_mu; e->p.Mt = e->d_Mt; e->p.logF = log_F; e->p.tri = kind != 0; e->lk = LK_MVN;
     e->p.Mtp = nullptr; e->p.mtp_len = 0;
+    e->p.mu_zero = 1;
+    for (int j = 0; j < d; ++j) if (!(mu[j] == 0.0) || std::signbit(mu[j])) e->p.mu_zero = 0;
     if (kind != 0 && ld <= 128) {   // packed triangle for k_logp_mvn_lds (dz_kernels.h tri_row_offset)
         const int rows = 4 * ((d + 3) / 4);
         std::vector<double> pk((size_t)dz::tri_row_offset(rows), 0.0);

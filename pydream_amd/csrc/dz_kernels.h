@@ -36,6 +36,7 @@ struct Params {
     // triangular factor, packed for k_logp_mvn_lds: k-row r keeps its first 16*(r/16+1) columns (the row tiles that
     // use it), rows back to back; mtp_len doubles (even)
     const double* Mtp; int mtp_len;
+    int mu_zero;     // every entry of mu is +0.0: x - mu == x exactly, kernels may skip the subtraction
     // wave-uniform Philox outputs of one generation, precomputed lane-parallel (k_draws / k_accept):
     // [nl][nslots] uint4; slot 0..2 = control stream idx 0..2, then npt slots per (phase, try)
     const uint4* draws; uint4* draws_next; int nslots, npt;

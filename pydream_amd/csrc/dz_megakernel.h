@@ -61,7 +61,7 @@ DZ_DEV int mega_unit(int j, int wv) { return (j & 1) ? 16 * j + (MEGA_WAVES - 1 
 
 // The (point tile, row tile) units of Y = V M^T for the point tiles [tile0, tile0+ntl) held in LDS; writes
 // q[point][t] = butterfly16 over i of y_{16t+i} s_{16t+i}  (MVN contract, dz_kernels.h).
-template <int NRT, bool TRI>
+template <int NRT, bool TRI, bool MZ>
 DZ_DEV void mfma_units(const Params& p, const double* __restrict__ Ms, const double* __restrict__ Pt, const double* __restrict__ mus,
                        double* __restrict__ qb, int tile0, int ntl, int wv, int l, int LDM, int LDP)
 {
@@ -90,7 +90,7 @@ DZ_DEV void mfma_units(const Params& p, const double* __restrict__ Ms, const dou
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c4 = 4 * (ks + q);
-                a[q] = ap[c4] - mp[c4];
+                a[q] = MZ ? ap[c4] : ap[c4] - mp[c4];
                 b[q] = bp[(size_t)q * bstep];
             }
 #pragma unroll
@@ -99,7 +99,7 @@ DZ_DEV void mfma_units(const Params& p, const double* __restrict__ Ms, const dou
         for (; ks < KS; ++ks) {
             const int c = 4 * ks + kq;
             const double* bp = TRI ? Ms + tri_row_offset(c) + r : Ms + (size_t)c * LDM + r;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * ks] - mp[4 * ks], *bp, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(MZ ? ap[4 * ks] : ap[4 * ks] - mp[4 * ks], *bp, acc, 0, 0, 0);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -229,7 +229,9 @@ __global__ __launch_bounds__(64 * MEGA_WAVES) void k_generations(const Params* _
             DZ_MSTAMP(1 + 4 * phase);
             __syncthreads();                                                         // points visible
             DZ_MSTAMP(2 + 4 * phase);
-            mfma_units<NRT, TRI>(p, Ms, Pt, mus, qb, phase, k - phase, wv, lane, L.LDM, L.LDP);     // mt_evaluate_logps :278, :302
+            // mt_evaluate_logps :278, :302 (x - 0.0 == x bit for bit, so a zero mean skips the subtraction and its LDS read)
+            if (p.mu_zero) mfma_units<NRT, TRI, true>(p, Ms, Pt, mus, qb, phase, k - phase, wv, lane, L.LDM, L.LDP);
+            else mfma_units<NRT, TRI, false>(p, Ms, Pt, mus, qb, phase, k - phase, wv, lane, L.LDM, L.LDP);
             DZ_MSTAMP(3 + 4 * phase);
             __syncthreads();                                                         // q visible
             DZ_MSTAMP(4 + 4 * phase);

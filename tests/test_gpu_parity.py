@@ -178,7 +178,8 @@ def test_persistent_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, k, tr
         monkeypatch.setenv("DZ_MEGA", "1" if mega else "0")
         e = Cls(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
                 adapt_crossover=1 if burnin else 0, crossover_burnin=burnin)
-        e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), M, tri, 0.0)
+        mu = np.linspace(-1.0, 1.0, d) if d in (10, 64) else np.zeros(d)      # (a zero mean takes a shorter code path)
+        e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(mu, M, tri, 0.0)
         launches = None
         if Cls is G.Engine:
             e.profile_enable(True); e.profile_reset()

@@ -574,9 +574,9 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
         double2 ra[NCH], rb[NCH];
         auto request = [&](int i) {
             const u32x4 w = uniform_draw(p, dsrc, pt_slot(p, phase, i, 1), gc, g);
-            const uint32_t r0 = mulhi_idx(w.x, M);
-            uint32_t r1 = mulhi_idx(w.y, M - 1u);
-            if (r1 >= r0) r1++;                                   // random.sample(range(M), 2) :662
+            const uint32_t r0 = __builtin_amdgcn_readfirstlane(mulhi_idx(w.x, M));
+            uint32_t r1 = __builtin_amdgcn_readfirstlane(mulhi_idx(w.y, M - 1u));
+            if (r1 >= r0) r1++;                                   // random.sample(range(M), 2) :662  (wave-uniform: kept on the scalar unit)
 #pragma unroll
             for (int it = 0; it < NCH; ++it) {
                 const int jj = 128 * it + 2 * lane;
@@ -622,7 +622,7 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
             if (i + 1 < i1) request(i + 1);
             propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * out_stride, sl + i, csn, false, cr_idx, 1, glev, dsrc);
             DZ_STAMP(p, phase, c, 3 + 2 * i);          // try i's arithmetic issued
-            if (prior_out) point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i);
+            if (prior_out) { if (LEAN) { if (lane == 0) prior_out[i] = 0.0; } else point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i); }   // LEAN: flat priors only
         }
         return;
     }
@@ -654,7 +654,7 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
             }
             if (i + 1 < i1) request(i + 1);
             propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * out_stride, sl + i, csn, true, cr_idx, delta, glev, dsrc);
-            if (prior_out) point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i);
+            if (prior_out) { if (LEAN) { if (lane == 0) prior_out[i] = 0.0; } else point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i); }
         }
         return;
     }

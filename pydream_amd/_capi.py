@@ -37,7 +37,7 @@ SYMBOLS = [
     "dz_version", "dz_last_error", "dz_device_count", "dz_create", "dz_destroy", "dz_set_bounds", "dz_set_gamma_table",
     "dz_set_history", "dz_set_state", "dz_set_cr_probs", "dz_set_gamma_probs", "dz_set_prior", "dz_set_likelihood_mvn",
     "dz_set_likelihood_mixture", "dz_set_likelihood_host", "dz_comm_unique_id", "dz_comm_init_rccl", "dz_set_exchange",
-    "dz_step", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_sync", "dz_trace_reset", "dz_generation", "dz_get_state", "dz_get_trace", "dz_get_history",
+    "dz_step", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_sync", "dz_trace_reset", "dz_generation", "dz_get_state", "dz_get_trace", "dz_get_trace_chains", "dz_get_history",
     "dz_get_cr_state", "dz_get_gamma_state", "dz_get_rhat", "dz_get_chain_moments", "dz_eval_logp", "dz_debug_propose",
     "dz_profile_enable", "dz_profile_get", "dz_profile_reset",
 ]
@@ -280,6 +280,12 @@ class Engine:
         self._chk(self.L.dz_get_trace(self.h, g0, ng, _p(out["X"]), _p(out["logp"]), _p(out["moved"]),
                                       _p(out["try_idx"]), _p(out["cr_idx"]), _p(out["snooker"])))
         return out
+
+    def get_trace_chains(self, g0, ng, out, row0=0):
+        """samples [g0, g0+ng) of every local chain into out[c, row0:row0+ng, :] (out: C-contiguous [nl, rows, d])."""
+        assert out.flags.c_contiguous and out.dtype == np.float64 and out.shape[0] == self.nl and out.shape[2] == self.d
+        base = out.ctypes.data + row0 * self.d * 8
+        self._chk(self.L.dz_get_trace_chains(self.h, C.c_int64(g0), C.c_int64(ng), C.c_void_p(base), C.c_int64(out.shape[1])))
 
     def get_history(self):
         rows = C.c_int64()

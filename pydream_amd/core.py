@@ -68,19 +68,31 @@ def _sample_dream_batched(eng, step, niterations, verbose, nverbose):
     engine in chunks that fit the device trace buffer and collect trace / log_ps per chain."""
     d = step.total_var_dimension
     nchains = eng.nl                                  # the chains this engine owns (all of them on one GPU)
-    sampled = [np.empty((niterations, d)) for _ in range(nchains)]
-    log_ps = [np.empty((niterations, 1)) for _ in range(nchains)]
     chunk = eng.cfg.trace_capacity
+    by_chain = hasattr(eng, "get_trace_chains")       # the HIP engine keeps the trace chain by chain: no host transposition
+    if by_chain:
+        S = np.empty((nchains, niterations, d))
+        LP = np.empty((nchains, niterations, 1))
+        sampled = [S[c] for c in range(nchains)]      # one (niterations, d) array per chain, as core.py:98/:127 return them
+        log_ps = [LP[c] for c in range(nchains)]
+    else:
+        sampled = [np.empty((niterations, d)) for _ in range(nchains)]
+        log_ps = [np.empty((niterations, 1)) for _ in range(nchains)]
     done = 0
     naccepts = 0
     while done < niterations:
         n = min(chunk, niterations - done)
         eng.trace_reset()
         eng.step(n)
-        tr = eng.get_trace(0, n)
-        for c in range(nchains):
-            sampled[c][done:done + n] = tr["X"][:, c, :]
-            log_ps[c][done:done + n, 0] = tr["logp"][:, c]
+        if by_chain:
+            eng.get_trace_chains(0, n, S, row0=done)
+            tr = eng.get_trace(0, n, with_X=False)
+            LP[:, done:done + n, 0] = tr["logp"].T
+        else:
+            tr = eng.get_trace(0, n)
+            for c in range(nchains):
+                sampled[c][done:done + n] = tr["X"][:, c, :]
+                log_ps[c][done:done + n, 0] = tr["logp"][:, c]
         naccepts += int(tr["moved"].sum())
         done += n
         if verbose:
@@ -173,7 +185,8 @@ def _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=None, mp_
     thin = step_instance.history_thin
     n_appends = (niterations + thin - 1) // thin + 1
     ld = (d + 15) // 16 * 16
-    trace_cap = int(max(1, min(niterations, (2 << 30) // (nl * ld * 8))))
+    # the device keeps whole chunks of the trace (up to 64 GiB of the 288 GB by default): normally the entire run
+    trace_cap = int(max(1, min(niterations, int(os.environ.get('DREAMZS_TRACE_BYTES', 64 << 30)) // (nl * ld * 8))))
     eng = (engine_cls or _capi.Engine)(nchains=nchains, nchains_local=nl, chain_offset=chain_offset, ndim=d, multitry=int(step_instance.multitry),
                        depairs=len(step_instance.DEpairs), ncr=int(step_instance.nCR), ngamma=int(step_instance.ngamma),
                        history_thin=int(thin), crossover_burnin=int(min(step_instance.crossover_burnin, 2 ** 31 - 1)),

@@ -558,6 +558,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
         rc |= ealloc(e, &e->d_dl, N); rc |= ealloc(e, &e->d_dlg, N); rc |= ealloc(e, &e->d_binc, N); rc |= ealloc(e, &e->d_bing, N);
     }
     if (tc) {
+        p.tcap = (long long)tc;
         rc |= ealloc(e, &p.tX, tc * nl * ld); rc |= ealloc(e, &p.tlogp, tc * nl);
         rc |= ealloc(e, &p.tmoved, tc * nl); rc |= ealloc(e, &p.tsnk, tc * nl); rc |= ealloc(e, &p.ttry, tc * nl); rc |= ealloc(e, &p.tcr, tc * nl);
     }
@@ -846,12 +847,42 @@ int dz_get_state(dz_engine* e, double* X, double* prior, double* like)
     return 0;
 }
 
+// device trace rows are chain-major [nl][tcap][ld]; X_out[c][i][:] = sample g0+i of chain c at X_out + (c*chain_stride + i)*d
+static int download_trace_rows(dz_engine* e, double* X, int64_t g0, int64_t ng, int64_t chain_stride_rows)
+{
+    const size_t nl = e->p.nl, d = e->p.d, ld = e->p.ld, tcap = (size_t)e->p.tcap;
+    DZCK(sync_all(e));
+    if (ng == 0) return 0;
+    // pinning the destination lets the DMA engines write it directly (several times the pageable rate); not fatal if refused
+    const size_t span = sizeof(double) * d * ((nl - 1) * (size_t)chain_stride_rows + (size_t)ng);
+    const bool pinned = span >= ((size_t)64 << 20) && hipHostRegister(X, span, hipHostRegisterDefault) == hipSuccess;
+    if (!pinned) (void)hipGetLastError();
+    int rc = 0;
+    if ((size_t)ng == tcap && (size_t)chain_stride_rows == (size_t)ng) {
+        // whole buffer: the chains' blocks are back to back on both sides -- one strided copy
+        if (hipMemcpy2DAsync(X, sizeof(double) * d, e->p.tX, sizeof(double) * ld, sizeof(double) * d, nl * (size_t)ng, hipMemcpyDeviceToHost, e->stream) != hipSuccess) rc = -1;
+    } else {
+        for (size_t c = 0; c < nl && !rc; ++c)
+            if (hipMemcpy2DAsync(X + c * (size_t)chain_stride_rows * d, sizeof(double) * d, e->p.tX + (c * tcap + (size_t)g0) * ld, sizeof(double) * ld,
+                                 sizeof(double) * d, (size_t)ng, hipMemcpyDeviceToHost, e->stream) != hipSuccess) rc = -1;
+    }
+    if (hipStreamSynchronize(e->stream) != hipSuccess) rc = -1;
+    if (pinned) hipHostUnregister(X);
+    return rc ? fail(std::string("trace download: ") + hipGetErrorString(hipGetLastError())) : 0;
+}
+
 int dz_get_trace(dz_engine* e, int64_t g0, int64_t ng, double* X, double* logp, uint8_t* moved, int32_t* try_idx, int32_t* cr_idx, uint8_t* snooker)
 {
     HIPCK(hipSetDevice(e->c.device));
     if (g0 < 0 || ng < 0 || g0 + ng > e->ntrace) return fail("trace range");
     const size_t nl = e->p.nl, o = (size_t)g0 * nl, n = (size_t)ng * nl;
-    if (X) DZCK(download_rows(e, X, e->p.tX + o * e->p.ld, n));
+    if (X && ng > 0) {   // generation-major output [ng][nl][d]: one strided copy per chain (rows nl*d apart on the host side)
+        const size_t d = e->p.d, ld = e->p.ld, tcap = (size_t)e->p.tcap;
+        DZCK(sync_all(e));
+        for (size_t c = 0; c < nl; ++c)
+            HIPCK(hipMemcpy2DAsync(X + c * d, sizeof(double) * nl * d, e->p.tX + (c * tcap + (size_t)g0) * ld, sizeof(double) * ld,
+                                   sizeof(double) * d, (size_t)ng, hipMemcpyDeviceToHost, e->stream));
+    }
     DZCK(sync_all(e));
     if (logp) HIPCK(hipMemcpy(logp, e->p.tlogp + o, sizeof(double) * n, hipMemcpyDeviceToHost));
     if (moved) HIPCK(hipMemcpy(moved, e->p.tmoved + o, n, hipMemcpyDeviceToHost));
@@ -859,6 +890,14 @@ int dz_get_trace(dz_engine* e, int64_t g0, int64_t ng, double* X, double* logp, 
     if (cr_idx) HIPCK(hipMemcpy(cr_idx, e->p.tcr + o, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
     if (snooker) HIPCK(hipMemcpy(snooker, e->p.tsnk + o, n, hipMemcpyDeviceToHost));
     return 0;
+}
+
+int dz_get_trace_chains(dz_engine* e, int64_t g0, int64_t ng, double* X, int64_t chain_stride_rows)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    if (g0 < 0 || ng < 0 || g0 + ng > e->ntrace) return fail("trace range");
+    if (!X || chain_stride_rows < ng) return fail("bad destination");
+    return download_trace_rows(e, X, g0, ng, chain_stride_rows);
 }
 
 int dz_get_history(dz_engine* e, double* Z, int64_t cap_rows, int64_t* rows)
@@ -891,7 +930,7 @@ static int chain_moments(dz_engine* e)
 {
     if (e->ntrace < 2) return fail("need at least 2 traced generations");
     const dz::Params& p = e->p;
-    hipLaunchKernelGGL(dz::k_chain_moments, dim3((p.d + 127) / 128, p.nl), dim3(128), 0, e->stream, p.tX, p.nl, p.d, p.ld, (int)e->ntrace, e->d_cmean, e->d_cvar);
+    hipLaunchKernelGGL(dz::k_chain_moments, dim3((p.d + 127) / 128, p.nl), dim3(128), 0, e->stream, p.tX, p.nl, p.d, p.ld, p.tcap, (int)e->ntrace, e->d_cmean, e->d_cvar);
     return launch_check("chain moments");
 }
 int dz_get_chain_moments(dz_engine* e, double* mean, double* var)

@@ -30,6 +30,7 @@ struct Params {
     double *cp_prev, *cp_new;
     // trace
     double *tX, *tlogp; uint8_t *tmoved, *tsnk; int32_t *ttry, *tcr;
+    long long tcap;      // trace capacity in generations; tX is CHAIN-major [nl][tcap][ld] (a chain's samples are one block, as run_dream returns them)
     // likelihood / prior
     const int32_t* pkind; const double *pa, *pb; int have_prior;
     const double *mu, *Mt; double logF; int tri; int J; const double* mixF;
@@ -521,7 +522,7 @@ DZ_DEV void accept_chain(const Params& p, uint32_t g, int64_t zbase, int c, int 
         if (jj < ld) {
             const double2 t = {xn[it][0], xn[it][1]};
             if (accept) *reinterpret_cast<double2*>(xrow + jj) = t;
-            if (trace_slot >= 0) *reinterpret_cast<double2*>(p.tX + ((size_t)trace_slot * p.nl + c) * ld + jj) = t;
+            if (trace_slot >= 0) *reinterpret_cast<double2*>(p.tX + ((size_t)c * p.tcap + trace_slot) * ld + jj) = t;
             if (append) *reinterpret_cast<double2*>(p.Z + (size_t)(zbase + (int64_t)gc) * ld + jj) = t;   // :933-936
             if (publish) *reinterpret_cast<double2*>(p.cp_new + (size_t)gc * ld + jj) = t;       // :447-449
         }
@@ -1239,14 +1240,14 @@ __global__ void k_adapt_update(Params p, const double* __restrict__ dl, const do
 // ------------------------------------------------------------------------------------------
 // Gelman_Rubin (convergence.py:3-20) from the device-resident trace
 // ------------------------------------------------------------------------------------------
-__global__ void k_chain_moments(const double* __restrict__ tX, int nl, int d, int ld, int nsamples, double* __restrict__ mean, double* __restrict__ var)
+__global__ void k_chain_moments(const double* __restrict__ tX, int nl, int d, int ld, long long tcap, int nsamples, double* __restrict__ mean, double* __restrict__ var)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
     if (j >= d) return;
     const int nb = nsamples / 2, n2 = nsamples - nb;
-    const double* x = tX + ((size_t)nb * nl + c) * ld + j;
-    const size_t st = (size_t)nl * ld;
+    const double* x = tX + ((size_t)c * tcap + nb) * ld + j;
+    const size_t st = (size_t)ld;
     double s = 0.0;
     for (int t = 0; t < n2; ++t) s = s + x[(size_t)t * st];
     const double m = s / (double)n2;

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64 * MEGA_WAVES) void k_generations(const Params* _
             if (active) {
                 if (jj < ld) {
                     if (XLDS ? last : accept) *reinterpret_cast<double2*>(p.X + (size_t)c * ld + jj) = xn;
-                    if (trace_slot0 >= 0) *reinterpret_cast<double2*>(p.tX + ((size_t)(trace_slot0 + gi) * p.nl + c) * ld + jj) = xn;
+                    if (trace_slot0 >= 0) *reinterpret_cast<double2*>(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj) = xn;
                     if (last && append_last) *reinterpret_cast<double2*>(p.Z + ((size_t)M + gc) * ld + jj) = xn;      // record_history :933-936
                 }
                 if (lane == 0) {

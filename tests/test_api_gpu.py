@@ -137,3 +137,23 @@ def test_converges_on_the_reference_example_target(tmp_path):
     S = np.concatenate([s[3000:] for s in sampled])
     np.testing.assert_allclose(S.var(axis=0), np.arange(1, d + 1), rtol=0.35)
     assert np.all(np.abs(S.mean(axis=0)) < 0.6)
+
+
+def test_trace_by_chain_equals_trace_by_generation():
+    """dz_get_trace_chains (the layout run_dream returns, core.py:98/:127) against dz_get_trace: whole buffer (single
+    strided copy) and a window written into the middle of a larger destination (per-chain copies)."""
+    from pydream_amd import _capi
+    N, d, G = 48, 10, 30
+    e = _capi.Engine(nchains=N, ndim=d, multitry=3, history_capacity=400 + N * 6, trace_capacity=G, seed=3)
+    Z = np.random.default_rng(0).normal(size=(400, d))
+    e.set_history(Z); e.set_state(Z[:N]); e.set_likelihood_mvn(np.zeros(d), np.eye(d), 0, 0.0)
+    e.step(G)
+    X = e.get_trace(0, G)["X"]                      # [G, N, d]
+    S = np.full((N, G, d), np.nan)
+    e.get_trace_chains(0, G, S)
+    np.testing.assert_array_equal(S, X.transpose(1, 0, 2))
+    S2 = np.full((N, 50, d), np.nan)
+    e.get_trace_chains(5, 20, S2, row0=7)
+    np.testing.assert_array_equal(S2[:, 7:27], X[5:25].transpose(1, 0, 2))
+    assert np.isnan(S2[:, :7]).all() and np.isnan(S2[:, 27:]).all()
+    e.close()

@@ -195,3 +195,35 @@ def test_persistent_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, k, tr
         assert_traces_identical(a[0], other[0])
         np.testing.assert_array_equal(a[1], other[1])
         np.testing.assert_array_equal(a[2], other[2])
+
+
+def test_full_size_run_recovers_the_target_moments(G):
+    """BASELINE headline size (4096 chains x 100-D MVN, multitry 5) through properties that do not depend on the size:
+    after burn-in the pooled samples have the target's analytic moments (mean 0, Var(x_i) = i, all correlations 0.5;
+    dream_ex_ndim_gaussian.py:30-36) and the chains agree with each other (R-hat over a 3000-generation window,
+    convergence.py:3-20, computed on the device trace)."""
+    N, d, burn, win = 4096, 100, 2000, 3000
+    P = H.mvn_precision(d)
+    U = np.linalg.cholesky((P + P.T) / 2).T
+    Z0 = H.seed_history(2 * N, d, 11)
+    e = G.Engine(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * ((burn + win) // 10 + 2), trace_capacity=win, seed=2026)
+    e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), U, 1, 0.0)
+    e.profile_enable(True); e.profile_reset()
+    e.step(burn)
+    e.trace_reset(); e.step(win)
+    assert e.profile_get("generations")[1] > 0          # this is the persistent-kernel path
+    e.profile_enable(False)
+    rhat = e.get_rhat()
+    S = np.empty((N, 40, d))
+    e.get_trace_chains(win - 40, 40, S)
+    X = S[:, ::20, :].reshape(-1, d)                     # pooled sample, 4096 chains x 2 points 20 generations apart
+    var_true = np.arange(1, d + 1.0)
+    assert np.all(np.abs(X.mean(axis=0)) < 0.08 * np.sqrt(var_true))
+    np.testing.assert_allclose(X.var(axis=0) / var_true, 1.0, atol=0.08)
+    C = np.corrcoef(X.T)
+    off = C[~np.eye(d, dtype=bool)]
+    assert abs(off.mean() - 0.5) < 0.02 and off.min() > 0.4 and off.max() < 0.6
+    assert rhat.max() < 1.2, rhat.max()
+    acc = e.get_trace(win - 40, 40, with_X=False)["moved"].mean()
+    assert 0.2 < acc < 0.7
+    e.close()

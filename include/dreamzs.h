@@ -96,6 +96,13 @@ int dz_comm_unique_id(void* id128);                                             
 int dz_comm_init_rccl(dz_engine* e, int32_t rank, int32_t world, const void* id128);
 int dz_set_exchange(dz_engine* e, dz_exchange_cb cb, void* user);
 
+/* Parallel tempering (core.py:131-236).  T[nchains]: the temperature of every (global) chain -- Dream.astep's T argument
+ * (Dream.py:193), the ladder of core.py:133-136 is computed by the caller.  swaps != 0 adds the swap step of
+ * core.py:185-221 after every generation (all chains on one GPU); dz_get_swaps returns, per traced generation, the pair
+ * that was drawn and whether the swap was accepted. */
+int dz_set_temperatures(dz_engine* e, const double* T, int32_t swaps);
+int dz_get_swaps(dz_engine* e, int64_t g0, int64_t ng, int32_t* out /* [ng][3]: chain a, chain b, accepted */);
+
 /* _sample_dream's loop (core.py:103-116): advance every local chain by `generations`
  * MT-DREAM(ZS) transitions (Dream.astep, Dream.py:193-422). Asynchronous on the engine's
  * stream; dz_sync() or any getter waits. */

@@ -293,6 +293,8 @@ struct orc_engine {
     int64_t gen;         /* generations done */
     int64_t ntrace;
     double *tX, *tlogp; uint8_t *tmoved, *tsnk; int32_t *ttry, *tcr;
+    /* parallel tempering (core.py:131-236): per-chain temperatures, one swap attempt per generation */
+    double* Tc; int tempering; int32_t* tswap;     /* tswap [trace_capacity][3]: chain a, chain b, accepted */
     /* scratch */
     double *pts, *refs, *work;
 };
@@ -341,6 +343,7 @@ int orc_destroy(orc_engine* e)
     free(e->g_probs); free(e->g_delta); free(e->g_n); free(e->own_cr); free(e->own_g);
     free(e->pkind); free(e->pa); free(e->pb); free(e->mu); free(e->Mx); free(e->mixF);
     free(e->tX); free(e->tlogp); free(e->tmoved); free(e->tsnk); free(e->ttry); free(e->tcr);
+    free(e->Tc); free(e->tswap);
     free(e->pts); free(e->refs); free(e->work); free(e);
     return 0;
 }
@@ -404,6 +407,22 @@ int orc_set_likelihood_mixture(orc_engine* e, int32_t J, const double* mu, const
 }
 int orc_set_likelihood_host(orc_engine* e, orc_logp_cb cb, void* user) { e->cb = cb; e->cb_user = user; e->lk = LK_HOST; return 0; }
 int orc_set_exchange(orc_engine* e, orc_exchange_cb cb, void* user) { e->xcb = cb; e->xcb_user = user; return 0; }
+int orc_set_temperatures(orc_engine* e, const double* T /* [N] */, int32_t swaps)
+{   /* core.py:133-136 ladder, handed over by the host; swaps != 0 enables the swap step */
+    if (e->nl != e->N && swaps) return fail("temperature swaps need all chains in one engine");
+    if (e->c.schedule != 2 && swaps) return fail("temperature swaps need schedule S2");
+    if (!e->Tc) e->Tc = zalloc(sizeof(double) * e->N);
+    memcpy(e->Tc, T, sizeof(double) * e->N);
+    e->tempering = swaps != 0;
+    if (e->tempering && !e->tswap) e->tswap = zalloc(sizeof(int32_t) * 3 * (size_t)(e->c.trace_capacity ? e->c.trace_capacity : 1));
+    return 0;
+}
+int orc_get_swaps(orc_engine* e, int64_t g0, int64_t ng, int32_t* out /* [ng][3] */)
+{
+    if (!e->tswap || g0 < 0 || g0 + ng > e->ntrace) return fail("swap log range");
+    memcpy(out, e->tswap + 3 * (size_t)g0, sizeof(int32_t) * 3 * (size_t)ng);
+    return 0;
+}
 int64_t orc_generation(orc_engine* e) { return e->gen; }
 
 /* ------------------------------------------------------------------ */
@@ -636,7 +655,7 @@ typedef struct {
 static int chain_step(orc_engine* e, int c, uint32_t g, int64_t M, const double* cr_probs, const double* g_probs,
                       double* xnew, step_res* R)
 {
-    const int d = e->d, k = e->k; const double T = e->c.temperature;
+    const int d = e->d, k = e->k; const double T = e->Tc ? e->Tc[e->c.chain_offset + c] : e->c.temperature;
     const uint32_t gc = (uint32_t)(e->c.chain_offset + c);
     const double* q0 = e->X + (size_t)c * d;
     ctrl_draws u; draw_ctrl(e->c.seed, gc, g, &u);
@@ -777,7 +796,10 @@ static void record_trace(orc_engine* e, int c, const double* xnew, const step_re
     if (e->c.trace_capacity == 0) return;
     size_t t = (size_t)e->ntrace, nl = (size_t)e->nl, d = (size_t)e->d;
     memcpy(e->tX + (t * nl + c) * d, xnew, sizeof(double) * d);
-    e->tlogp[t * nl + c] = R->like_new + R->prior_new;
+    {   /* core.py:115 (like + prior); with a temperature ladder core.py:178 (T*like + prior); 1.0*x == x */
+        const double T = e->Tc ? e->Tc[e->c.chain_offset + c] : e->c.temperature;
+        e->tlogp[t * nl + c] = T * R->like_new + R->prior_new;
+    }
     e->tmoved[t * nl + c] = (uint8_t)R->moved; e->ttry[t * nl + c] = R->sel; e->tcr[t * nl + c] = R->cr_idx; e->tsnk[t * nl + c] = (uint8_t)R->snk;
 }
 
@@ -843,6 +865,24 @@ static int generation_s2(orc_engine* e)
         if (e->M + N > e->c.history_capacity) { free(Xn); free(R); return fail("history capacity exceeded"); }
         rc = exchange(e, e->X, e->Z + (size_t)e->M * d, d);
         e->M += N;
+    }
+    /* temperature swap (core.py:185-221): one random pair per generation, after every chain's step */
+    if (e->tempering && !rc) {
+        uint32_t w[4];
+        orc_philox4x32_10(e->c.seed, 0u, orc_stream_id(4 /* K_SWAP */, 0, 0, 0), 0u, g, w);
+        const uint32_t a = (uint32_t)(((uint64_t)w[0] * (uint64_t)N) >> 32);
+        uint32_t b = (uint32_t)(((uint64_t)w[1] * (uint64_t)(N - 1)) >> 32);
+        if (b >= a) b++;                                                        /* np.random.choice(nchains, 2, replace=False) :185 */
+        const double u = orc_u53(w[2], w[3]);
+        const double T1 = e->Tc[a], T2 = e->Tc[b], l1 = e->llike[a], l2 = e->llike[b];
+        const double alpha = ((T1 * l2) + (T2 * l1)) - ((T1 * l1) + (T2 * l2));  /* :195 */
+        const int acc = orc_log(u) < alpha;                                     /* :197 */
+        if (acc) {
+            for (int j = 0; j < d; ++j) { double t = e->X[(size_t)a * d + j]; e->X[(size_t)a * d + j] = e->X[(size_t)b * d + j]; e->X[(size_t)b * d + j] = t; }
+            double t = e->llike[a]; e->llike[a] = e->llike[b]; e->llike[b] = t;
+            t = e->lprior[a]; e->lprior[a] = e->lprior[b]; e->lprior[b] = t;
+        }
+        if (e->c.trace_capacity) { int32_t* q = e->tswap + 3 * (size_t)(e->ntrace - 1); q[0] = (int32_t)a; q[1] = (int32_t)b; q[2] = acc; }
     }
     free(Xn); free(R);
     e->gen++;

@@ -81,6 +81,8 @@ int orc_set_likelihood_mvn(orc_engine* e, const double* mu, const double* M, int
 int orc_set_likelihood_mixture(orc_engine* e, int32_t J, const double* mu, const double* log_F);
 int orc_set_likelihood_host(orc_engine* e, orc_logp_cb cb, void* user);
 int orc_set_exchange(orc_engine* e, orc_exchange_cb cb, void* user);
+int orc_set_temperatures(orc_engine* e, const double* T /* [nchains] */, int32_t swaps);   /* core.py:131-236 */
+int orc_get_swaps(orc_engine* e, int64_t g0, int64_t ng, int32_t* out /* [ng][3]: a, b, accepted */);
 
 int orc_step(orc_engine* e, int64_t generations);
 int orc_trace_reset(orc_engine* e);

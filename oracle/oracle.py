@@ -256,6 +256,17 @@ class Engine:
         self._keep.append(cb)
         self._chk(self.L.orc_set_likelihood_host(self.h, cb, None))
 
+    def set_temperatures(self, T, swaps=True):
+        T = _f64(T)
+        assert len(T) == self.N
+        self._chk(self.L.orc_set_temperatures(self.h, _p(T), int(bool(swaps))))
+
+    def get_swaps(self, g0, ng):
+        out = np.zeros((ng, 3), np.int32)
+        self.L.orc_get_swaps.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        self._chk(self.L.orc_get_swaps(self.h, g0, ng, _p(out)))
+        return out
+
     def set_exchange(self, fn):
         """fn(send: bytes-like, nbytes) -> bytes of all ranks' blocks in rank order"""
         def tramp(send, recv, nbytes, user):

@@ -36,7 +36,7 @@ XCHG_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 SYMBOLS = [
     "dz_version", "dz_last_error", "dz_device_count", "dz_create", "dz_destroy", "dz_set_bounds", "dz_set_gamma_table",
     "dz_set_history", "dz_set_state", "dz_set_cr_probs", "dz_set_gamma_probs", "dz_set_prior", "dz_set_likelihood_mvn",
-    "dz_set_likelihood_mixture", "dz_set_likelihood_host", "dz_comm_unique_id", "dz_comm_init_rccl", "dz_set_exchange",
+    "dz_set_likelihood_mixture", "dz_set_likelihood_host", "dz_comm_unique_id", "dz_comm_init_rccl", "dz_set_exchange", "dz_set_temperatures", "dz_get_swaps",
     "dz_step", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_sync", "dz_trace_reset", "dz_generation", "dz_get_state", "dz_get_trace", "dz_get_trace_chains", "dz_get_history",
     "dz_get_cr_state", "dz_get_gamma_state", "dz_get_rhat", "dz_get_chain_moments", "dz_eval_logp", "dz_debug_propose",
     "dz_profile_enable", "dz_profile_get", "dz_profile_reset",
@@ -237,6 +237,16 @@ class Engine:
 
     def comm_init_rccl(self, rank, world, unique_id):
         self._chk(self.L.dz_comm_init_rccl(self.h, rank, world, C.c_char_p(unique_id)))
+
+    def set_temperatures(self, T, swaps=True):
+        T = _f64(T)
+        assert len(T) == self.N
+        self._chk(self.L.dz_set_temperatures(self.h, _p(T), int(bool(swaps))))
+
+    def get_swaps(self, g0, ng):
+        out = np.zeros((ng, 3), np.int32)
+        self._chk(self.L.dz_get_swaps(self.h, C.c_int64(g0), C.c_int64(ng), _p(out)))
+        return out
 
     # ---- stepping ----
     def step(self, generations=1):

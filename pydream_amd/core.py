@@ -20,7 +20,9 @@ def run_dream(parameters, likelihood, nchains=5, niterations=50000, start=None, 
     parameters: iterable of SampledParam class
     likelihood: function ``f(vec[d]) -> float`` -- or one of ``pydream_amd.likelihoods`` to evaluate it on the device
     nchains, niterations, start, restart, verbose, nverbose: as in the reference
-    tempering: only False is supported (the reference's parallel tempering is untested upstream, core.py:30-31)
+    tempering: parallel tempering as in the reference (core.py:131-236): the ladder T_i = 0.001**(i/nchains), one
+        temperature-swap attempt per iteration; returns arrays of shape (nchains, 2*niterations, d) and
+        (nchains, 2*niterations, 1) with the samples before and after each swap attempt interleaved
     mp_context: accepted for compatibility, ignored (there are no worker processes)
     kwargs: passed to Dream (see Dream).  Extra keys understood here: ``seed`` (int, key of the random
         contract; default drawn from the OS), ``device`` (HIP device ordinal).
@@ -35,9 +37,6 @@ def run_dream(parameters, likelihood, nchains=5, niterations=50000, start=None, 
             raise Exception('Restart run specified but no start positions given.')
         if 'model_name' not in kwargs:
             raise Exception('Restart run specified but no model name to load history and crossover value files from given.')
-    if tempering:
-        raise NotImplementedError('parallel tempering is outside the accelerated hot path (core.py:131-248)')
-
     if type(parameters) is not list:
         parameters = [parameters]
 
@@ -56,10 +55,56 @@ def run_dream(parameters, likelihood, nchains=5, niterations=50000, start=None, 
                                 seed=kwargs.get('seed'), device=kwargs.get('device', 0))
     try:
         pool._initializer(*pool._initargs)
-        sampled_params, log_ps = _sample_dream_batched(pool.engine, step_instance, niterations, verbose, nverbose)
+        if tempering:
+            sampled_params, log_ps = _sample_dream_pt_batched(pool.engine, step_instance, nchains, niterations, verbose)
+        else:
+            sampled_params, log_ps = _sample_dream_batched(pool.engine, step_instance, niterations, verbose, nverbose)
     finally:
         pool.close()
         pool.join()
+    return sampled_params, log_ps
+
+
+def _sample_dream_pt_batched(eng, step, nchains, niterations, verbose):
+    """core._sample_dream_pt (core.py:131-236) on the engine: every chain steps at its own temperature
+    (Dream.astep's T), then one random pair attempts a temperature swap; sampled_params[:, 2i] holds the states after
+    the steps of iteration i, [:, 2i+1] the states after its swap attempt (log_ps likewise, T*loglike + logprior)."""
+    if eng.nl != nchains:
+        raise Exception('parallel tempering needs all chains on one GPU')
+    d = step.total_var_dimension
+    T = np.zeros((nchains))
+    T[0] = 1.
+    for i in range(nchains):
+        T[i] = np.power(.001, (float(i) / nchains))                      # core.py:133-136
+    eng.set_temperatures(T, swaps=True)
+    sampled_params = np.zeros((nchains, niterations * 2, d))
+    log_ps = np.zeros((nchains, niterations * 2, 1))
+    chunk = eng.cfg.trace_capacity
+    done = 0
+    while done < niterations:
+        n = min(chunk, niterations - done)
+        eng.trace_reset()
+        eng.step(n)
+        tr = eng.get_trace(0, n)
+        sw = eng.get_swaps(0, n)
+        X = tr["X"].transpose(1, 0, 2)                                   # [chain, iteration, d], before the swaps
+        L = tr["logp"].T
+        rows = slice(2 * done, 2 * (done + n), 2)
+        sampled_params[:, rows] = X
+        log_ps[:, rows, 0] = L
+        Xs, Ls = X.copy(), L.copy()
+        for i in np.nonzero(sw[:, 2])[0]:                                # accepted swaps exchange the pair (core.py:204-215)
+            a, b = sw[i, 0], sw[i, 1]
+            Xs[[a, b], i] = X[[b, a], i]
+            Ls[[a, b], i] = L[[b, a], i]
+        rows = slice(2 * done + 1, 2 * (done + n), 2)
+        sampled_params[:, rows] = Xs
+        log_ps[:, rows, 0] = Ls
+        done += n
+        if verbose:
+            print('Iteration: ', done, ' overall temp swap acceptance rate: ', float(sw[:, 2].mean()))
+    if step.save_history:
+        _save_history_to_disc(eng, step)
     return sampled_params, log_ps
 
 

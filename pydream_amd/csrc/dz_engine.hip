@@ -107,6 +107,7 @@ struct dz_engine {
     bool fuse = true;               // DZ_FUSE=0 disables the accept+propose fusion
     bool mega = true;               // the persistent generation kernel serves every eligible configuration (mega_eligible); DZ_MEGA=0 forces the multi-kernel path
     int mega_max_gen = 1 << 20;     // DZ_MEGA_MAXGEN: generations per launch cap (measurement)
+    bool tempering = false; double* d_Tc = nullptr; int32_t* d_tswap = nullptr;    // parallel tempering (dz_set_temperatures)
     bool pending_accept = false;    // generation gen-1's Metropolis step has been deferred into the next proposal kernel
     int64_t pending_slot = -1;
     int propose_split = 1;          // waves per chain in k_propose (DZ_PROPOSE_SPLIT)
@@ -360,7 +361,7 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
     const int64_t slot = (traced && e->c.trace_capacity) ? e->ntrace : -1;
     // the Metropolis step of this generation can ride in front of the next generation's proposal kernel when
     // nothing shared changes in between (no history append, no published positions) and a generation follows
-    const bool defer = full && e->fuse && more_follow && !append && !publish && e->propose_split == 1 && e->lk != LK_HOST;
+    const bool defer = full && e->fuse && more_follow && !append && !publish && e->propose_split == 1 && e->lk != LK_HOST && !e->tempering;
     const int64_t zbase = full ? e->M : e->M - (int64_t)(p.off + c0);
     for (int s = 0; s < L; ++s) {
         const int lc0 = c0 + (int)((int64_t)nc * s / L), lc1 = c0 + (int)((int64_t)nc * (s + 1) / L), lnc = lc1 - lc0;
@@ -397,6 +398,11 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
         if (append) { if (full) DZCK(allgather_rows(e, p.Z + (size_t)e->M * p.ld)); e->M += nrows; }
         e->need_join = true;
     }
+    if (e->tempering && full) {      // temperature swap (core.py:185-221): after every chain's step and the updates above
+        if (L > 1) { DZCK(join_all(e)); e->need_join = true; }
+        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_pt_swap<NCH>, dim3(1), dim3(64), 0, e->stream, p, g, slot));
+        DZCK(launch_check("k_pt_swap"));
+    }
     for (int c = c0; c < c0 + nc; ++c) e->gen_c[c] = (int64_t)g + 1;
     if (full) e->gen = (int64_t)g + 1;
     if (slot >= 0) e->ntrace++;
@@ -414,7 +420,7 @@ bool mega_xlds(const dz_engine* e) { return mega_lds_bytes(e, true) <= (size_t)1
 bool mega_eligible(const dz_engine* e)
 {
     const dz::Params& p = e->p;
-    return e->mega && e->lk == LK_MVN && !p.hard && !p.have_prior && p.ld <= 128 && p.k >= 3 && p.k <= dz::MAXK && p.depairs == 1 &&
+    return e->mega && !p.Tc && e->lk == LK_MVN && !p.hard && !p.have_prior && p.ld <= 128 && p.k >= 3 && p.k <= dz::MAXK && p.depairs == 1 &&
            p.nslots <= 64 && (!p.tri || p.Mtp) && mega_lds_bytes(e, false) <= (size_t)160 * 1024;
 }
 // number of generations, starting at g, that one launch may cover: none of them publishes positions
@@ -761,6 +767,28 @@ int dz_comm_init_rccl(dz_engine* e, int32_t rank, int32_t world, const void* id1
 }
 
 int dz_set_exchange(dz_engine* e, dz_exchange_cb cb, void* user) { e->xcb = cb; e->xcb_user = user; return 0; }
+
+int dz_set_temperatures(dz_engine* e, const double* T, int32_t swaps)
+{   // core.py:133-136 (the ladder is the host's), :185-221 (swaps != 0: one swap attempt per generation)
+    HIPCK(hipSetDevice(e->c.device));
+    if (swaps && e->world > 1) return fail("temperature swaps need all chains on one GPU");
+    DZCK(sync_all(e));
+    if (!e->d_Tc) DZCK(ealloc(e, &e->d_Tc, (size_t)e->p.N));
+    HIPCK(hipMemcpy(e->d_Tc, T, sizeof(double) * e->p.N, hipMemcpyHostToDevice));
+    e->p.Tc = e->d_Tc;
+    e->tempering = swaps != 0;
+    if (e->tempering && !e->d_tswap) { DZCK(ealloc(e, &e->d_tswap, (size_t)3 * std::max<int64_t>(1, e->c.trace_capacity))); e->p.tswap = e->d_tswap; }
+    e->draws_gen = -1;
+    return 0;
+}
+int dz_get_swaps(dz_engine* e, int64_t g0, int64_t ng, int32_t* out)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    if (!e->d_tswap || g0 < 0 || ng < 0 || g0 + ng > e->ntrace) return fail("swap log range");
+    DZCK(sync_all(e));
+    HIPCK(hipMemcpy(out, e->d_tswap + 3 * g0, sizeof(int32_t) * 3 * (size_t)ng, hipMemcpyDeviceToHost));
+    return 0;
+}
 
 int dz_step(dz_engine* e, int64_t generations)
 {

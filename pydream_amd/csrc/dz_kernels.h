@@ -37,6 +37,8 @@ struct Params {
     // triangular factor, packed for k_logp_mvn_lds: k-row r keeps its first 16*(r/16+1) columns (the row tiles that
     // use it), rows back to back; mtp_len doubles (even)
     const double* Mtp; int mtp_len;
+    const double* Tc;        // [N] per-chain temperatures (parallel tempering, core.py:133-136) or null: every chain at T
+    int32_t* tswap;          // [trace capacity][3] swap log: chain a, chain b, accepted
     int mu_zero;     // every entry of mu is +0.0: x - mu == x exactly, kernels may skip the subtraction
     // wave-uniform Philox outputs of one generation, precomputed lane-parallel (k_draws / k_accept):
     // [nl][nslots] uint4; slot 0..2 = control stream idx 0..2, then npt slots per (phase, try)
@@ -57,6 +59,9 @@ struct Params {
 
 // offset of k-row r in the packed triangular layout: row block b = r/16 has 16*(b+1) columns
 __host__ __device__ inline int tri_row_offset(int r) { const int b = r >> 4; return 128 * b * (b + 1) + (r - 16 * b) * 16 * (b + 1); }
+
+// temperature of local chain c (Dream.astep's T argument, Dream.py:193)
+DZ_DEV double chain_T(const Params& p, int c) { return p.Tc ? p.Tc[p.off + c] : p.T; }
 
 struct StepFlags { bool snk; int cr_idx, delta, glev; };
 
@@ -89,7 +94,7 @@ DZ_DEV int mt_select(const Params& p, int c, double u_sel, int lane, bool* anyfi
 {
     const int k = p.k;
     double lp = -__builtin_huge_val();
-    if (lane < k) lp = p.p_prior[c * k + lane] + p.T * p.p_like[c * k + lane];
+    if (lane < k) lp = p.p_prior[c * k + lane] + chain_T(p, c) * p.p_like[c * k + lane];
     return mt_select_vals(k, lp, u_sel, lane, anyfinite);
 }
 
@@ -476,10 +481,11 @@ DZ_DEV void accept_chain(const Params& p, uint32_t g, int64_t zbase, int c, int 
         dnext.have = p.nslots <= 64; dnext.mine = make_uint4(w0.x, w0.y, w0.z, w0.w);
     }
     const double last_prior = p.lprior[c], last_like = p.llike[c];
-    const double last_logp = p.T * last_like + last_prior;                     // :243, :268
+    const double T = chain_T(p, c);
+    const double last_logp = T * last_like + last_prior;                       // :243, :268
     double ratio; int sel = 0;
     if (k == 1) {
-        const double q_logp = p.T * p.p_like[c] + p.p_prior[c];                // :274
+        const double q_logp = T * p.p_like[c] + p.p_prior[c];                  // :274
         if (f.snk) ratio = nan_to_num((q_logp + p.p_slogp[c]) - (last_logp + p.cur_snk[c]));   // :326-332
         else ratio = nan_to_num(q_logp) - nan_to_num(last_logp);               // :334
     } else {
@@ -487,12 +493,12 @@ DZ_DEV void accept_chain(const Params& p, uint32_t g, int64_t zbase, int c, int 
         // lane i < k holds proposal term A_i, lane 16+i holds reference term B_i (:306-317)
         double val = -__builtin_huge_val();
         if (lane < k) {
-            val = p.p_prior[c * k + lane] + p.T * p.p_like[c * k + lane];                                  // :279
+            val = p.p_prior[c * k + lane] + T * p.p_like[c * k + lane];                                    // :279
             if (f.snk) val = val + p.p_slogp[c * k + lane];                                              // :307
         } else if (lane >= 16 && lane < 16 + k) {
             const int i = lane - 16;
-            val = i < k - 1 ? p.T * p.r_like[c * (k - 1) + i] + p.r_prior[c * (k - 1) + i]              // :303
-                            : p.T * last_like + last_prior;                                              // :877-879
+            val = i < k - 1 ? T * p.r_like[c * (k - 1) + i] + p.r_prior[c * (k - 1) + i]                // :303
+                            : T * last_like + last_prior;                                                // :877-879
             if (f.snk) { const double sr = i < k - 1 ? p.r_slogp[c * (k - 1) + i] : 0.0; val = (val + sr) + p.p_slogp[c * k + i]; }   // :312-313
         }
         ratio = mt_log_ratio(k, val);
@@ -531,7 +537,7 @@ DZ_DEV void accept_chain(const Params& p, uint32_t g, int64_t zbase, int c, int 
         p.lprior[c] = npri; p.llike[c] = nlik;
         if (trace_slot >= 0) {
             const size_t o = (size_t)trace_slot * p.nl + c;
-            p.tlogp[o] = nlik + npri;                                          // core.py:115
+            p.tlogp[o] = T * nlik + npri;                                      // core.py:115; with a temperature ladder core.py:178 (1.0 * x == x)
             p.tmoved[o] = moved ? 1 : 0; p.ttry[o] = sel; p.tcr[o] = f.cr_idx; p.tsnk[o] = f.snk ? 1 : 0;
         }
     }
@@ -1103,6 +1109,38 @@ __global__ __launch_bounds__(1024) void k_accept(Params p, uint32_t g, int64_t z
 
 // uniform draws of generation g for local chains [c0, c0+nc): one lane per (chain, slot); the lanes of
 // slot 0 also derive the chain's control decisions (needs the CURRENT crossover / gamma-level probabilities)
+// Temperature swap of parallel tempering (core.py:185-221): one random pair per generation, after every chain's step
+// and the end-of-generation updates.  One wave; lanes share the row exchange.  Stream SWAP (=4) of the random contract.
+template <int NCH>
+__global__ __launch_bounds__(64) void k_pt_swap(Params p, uint32_t g, int64_t trace_slot)
+{
+    const int lane = threadIdx.x & 63;
+    const u32x4 w = philox(p.k0, p.k1, 0u, stream_id(4u, 0u, 0u), 0u, g);
+    const uint32_t a = mulhi_idx(w.x, (uint32_t)p.N);
+    uint32_t b = mulhi_idx(w.y, (uint32_t)p.N - 1u);
+    if (b >= a) b++;                                                               // np.random.choice(nchains, 2, replace=False) :185
+    const double u = u53(w.z, w.w);
+    const double T1 = p.Tc[a], T2 = p.Tc[b], l1 = p.llike[a], l2 = p.llike[b];
+    const double alpha = ((T1 * l2) + (T2 * l1)) - ((T1 * l1) + (T2 * l2));         // :195
+    const bool acc = dlog(u) < alpha;                                              // :197
+    if (acc) {
+        double* xa = p.X + (size_t)a * p.ld; double* xb = p.X + (size_t)b * p.ld;
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) {
+            const int jj = 128 * it + 2 * lane;
+            if (jj < p.ld) {
+                const double2 ta = *reinterpret_cast<const double2*>(xa + jj), tb = *reinterpret_cast<const double2*>(xb + jj);
+                *reinterpret_cast<double2*>(xa + jj) = tb; *reinterpret_cast<double2*>(xb + jj) = ta;
+            }
+        }
+        if (lane == 0) {
+            const double pa = p.lprior[a], pb = p.lprior[b];
+            p.llike[a] = l2; p.llike[b] = l1; p.lprior[a] = pb; p.lprior[b] = pa;
+        }
+    }
+    if (lane == 0 && trace_slot >= 0) { int32_t* q = p.tswap + 3 * trace_slot; q[0] = (int32_t)a; q[1] = (int32_t)b; q[2] = acc ? 1 : 0; }
+}
+
 __global__ void k_draws(Params p, uint32_t g, int c0, int nc, uint4* __restrict__ out, ChainCtl* __restrict__ ctl)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

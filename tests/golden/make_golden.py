@@ -39,6 +39,7 @@ from oracle import oracle as O  # noqa: E402  (test infrastructure)
 import pydream.Dream as RD  # noqa: E402
 from pydream import Dream_shared_vars as SV  # noqa: E402
 from pydream.core import _setup_mp_dream_pool  # noqa: E402
+import pydream.core as RC  # noqa: E402
 from pydream.model import Model  # noqa: E402
 from pydream.parameters import FlatParam, SampledParam  # noqa: E402
 from pydream.convergence import Gelman_Rubin  # noqa: E402
@@ -335,6 +336,131 @@ def run_reference(params, likelihood, Z0, starts, N, G, seed, schedule, dream_kw
 
 
 # --------------------------------------------------------------------------
+# parallel tempering from the reference (core.py:131-248): `_sample_dream_pt` itself runs, with a pool whose map()
+# executes the reference's `_sample_dream_pt_chain` for every chain in this process (schedule S2: the deferred
+# end-of-generation updates are flushed after the last chain), and with core.py's numpy rebound to a proxy that
+# serves the swap draws of the contract: stream SWAP(=4), counter (0, stream, 0, generation):
+# (w0, w1) -> np.random.choice(nchains, 2, replace=False) (:185), u53(w2, w3) -> np.random.uniform() (:197).
+# --------------------------------------------------------------------------
+class CoreRandom:
+    def __init__(self, seed, pool):
+        self.seed, self.pool = seed, pool
+
+    def _w(self):
+        return O.philox(self.seed, 0, O.stream_id(4, 0, 0), 0, self.pool.g - 1)
+
+    def choice(self, n, size, replace=False):
+        assert size == 2 and not replace
+        w = self._w()
+        a = (int(w[0]) * n) >> 32
+        b = (int(w[1]) * (n - 1)) >> 32
+        if b >= a:
+            b += 1
+        self.pool.swaps.append([a, b])
+        return np.array([a, b])
+
+    def uniform(self):
+        w = self._w()
+        return O.u53(w[2], w[3])
+
+
+class CoreNPProxy:
+    def __init__(self, seed, pool):
+        self.random = CoreRandom(seed, pool)
+
+    def log(self, x):
+        return np.float64(O.log(float(x)))           # np.log(np.random.uniform()) :197 -- the contract's log
+
+    def __getattr__(self, n):
+        return getattr(np, n)
+
+
+class InProcessPool:
+    """pool.map(_sample_dream_pt_chain, args) without processes; per-chain Dream copies like the pickled ones."""
+
+    def __init__(self, rnd, step, N, burnin):
+        self.rnd, self.step, self.N, self.g, self.chains, self.swaps, self.log, self.burnin = rnd, step, N, 0, None, [], [], burnin
+
+    def map(self, fn, args):
+        args = list(args)
+        if self.chains is None:
+            self.chains = [copy.copy(self.step) for _ in range(self.N)]
+            for c in self.chains:
+                c.queue = []
+        out = []
+        row = []
+        for ci, a in enumerate(args):
+            self.rnd.begin_step(ci, self.g, self.step.p_gamma_unity)
+            if self.g == self.step.crossover_burnin:          # (set by _setup_mp_dream_pool when it was None)
+                SV.nchains.value = self.N - 1          # lets the barrier at Dream.py:403 fall through
+            res = fn((self.chains[ci],) + tuple(a[1:]))
+            out.append((np.array(res[0], dtype=float).copy(), res[1], res[2], self.chains[ci]))
+            row.append((self.rnd.log["sel"], self.rnd.log["cr_idx"], self.rnd.log["snooker"]))
+        for kind in ("pos", "cr", "gam", "hist"):                     # schedule S2 flush, as in run_reference
+            for c in self.chains:
+                for (kk, aa, kw) in c.queue:
+                    if kk == kind:
+                        c.iter -= 1
+                        BASE[kind](c, *aa, **kw)
+                        c.iter += 1
+        for c in self.chains:
+            c.queue = []
+        self.log.append(row)
+        self.g += 1
+        return out
+
+
+def run_reference_pt(params, likelihood, Z0, starts, N, G, seed, dream_kwargs, workdir):
+    d = Z0.shape[1]
+    hist_file = os.path.join(workdir, "seed_hist.npy")
+    np.save(hist_file, Z0)
+    model = Model(likelihood=likelihood, sampled_parameters=params)
+    step = DeferredDream(model=model, variables=None, history_file=hist_file, start_random=False, save_history=False,
+                         verbose=False, **dream_kwargs)
+    rnd = ContractRandom(seed, step.multitry, ncr_ctrl_has_snooker=(step.snooker != 0))
+    install(rnd)
+    fake = InProcessPool(rnd, step, N, step.crossover_burnin)
+    RC.np = CoreNPProxy(seed, fake)
+    try:
+        pool = _setup_mp_dream_pool(N, G, step, start_pt=[starts[i] for i in range(N)])
+        pool._initializer(*pool._initargs)
+        pool.close()
+        pool.join()
+        sampled, log_ps = RC._sample_dream_pt(N, G, step, [starts[i].copy() for i in range(N)], fake, False)
+        M = int(SV.count.value + step.nseedchains)
+        dec = np.array(fake.log, dtype=np.int32)                                   # [G, N, 3]
+        T = np.array([np.power(.001, (float(i) / N)) for i in range(N)])           # core.py:133-136
+        return dict(pt_sampled=np.asarray(sampled), pt_log_ps=np.asarray(log_ps), pt_swaps=np.array(fake.swaps, np.int32),
+                    try_idx=dec[:, :, 0], cr_idx=dec[:, :, 1], snooker=dec[:, :, 2].astype(np.uint8), T=T,
+                    Z_tail=np.array(SV.history[0:M * d]).reshape(M, d)[len(Z0):])
+    finally:
+        RC.np = np
+        uninstall()
+
+
+def pt_case(name, *, d, N, G, k, seed, rng_seed=0):
+    rng = np.random.default_rng(rng_seed)
+    params = [FlatParam(test_value=np.zeros(d))]
+    nseed = max(10 * d, 2 * N)
+    Z0 = rng.uniform(-5, 15, (nseed, d))
+    invC, log_F, like = mvn_target(d)
+    starts = Z0[:N].copy()
+    kw = dict(multitry=k, adapt_crossover=False)
+    with tempfile.TemporaryDirectory() as wd:
+        cwd = os.getcwd()
+        os.chdir(wd)
+        try:
+            out = run_reference_pt(params, like, Z0, starts, N, G, seed, kw, wd)
+        finally:
+            os.chdir(cwd)
+    save(name, Z0=Z0, starts=starts, invC=invC, log_F=log_F, cfg_d=d, cfg_N=N, cfg_G=G, cfg_k=k, cfg_seed=seed, **out)
+    sw = out["pt_swaps"]
+    acc = [(not np.array_equal(out["pt_sampled"][sw[g, 0], 2 * g], out["pt_sampled"][sw[g, 0], 2 * g + 1])) for g in range(G)]
+    print("   ", name, "swap acceptance", np.mean(acc), "move acceptance (coldest chain)",
+          np.mean(np.any(np.diff(out["pt_sampled"][0, ::2], axis=0) != 0, axis=1)))
+
+
+# --------------------------------------------------------------------------
 # target densities of the examples (restated from the cited lines; the d=200
 # MVN and the 2-component mixture below call the reference modules themselves)
 # --------------------------------------------------------------------------
@@ -529,6 +655,9 @@ def density_cases():
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "pt":
+        pt_case("trace_pt_mvn10", d=10, N=6, G=150, k=5, seed=23)
+        return
     function_cases()
     density_cases()
     # T1: the C1 plumbing config (3 chains, 10-D MVN, multitry 5), unmodified reference, schedule S1
@@ -555,6 +684,8 @@ def main():
     # T6: C3-shaped, small: 3-component mixture with crossover adaptation
     trace_case("trace_s2_mix3", d=20, N=8, G=80, k=5, schedule=2, seed=17, target=("mix", (-5, 0, 5), (1 / 6., 1 / 3., 1 / 2.)),
                dream_kwargs=dict(adapt_crossover=True, crossover_burnin=30))
+    # T7: parallel tempering (core.py:131-248): temperature ladder, one swap attempt per iteration
+    pt_case("trace_pt_mvn10", d=10, N=6, G=150, k=5, seed=23)
 
 
 if __name__ == "__main__":

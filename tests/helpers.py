@@ -74,3 +74,51 @@ def seed_history(rows, d, seed, lo=-5.0, hi=15.0):
     """iid U(lo,hi) seed archive (the shipped example uses a Latin hypercube on [-5,15],
     dream_ex_ndim_gaussian.py:17-26, 45)."""
     return np.random.default_rng(seed).uniform(lo, hi, (rows, d))
+
+
+def pt_engine_from_fixture(EngineCls, fx, **over):
+    """engine for the parallel-tempering fixture (tests/golden/trace_pt_*.npz; reference defaults otherwise)."""
+    d, N, G, k = int(fx["cfg_d"]), int(fx["cfg_N"]), int(fx["cfg_G"]), int(fx["cfg_k"])
+    Z0 = fx["Z0"]
+    kw = dict(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (G // 10 + 2), trace_capacity=G, seed=int(fx["cfg_seed"]),
+              adapt_crossover=0, crossover_burnin=G // 10)
+    kw.update(over)
+    e = EngineCls(**kw)
+    e.set_history(Z0)
+    e.set_likelihood_mvn(np.zeros(d), fx["invC"], 0, float(fx["log_F"]))
+    e.set_state(fx["starts"][:N])
+    e.set_temperatures(fx["T"], swaps=True)
+    return e
+
+
+def pt_arrays(tr, swaps):
+    """sampled_params / log_ps of core._sample_dream_pt (core.py:144-145, :179-181, :223-225) from an engine's
+    pre-swap trace and its swap log: rows 2i = after the steps of iteration i, rows 2i+1 = after its swap attempt."""
+    X, lp = tr["X"], tr["logp"]                        # [G, N, d], [G, N]
+    G, N, d = X.shape
+    S = np.zeros((N, 2 * G, d)); L = np.zeros((N, 2 * G, 1))
+    for g in range(G):
+        xa, la = X[g].copy(), lp[g].copy()
+        S[:, 2 * g], L[:, 2 * g, 0] = xa, la
+        a, b, acc = swaps[g]
+        if acc:
+            xa[[a, b]] = xa[[b, a]]; la[[a, b]] = la[[b, a]]
+        S[:, 2 * g + 1], L[:, 2 * g + 1, 0] = xa, la
+    return S, L
+
+
+def compare_pt_with_reference(e, fx, x_rtol=1e-9, logp_atol=1e-10):
+    G = int(fx["cfg_G"])
+    tr = e.get_trace(0, G)
+    sw = e.get_swaps(0, G)
+    np.testing.assert_array_equal(sw[:, :2], fx["pt_swaps"])
+    np.testing.assert_array_equal(tr["snooker"], fx["snooker"])
+    np.testing.assert_array_equal(tr["cr_idx"], fx["cr_idx"])
+    np.testing.assert_array_equal(tr["try_idx"], fx["try_idx"])
+    S, L = pt_arrays(tr, sw)
+    ref_acc = np.array([not np.array_equal(fx["pt_sampled"][fx["pt_swaps"][g, 0], 2 * g], fx["pt_sampled"][fx["pt_swaps"][g, 0], 2 * g + 1]) for g in range(G)])
+    np.testing.assert_array_equal(sw[:, 2].astype(bool), ref_acc)          # the accepted-swap sequence
+    np.testing.assert_allclose(S, fx["pt_sampled"], rtol=x_rtol, atol=1e-11)
+    np.testing.assert_allclose(L, fx["pt_log_ps"], rtol=0, atol=logp_atol)
+    np.testing.assert_allclose(e.get_history()[len(fx["Z0"]):], fx["Z_tail"], rtol=x_rtol, atol=1e-11)
+    return tr, sw

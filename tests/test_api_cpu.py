@@ -116,5 +116,4 @@ def test_run_dream_validation_errors():
         run_dream(p, l, nchains=2, niterations=10, verbose=False)
     with pytest.raises(Exception, match="seeded starting history is insufficient"):
         run_dream(p, l, nchains=30, niterations=10, verbose=False)          # default nseedchains = 40 < 2*30
-    with pytest.raises(NotImplementedError):
-        run_dream(p, l, nchains=5, niterations=10, verbose=False, tempering=True)
+

@@ -157,3 +157,22 @@ def test_trace_by_chain_equals_trace_by_generation():
     np.testing.assert_array_equal(S2[:, 7:27], X[5:25].transpose(1, 0, 2))
     assert np.isnan(S2[:, :7]).all() and np.isnan(S2[:, 27:]).all()
     e.close()
+
+
+def test_run_dream_parallel_tempering_equals_reference(tmp_path):
+    """test_dream.py:586-605 (return shapes) and more: run_dream(tempering=True) reproduces the arrays the reference's
+    own _sample_dream_pt produced for the same seed (tests/golden/trace_pt_mvn10.npz, made by make_golden.py)."""
+    from tests import helpers as H
+    from pydream_amd.likelihoods import MVNormalLogLike
+    from pydream_amd.parameters import FlatParam
+    fx = H.load("trace_pt_mvn10")
+    d, N, n = int(fx["cfg_d"]), int(fx["cfg_N"]), int(fx["cfg_G"])
+    os.chdir(tmp_path)
+    np.save("seed.npy", fx["Z0"])
+    like = MVNormalLogLike(fx["invC"], log_F=float(fx["log_F"]), factorize=False)
+    sampled, log_ps = run_dream([FlatParam(test_value=np.zeros(d))], like, nchains=N, niterations=n, tempering=True, verbose=False,
+                                start=[fx["starts"][i] for i in range(N)], start_random=False, history_file="seed.npy",
+                                multitry=int(fx["cfg_k"]), adapt_crossover=False, save_history=False, seed=int(fx["cfg_seed"]))
+    assert sampled.shape == (N, 2 * n, d) and log_ps.shape == (N, 2 * n, 1)
+    np.testing.assert_allclose(sampled, fx["pt_sampled"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(log_ps, fx["pt_log_ps"], rtol=0, atol=1e-10)

@@ -227,3 +227,32 @@ def test_full_size_run_recovers_the_target_moments(G):
     acc = e.get_trace(win - 40, 40, with_X=False)["moved"].mean()
     assert 0.2 < acc < 0.7
     e.close()
+
+
+def test_parallel_tempering_reference_and_oracle(G, O):
+    """parallel tempering (core.py:131-236): HIP == reference fixture (both interleaved sample streams, swap pairs,
+    accepted-swap sequence, history) and HIP == oracle bit for bit, also at a size the fixture does not cover."""
+    fx = H.load("trace_pt_mvn10")
+    n = int(fx["cfg_G"])
+    e, o = H.pt_engine_from_fixture(G.Engine, fx), H.pt_engine_from_fixture(O.Engine, fx)
+    e.step(n); o.step(n)
+    H.compare_pt_with_reference(e, fx)
+    assert_traces_identical(e.get_trace(0, n), o.get_trace(0, n))
+    np.testing.assert_array_equal(e.get_swaps(0, n), o.get_swaps(0, n))
+    # 256 chains x 100-D, 60 generations
+    N, d, n, seed = 256, 100, 60, 31
+    P = H.mvn_precision(d)
+    Z0 = H.seed_history(max(10 * d, 2 * N), d, seed)
+    T = np.array([np.power(.001, float(i) / N) for i in range(N)])
+    out = []
+    for Cls in (G.Engine, O.Engine):
+        en = Cls(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed)
+        en.set_history(Z0); en.set_state(Z0[:N]); en.set_likelihood_mvn(np.zeros(d), P, 0, 0.0); en.set_temperatures(T)
+        en.step(n)
+        out.append((en.get_trace(0, n), en.get_swaps(0, n), en.get_history(), en.get_state()))
+    assert_traces_identical(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    for a, b in zip(out[0][3], out[1][3]):
+        np.testing.assert_array_equal(a, b)
+    assert out[0][1][:, 2].sum() > 0                    # some swaps were accepted

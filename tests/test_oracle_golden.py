@@ -102,3 +102,14 @@ def test_gelman_rubin_matches_reference():
     """convergence.py:3-20"""
     fx = H.load("densities")
     np.testing.assert_allclose(O.gelman_rubin(fx["gr_traces"]), fx["gr_rhat"], rtol=1e-12)
+
+
+def test_parallel_tempering_matches_reference():
+    """core._sample_dream_pt (core.py:131-236) itself, run in one process by tests/golden/make_golden.py: temperature
+    ladder, per-chain T inside astep, one swap attempt per iteration -- oracle == reference on both interleaved sample
+    streams, the swap pairs, the accepted-swap sequence and the history."""
+    fx = H.load("trace_pt_mvn10")
+    e = H.pt_engine_from_fixture(O.Engine, fx)
+    e.step(int(fx["cfg_G"]))
+    tr, sw = H.compare_pt_with_reference(e, fx)
+    assert 3 <= sw[:, 2].sum() <= 60

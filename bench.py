@@ -95,17 +95,35 @@ def measured_traffic(args, n_local, kernel_class, gens_per_launch):
 
 
 def cpu_baseline(args):
-    """The CPU restatement (oracle, scalar C, one core) on a bounded sample of the same workload."""
+    """The CPU restatement (oracle/dreamzs_oracle.c: scalar C, the chains of a generation spread over the host's cores
+    with OpenMP, as the reference spreads them over processes) on a bounded sample of the same workload: the same
+    chain count, as many generations as fit in about 10 s."""
+    if "OMP_NUM_THREADS" not in os.environ:           # the cores this process may really use: affinity and cgroup quota
+        n = len(os.sched_getaffinity(0))
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+            if quota != "max":
+                n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+        except (OSError, ValueError):
+            pass
+        os.environ["OMP_NUM_THREADS"] = str(n)
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     from oracle import oracle as O
-    nc, g = args.cpu_chains, args.cpu_steps
-    e = setup_engine(O.Engine, args, nc, nc, 0, g + 2, schedule=2, trace_capacity=0)
+    nc = args.cpu_chains
+    cores = O.threads()
+    probe = 4
+    e = setup_engine(O.Engine, args, nc, nc, 0, 8100, schedule=2, trace_capacity=0)      # (the archive is calloc-ed: untouched rows cost nothing)
     e.step(2)
+    t0 = time.perf_counter()
+    e.step(probe)
+    per_gen = (time.perf_counter() - t0) / probe
+    g = args.cpu_steps if args.cpu_steps > 0 else int(max(10, min(8000, args.cpu_seconds / per_gen)))
     t0 = time.perf_counter()
     e.step(g)
     dt = time.perf_counter() - t0
-    return {"value": nc * args.multitry * g / dt, "unit": "proposals/s", "cores": 1, "kind": "port",
-            "sample": "%d chains x %d generations of the same %d-D %s target, multitry=%d, oracle/dreamzs_oracle.c, %.1f s"
-                      % (nc, g, args.dim, args.target, args.multitry, dt)}
+    return {"value": nc * args.multitry * g / dt, "unit": "proposals/s", "cores": cores, "kind": "port",
+            "sample": "%d chains x %d generations of the same %d-D %s target, multitry=%d, oracle/dreamzs_oracle.c with %d OpenMP "
+                      "thread(s) over the chains, %.1f s" % (nc, g, args.dim, args.target, args.multitry, cores, dt)}
 
 
 def main():
@@ -126,8 +144,9 @@ def main():
                     help="form of the MVN whitening matrix: tri = Cholesky factor of the precision (what "
                          "pydream_amd.likelihoods.MVNormalLogLike builds), dense = full precision matrix")
     ap.add_argument("--snooker", type=float, default=0.1, help="snooker probability (reference default 0.1)")
-    ap.add_argument("--cpu-chains", type=int, default=512)
-    ap.add_argument("--cpu-steps", type=int, default=400)
+    ap.add_argument("--cpu-chains", type=int, default=4096)
+    ap.add_argument("--cpu-steps", type=int, default=0, help="generations of the CPU baseline (0: as many as fit --cpu-seconds)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not time individual kernels with HIP events")
     args = ap.parse_args()

@@ -19,6 +19,9 @@
 #include "dreamzs_oracle.h"
 
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <float.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -30,6 +33,14 @@
 static __thread char g_err[512];
 static int fail(const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); return -1; }
 int orc_version(void) { return ORC_VERSION; }
+int orc_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 const char* orc_last_error(void) { return g_err; }
 
 /* ------------------------------------------------------------------ */
@@ -819,6 +830,26 @@ static int generation_s2(orc_engine* e)
     double* Xn = zalloc(sizeof(double) * nl * d); step_res* R = zalloc(sizeof(step_res) * nl);
     int rc = 0;
     if (g == 0 && (e->c.adapt_crossover || e->c.adapt_gamma)) rc = exchange(e, e->X, e->cp_new, d);
+    /* The chains of a generation are independent (schedule S2), so the CPU baseline may spread them over the host's
+     * cores the way the reference spreads them over processes: each thread works on a shallow copy of the engine with
+     * private scratch.  Results do not depend on the thread count.  The Python likelihood callback stays serial. */
+#ifdef _OPENMP
+    if (e->lk != LK_HOST && omp_get_max_threads() > 1 && nl > 1) {
+        #pragma omp parallel
+        {
+            orc_engine te = *e;
+            te.pts = zalloc(sizeof(double) * e->k * d); te.refs = zalloc(sizeof(double) * e->k * d); te.work = zalloc(sizeof(double) * 8 * d);
+            int trc = 0;
+            #pragma omp for schedule(static)
+            for (int c = 0; c < nl; ++c) if (!trc) trc = chain_step(&te, c, g, e->M, e->cr_probs, e->g_probs, Xn + (size_t)c * d, &R[c]);
+            if (trc) {
+                #pragma omp critical
+                rc = trc;
+            }
+            free(te.pts); free(te.refs); free(te.work);
+        }
+    } else
+#endif
     for (int c = 0; c < nl && !rc; ++c) rc = chain_step(e, c, g, e->M, e->cr_probs, e->g_probs, Xn + (size_t)c * d, &R[c]);
     if (rc) { free(Xn); free(R); return rc; }
     for (int c = 0; c < nl; ++c) {

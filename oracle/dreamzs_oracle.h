@@ -65,6 +65,7 @@ typedef int (*orc_logp_cb)(const double* X, int64_t n, int32_t d, double* prior,
 typedef int (*orc_exchange_cb)(const void* send, void* recv, int64_t bytes, void* user);
 
 int         orc_version(void);
+int         orc_threads(void);     /* OpenMP threads the S2 chain loop will use (OMP_NUM_THREADS; 1 without OpenMP) */
 const char* orc_last_error(void);
 
 int orc_create(const orc_config* cfg, orc_engine** out);

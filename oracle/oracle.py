@@ -117,6 +117,11 @@ def u16(h):
     return float(lib().orc_u16(int(h) & 0xffff))
 
 
+def threads():
+    """OpenMP threads the oracle's lockstep generation spreads the chains over (OMP_NUM_THREADS)."""
+    return int(lib().orc_threads())
+
+
 def exp(x):
     return float(lib().orc_exp(float(x)))
 

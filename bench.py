@@ -98,16 +98,6 @@ def cpu_baseline(args):
     """The CPU restatement (oracle/dreamzs_oracle.c: scalar C, the chains of a generation spread over the host's cores
     with OpenMP, as the reference spreads them over processes) on a bounded sample of the same workload: the same
     chain count, as many generations as fit in about 10 s."""
-    if "OMP_NUM_THREADS" not in os.environ:           # the cores this process may really use: affinity and cgroup quota
-        n = len(os.sched_getaffinity(0))
-        try:
-            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-            if quota != "max":
-                n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
-        except (OSError, ValueError):
-            pass
-        os.environ["OMP_NUM_THREADS"] = str(n)
-    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     from oracle import oracle as O
     nc = args.cpu_chains
     cores = O.threads()
@@ -133,7 +123,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--spinup", type=int, default=2000,
                     help="untimed generations run before the W warm-up steps so that the GPU leaves its idle clock "
-                         "state (a cold MI355X needs ~0.1 s of load; without it short runs vary 3x)")
+                         "state (a cold MI355X needs ~0.1 s of load; without it short runs vary 3x); more are added, up "
+                         "to 4x, until --spinup-seconds of load have passed (small workloads finish 2000 generations sooner)")
+    ap.add_argument("--spinup-seconds", type=float, default=0.15)
     ap.add_argument("--chains-per-gpu", type=int, default=4096)
     ap.add_argument("--dim", type=int, default=100)
     ap.add_argument("--multitry", type=int, default=5)
@@ -168,7 +160,7 @@ def main():
 
     n_local = args.chains_per_gpu
     n_global = n_local * world
-    total = args.spinup + 2 * args.steps + args.warmup      # spin-up + warm-up + timed pass + HIP-event pass
+    total = 4 * args.spinup + 2 * args.steps + args.warmup  # spin-up (at most 4x) + warm-up + timed pass + HIP-event pass
     e = setup_engine(_capi.Engine, args, n_global, n_local, rank * n_local, total, device=local_rank)
     if world > 1:
         ids = [_capi.comm_unique_id() if rank == 0 else None]
@@ -181,9 +173,15 @@ def main():
             dist.barrier()
 
     chunk = max(1, min(args.spinup, max(args.steps, args.warmup, 2)))
-    for g0 in range(0, args.spinup, chunk):           # clock spin-up (untimed, not part of W or K)
+    spun, t_spin = 0, time.perf_counter()
+    # (with several ranks every e.step is a collective sequence, so the count must not depend on a local clock)
+    extend = lambda: world == 1 and spun < 4 * args.spinup and time.perf_counter() - t_spin < args.spinup_seconds
+    while spun < args.spinup or extend():
+        n = min(chunk, (args.spinup if spun < args.spinup else 4 * args.spinup) - spun)      # clock spin-up (untimed, not part of W or K)
         e.trace_reset()
-        e.step(min(chunk, args.spinup - g0))
+        e.step(n)
+        e.sync()
+        spun += n
     barrier()
     e.trace_reset()
     e.step(args.warmup)
@@ -248,7 +246,7 @@ def main():
                    "chains_global": n_global, "chains_per_gpu": n_local, "ndim": args.dim, "multitry": args.multitry,
                    "parallelism": "chains sharded x%d, Z replicated by RCCL all-gather" % world if world > 1 else "single GPU"},
         "logp_points_per_s": n_global * (2 * args.multitry - 1) * args.steps / dt,
-        "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps, "spinup_generations": args.spinup,
+        "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps, "spinup_generations": spun,
         "acceptance_rate": acc, "rhat_max": float(np.max(rhat)),
     }
     if prof:

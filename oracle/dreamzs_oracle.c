@@ -834,8 +834,10 @@ static int generation_s2(orc_engine* e)
      * cores the way the reference spreads them over processes: each thread works on a shallow copy of the engine with
      * private scratch.  Results do not depend on the thread count.  The Python likelihood callback stays serial. */
 #ifdef _OPENMP
-    if (e->lk != LK_HOST && omp_get_max_threads() > 1 && nl > 1) {
-        #pragma omp parallel
+    int nthr = omp_get_max_threads();
+    if (nthr > nl / 16) nthr = nl / 16;              /* at least 16 chains per thread, or it is not worth a team */
+    if (e->lk != LK_HOST && nthr > 1) {
+        #pragma omp parallel num_threads(nthr)
         {
             orc_engine te = *e;
             te.pts = zalloc(sizeof(double) * e->k * d); te.refs = zalloc(sizeof(double) * e->k * d); te.work = zalloc(sizeof(double) * 8 * d);

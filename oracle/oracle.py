@@ -44,6 +44,16 @@ def lib():
     global _lib
     if _lib is None:
         build()
+        if "OMP_NUM_THREADS" not in os.environ:       # the cores this process may really use: affinity and cgroup quota
+            n = len(os.sched_getaffinity(0))
+            try:
+                quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+                if quota != "max":
+                    n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+            except (OSError, ValueError):
+                pass
+            os.environ["OMP_NUM_THREADS"] = str(n)
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         L = C.CDLL(LIB_PATH)
         L.orc_last_error.restype = C.c_char_p
         L.orc_generation.restype = C.c_int64

@@ -107,6 +107,7 @@ struct dz_engine {
     bool fuse = true;               // DZ_FUSE=0 disables the accept+propose fusion
     bool mega = true;               // the persistent generation kernel serves every eligible configuration (mega_eligible); DZ_MEGA=0 forces the multi-kernel path
     int mega_max_gen = 1 << 20;     // DZ_MEGA_MAXGEN: generations per launch cap (measurement)
+    int mega_ch = 0;                // DZ_MEGA_CHAINS: force 16 / 8 / 4 chains per block (0: by chain count)
     bool tempering = false; double* d_Tc = nullptr; int32_t* d_tswap = nullptr;    // parallel tempering (dz_set_temperatures)
     bool pending_accept = false;    // generation gen-1's Metropolis step has been deferred into the next proposal kernel
     int64_t pending_slot = -1;
@@ -412,9 +413,16 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
 // ---- persistent generation kernel (dz_megakernel.h) -------------------------------------------------
 // chain states, gamma table and decisions ride in LDS next to the matrix whenever that fits (the packed triangle at
 // d=100 leaves room; the dense square does not)
+// chains (= waves) per block: 16 once that still gives every CU a block, else 8 or 4 (C2: 1024 chains -> 256 blocks of 4)
+int mega_chains(const dz_engine* e)
+{
+    if (e->mega_ch) return e->mega_ch;
+    for (int ch = dz::MEGA_CHAINS; ch > 4; ch >>= 1) if (e->p.nl / ch >= e->num_cu) return ch;
+    return 4;
+}
 size_t mega_lds_bytes(const dz_engine* e, bool xlds)
 {
-    return sizeof(double) * (size_t)dz::mega_layout(e->p.d, e->p.k, e->p.ld / 16, e->p.ncr, e->p.ngamma, e->p.tri != 0, xlds).total;
+    return sizeof(double) * (size_t)dz::mega_layout(e->p.d, e->p.k, e->p.ld / 16, e->p.ncr, e->p.ngamma, e->p.tri != 0, xlds, mega_chains(e)).total;
 }
 bool mega_xlds(const dz_engine* e) { return mega_lds_bytes(e, true) <= (size_t)160 * 1024; }
 bool mega_eligible(const dz_engine* e)
@@ -443,7 +451,8 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
     DZCK(join_all(e));
     const int64_t slot0 = e->c.trace_capacity ? e->ntrace : -1;
     const int nrt = p.ld / 16;
-    const dim3 grid((p.nl + dz::MEGA_CHAINS - 1) / dz::MEGA_CHAINS), block(64 * dz::MEGA_WAVES);
+    const int ch = mega_chains(e);
+    const dim3 grid((p.nl + ch - 1) / ch), block(64 * ch);
     const bool xlds = mega_xlds(e);
     const size_t lds = mega_lds_bytes(e, xlds);
     if (!e->params_uploaded || memcmp(&e->p_shadow, &p, sizeof(dz::Params)) != 0) {   // the kernel reads Params through a pointer
@@ -452,7 +461,8 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
         e->params_uploaded = true;
     }
     {
-#define DZ_MEGA_LAUNCH(NRT_, TRI_, X_) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations<NRT_, TRI_, X_>), grid, block, lds, (const dz::Params*)e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0)
+#define DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, CH_) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations<NRT_, TRI_, X_, CH_>), grid, block, lds, (const dz::Params*)e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0)
+#define DZ_MEGA_LAUNCH(NRT_, TRI_, X_) do { if (ch == 16) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 16); else if (ch == 8) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 8); else DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 4); } while (0)
 #define DZ_MEGA_CASE(NRT_)                                                              \
     case NRT_:                                                                          \
         if (p.tri) { if (xlds) DZ_MEGA_LAUNCH(NRT_, true, true); else DZ_MEGA_LAUNCH(NRT_, true, false); }    \
@@ -461,6 +471,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
         switch (nrt) { DZ_MEGA_CASE(1) DZ_MEGA_CASE(2) DZ_MEGA_CASE(3) DZ_MEGA_CASE(4) DZ_MEGA_CASE(5) DZ_MEGA_CASE(6) DZ_MEGA_CASE(7) DZ_MEGA_CASE(8) }
 #undef DZ_MEGA_CASE
 #undef DZ_MEGA_LAUNCH
+#undef DZ_MEGA_LAUNCH_CH
     }
     DZCK(launch_check("k_generations"));
     if (append_last) { DZCK(allgather_rows(e, p.Z + (size_t)e->M * p.ld)); e->M += p.N; }
@@ -509,6 +520,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     if (const char* kv = getenv("DZ_FUSE")) e->fuse = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA")) e->mega = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_MAXGEN")) e->mega_max_gen = std::max(1, atoi(kv));
+    if (const char* kv = getenv("DZ_MEGA_CHAINS")) { const int v = atoi(kv); e->mega_ch = (v == 16 || v == 8 || v == 4) ? v : 0; }
     if (const char* kv = getenv("DZ_WPB")) e->waves_per_block = atoi(kv);
     if (const char* kv = getenv("DZ_PROPOSE_SPLIT")) e->propose_split = atoi(kv);
     if (const char* kv = getenv("DZ_MFMA_PT")) e->force_pt = atoi(kv) == 2 ? 2 : atoi(kv) == 1 ? 1 : 0;

@@ -26,53 +26,60 @@
 
 namespace dz {
 
-constexpr int MEGA_CHAINS = 16;      // chains per block
-constexpr int MEGA_WAVES = 16;       // waves per block
+constexpr int MEGA_CHAINS = 16;      // chains (= waves) per block at full size; 8 or 4 when there are too few chains to give every CU a block
 
-struct MegaLayout { int LDM, LDP, off_P, off_q, off_sP, off_sS, off_sL, off_rP, off_rS, off_mu, off_pr, off_st, off_dec, off_gt, off_X, total; };
+struct MegaLayout { int LDM, LDP, rows, off_P, off_q, off_sP, off_sS, off_sL, off_rP, off_rS, off_mu, off_pr, off_st, off_dec, off_gt, off_X, total; };
 
-__host__ __device__ inline MegaLayout mega_layout(int d, int k, int nrt, int ncr, int ngamma, bool tri, bool xlds)
+// point rows of a block: try i of chain c at row i*ch + c; tiles are 16 consecutive rows, from row 0 (k tries) or from
+// row ch (the k-1 reference tries); rows past the last point stay zero
+__host__ __device__ inline int mega_rows(int k, int ch)
+{
+    const int a = 16 * ((k * ch + 15) / 16), b = ch + 16 * (((k - 1) * ch + 15) / 16);
+    return a > b ? a : b;
+}
+__host__ __device__ inline MegaLayout mega_layout(int d, int k, int nrt, int ncr, int ngamma, bool tri, bool xlds, int ch = MEGA_CHAINS)
 {
     MegaLayout L;
     const int ks4 = 4 * ((d + 3) / 4);
     L.LDM = d + 2;                    // dense matrix row (k index c): d entries + pad; rows d..ks4-1 are zero
     L.LDP = ks4 + 1;                  // point row: zero padded to the k-steps; odd stride keeps the A-layout reads (16 rows x 4 cols) off one bank
     L.off_P = tri ? tri_row_offset(ks4) : ks4 * L.LDM + 16;       // (+16: the last row tile's column reads run past the last row's end)
-    L.off_q = L.off_P + MEGA_CHAINS * k * L.LDP;
-    L.off_sP = L.off_q + MEGA_CHAINS * k * nrt;
-    L.off_sS = L.off_sP + MEGA_CHAINS * k;
-    L.off_sL = L.off_sS + MEGA_CHAINS * k;
-    L.off_rP = L.off_sL + MEGA_CHAINS * k;
-    L.off_rS = L.off_rP + MEGA_CHAINS * k;
-    L.off_mu = L.off_rS + MEGA_CHAINS * k;
+    L.rows = mega_rows(k, ch);
+    L.off_q = L.off_P + L.rows * L.LDP;
+    L.off_sP = L.off_q + L.rows * nrt;
+    L.off_sS = L.off_sP + ch * k;
+    L.off_sL = L.off_sS + ch * k;
+    L.off_rP = L.off_sL + ch * k;
+    L.off_rS = L.off_rP + ch * k;
+    L.off_mu = L.off_rS + ch * k;
     L.off_pr = L.off_mu + ks4 + 4;               // (mu zero padded to the k-steps) crossover / gamma-level probabilities
     L.off_st = L.off_pr + ncr + ngamma;          // per chain: lprior, llike, sel|fin
-    L.off_dec = L.off_st + 4 * MEGA_CHAINS;      // per chain and generation: u_sel, u_acc, snooker, CR index, gamma level
-    L.off_gt = L.off_dec + 8 * MEGA_CHAINS;      // gamma_arr[level-1][0][:]
+    L.off_dec = L.off_st + 4 * ch;      // per chain and generation: u_sel, u_acc, snooker, CR index, gamma level
+    L.off_gt = L.off_dec + 8 * ch;      // gamma_arr[level-1][0][:]
     L.off_X = L.off_gt + ngamma * d + (d & 1);   // chain states (XLDS)
-    L.total = L.off_X + (xlds ? MEGA_CHAINS * L.LDP : 0);
+    L.total = L.off_X + (xlds ? ch * L.LDP : 0);
     L.total += L.total & 1;
     return L;
 }
 
 // Unit u (0 .. ntl*NRT-1) in dealing order: row tile first (heaviest first for the triangular factor), then point tile.
-// Wave w takes the units w, 31-w, 32+w, 63-w, ... (snake), which evens out the k-steps per wave and per SIMD.
-DZ_DEV int mega_unit(int j, int wv) { return (j & 1) ? 16 * j + (MEGA_WAVES - 1 - wv) : 16 * j + wv; }
+// Wave w of tw takes the units w, 2tw-1-w, 2tw+w, ... (snake), which evens out the k-steps per wave and per SIMD.
+DZ_DEV int mega_unit(int j, int wv, int tw) { return (j & 1) ? tw * j + (tw - 1 - wv) : tw * j + wv; }
 
-// The (point tile, row tile) units of Y = V M^T for the point tiles [tile0, tile0+ntl) held in LDS; writes
+// The (point tile, row tile) units of Y = V M^T for the ntl point tiles of 16 rows starting at row row0 of the LDS point area; writes
 // q[point][t] = butterfly16 over i of y_{16t+i} s_{16t+i}  (MVN contract, dz_kernels.h).
 template <int NRT, bool TRI, bool MZ>
 DZ_DEV void mfma_units(const Params& p, const double* __restrict__ Ms, const double* __restrict__ Pt, const double* __restrict__ mus,
-                       double* __restrict__ qb, int tile0, int ntl, int wv, int l, int LDM, int LDP)
+                       double* __restrict__ qb, int row0, int ntl, int wv, int tw, int l, int LDM, int LDP)
 {
     const int d = p.d, KS = (d + 3) >> 2;
     const int pi = l & 15, kq = l >> 4;
     for (int j = 0;; ++j) {
-        const int u = mega_unit(j, wv);
-        if (16 * j >= ntl * NRT) break;
+        const int u = mega_unit(j, wv, tw);
+        if (tw * j >= ntl * NRT) break;
         if (u >= ntl * NRT) continue;
-        const int t = u / ntl, tile = tile0 + (u - t * ntl);
-        const double* ap = Pt + (size_t)(tile * 16 + pi) * LDP + kq;
+        const int t = u / ntl, trow = row0 + 16 * (u - t * ntl);           // the tile's first point row
+        const double* ap = Pt + (size_t)(trow + pi) * LDP + kq;
         const double* mp = mus + kq;
         const int r = 16 * t + pi;
         const bool rok = r < d;
@@ -103,7 +110,7 @@ DZ_DEV void mfma_units(const Params& p, const double* __restrict__ Ms, const dou
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int pt = tile * 16 + kq + 4 * e;
+            const int pt = trow + kq + 4 * e;
             const double y = acc[e];
             const double sv = TRI ? y : (rok ? Pt[(size_t)pt * LDP + r] - mus[r] : 0.0);
             const double q = bfly16(rok ? y * sv : 0.0);
@@ -112,16 +119,15 @@ DZ_DEV void mfma_units(const Params& p, const double* __restrict__ Ms, const dou
     }
 }
 
-template <int NRT, bool TRI, bool XLDS>
-__global__ __launch_bounds__(64 * MEGA_WAVES) void k_generations(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int append_last)
+template <int NRT, bool TRI, bool XLDS, int CH>
+__global__ __launch_bounds__(64 * CH) void k_generations(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int append_last)
 {
     const Params& p = *pp;       // read through the scalar cache on demand: keeps the ~70 fields out of the SGPR file
     constexpr int NCH = 1;
-    constexpr int NT = 64 * MEGA_WAVES;
-    static_assert(MEGA_CHAINS == MEGA_WAVES, "one wave per chain");
+    constexpr int NT = 64 * CH;                        // one wave per chain
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int d = p.d, k = p.k, ld = p.ld;
-    const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, XLDS);
+    const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, XLDS, CH);
     double* Ms = smem;
     double* Pt = smem + L.off_P;
     double* qb = smem + L.off_q;
@@ -135,11 +141,11 @@ __global__ __launch_bounds__(64 * MEGA_WAVES) void k_generations(const Params* _
     double* Xs = smem + L.off_X;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int cl = wv;                                                   // chain inside the block
-    const int cg = blockIdx.x * MEGA_CHAINS + cl;
+    const int cg = blockIdx.x * CH + cl;
     const bool active = cg < p.nl;
     const int c = min(cg, p.nl - 1);
     const uint32_t gc = (uint32_t)(p.off + c);
-    const int tstride = 16 * L.LDP;                                      // try i of chain cl: Pt + (16 i + cl) LDP
+    const int tstride = CH * L.LDP;                                      // try i of chain cl: Pt + (CH i + cl) LDP
     double* region = Pt + (size_t)cl * L.LDP;
 
     // ---- stage the matrix, mu, the selection probabilities, the gamma table, the chains' logp (and states)
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(64 * MEGA_WAVES) void k_generations(const Params* _
             Ms[i] = (row < d && col < d) ? p.Mt[(size_t)row * ld + col] : 0.0;
         }
     }
-    for (int i = threadIdx.x; i < MEGA_CHAINS * k * L.LDP; i += NT) Pt[i] = 0.0;
+    for (int i = threadIdx.x; i < L.rows * L.LDP; i += NT) Pt[i] = 0.0;
     if (threadIdx.x < 4 * ((d + 3) / 4) + 4) mus[threadIdx.x] = threadIdx.x < d ? p.mu[threadIdx.x] : 0.0;
     if (threadIdx.x < p.ncr) probs[threadIdx.x] = p.cr_probs[threadIdx.x];
     if (threadIdx.x < p.ngamma) probs[p.ncr + threadIdx.x] = p.g_probs[threadIdx.x];
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(64 * MEGA_WAVES) void k_generations(const Params* _
     __syncthreads();
 
 #ifdef DZ_EXP_STAMPS
-#define DZ_MSTAMP(i_) do { if (gi == ngen - 1 && lane == 0) p.dbg[((size_t)3 * p.nl + blockIdx.x * MEGA_WAVES + wv) * 16 + (i_)] = __builtin_readcyclecounter(); } while (0)
+#define DZ_MSTAMP(i_) do { if (gi == ngen - 1 && lane == 0) p.dbg[((size_t)3 * p.nl + blockIdx.x * CH + wv) * 16 + (i_)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define DZ_MSTAMP(i_) do { } while (0)
 #endif
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(64 * MEGA_WAVES) void k_generations(const Params* _
                 // likelihoods of the chain's k points, mt_choose_proposal_pt (:291)
                 double lp = -__builtin_huge_val();
                 if (lane < k) {
-                    const int pt = lane * 16 + cl;
+                    const int pt = lane * CH + cl;
                     double Q = 0.0;
                     for (int t = 0; t < NRT; ++t) Q = Q + qb[pt * NRT + t];
                     const double lk = nan_to_ninf(p.logF - 0.5 * Q);
@@ -230,8 +236,11 @@ __global__ __launch_bounds__(64 * MEGA_WAVES) void k_generations(const Params* _
             __syncthreads();                                                         // points visible
             DZ_MSTAMP(2 + 4 * phase);
             // mt_evaluate_logps :278, :302 (x - 0.0 == x bit for bit, so a zero mean skips the subtraction and its LDS read)
-            if (p.mu_zero) mfma_units<NRT, TRI, true>(p, Ms, Pt, mus, qb, phase, k - phase, wv, lane, L.LDM, L.LDP);
-            else mfma_units<NRT, TRI, false>(p, Ms, Pt, mus, qb, phase, k - phase, wv, lane, L.LDM, L.LDP);
+            {
+                const int row0 = phase ? CH : 0, ntl = ((k - phase) * CH + 15) / 16;
+                if (p.mu_zero) mfma_units<NRT, TRI, true>(p, Ms, Pt, mus, qb, row0, ntl, wv, CH, lane, L.LDM, L.LDP);
+                else mfma_units<NRT, TRI, false>(p, Ms, Pt, mus, qb, row0, ntl, wv, CH, lane, L.LDM, L.LDP);
+            }
             DZ_MSTAMP(3 + 4 * phase);
             __syncthreads();                                                         // q visible
             DZ_MSTAMP(4 + 4 * phase);
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(64 * MEGA_WAVES) void k_generations(const Params* _
             } else if (lane >= 16 && lane < 16 + k) {
                 const int i = lane - 16;
                 if (i < k - 1) {
-                    const int pt = (1 + i) * 16 + cl;
+                    const int pt = (1 + i) * CH + cl;
                     double Q = 0.0;
                     for (int t = 0; t < NRT; ++t) Q = Q + qb[pt * NRT + t];
                     val = p.T * nan_to_ninf(p.logF - 0.5 * Q) + rP[cl * (k - 1) + i];                     // :303

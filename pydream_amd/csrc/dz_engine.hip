@@ -79,6 +79,7 @@ struct dz_engine {
     int nlanes = 1; hipStream_t lane_stream[8] = {nullptr}; hipEvent_t lane_ev[8] = {nullptr}; bool need_join = true;
     // bounded host run-ahead: a marker every ra_stride generations, the host never gets more than 3 markers ahead
     dz::Params p_shadow; bool params_uploaded = false;    // what d_params holds
+    double* d_qpart = nullptr; size_t qpart_len = 0; bool force_big = false;    // row-tile sums of the tiled large-d likelihood; DZ_LOGP_BIG=1: the one-wave-per-tile kernel
     int logp_waves = 0;      // DZ_LOGP_WAVES: force the block size of k_logp_mvn_lds (tuning)
     int ra_stride = 32; hipEvent_t ra_ev[4] = {nullptr}; bool ra_used[4] = {false, false, false, false}; int64_t ra_n = 0;
     int nch = 1;
@@ -111,7 +112,7 @@ struct dz_engine {
     bool tempering = false; double* d_Tc = nullptr; int32_t* d_tswap = nullptr;    // parallel tempering (dz_set_temperatures)
     bool pending_accept = false;    // generation gen-1's Metropolis step has been deferred into the next proposal kernel
     int64_t pending_slot = -1;
-    int propose_split = 1;          // waves per chain in k_propose (DZ_PROPOSE_SPLIT)
+    int propose_split = 0;          // waves per chain in k_propose (DZ_PROPOSE_SPLIT); 0 = by problem shape
     int force_pt = 0;               // measurement switch: DZ_MFMA_PT=1|2 forces the point tiles per wave
     std::vector<hipEvent_t> ev_pool;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[PR_COUNT];
@@ -249,8 +250,22 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
                 switch (nrt) { DZ_MFMA_CASE(1) DZ_MFMA_CASE(2) DZ_MFMA_CASE(3) DZ_MFMA_CASE(4) DZ_MFMA_CASE(5) DZ_MFMA_CASE(6) DZ_MFMA_CASE(7) DZ_MFMA_CASE(8) }
 #undef DZ_MFMA_CASE
             } else {
-                constexpr int RTC = 8;
-                hipLaunchKernelGGL(dz::k_logp_mvn_mfma_big<RTC>, dim3((n + 63) / 64), block, 0, st, e->p, pts, n, prior, like);
+                // tiled product: waves = point-tile groups x row-tile groups; per-row-tile sums through a scratch array
+                constexpr int PT = 2, RTC = 4;
+                const int nrtb = (e->p.d + 15) / 16, nrg = (nrtb + RTC - 1) / RTC, npg = (n + 16 * PT - 1) / (16 * PT);
+                const size_t need = (size_t)n * nrtb;
+                if (need > e->qpart_len) {
+                    DZCK(sync_all(e));
+                    if (e->d_qpart) hipFree(e->d_qpart);
+                    e->d_qpart = nullptr; e->qpart_len = 0;
+                    DZCK(dalloc(&e->d_qpart, need));
+                    e->qpart_len = need;
+                }
+                if (e->force_big) hipLaunchKernelGGL(dz::k_logp_mvn_mfma_big<8>, dim3((n + 63) / 64), block, 0, st, e->p, pts, n, prior, like);
+                else {
+                    hipLaunchKernelGGL((dz::k_logp_mvn_mfma_tiled<PT, RTC>), dim3((npg * nrg + 3) / 4), block, 0, st, e->p, pts, n, e->d_qpart);
+                    hipLaunchKernelGGL(dz::k_q_finish, dim3((n + 255) / 256), dim3(256), 0, st, e->p, (const double*)e->d_qpart, n, nrtb, prior, like);
+                }
             }
             if (e->p.have_prior) NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_prior_only<NCH>, grid, block, 0, st, e->p, pts, n, prior));
         }
@@ -358,11 +373,14 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
     }
     // waves per block: 16 (one block fills a CU's 4 SIMDs evenly) once there is at least one such block per CU
     const int wpb = e->waves_per_block ? e->waves_per_block : ((nc / L) >= 16 * e->num_cu ? 16 : 4);
-    const int sp0 = std::max(1, std::min(k, e->propose_split)), sp1 = std::max(1, std::min(k - 1, e->propose_split));
+    // one wave per (chain, try) pays when a try is long and the chains are few: d > 512 (measured at 512 x 1000-D: +17%;
+    // at d <= 200 the per-chain wave with its fused Metropolis step is faster)
+    const int split = e->propose_split > 0 ? e->propose_split : (e->nch >= 8 ? k : 1);
+    const int sp0 = std::max(1, std::min(k, split)), sp1 = std::max(1, std::min(k - 1, split));
     const int64_t slot = (traced && e->c.trace_capacity) ? e->ntrace : -1;
     // the Metropolis step of this generation can ride in front of the next generation's proposal kernel when
     // nothing shared changes in between (no history append, no published positions) and a generation follows
-    const bool defer = full && e->fuse && more_follow && !append && !publish && e->propose_split == 1 && e->lk != LK_HOST && !e->tempering;
+    const bool defer = full && e->fuse && more_follow && !append && !publish && split == 1 && e->lk != LK_HOST && !e->tempering;
     const int64_t zbase = full ? e->M : e->M - (int64_t)(p.off + c0);
     for (int s = 0; s < L; ++s) {
         const int lc0 = c0 + (int)((int64_t)nc * s / L), lc1 = c0 + (int)((int64_t)nc * (s + 1) / L), lnc = lc1 - lc0;
@@ -545,6 +563,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
         for (int s = 1; s < e->nlanes; ++s) HIPCK(hipStreamCreateWithFlags(&e->lane_stream[s], hipStreamNonBlocking));
         for (int s = 0; s < e->nlanes; ++s) HIPCK(hipEventCreateWithFlags(&e->lane_ev[s], hipEventDisableTiming));
         if (const char* ra = getenv("DZ_RUNAHEAD")) e->ra_stride = std::max(0, atoi(ra));
+        if (const char* fb = getenv("DZ_LOGP_BIG")) e->force_big = atoi(fb) != 0;
         if (const char* lw = getenv("DZ_LOGP_WAVES")) e->logp_waves = std::max(4, std::min(8, atoi(lw)));
         for (int s = 0; s < 4; ++s) HIPCK(hipEventCreateWithFlags(&e->ra_ev[s], hipEventDisableTiming));
     }
@@ -619,6 +638,7 @@ int dz_destroy(dz_engine* e)
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     for (void* q : e->to_free) hipFree(q);
     if (e->d_scratch) hipFree(e->d_scratch);
+    if (e->d_qpart) hipFree(e->d_qpart);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
     return 0;
@@ -999,6 +1019,7 @@ static int need_scratch(dz_engine* e, size_t rows)
 {
     if (e->scratch_rows >= rows) return 0;
     if (e->d_scratch) hipFree(e->d_scratch);
+    if (e->d_qpart) hipFree(e->d_qpart);
     e->d_scratch = nullptr; e->scratch_rows = 0;
     HIPCK(hipMalloc((void**)&e->d_scratch, sizeof(double) * (rows * e->p.ld + 4 * rows)));
     e->scratch_rows = rows;

@@ -1023,6 +1023,90 @@ __global__ __launch_bounds__(256) void k_logp_mvn_mfma_big(Params p, const doubl
     }
 }
 
+// Large d (ld > 128): the quadratic form as a tiled product.  One wave owns PT point tiles x RTC row tiles and walks k
+// once (B operands shared by the PT tiles, A operands by the RTC row tiles); the grid covers point-tile groups x
+// row-tile groups, so 2560 points x 63 row tiles give 1280 waves instead of the 160 of the one-wave-per-point-tile
+// form (C5: 905 -> see DESIGN.md).  Row-tile sums q[point][t] go to a scratch array; k_q_finish adds them in ascending
+// t, which keeps the contract (Q = q_0 + q_1 + ...) independent of how the tiles were spread.
+template <int PT, int RTC>
+__global__ __launch_bounds__(256) void k_logp_mvn_mfma_tiled(Params p, const double* __restrict__ pts, int npts, double* __restrict__ qpart)
+{
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int pi = l & 15, kq = l >> 4;
+    const int ld = p.ld, d = p.d;
+    const int KS = (d + 3) >> 2, NRT = (d + 15) >> 4;
+    const int nrg = (NRT + RTC - 1) / RTC;
+    const int unit = blockIdx.x * 4 + wv;                 // (point group, row group), row group fastest: neighbours share A rows
+    const int pg = unit / nrg, rg = unit - pg * nrg;
+    const int p0 = pg * 16 * PT;
+    if (p0 >= npts) return;
+    const int rt0 = rg * RTC;
+    const double* xrow[PT];
+#pragma unroll
+    for (int u = 0; u < PT; ++u) xrow[u] = pts + (size_t)min(p0 + 16 * u + pi, npts - 1) * ld;
+    dz_double4 acc[PT][RTC];
+#pragma unroll
+    for (int u = 0; u < PT; ++u)
+#pragma unroll
+        for (int t = 0; t < RTC; ++t) acc[u][t] = dz_double4{0.0, 0.0, 0.0, 0.0};
+    const int ks0 = p.tri ? 4 * rt0 : 0;
+    double a_n[PT], b_n[RTC];
+    {
+        const int c = 4 * ks0 + kq;
+#pragma unroll
+        for (int u = 0; u < PT; ++u) a_n[u] = xrow[u][c] - p.mu[c];
+#pragma unroll
+        for (int t = 0; t < RTC; ++t) b_n[t] = p.Mt[(size_t)c * ld + 16 * min(rt0 + t, NRT - 1) + pi];
+    }
+    for (int ks = ks0; ks < KS; ++ks) {
+        double a[PT], b[RTC];
+#pragma unroll
+        for (int u = 0; u < PT; ++u) a[u] = a_n[u];
+#pragma unroll
+        for (int t = 0; t < RTC; ++t) b[t] = b_n[t];
+        if (ks + 1 < KS) {                                // operands of the next k-step are in flight during this one's MFMAs
+            const int c = 4 * (ks + 1) + kq;
+#pragma unroll
+            for (int u = 0; u < PT; ++u) a_n[u] = xrow[u][c] - p.mu[c];
+#pragma unroll
+            for (int t = 0; t < RTC; ++t) b_n[t] = p.Mt[(size_t)c * ld + 16 * min(rt0 + t, NRT - 1) + pi];
+        }
+#pragma unroll
+        for (int t = 0; t < RTC; ++t) {
+            const int rt = rt0 + t;
+            if (rt < NRT && (!p.tri || ks >= 4 * rt)) {
+#pragma unroll
+                for (int u = 0; u < PT; ++u) acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[t], acc[u][t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PT; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int pt = p0 + 16 * u + kq + 4 * e;
+            const double* xs = pts + (size_t)min(pt, npts - 1) * ld;
+#pragma unroll
+            for (int t = 0; t < RTC; ++t) {
+                const int r = 16 * (rt0 + t) + pi;
+                if (rt0 + t < NRT) {
+                    const double y = acc[u][t][e];
+                    const double qv = bfly16(r < d ? y * (p.tri ? y : xs[r] - p.mu[r]) : 0.0);
+                    if (pi == 0 && pt < npts) qpart[(size_t)pt * NRT + rt0 + t] = qv;
+                }
+            }
+        }
+}
+__global__ void k_q_finish(Params p, const double* __restrict__ qpart, int npts, int nrt, double* prior_out, double* like_out)
+{
+    const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt >= npts) return;
+    double Q = 0.0;
+    for (int t = 0; t < nrt; ++t) Q = Q + qpart[(size_t)pt * nrt + t];
+    like_out[pt] = nan_to_ninf(p.logF - 0.5 * Q);
+    if (!p.have_prior) prior_out[pt] = 0.0;
+}
+
 // prior only (wave per point), used beside the MFMA likelihood kernel when priors are not flat
 template <int NCH>
 __global__ __launch_bounds__(256) void k_prior_only(Params p, const double* __restrict__ pts, int npts, double* prior_out)

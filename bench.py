@@ -160,7 +160,8 @@ def main():
 
     n_local = args.chains_per_gpu
     n_global = n_local * world
-    total = 4 * args.spinup + 2 * args.steps + args.warmup  # spin-up (at most 4x) + warm-up + timed pass + HIP-event pass
+    # spin-up (single GPU: extended by time up to 4x) + warm-up + timed pass + HIP-event pass: sizes the replicated archive
+    total = (4 if world == 1 else 1) * args.spinup + 2 * args.steps + args.warmup
     e = setup_engine(_capi.Engine, args, n_global, n_local, rank * n_local, total, device=local_rank)
     if world > 1:
         ids = [_capi.comm_unique_id() if rank == 0 else None]

@@ -162,11 +162,13 @@ def main():
     n_global = n_local * world
     # spin-up (single GPU: extended by time up to 4x) + warm-up + timed pass + HIP-event pass: sizes the replicated archive
     total = (4 if world == 1 else 1) * args.spinup + 2 * args.steps + args.warmup
-    e = setup_engine(_capi.Engine, args, n_global, n_local, rank * n_local, total, device=local_rank)
+    # (DZ_BENCH_TRANSPORT=host and DZ_BENCH_DEVICE exist so that the multi-rank control flow can be rehearsed on a
+    #  one-GPU box: ranks share the device and exchange through the host; measurements use RCCL, one rank per GPU)
+    device = int(os.environ.get("DZ_BENCH_DEVICE", local_rank))
+    e = setup_engine(_capi.Engine, args, n_global, n_local, rank * n_local, total, device=device)
     if world > 1:
-        ids = [_capi.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        e.comm_init_rccl(rank, world, ids[0])
+        from pydream_amd.distributed import attach_transport
+        attach_transport(e, rank, world, transport=os.environ.get("DZ_BENCH_TRANSPORT", "rccl"))
 
     def barrier():
         e.sync()

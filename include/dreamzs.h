@@ -125,7 +125,10 @@ int dz_get_trace(dz_engine* e, int64_t g0, int64_t ng, double* X, double* logp,
 /* the same samples chain by chain, the shape run_dream returns (core.py:98, :127: one (niterations, d) array per
  * chain): sample g0+i of local chain c goes to X[(c*chain_stride_rows + i)*d ...].  The device keeps the trace in
  * this order, so a whole-buffer request is a single strided copy. */
-int dz_get_trace_chains(dz_engine* e, int64_t g0, int64_t ng, double* X, int64_t chain_stride_rows);
+int dz_get_trace_chains(dz_engine* e, int64_t g0, int64_t ng, double* X, int64_t chain_stride_rows, double* logp /* [nl][chain_stride_rows] or NULL */);
+/* optional: page-lock the destination beforehand (e.g. from a second thread while dz_step runs) */
+int dz_host_register(void* ptr, int64_t bytes);
+int dz_host_unregister(void* ptr);
 int dz_get_history(dz_engine* e, double* Z, int64_t cap_rows, int64_t* rows);       /* Dream_shared_vars.history / count */
 int dz_get_cr_state(dz_engine* e, double* probs, double* delta_m, double* n_updates);     /* cross_probs, delta_m, ncr_updates */
 int dz_get_gamma_state(dz_engine* e, double* probs, double* delta_m, double* n_updates);  /* gamma_level_probs, ... */

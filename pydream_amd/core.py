@@ -125,14 +125,22 @@ def _sample_dream_batched(eng, step, niterations, verbose, nverbose):
         log_ps = [np.empty((niterations, 1)) for _ in range(nchains)]
     done = 0
     naccepts = 0
+    pin = None
+    if by_chain and S.nbytes >= (64 << 20):
+        # fault in and page-lock the result array on a second thread while the GPU runs the first chunk
+        import threading
+        pinned = []
+        pin = threading.Thread(target=lambda: pinned.append(eng.host_register(S)))
+        pin.start()
     while done < niterations:
         n = min(chunk, niterations - done)
         eng.trace_reset()
         eng.step(n)
         if by_chain:
-            eng.get_trace_chains(0, n, S, row0=done)
-            tr = eng.get_trace(0, n, with_X=False)
-            LP[:, done:done + n, 0] = tr["logp"].T
+            if pin is not None and pin.is_alive():
+                pin.join()
+            eng.get_trace_chains(0, n, S, row0=done, logp_out=LP)
+            tr = eng.get_trace(0, n, with_X=False, with_logp=False)
         else:
             tr = eng.get_trace(0, n)
             for c in range(nchains):
@@ -143,6 +151,10 @@ def _sample_dream_batched(eng, step, niterations, verbose, nverbose):
         if verbose:
             print('Iteration: ', done, ' acceptance rate: ', naccepts / float(done * nchains),
                   ' acceptance rate over last %d iterations: ' % n, float(tr["moved"].mean()))
+    if pin is not None:
+        pin.join()
+        if pinned and pinned[0]:
+            eng.host_unregister(S)
     if step.save_history:
         _save_history_to_disc(eng, step)
     return sampled, log_ps

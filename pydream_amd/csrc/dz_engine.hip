@@ -952,12 +952,40 @@ int dz_get_trace(dz_engine* e, int64_t g0, int64_t ng, double* X, double* logp, 
     return 0;
 }
 
-int dz_get_trace_chains(dz_engine* e, int64_t g0, int64_t ng, double* X, int64_t chain_stride_rows)
+int dz_get_trace_chains(dz_engine* e, int64_t g0, int64_t ng, double* X, int64_t chain_stride_rows, double* logp)
 {
     HIPCK(hipSetDevice(e->c.device));
     if (g0 < 0 || ng < 0 || g0 + ng > e->ntrace) return fail("trace range");
-    if (!X || chain_stride_rows < ng) return fail("bad destination");
-    return download_trace_rows(e, X, g0, ng, chain_stride_rows);
+    if (chain_stride_rows < ng) return fail("bad destination");
+    if (X) DZCK(download_trace_rows(e, X, g0, ng, chain_stride_rows));
+    if (logp && ng > 0) {   // log_ps chain by chain: transposed on the device, then one strided copy
+        const size_t nl = e->p.nl, need = nl * (size_t)ng;
+        if (need > e->qpart_len) {
+            DZCK(sync_all(e));
+            if (e->d_qpart) hipFree(e->d_qpart);
+            e->d_qpart = nullptr; e->qpart_len = 0;
+            DZCK(dalloc(&e->d_qpart, need));
+            e->qpart_len = need;
+        }
+        hipLaunchKernelGGL(dz::k_transpose_logp, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, e->stream, (const double*)e->p.tlogp, (int)nl, g0, (int)ng, e->d_qpart);
+        DZCK(launch_check("k_transpose_logp"));
+        HIPCK(hipMemcpy2DAsync(logp, sizeof(double) * (size_t)chain_stride_rows, e->d_qpart, sizeof(double) * (size_t)ng, sizeof(double) * (size_t)ng, nl,
+                               hipMemcpyDeviceToHost, e->stream));
+        HIPCK(hipStreamSynchronize(e->stream));
+    }
+    return 0;
+}
+
+// page-lock a host array ahead of a download (first-touch faults and pinning then overlap the run instead of the copy)
+int dz_host_register(void* ptr, int64_t bytes)
+{
+    if (hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return fail("hipHostRegister failed"); }
+    return 0;
+}
+int dz_host_unregister(void* ptr)
+{
+    if (hipHostUnregister(ptr) != hipSuccess) { (void)hipGetLastError(); return fail("hipHostUnregister failed"); }
+    return 0;
 }
 
 int dz_get_history(dz_engine* e, double* Z, int64_t cap_rows, int64_t* rows)

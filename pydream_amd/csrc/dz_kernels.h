@@ -1097,6 +1097,14 @@ __global__ __launch_bounds__(256) void k_logp_mvn_mfma_tiled(Params p, const dou
             }
         }
 }
+// tlogp [generation][chain] -> [chain][generation] for the chain-by-chain download (dz_get_trace_chains)
+__global__ void k_transpose_logp(const double* __restrict__ src, int nl, int64_t g0, int ng, double* __restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // over dst: c * ng + g
+    if (i >= (int64_t)nl * ng) return;
+    const int64_t c = i / ng, g = i - c * ng;
+    dst[i] = src[(g0 + g) * nl + c];
+}
 __global__ void k_q_finish(Params p, const double* __restrict__ qpart, int npts, int nrt, double* prior_out, double* like_out)
 {
     const int pt = blockIdx.x * blockDim.x + threadIdx.x;

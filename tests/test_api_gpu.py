@@ -150,11 +150,16 @@ def test_trace_by_chain_equals_trace_by_generation():
     e.step(G)
     X = e.get_trace(0, G)["X"]                      # [G, N, d]
     S = np.full((N, G, d), np.nan)
-    e.get_trace_chains(0, G, S)
+    LP = np.full((N, G, 1), np.nan)
+    e.get_trace_chains(0, G, S, logp_out=LP)
     np.testing.assert_array_equal(S, X.transpose(1, 0, 2))
+    np.testing.assert_array_equal(LP[:, :, 0], e.get_trace(0, G, with_X=False)["logp"].T)
     S2 = np.full((N, 50, d), np.nan)
-    e.get_trace_chains(5, 20, S2, row0=7)
+    L2 = np.full((N, 50), np.nan)
+    e.get_trace_chains(5, 20, S2, row0=7, logp_out=L2)
     np.testing.assert_array_equal(S2[:, 7:27], X[5:25].transpose(1, 0, 2))
+    np.testing.assert_array_equal(L2[:, 7:27], e.get_trace(5, 20, with_X=False)["logp"].T)
+    assert np.isnan(L2[:, :7]).all() and np.isnan(L2[:, 27:]).all()
     assert np.isnan(S2[:, :7]).all() and np.isnan(S2[:, 27:]).all()
     e.close()
 

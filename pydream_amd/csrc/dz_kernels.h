@@ -565,11 +565,7 @@ DZ_DEV void point_prior(const Params& p, const double* row, int lane, double* pr
 template <int NCH, bool AL16, bool GENERIC = true, bool LEAN = false>
 DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int c, uint32_t gc, int i0, int i1, int n, int lane,
                         const double (&xb)[NCH][2], const double (&gt)[NCH][2], bool snk, int cr_idx, int delta, int glev, const DrawSrc& dsrc,
-                        double* out, int out_stride, double* sl, double* csn, double* prior_out
-#ifdef DZ_EXP_PF
-                        , __attribute__((address_space(3))) void* pf_sink = nullptr
-#endif
-                        )
+                        double* out, int out_stride, double* sl, double* csn, double* prior_out)
 {
     // software pipeline over the tries: the Z rows of try i+1 are requested before try i's arithmetic starts,
     // and no scalar memory wait sits in between because the draws are already in registers
@@ -599,22 +595,6 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
         };
 #pragma unroll
         for (int it = 0; it < NCH; ++it) { ra[it] = double2{0.0, 0.0}; rb[it] = double2{0.0, 0.0}; }
-#ifdef DZ_EXP_PF
-        if (pf_sink) {   // warm L2 with the rows of the later tries: LDS-DMA loads into a sink nobody reads (no VGPR, no wait)
-            for (int i = i0 + 1; i < i1; ++i) {
-                const u32x4 w = uniform_draw(p, dsrc, pt_slot(p, phase, i, 1), gc, g);
-                const uint32_t r0 = mulhi_idx(w.x, M);
-                uint32_t r1 = mulhi_idx(w.y, M - 1u);
-                if (r1 >= r0) r1++;
-#pragma unroll
-                for (int it = 0; it < NCH; ++it) {
-                    const int jc = min(128 * it + 2 * lane, p.ld - 2);
-                    __builtin_amdgcn_global_load_lds(p.Z + (size_t)r0 * p.ld + jc, pf_sink, 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds(p.Z + (size_t)r1 * p.ld + jc, pf_sink, 16, 0, 0);
-                }
-            }
-        }
-#endif
         request(i0);
         for (int i = i0; i < i1; ++i) {
             RowTerms<NCH> rt;
@@ -726,13 +706,7 @@ __global__ __launch_bounds__(1024) void k_propose(Params p, int phase, uint32_t 
     const bool snk = ct.snk != 0;
     double* csn = (phase == 0 && p.k == 1) ? p.cur_snk + c : nullptr;
     DZ_STAMP(p, phase, c, 1);
-#ifdef DZ_EXP_PF
-    __shared__ __attribute__((aligned(16))) double pf_area[128];
-    propose_set<NCH, true>(p, phase, g, M, c, gc, i0, i1, n, lane, xb, gt, snk, ct.cr_idx, ct.delta, ct.glev, dsrc, out, p.ld, sl, csn, nullptr,
-                           (__attribute__((address_space(3))) void*)pf_area);
-#else
     propose_set<NCH, true>(p, phase, g, M, c, gc, i0, i1, n, lane, xb, gt, snk, ct.cr_idx, ct.delta, ct.glev, dsrc, out, p.ld, sl, csn, nullptr);
-#endif
     DZ_STAMP(p, phase, c, 15);
 }
 

@@ -79,7 +79,8 @@ struct dz_engine {
     int nlanes = 1; hipStream_t lane_stream[8] = {nullptr}; hipEvent_t lane_ev[8] = {nullptr}; bool need_join = true;
     // bounded host run-ahead: a marker every ra_stride generations, the host never gets more than 3 markers ahead
     dz::Params p_shadow; bool params_uploaded = false;    // what d_params holds
-    double* d_qpart = nullptr; size_t qpart_len = 0; bool force_big = false;    // row-tile sums of the tiled large-d likelihood; DZ_LOGP_BIG=1: the one-wave-per-tile kernel
+    void* h_pin = nullptr;          // page-locked bounce buffer for downloads into pageable memory (d2h_2d)
+    double* d_qpart = nullptr; size_t qpart_len = 0; bool force_big = false; bool logp_gemm = true;    // DZ_LOGP_GEMM=0: no LDS-tiled product; row-tile sums of the tiled large-d likelihood; DZ_LOGP_BIG=1: the one-wave-per-tile kernel
     int logp_waves = 0;      // DZ_LOGP_WAVES: force the block size of k_logp_mvn_lds (tuning)
     int ra_stride = 32; hipEvent_t ra_ev[4] = {nullptr}; bool ra_used[4] = {false, false, false, false}; int64_t ra_n = 0;
     int nch = 1;
@@ -162,6 +163,25 @@ int sync_all(dz_engine* e)
     return 0;
 }
 
+// Device -> pageable host, 2-D: through a page-locked bounce buffer owned by the engine (stream-ordered copy, wait, then
+// plain memcpy).  Asynchronous and blocking 2-D copies straight into pageable memory both misbehaved on this stack
+// (a rare late landing after the stream wait; zeros from the blocking form once several engines had lived in the process).
+int d2h_2d(dz_engine* e, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height)
+{
+    if (!width || !height) return 0;
+    constexpr size_t CAP = (size_t)32 << 20;
+    if (!e->h_pin) { if (hipHostMalloc(&e->h_pin, CAP, hipHostMallocDefault) != hipSuccess) { e->h_pin = nullptr; return fail("hipHostMalloc (bounce buffer) failed"); } }
+    if (width > CAP) return fail("row too long for the bounce buffer");
+    const size_t rows_per = std::max<size_t>(1, CAP / width);
+    for (size_t r0 = 0; r0 < height; r0 += rows_per) {
+        const size_t nr = std::min(rows_per, height - r0);
+        HIPCK(hipMemcpy2DAsync(e->h_pin, width, (const char*)src + r0 * spitch, spitch, width, nr, hipMemcpyDeviceToHost, e->stream));
+        HIPCK(hipStreamSynchronize(e->stream));
+        for (size_t r = 0; r < nr; ++r) memcpy((char*)dst + (r0 + r) * dpitch, (const char*)e->h_pin + r * width, width);
+    }
+    return 0;
+}
+
 template <class T> int ealloc(dz_engine* e, T** p, size_t n)
 {
     DZCK(dalloc(p, n));
@@ -180,10 +200,8 @@ int upload_padded(dz_engine* e, double* dst, const double* src, int rows, double
 }
 int download_rows(dz_engine* e, double* dst, const double* src, size_t rows)
 {   // src [rows,ld] device -> dst [rows,d] host
-    HIPCK(hipMemcpy2DAsync(dst, sizeof(double) * e->p.d, src, sizeof(double) * e->p.ld, sizeof(double) * e->p.d, rows,
-                           hipMemcpyDeviceToHost, e->stream));
     DZCK(sync_all(e));
-    return 0;
+    return d2h_2d(e, dst, sizeof(double) * e->p.d, src, sizeof(double) * e->p.ld, sizeof(double) * e->p.d, rows);
 }
 
 #define NCH_DISPATCH(e, CALL)                      \
@@ -257,12 +275,17 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
                 if (need > e->qpart_len) {
                     DZCK(sync_all(e));
                     if (e->d_qpart) hipFree(e->d_qpart);
+    if (e->h_pin) hipHostFree(e->h_pin);
                     e->d_qpart = nullptr; e->qpart_len = 0;
                     DZCK(dalloc(&e->d_qpart, need));
                     e->qpart_len = need;
                 }
                 if (e->force_big) hipLaunchKernelGGL(dz::k_logp_mvn_mfma_big<8>, dim3((n + 63) / 64), block, 0, st, e->p, pts, n, prior, like);
                 else {
+                    if (e->logp_gemm && n >= 512) {            // enough points to fill the chip with 64 x 64 block tiles
+                        const int nbm = (n + 63) / 64, nbn = (nrtb * 16 + 63) / 64;
+                        hipLaunchKernelGGL(dz::k_logp_mvn_gemm, dim3(nbm * nbn), block, 0, st, e->p, pts, n, e->d_qpart);
+                    } else
                     hipLaunchKernelGGL((dz::k_logp_mvn_mfma_tiled<PT, RTC>), dim3((npg * nrg + 3) / 4), block, 0, st, e->p, pts, n, e->d_qpart);
                     hipLaunchKernelGGL(dz::k_q_finish, dim3((n + 255) / 256), dim3(256), 0, st, e->p, (const double*)e->d_qpart, n, nrtb, prior, like);
                 }
@@ -564,6 +587,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
         for (int s = 0; s < e->nlanes; ++s) HIPCK(hipEventCreateWithFlags(&e->lane_ev[s], hipEventDisableTiming));
         if (const char* ra = getenv("DZ_RUNAHEAD")) e->ra_stride = std::max(0, atoi(ra));
         if (const char* fb = getenv("DZ_LOGP_BIG")) e->force_big = atoi(fb) != 0;
+        if (const char* fg = getenv("DZ_LOGP_GEMM")) e->logp_gemm = atoi(fg) != 0;
         if (const char* lw = getenv("DZ_LOGP_WAVES")) e->logp_waves = std::max(4, std::min(8, atoi(lw)));
         for (int s = 0; s < 4; ++s) HIPCK(hipEventCreateWithFlags(&e->ra_ev[s], hipEventDisableTiming));
     }
@@ -918,13 +942,17 @@ static int download_trace_rows(dz_engine* e, double* X, int64_t g0, int64_t ng, 
     const bool pinned = span >= ((size_t)64 << 20) && hipHostRegister(X, span, hipHostRegisterDefault) == hipSuccess;
     if (!pinned) (void)hipGetLastError();
     int rc = 0;
+    auto copy2d = [&](double* dst, size_t dpitch, const double* src, size_t spitch, size_t width, size_t height) {
+        if (pinned) return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, e->stream);
+        return d2h_2d(e, dst, dpitch, src, spitch, width, height) ? hipErrorUnknown : hipSuccess;
+    };
     if ((size_t)ng == tcap && (size_t)chain_stride_rows == (size_t)ng) {
         // whole buffer: the chains' blocks are back to back on both sides -- one strided copy
-        if (hipMemcpy2DAsync(X, sizeof(double) * d, e->p.tX, sizeof(double) * ld, sizeof(double) * d, nl * (size_t)ng, hipMemcpyDeviceToHost, e->stream) != hipSuccess) rc = -1;
+        if (copy2d(X, sizeof(double) * d, e->p.tX, sizeof(double) * ld, sizeof(double) * d, nl * (size_t)ng) != hipSuccess) rc = -1;
     } else {
         for (size_t c = 0; c < nl && !rc; ++c)
-            if (hipMemcpy2DAsync(X + c * (size_t)chain_stride_rows * d, sizeof(double) * d, e->p.tX + (c * tcap + (size_t)g0) * ld, sizeof(double) * ld,
-                                 sizeof(double) * d, (size_t)ng, hipMemcpyDeviceToHost, e->stream) != hipSuccess) rc = -1;
+            if (copy2d(X + c * (size_t)chain_stride_rows * d, sizeof(double) * d, e->p.tX + (c * tcap + (size_t)g0) * ld, sizeof(double) * ld,
+                       sizeof(double) * d, (size_t)ng) != hipSuccess) rc = -1;
     }
     if (hipStreamSynchronize(e->stream) != hipSuccess) rc = -1;
     if (pinned) hipHostUnregister(X);
@@ -940,8 +968,7 @@ int dz_get_trace(dz_engine* e, int64_t g0, int64_t ng, double* X, double* logp, 
         const size_t d = e->p.d, ld = e->p.ld, tcap = (size_t)e->p.tcap;
         DZCK(sync_all(e));
         for (size_t c = 0; c < nl; ++c)
-            HIPCK(hipMemcpy2DAsync(X + c * d, sizeof(double) * nl * d, e->p.tX + (c * tcap + (size_t)g0) * ld, sizeof(double) * ld,
-                                   sizeof(double) * d, (size_t)ng, hipMemcpyDeviceToHost, e->stream));
+            DZCK(d2h_2d(e, X + c * d, sizeof(double) * nl * d, e->p.tX + (c * tcap + (size_t)g0) * ld, sizeof(double) * ld, sizeof(double) * d, (size_t)ng));
     }
     DZCK(sync_all(e));
     if (logp) HIPCK(hipMemcpy(logp, e->p.tlogp + o, sizeof(double) * n, hipMemcpyDeviceToHost));
@@ -969,9 +996,7 @@ int dz_get_trace_chains(dz_engine* e, int64_t g0, int64_t ng, double* X, int64_t
         }
         hipLaunchKernelGGL(dz::k_transpose_logp, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, e->stream, (const double*)e->p.tlogp, (int)nl, g0, (int)ng, e->d_qpart);
         DZCK(launch_check("k_transpose_logp"));
-        HIPCK(hipMemcpy2DAsync(logp, sizeof(double) * (size_t)chain_stride_rows, e->d_qpart, sizeof(double) * (size_t)ng, sizeof(double) * (size_t)ng, nl,
-                               hipMemcpyDeviceToHost, e->stream));
-        HIPCK(hipStreamSynchronize(e->stream));
+        DZCK(d2h_2d(e, logp, sizeof(double) * (size_t)chain_stride_rows, e->d_qpart, sizeof(double) * (size_t)ng, sizeof(double) * (size_t)ng, nl));
     }
     return 0;
 }

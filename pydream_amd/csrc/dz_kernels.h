@@ -1071,6 +1071,97 @@ __global__ __launch_bounds__(256) void k_logp_mvn_mfma_tiled(Params p, const dou
             }
         }
 }
+// Large d, many points: the quadratic form as an LDS-tiled product.  A block of 4 waves owns 64 points x 64 rows; it
+// walks k in chunks of 16, staging the point chunk (transposed to [k][point], mean subtracted) and the matrix chunk
+// ([k][row], as stored) in LDS, double buffered; wave (wm, wn) owns 2 point tiles x 2 row tiles = four accumulators, each
+// summed over k in ascending order by one MFMA chain -- the contract's order.  Row-tile sums go to the scratch array
+// of k_q_finish.  Triangular factor: a block starts at k = 64*bn and a row tile joins at k = 16*rt.
+__global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* __restrict__ pts, int npts, double* __restrict__ qpart)
+{
+    constexpr int BM = 64, BN = 64, BK = 16, LDA = BM + 2, LDB = BN;
+    __shared__ __attribute__((aligned(16))) double As[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) double Bs[2][BK * LDB];
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
+    const int pi = l & 15, kq = l >> 4;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int ld = p.ld, d = p.d;
+    const int KS = (d + 3) >> 2, NRT = (d + 15) >> 4;
+    const int nbn = (NRT * 16 + BN - 1) / BN;
+    const int bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn;
+    const int p0 = bm * BM;
+    const int kc0 = p.tri ? (BN * bn) / BK : 0, nkc = (4 * KS + BK - 1) / BK;       // chunks of 16 k
+    // loader roles: A: thread -> (point = tid / 4, four k's = 4*(tid%4)..+3); B: thread -> (k row = tid / 16, four rows = 4*(tid%16)..+3)
+    const int a_pt = tid >> 2, a_k = 4 * (tid & 3);
+    const int b_k = tid >> 4, b_r = 4 * (tid & 15);
+    const double* arow = pts + (size_t)min(p0 + a_pt, npts - 1) * ld;
+    double ra[4], rb[4];
+    // rows of pts, mu and Mt are zero padded to ld (a multiple of 16 >= 4*KS), so whole 32-byte groups can be read
+    auto gload = [&](int kc) {
+        const int k = kc * BK + a_k;
+        if (k < ld) {
+            const double2 x0 = *reinterpret_cast<const double2*>(arow + k), x1 = *reinterpret_cast<const double2*>(arow + k + 2);
+            const double2 m0 = *reinterpret_cast<const double2*>(p.mu + k), m1 = *reinterpret_cast<const double2*>(p.mu + k + 2);
+            ra[0] = x0.x - m0.x; ra[1] = x0.y - m0.y; ra[2] = x1.x - m1.x; ra[3] = x1.y - m1.y;
+        } else { ra[0] = 0.0; ra[1] = 0.0; ra[2] = 0.0; ra[3] = 0.0; }
+        const int kb = kc * BK + b_k, r = BN * bn + b_r;
+        if (kb < ld && r < ld) {
+            const double2 b0 = *reinterpret_cast<const double2*>(p.Mt + (size_t)kb * ld + r), b1 = *reinterpret_cast<const double2*>(p.Mt + (size_t)kb * ld + r + 2);
+            rb[0] = b0.x; rb[1] = b0.y; rb[2] = b1.x; rb[3] = b1.y;
+        } else { rb[0] = 0.0; rb[1] = 0.0; rb[2] = 0.0; rb[3] = 0.0; }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) As[buf][(a_k + j) * LDA + a_pt] = ra[j];
+        *reinterpret_cast<double2*>(&Bs[buf][b_k * LDB + b_r]) = double2{rb[0], rb[1]};
+        *reinterpret_cast<double2*>(&Bs[buf][b_k * LDB + b_r + 2]) = double2{rb[2], rb[3]};
+    };
+    dz_double4 acc[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[u][t] = dz_double4{0.0, 0.0, 0.0, 0.0};
+    const int rt0 = (BN / 16) * bn + 2 * wn;                       // this wave's first row tile
+    gload(kc0); lstore(0);
+    __syncthreads();
+    for (int kc = kc0; kc < nkc; ++kc) {
+        const int buf = (kc - kc0) & 1;
+        if (kc + 1 < nkc) gload(kc + 1);                           // next chunk in flight during this chunk's MFMAs
+#pragma unroll
+        for (int q = 0; q < BK / 4; ++q) {
+            const int ks = kc * (BK / 4) + q;
+            double a[2], b[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) a[u] = As[buf][(4 * q + kq) * LDA + 32 * wm + 16 * u + pi];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) b[t] = Bs[buf][(4 * q + kq) * LDB + 32 * wn + 16 * t + pi];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                if (ks < KS && rt0 + t < NRT && (!p.tri || ks >= 4 * (rt0 + t))) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[t], acc[u][t], 0, 0, 0);
+                }
+        }
+        if (kc + 1 < nkc) lstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int pt = p0 + 32 * wm + 16 * u + kq + 4 * e;
+            const double* xs = pts + (size_t)min(pt, npts - 1) * ld;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int r = 16 * (rt0 + t) + pi;
+                if (rt0 + t < NRT) {
+                    const double y = acc[u][t][e];
+                    const double qv = bfly16(r < d ? y * (p.tri ? y : xs[r] - p.mu[r]) : 0.0);
+                    if (pi == 0 && pt < npts) qpart[(size_t)pt * NRT + rt0 + t] = qv;
+                }
+            }
+        }
+}
+
 // tlogp [generation][chain] -> [chain][generation] for the chain-by-chain download (dz_get_trace_chains)
 __global__ void k_transpose_logp(const double* __restrict__ src, int nl, int64_t g0, int ng, double* __restrict__ dst)
 {

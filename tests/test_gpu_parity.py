@@ -257,3 +257,22 @@ def test_parallel_tempering_reference_and_oracle(G, O):
     for a, b in zip(out[0][3], out[1][3]):
         np.testing.assert_array_equal(a, b)
     assert out[0][1][:, 2].sum() > 0                    # some swaps were accepted
+
+
+@pytest.mark.parametrize("N,d,tri,gemm", [(160, 333, 1, 1), (200, 200, 0, 1), (160, 333, 1, 0), (128, 1000, 1, 1)])
+def test_large_d_likelihood_kernels_against_oracle(G, O, N, d, tri, gemm, monkeypatch):
+    """ld > 128: the LDS-tiled product (k_logp_mvn_gemm, >= 512 points per launch) and the register-operand tiled
+    kernel (DZ_LOGP_GEMM=0) against the oracle -- dimensions that are not multiples of 16 or 64, non-zero mean, dense and
+    triangular matrix; everything bit-exact (the row-tile sums are added in the same order whatever kernel made them)."""
+    monkeypatch.setenv("DZ_LOGP_GEMM", str(gemm))
+    n, seed = 3, 9
+    P = H.mvn_precision(d)
+    M = np.linalg.cholesky((P + P.T) / 2).T if tri else P
+    Z0 = H.seed_history(max(10 * d, 2 * N), d, seed)
+    out = []
+    for Cls in (G.Engine, O.Engine):
+        e = Cls(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * 3, trace_capacity=n, seed=seed)
+        e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.linspace(-1, 1, d), M, tri, 0.0)
+        e.step(n)
+        out.append(e.get_trace(0, n))
+    assert_traces_identical(out[0], out[1])

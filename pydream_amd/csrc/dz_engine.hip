@@ -466,9 +466,17 @@ size_t mega_lds_bytes(const dz_engine* e, bool xlds)
     return sizeof(double) * (size_t)dz::mega_layout(e->p.d, e->p.k, e->p.ld / 16, e->p.ncr, e->p.ngamma, e->p.tri != 0, xlds, mega_chains(e)).total;
 }
 bool mega_xlds(const dz_engine* e) { return mega_lds_bytes(e, true) <= (size_t)160 * 1024; }
+// the barrier-free variant for the mixture likelihood (k_generations_mix)
+bool mega_mix_eligible(const dz_engine* e)
+{
+    const dz::Params& p = e->p;
+    return e->mega && !p.Tc && e->lk == LK_MIX && !p.hard && !p.have_prior && p.ld <= 128 && p.k >= 3 && p.k <= dz::MAXK && p.depairs == 1 &&
+           p.nslots <= 64 && p.J <= 32;
+}
 bool mega_eligible(const dz_engine* e)
 {
     const dz::Params& p = e->p;
+    if (mega_mix_eligible(e)) return true;
     return e->mega && !p.Tc && e->lk == LK_MVN && !p.hard && !p.have_prior && p.ld <= 128 && p.k >= 3 && p.k <= dz::MAXK && p.depairs == 1 &&
            p.nslots <= 64 && (!p.tri || p.Mtp) && mega_lds_bytes(e, false) <= (size_t)160 * 1024;
 }
@@ -491,6 +499,24 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
     if (append_last && e->M + p.N > e->c.history_capacity) return fail("history capacity exceeded");
     DZCK(join_all(e));
     const int64_t slot0 = e->c.trace_capacity ? e->ntrace : -1;
+    if (e->lk == LK_MIX) {
+        if (!e->params_uploaded || memcmp(&e->p_shadow, &p, sizeof(dz::Params)) != 0) {
+            HIPCK(hipMemcpyAsync(e->d_params, &p, sizeof(dz::Params), hipMemcpyHostToDevice, e->stream));
+            memcpy(&e->p_shadow, &p, sizeof(dz::Params));
+            e->params_uploaded = true;
+        }
+        const dim3 gridm((p.nl + dz::MIXW - 1) / dz::MIXW), blockm(64 * dz::MIXW);
+        const size_t ldsm = sizeof(double) * (size_t)dz::MIXW * dz::mega_mix_wave_doubles(p.d, p.k, p.J);
+        DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, dz::k_generations_mix, gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0);
+        DZCK(launch_check("k_generations_mix"));
+        if (append_last) { DZCK(allgather_rows(e, p.Z + (size_t)e->M * p.ld)); e->M += p.N; }
+        e->need_join = true;
+        e->draws_gen = -1;
+        e->gen = (int64_t)g + n;
+        for (auto& gcv : e->gen_c) gcv = e->gen;
+        if (slot0 >= 0) e->ntrace += n;
+        return 0;
+    }
     const int nrt = p.ld / 16;
     const int ch = mega_chains(e);
     const dim3 grid((p.nl + ch - 1) / ch), block(64 * ch);

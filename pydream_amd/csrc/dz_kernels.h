@@ -1198,6 +1198,31 @@ __global__ __launch_bounds__(256) void k_prior_only(Params p, const double* __re
     if (lane == 0) prior_out[pt] = nan_to_ninf(prior);
 }
 
+// log-likelihood of one point under the Gaussian mixture (identity covariances, mixturemodel.py:37-48); the point sits in
+// the wave's registers, lh is scratch for the J component terms (any memory the wave owns)
+template <int NCH>
+DZ_DEV double mix_like_wave(const Params& p, const double (&x)[NCH][2], int lane, double* __restrict__ lh)
+{
+    double mx = -__builtin_huge_val();
+    for (int j = 0; j < p.J; ++j) {
+        double acc = 0.0;
+#pragma unroll
+        for (int it = 0; it < NCH; ++it)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int jd = 128 * it + 2 * lane + s;
+                if (jd < p.d) { const double t = x[it][s] - p.mu[(size_t)j * p.ld + jd]; acc = fma(t, t, acc); }
+            }
+        const double S = wave_bfly(acc);
+        const double v = -0.5 * S + p.mixF[j];
+        if (lane == 0) lh[j] = v;
+        if (v > mx) mx = v;
+    }
+    double dens = 0.0;
+    for (int j = 0; j < p.J; ++j) dens = dens + dexp(lh[j] - mx);
+    return nan_to_ninf(dlog(dens) + mx);
+}
+
 // Gaussian mixture, identity covariances (examples/mixturemodel/mixturemodel.py:37-48)
 template <int NCH>
 __global__ __launch_bounds__(256) void k_logp_mix(Params p, const double* __restrict__ pts, int npts, double* prior_out, double* like_out)

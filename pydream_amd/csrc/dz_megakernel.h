@@ -302,4 +302,149 @@ __global__ __launch_bounds__(64 * CH) void k_generations(const Params* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same persistent scheme for a likelihood a single wave evaluates on its own (Gaussian mixture): nothing is shared
+// between the chains of a block, so there are no tiles and no barriers at all -- every wave carries its chain through the
+// generations of the launch independently (its k points in an LDS region it alone touches, its state in registers).
+// Eligibility as for k_generations (flat priors, no bounds, DEpairs = 1, ld <= 128, outside the crossover burn-in).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int MIXW = 4;       // waves (= chains) per block
+
+__host__ __device__ inline int mega_mix_wave_doubles(int d, int k, int J) { return k * (4 * ((d + 3) / 4) + 1) + 5 * k + k * J + 8 + (k & 1); }
+
+__global__ __launch_bounds__(64 * MIXW) void k_generations_mix(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int append_last)
+{
+    const Params& p = *pp;
+    constexpr int NCH = 1;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int d = p.d, k = p.k, ld = p.ld;
+    const int LDP = 4 * ((d + 3) / 4) + 1;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* region = smem + (size_t)wv * mega_mix_wave_doubles(d, k, p.J);     // [k][LDP] the chain's points
+    double* sP = region + (size_t)k * LDP; double* sS = sP + k; double* sL = sS + k; double* rS = sL + k; double* rL = rS + k;
+    double* lh = rL + k;                                                    // [k][J] mixture component terms; then [8] decisions
+    double* dec = lh + (size_t)k * p.J;
+    const int cg = blockIdx.x * MIXW + wv;
+    const bool active = cg < p.nl;
+    const int c = min(cg, p.nl - 1);
+    const uint32_t gc = (uint32_t)(p.off + c);
+    double xs[NCH][2];                                                      // the chain's state lives in registers
+    load_row<NCH>(p.X + (size_t)c * ld, ld, lane, xs);
+    double lpri = p.lprior[c], llik = p.llike[c];
+    for (int gi = 0; gi < ngen; ++gi) {
+        const uint32_t g = g0 + (uint32_t)gi;
+        const bool last = gi == ngen - 1;
+        int sel = 0; bool fin = true;
+        for (int phase = 0; phase < 2; ++phase) {
+            DrawSrc ds; ds.have = true; ds.mine = make_uint4(0, 0, 0, 0);
+            if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g); ds.mine = make_uint4(w.x, w.y, w.z, w.w); }
+            StepFlags f;
+            double base[NCH][2];
+            if (phase == 0) {
+                Ctrl u;
+                const u32x4 w0 = uniform_draw(p, ds, 0, gc, g), w1 = uniform_draw(p, ds, 1, gc, g), w2 = uniform_draw(p, ds, 2, gc, g);
+                u.u_snk = u53(w0.x, w0.y); u.u_cr = u53(w0.z, w0.w); u.u_de = u53(w1.x, w1.y); u.u_glev = u53(w1.z, w1.w);
+                u.u_sel = u53(w2.x, w2.y); u.u_acc = u53(w2.z, w2.w);
+                f = step_flags(p, u);                                               // Dream.py:246-256
+                if (lane == 0) { dec[0] = u.u_sel; dec[1] = u.u_acc; dec[2] = f.snk ? 1.0 : 0.0; dec[3] = (double)f.cr_idx; dec[4] = (double)f.glev; }
+                base[0][0] = xs[0][0]; base[0][1] = xs[0][1];
+            } else {
+                f.snk = dec[2] != 0.0; f.cr_idx = (int)dec[3]; f.delta = 1; f.glev = (int)dec[4];
+                double lp = -__builtin_huge_val();
+                if (lane < k) lp = sP[lane] + p.T * sL[lane];                       // :279, mt_choose_proposal_pt :291
+                sel = mt_select_vals(k, lp, dec[0], lane, &fin);
+                const double* row = region + (size_t)sel * LDP;
+                base[0][0] = 2 * lane < d ? row[2 * lane] : 0.0; base[0][1] = 2 * lane + 1 < d ? row[2 * lane + 1] : 0.0;
+                if (2 * lane < d) region[2 * lane] = base[0][0];                    // the selected proposal now sits in row 0
+                if (2 * lane + 1 < d) region[2 * lane + 1] = base[0][1];
+            }
+            double gt[NCH][2];
+            load_gamma_row<NCH>(p, f.glev, 1, lane, gt);
+            const int n = k - phase;
+            double* rows = region + (size_t)phase * LDP;
+            propose_set<NCH, false, false, true>(p, phase, g, M, c, gc, 0, n, n, lane, base, gt, f.snk, f.cr_idx, 1, f.glev, ds,
+                                                 rows, LDP, (phase ? rS : sS), nullptr, (phase ? lh : sP));   // (flat priors: in phase 1 the prior slot is scratch)
+            // mt_evaluate_logps :278, :302 -- by this wave, for its own points.  The squared distances to the J means need the
+            // whole wave (one butterfly each); the log-sum-exp of a point is scalar work, so lane i does it for point i and
+            // the n points cost one pass of exp / log instead of n (same operations per point as k_logp_mix).
+            // (points in groups of GP: GP independent reductions in flight per component, and each mean is read once per group)
+            constexpr int GP = 4;
+            for (int i0 = 0; i0 < n; i0 += GP) {
+                double x0[GP], x1[GP];
+#pragma unroll
+                for (int u = 0; u < GP; ++u) {
+                    const double* row = rows + (size_t)min(i0 + u, n - 1) * LDP;
+                    x0[u] = 2 * lane < d ? row[2 * lane] : 0.0; x1[u] = 2 * lane + 1 < d ? row[2 * lane + 1] : 0.0;
+                }
+                for (int j = 0; j < p.J; ++j) {
+                    const double* mj = p.mu + (size_t)j * p.ld;
+                    const double m0 = 2 * lane < d ? mj[2 * lane] : 0.0, m1 = 2 * lane + 1 < d ? mj[2 * lane + 1] : 0.0;
+                    double S[GP];
+#pragma unroll
+                    for (int u = 0; u < GP; ++u) {
+                        double acc = 0.0;
+                        if (2 * lane < d) { const double t = x0[u] - m0; acc = fma(t, t, acc); }
+                        if (2 * lane + 1 < d) { const double t = x1[u] - m1; acc = fma(t, t, acc); }
+                        S[u] = acc;
+                    }
+#pragma unroll
+                    for (int u = 0; u < GP; ++u) S[u] = wave_bfly(S[u]);
+#pragma unroll
+                    for (int u = 0; u < GP; ++u) if (lane == 0 && i0 + u < n) lh[(i0 + u) * p.J + j] = -0.5 * S[u] + p.mixF[j];
+                }
+            }
+            {
+                const int i = lane < n ? lane : 0;
+                double mx = -__builtin_huge_val();
+                for (int j = 0; j < p.J; ++j) { const double v = lh[i * p.J + j]; if (v > mx) mx = v; }
+                double dens = 0.0;
+                for (int j = 0; j < p.J; ++j) dens = dens + dexp(lh[i * p.J + j] - mx);
+                const double lk = nan_to_ninf(dlog(dens) + mx);
+                if (lane < n) (phase ? rL : sL)[lane] = lk;
+            }
+        }
+        // ---- Metropolis step (:305-347), trace (core.py:114-116), record_history (:919-938)
+        {
+            const double u_acc = dec[1];
+            const bool snk = dec[2] != 0.0;
+            const int cr_idx = (int)dec[3];
+            double val = -__builtin_huge_val();
+            if (lane < k) {
+                val = sP[lane] + p.T * sL[lane];                                    // :279
+                if (snk) val = val + sS[lane];                                      // :307
+            } else if (lane >= 16 && lane < 16 + k) {
+                const int i = lane - 16;
+                val = i < k - 1 ? p.T * rL[i] + 0.0 : p.T * llik + lpri;            // :303, :877-879 (flat priors)
+                if (snk) { const double sr = i < k - 1 ? rS[i] : 0.0; val = (val + sr) + sS[i]; }   // :312-313
+            }
+            double ratio = mt_log_ratio(k, val);
+            if (!fin) ratio = -__builtin_huge_val();                                // DESIGN.md deviation D1
+            const bool accept = is_finite(ratio) && (dlog(u_acc) < ratio);          // :993
+            const int jj = 2 * lane;
+            const double2 xo = {xs[0][0], xs[0][1]};
+            double2 xn = xo;
+            if (accept) { xn.x = jj < d ? region[jj] : 0.0; xn.y = jj + 1 < d ? region[jj + 1] : 0.0; }
+            const bool moved = __any((xn.x != xo.x) || (xn.y != xo.y));             // core.py:120
+            const double npri = accept ? sP[sel] : lpri, nlik = accept ? sL[sel] : llik;    // :345-347
+            xs[0][0] = xn.x; xs[0][1] = xn.y;
+            if (active) {
+                if (jj < ld) {
+                    if (last) *reinterpret_cast<double2*>(p.X + (size_t)c * ld + jj) = xn;
+                    if (trace_slot0 >= 0) *reinterpret_cast<double2*>(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj) = xn;
+                    if (last && append_last) *reinterpret_cast<double2*>(p.Z + ((size_t)M + gc) * ld + jj) = xn;      // record_history :933-936
+                }
+                if (lane == 0) {
+                    if (trace_slot0 >= 0) {
+                        const size_t o = (size_t)(trace_slot0 + gi) * p.nl + c;
+                        p.tlogp[o] = nlik + npri;                                   // core.py:115
+                        p.tmoved[o] = moved ? 1 : 0; p.ttry[o] = sel; p.tcr[o] = cr_idx; p.tsnk[o] = snk ? 1 : 0;
+                    }
+                    if (last) { p.lprior[c] = npri; p.llike[c] = nlik; }
+                }
+            }
+            lpri = npri; llik = nlik;
+        }
+    }
+}
+
 }  // namespace dz

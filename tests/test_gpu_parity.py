@@ -276,3 +276,35 @@ def test_large_d_likelihood_kernels_against_oracle(G, O, N, d, tri, gemm, monkey
         e.step(n)
         out.append(e.get_trace(0, n))
     assert_traces_identical(out[0], out[1])
+
+
+@pytest.mark.parametrize("N,d,J,burnin", [(512, 100, 3, 0), (70, 20, 2, 0), (256, 100, 3, 15)])
+def test_persistent_mixture_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, J, burnin, monkeypatch):
+    """k_generations_mix (mixture likelihood: every wave carries its chain on its own, no barriers) against the
+    multi-kernel path and the oracle, bit for bit: across history appends, a ragged last block, and with a crossover
+    burn-in in front (configs[2] shape)."""
+    n, seed = 36, 41
+    mu = np.array([np.full(d, m) for m in np.linspace(-5.0, 5.0, J)])
+    logF = np.log(np.arange(1, J + 1) / np.arange(1, J + 1).sum()) - (d / 2.) * np.log(2 * np.pi)
+    Z0 = H.seed_history(max(10 * d, 2 * N), d, seed, lo=-8, hi=8)
+
+    def run(Cls, mega):
+        monkeypatch.setenv("DZ_MEGA", "1" if mega else "0")
+        e = Cls(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
+                adapt_crossover=1 if burnin else 0, crossover_burnin=burnin)
+        e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mixture(mu, logF)
+        launches = None
+        if Cls is G.Engine:
+            e.profile_enable(True); e.profile_reset()
+        e.step(n)
+        if Cls is G.Engine:
+            launches = e.profile_get("generations")[1]
+            e.profile_enable(False)
+        return e.get_trace(0, n), e.get_history(), e.get_cr_state()[0], launches
+
+    a, b, o = run(G.Engine, True), run(G.Engine, False), run(O.Engine, False)
+    assert a[3] > 0 and b[3] == 0
+    for other in (b, o):
+        assert_traces_identical(a[0], other[0])
+        np.testing.assert_array_equal(a[1], other[1])
+        np.testing.assert_array_equal(a[2], other[2])

@@ -194,10 +194,32 @@ DZ_DEV double bfly16(double v)
     v = v + row_ror<1>(v);
     return v;
 }
+// x[i] + x[i ^ 32] and x[i] + x[i ^ 16] with gfx950's lane-swap instructions (VALU, no LDS crossbar round trip):
+// v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second; with both operands
+// equal to x the two results hold (x_lo, x_lo) and (x_hi, x_hi) by halves, so their sum is x[i] + x[i ^ 32] in every lane
+// (addition commutes, the bits are those of the xor butterfly).  v_permlane16_swap does the same for odd and even rows.
+DZ_DEV double swap32_sum(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const auto lo = __builtin_amdgcn_permlane32_swap((int)(b & 0xffffffffll), (int)(b & 0xffffffffll), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((int)(b >> 32), (int)(b >> 32), false, false);
+    const double a = __longlong_as_double(((long long)(int)hi[0] << 32) | (unsigned int)lo[0]);
+    const double c = __longlong_as_double(((long long)(int)hi[1] << 32) | (unsigned int)lo[1]);
+    return a + c;
+}
+DZ_DEV double swap16_sum(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const auto lo = __builtin_amdgcn_permlane16_swap((int)(b & 0xffffffffll), (int)(b & 0xffffffffll), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((int)(b >> 32), (int)(b >> 32), false, false);
+    const double a = __longlong_as_double(((long long)(int)hi[0] << 32) | (unsigned int)lo[0]);
+    const double c = __longlong_as_double(((long long)(int)hi[1] << 32) | (unsigned int)lo[1]);
+    return a + c;
+}
 DZ_DEV double wave_bfly(double v)
 {
-    v = v + __shfl_xor(v, 32, 64);
-    v = v + __shfl_xor(v, 16, 64);
+    v = swap32_sum(v);
+    v = swap16_sum(v);
     return bfly16(v);       // all four rows now hold the same 16 values
 }
 // value of lane ln (wave-uniform index) -- v_readlane, no LDS crossbar round trip

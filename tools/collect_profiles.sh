@@ -34,5 +34,13 @@ json.dump(out,open("gpurun_out/${tag}_pmc_summary.json","w"),indent=1)
 for k,v in out.items():
     print(k,{c:round(x) for c,x in v.items()})
 PY
+# generations of a PMC pass = spin-up (extended by time on one GPU) + warm-up + steps, read back from its bench line
+gens=$(python - <<PY
+import json,re
+line=[l for l in open("gpurun_out/${tag}_pmc_3.log") if l.startswith('{"metric"')][-1]
+d=json.loads(line); print(d["spinup_generations"]+d["warmup"]+d["steps"])
+PY
+)
+python tools/traffic_from_pmc.py gpurun_out/${tag}_pmc_summary.json $gens gpurun_out/${tag}_traffic.json
 find gpurun_out/${tag}_stats -name '*kernel_stats.csv' | head -1 | xargs -r head -12
 python tools/benchline.py < gpurun_out/${tag}_bench.json

@@ -301,8 +301,8 @@ DZ_DEV void reduce_rows(const ZRows<NCH>& zr, bool snk, RowTerms<NCH>& rt)
 template <int NCH, bool AL16 = true, bool LEAN = false>
 DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, int c, int i, int n, int lane,
                           const double (&xb)[NCH][2], const double (&gt)[NCH][2], const RowTerms<NCH>& zr, double* __restrict__ out, double* slogp_out,
-                          double* cur_snk_out, bool snk, int cr_idx, int delta, int glev, const DrawSrc& dr)
-{
+                          double* cur_snk_out, bool snk, int cr_idx, int delta, int glev, const DrawSrc& dr, const u32x4* wpre = nullptr)
+{   // wpre: the DIM draw of chunk 0, computed by the caller one try ahead (software pipelining, NCH == 1)
     const int d = p.d, ld = p.ld;
     const uint32_t gc = (uint32_t)(p.off + c);
     const uint64_t thr = crossover_threshold((double)(cr_idx + 1) / (double)p.ncr);   // CR = CR_values[m], :146
@@ -318,7 +318,7 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
             const int j0 = 128 * it + 2 * lane;    // the lane's two dimensions j0, j0+1 = pair j0/2
             keep[it][0] = false; keep[it][1] = false; e1[it][0] = 0.0; e1[it][1] = 0.0; zt[it][0] = 0.0; zt[it][1] = 0.0;
             if (j0 < d) {
-                const u32x4 w = philox(p.k0, p.k1, (uint32_t)(j0 >> 1), s_dim, gc, g);
+                const u32x4 w = (NCH == 1 && wpre) ? *wpre : philox(p.k0, p.k1, (uint32_t)(j0 >> 1), s_dim, gc, g);
                 float z0, z1;
                 normal32_pair(w.z, w.w, z0, z1);
                 keep[it][0] = (uint64_t)(w.x & 0xffffu) < thr;               // U_j < CR
@@ -596,7 +596,15 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
 #pragma unroll
         for (int it = 0; it < NCH; ++it) { ra[it] = double2{0.0, 0.0}; rb[it] = double2{0.0, 0.0}; }
         request(i0);
+        // the Philox call of try i+1 is issued before try i's Box-Muller and proposal arithmetic: two independent
+        // dependency chains for the scheduler to interleave (a wave is latency-bound at 4 waves per SIMD)
+        auto dimdraw = [&](int i) { return philox(p.k0, p.k1, (uint32_t)lane, stream_id(K_DIM, (uint32_t)i, (uint32_t)phase), gc, g); };
+        // (not in the persistent kernel: LEAN -- its 128-register budget has no room for the extra draw; measured -4% there, +1% here)
+        constexpr bool AHEAD = NCH == 1 && !LEAN;
+        u32x4 wn = AHEAD ? dimdraw(i0) : u32x4{0, 0, 0, 0};
         for (int i = i0; i < i1; ++i) {
+            const u32x4 wcur = wn;
+            if (AHEAD) wn = dimdraw(min(i + 1, i1 - 1));
             RowTerms<NCH> rt;
 #pragma unroll
             for (int it = 0; it < NCH; ++it) {
@@ -607,7 +615,8 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
             //  10% SLOWER: during the tries the kernel already moves ~4 TB/s, so latency is not what limits it)
             DZ_STAMP(p, phase, c, 2 + 2 * i);          // rows of try i have arrived
             if (i + 1 < i1) request(i + 1);
-            propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * out_stride, sl + i, csn, false, cr_idx, 1, glev, dsrc);
+            propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * out_stride, sl + i, csn, false, cr_idx, 1, glev, dsrc,
+                                           AHEAD ? &wcur : nullptr);
             DZ_STAMP(p, phase, c, 3 + 2 * i);          // try i's arithmetic issued
             if (prior_out) { if (LEAN) { if (lane == 0) prior_out[i] = 0.0; } else point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i); }   // LEAN: flat priors only
         }

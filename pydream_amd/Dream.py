@@ -150,8 +150,6 @@ class Dream():
         eng = getattr(Dream_shared_vars, "engine", None)
         if eng is None:
             raise Exception('Dream should be run with multiple chains in parallel.  Set nchains > 1.')   # Dream.py:236
-        if T != 1.:
-            raise NotImplementedError('parallel tempering (T != 1) is outside the accelerated hot path')
         if self.chain_n is None:                      # Dream.py:198-200: claim a chain id, counting down
             Dream_shared_vars.nchains_counter -= 1
             self.chain_n = Dream_shared_vars.nchains_counter
@@ -162,6 +160,12 @@ class Dream():
                 q0 = Dream_shared_vars.draw_from_prior(self.variables)
         q0 = np.asarray(q0, dtype=float).reshape(-1)
         c = self.chain_n
+        temps = Dream_shared_vars.temperatures
+        if temps is None and T != 1.:
+            temps = Dream_shared_vars.temperatures = np.ones(eng.N)
+        if temps is not None and temps[eng.cfg.chain_offset + c] != T:     # this chain's T (Dream.py:193, core.py:240-246)
+            temps[eng.cfg.chain_offset + c] = T
+            eng.set_temperatures(temps, swaps=False)
         cur = Dream_shared_vars.host_state.get(c)
         if last_loglike is not None:                  # Dream.py:240-243
             eng.set_chain_state(c, q0, last_logprior, last_loglike)
@@ -171,6 +175,6 @@ class Dream():
         q_new, pr, lk = eng.get_chain_state(c)
         Dream_shared_vars.host_state[c] = q_new.copy()
         self.last_prior, self.last_like = float(pr), float(lk)
-        self.last_logp = self.last_prior + self.last_like
+        self.last_logp = T * self.last_like + self.last_prior       # Dream.py:243
         self.iter += 1
         return q_new, self.last_prior, self.last_like

@@ -12,6 +12,7 @@ import numpy as np
 engine = None             # pydream_amd._capi.Engine
 nchains_counter = 0       # counts down as Dream instances claim chain ids (Dream.py:198-200)
 host_state = {}           # chain id -> last state returned by astep
+temperatures = None       # per-chain T once an astep call used T != 1 (parallel tempering driven from the host)
 rng = None                # numpy RandomState used for prior draws (history seeding, random starts)
 
 

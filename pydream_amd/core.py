@@ -207,6 +207,7 @@ def _mp_dream_init(engine, nchains):
     Dream_shared_vars.engine = engine
     Dream_shared_vars.nchains_counter = nchains
     Dream_shared_vars.host_state = {}
+    Dream_shared_vars.temperatures = None
 
 
 def _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=None, mp_context=None, seed=None, device=0,

@@ -181,3 +181,40 @@ def test_run_dream_parallel_tempering_equals_reference(tmp_path):
     assert sampled.shape == (N, 2 * n, d) and log_ps.shape == (N, 2 * n, 1)
     np.testing.assert_allclose(sampled, fx["pt_sampled"], rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(log_ps, fx["pt_log_ps"], rtol=0, atol=1e-10)
+
+
+def test_astep_with_temperature_equals_oracle(tmp_path):
+    """Dream.astep(q0, T, last_loglike, last_logprior) the way core._sample_dream_pt_chain calls it (core.py:238-248):
+    round-robin over the chains, each at its own temperature, against the oracle's schedule S1 with the same ladder."""
+    import copy
+    from oracle import oracle as O
+    fx = H.load("trace_s1_c1")
+    d, N, G = int(fx["cfg_d"]), int(fx["cfg_N"]), 40
+    T = np.array([np.power(.001, float(i) / N) for i in range(N)])
+    hist = tmp_path / "seed.npy"
+    np.save(hist, fx["Z0"])
+    like = MVNormalLogLike(fx["invC"], log_F=float(fx["log_F"]), factorize=False)
+    step = Dream(model=Model(like, [FlatParam(np.zeros(d))]), history_file=str(hist), start_random=False, save_history=False,
+                 multitry=5, adapt_crossover=False, crossover_burnin=10 ** 9)
+    pool = _setup_mp_dream_pool(N, G, step, start_pt=[fx["starts"][i] for i in range(N)], seed=int(fx["cfg_seed"]))
+    pool._initializer(*pool._initargs)
+    try:
+        chains = [copy.copy(step) for _ in range(N)]
+        for k in range(N):
+            chains[k].chain_n = None
+        x = {c: fx["starts"][c].copy() for c in range(N)}
+        last = {c: (None, None) for c in range(N)}
+        X = np.zeros((G, N, d))
+        for g in range(G):
+            for c in range(N):
+                if g == 0:
+                    Dream_shared_vars.nchains_counter = c + 1
+                q, pr, lk = chains[c].astep(x[c], T[c], last[c][0], last[c][1])
+                x[c] = q; X[g, c] = q; last[c] = (lk, pr)
+        o = H.engine_from_trace_fixture(O.Engine, fx, trace_capacity=G, history_capacity=len(fx["Z0"]) + N * (G // 10 + 2))      # schedule S1
+        o.set_temperatures(T, swaps=False)
+        o.step(G)
+        np.testing.assert_array_equal(X, o.get_trace(0, G)["X"])
+        assert not np.array_equal(X, fx["X"][:G])          # the temperatures did change the walk
+    finally:
+        pool.close(); pool.join()

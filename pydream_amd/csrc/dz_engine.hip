@@ -284,7 +284,7 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
                 else {
                     if (e->logp_gemm && n >= 512) {            // enough points to fill the chip with 64 x 64 block tiles
                         const int nbm = (n + 63) / 64, nbn = (nrtb * 16 + 63) / 64;
-                        hipLaunchKernelGGL(dz::k_logp_mvn_gemm, dim3(nbm * nbn), block, 0, st, e->p, pts, n, e->d_qpart);
+                        hipLaunchKernelGGL(dz::k_logp_mvn_gemm, dim3(nbm * nbn), block, 0, st, e->p, pts, n, e->d_qpart, e->num_cu);
                     } else
                     hipLaunchKernelGGL((dz::k_logp_mvn_mfma_tiled<PT, RTC>), dim3((npg * nrg + 3) / 4), block, 0, st, e->p, pts, n, e->d_qpart);
                     hipLaunchKernelGGL(dz::k_q_finish, dim3((n + 255) / 256), dim3(256), 0, st, e->p, (const double*)e->d_qpart, n, nrtb, prior, like);

@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(256) void k_logp_mvn_mfma_tiled(Params p, const dou
 // ([k][row], as stored) in LDS, double buffered; wave (wm, wn) owns 2 point tiles x 2 row tiles = four accumulators, each
 // summed over k in ascending order by one MFMA chain -- the contract's order.  Row-tile sums go to the scratch array
 // of k_q_finish.  Triangular factor: a block starts at k = 64*bn and a row tile joins at k = 16*rt.
-__global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* __restrict__ pts, int npts, double* __restrict__ qpart)
+__global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* __restrict__ pts, int npts, double* __restrict__ qpart, int ncu)
 {
     constexpr int BM = 64, BN = 64, BK = 16, LDA = BM + 2, LDB = BN;
     __shared__ __attribute__((aligned(16))) double As[2][BK * LDA];
@@ -1096,7 +1096,16 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
     const int ld = p.ld, d = p.d;
     const int KS = (d + 3) >> 2, NRT = (d + 15) >> 4;
     const int nbn = (NRT * 16 + BN - 1) / BN;
-    const int bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn;
+    // All blocks are resident at once and land on the CUs round-robin, so nothing rebalances the triangular factor's
+    // uneven blocks (bn = 0 walks all of k, the last bn almost none).  Blocks are therefore numbered from a list sorted
+    // heaviest first, taken alternately from its two ends per round of ncu blocks: every CU gets heavy + light.
+    const int nbm = (int)gridDim.x / nbn;
+    int li;
+    {
+        const int b = blockIdx.x, q = b / ncu, c = b - q * ncu;
+        li = (q & 1) ? (int)gridDim.x - 1 - ((q >> 1) * ncu + c) : (q >> 1) * ncu + c;
+    }
+    const int bn = li / nbm, bm = li - bn * nbm;
     const int p0 = bm * BM;
     const int kc0 = p.tri ? (BN * bn) / BK : 0, nkc = (4 * KS + BK - 1) / BK;       // chunks of 16 k
     // loader roles: A: thread -> (point = tid / 4, four k's = 4*(tid%4)..+3); B: thread -> (k row = tid / 16, four rows = 4*(tid%16)..+3)

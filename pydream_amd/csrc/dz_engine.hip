@@ -395,7 +395,7 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
         }
     }
     // waves per block: 16 (one block fills a CU's 4 SIMDs evenly) once there is at least one such block per CU
-    const int wpb = e->waves_per_block ? e->waves_per_block : ((nc / L) >= 16 * e->num_cu ? 16 : 4);
+    const int wpb = e->nch >= 4 ? 4 : (e->waves_per_block ? e->waves_per_block : ((nc / L) >= 16 * e->num_cu ? 16 : 4));    // (k_propose<NCH >= 4> is built for 4-wave blocks)
     // one wave per (chain, try) pays when a try is long and the chains are few: d > 512 (measured at 512 x 1000-D: +17%;
     // at d <= 200 the per-chain wave with its fused Metropolis step is faster)
     const int split = e->propose_split > 0 ? e->propose_split : (e->nch >= 8 ? k : 1);

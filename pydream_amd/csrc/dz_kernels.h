@@ -668,7 +668,9 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
 // loops over the tries); split = n: one wave per (chain, try).  The host picks by problem size: per-chain
 // waves do ~35% fewer instructions, per-try waves expose 5x more parallelism.
 template <int NCH>
-__global__ __launch_bounds__(1024) void k_propose(Params p, int phase, uint32_t g, uint32_t M, int c0, int nc, int split, int fuse_accept, int64_t fuse_slot)
+// (blocks of 16 waves cap a wave at 128 registers; from four 128-dimension chunks per lane on that spilled hundreds of them --
+//  1093 at NCH = 8 --, so those variants run in 4-wave blocks with the full register file per wave)
+__global__ __launch_bounds__(NCH >= 4 ? 256 : 1024) void k_propose(Params p, int phase, uint32_t g, uint32_t M, int c0, int nc, int split, int fuse_accept, int64_t fuse_slot)
 {
     const int n = phase == 0 ? p.k : p.k - 1;
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));

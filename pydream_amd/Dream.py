@@ -22,8 +22,9 @@ class Dream():
     nCR : int, adapt_crossover : bool, adapt_gamma : bool, crossover_burnin : int
     DEpairs : int, lamb : float, zeta : float, history_thin : int, snooker : float, p_gamma_unity : float
     gamma_levels : int, start_random : bool, save_history : bool, history_file / crossover_file / gamma_file : str
-    multitry : bool or int, parallel : bool (accepted, ignored: every try is evaluated in one device batch)
-    verbose : bool, model_name : str, hardboundaries : bool, mp_context : ignored
+    multitry : bool or int, parallel : bool (every try is evaluated in one batch anyway; True makes a Python likelihood
+        use worker processes from the first batch on instead of once a batch has proved slow -- model.HostEvaluator)
+    verbose : bool, model_name : str, hardboundaries : bool, mp_context : start method of those worker processes
     """
 
     def __init__(self, model, variables=None, nseedchains=None, nCR=3, adapt_crossover=True, adapt_gamma=False,

@@ -187,13 +187,15 @@ class _EnginePool:
     "workers" are the GPU; ``_initializer(*_initargs)`` publishes the engine the way _mp_dream_init
     publishes the shared arrays (core.py:316-327); ``close``/``join`` release it."""
 
-    def __init__(self, engine, nchains):
+    def __init__(self, engine, nchains, host_eval=None):
         self.engine = engine
+        self.host_eval = host_eval
         self._initializer = _mp_dream_init
         self._initargs = (engine, nchains)
 
     def close(self):
-        pass
+        if self.host_eval is not None:
+            self.host_eval.close()
 
     def join(self):
         if Dream_shared_vars.engine is self.engine:
@@ -266,10 +268,13 @@ def _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=None, mp_
     if dev_prior is not None:
         eng.set_prior(*dev_prior)
     like = model.likelihood
+    host_eval = None
     if hasattr(like, "_dz_apply") and dev_prior is not None:
         like._dz_apply(eng)                           # likelihood AND priors on the device
     else:
-        eng.set_likelihood_host(lambda X: model.batch_logp(X, with_prior=dev_prior is None))
+        from .model import HostEvaluator
+        host_eval = HostEvaluator(model, dev_prior is None, nchains, mp_context=mp_context, force=bool(getattr(step_instance, 'parallel', False)))
+        eng.set_likelihood_host(host_eval)
 
     # start positions (core.py:74-78; Dream.py:221-225 for random starts)
     if start_pt is None:
@@ -281,4 +286,4 @@ def _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=None, mp_
     if len(X0) != nchains:
         raise Exception('start must be one vector or a list of nchains vectors')
     eng.set_state(X0[chain_offset:chain_offset + nl])
-    return _EnginePool(eng, nchains)
+    return _EnginePool(eng, nchains, host_eval)

@@ -1,5 +1,67 @@
 """Model: the likelihood/prior boundary -- same interface as pydream/model.py."""
+import multiprocessing
+import os
+import time
+
 import numpy as np
+
+_worker_model = None          # set in the worker processes of HostEvaluator
+
+
+def _worker_init(model):
+    global _worker_model
+    _worker_model = model
+
+
+def _worker_eval(args):
+    X, with_prior = args
+    return _worker_model.batch_logp(X, with_prior)
+
+
+class HostEvaluator:
+    """Evaluates a Python likelihood for a batch of points, over worker processes when that pays.
+
+    The reference runs every chain in its own process (core.py:250-314), so an expensive Python likelihood is
+    evaluated nchains-fold in parallel there; here all chains' points arrive in one batch per pass, and the batch is
+    split over `workers` processes.  Cheap likelihoods stay in-process: the pool is only started once a serial batch
+    has taken longer than `threshold` seconds.  workers: DREAMZS_HOST_WORKERS, else min(nchains, usable cores);
+    0 or 1 disables.  mp_context: as in the reference (core.py:11, :307-311); None = the platform default."""
+
+    def __init__(self, model, with_prior, nchains, mp_context=None, force=False, threshold=2e-3):
+        self.model, self.with_prior, self.threshold, self.force = model, with_prior, threshold, force
+        env = os.environ.get("DREAMZS_HOST_WORKERS")
+        if env is not None:
+            self.workers = max(0, int(env))
+        else:
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count() or 1
+            self.workers = min(int(nchains), cores)
+        self.ctx = mp_context
+        self.pool = None
+        self.serial_time = 0.0
+
+    def __call__(self, X):
+        n = len(X)
+        use_pool = self.workers > 1 and n >= 2 and (self.pool is not None or self.force or self.serial_time > self.threshold)
+        if not use_pool:
+            t0 = time.perf_counter()
+            out = self.model.batch_logp(X, self.with_prior)
+            self.serial_time = time.perf_counter() - t0
+            return out
+        if self.pool is None:
+            ctx = multiprocessing.get_context(self.ctx) if isinstance(self.ctx, str) or self.ctx is None else self.ctx
+            self.pool = ctx.Pool(self.workers, initializer=_worker_init, initargs=(self.model,))
+        parts = np.array_split(np.ascontiguousarray(X), min(self.workers, n))
+        res = self.pool.map(_worker_eval, [(part, self.with_prior) for part in parts])
+        return np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res])
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.terminate()
+            self.pool.join()
+            self.pool = None
 
 
 class Model():

@@ -218,3 +218,31 @@ def test_astep_with_temperature_equals_oracle(tmp_path):
         assert not np.array_equal(X, fx["X"][:G])          # the temperatures did change the walk
     finally:
         pool.close(); pool.join()
+
+
+def _slow_like(x):
+    import time
+    time.sleep(0.002)
+    return -.5 * float(np.sum(x * x))
+
+
+def test_python_likelihood_over_worker_processes():
+    """An expensive Python likelihood is spread over worker processes (the reference gets that from one process per
+    chain, core.py:250-314): same samples as the in-process evaluation, and faster."""
+    import time
+    d, N, n = 6, 8, 12
+    hist = "/tmp/_dz_seed_w%d.npy" % os.getpid()
+    np.save(hist, H.seed_history(80, d, 5))
+    kw = dict(nchains=N, niterations=n, verbose=False, save_history=False, history_file=hist, multitry=5, seed=9,
+              start=[H.seed_history(80, d, 5)[i] for i in range(N)])
+    out = {}
+    for workers in ("1", "8"):
+        os.environ["DREAMZS_HOST_WORKERS"] = workers
+        t0 = time.perf_counter()
+        out[workers] = run_dream([FlatParam(np.zeros(d))], _slow_like, **kw)
+        out[workers + "t"] = time.perf_counter() - t0
+    del os.environ["DREAMZS_HOST_WORKERS"]
+    os.remove(hist)
+    np.testing.assert_array_equal(np.array(out["1"][0]), np.array(out["8"][0]))
+    np.testing.assert_array_equal(np.array(out["1"][1]), np.array(out["8"][1]))
+    assert out["8t"] < 0.6 * out["1t"], (out["1t"], out["8t"])

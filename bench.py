@@ -166,9 +166,23 @@ def main():
     #  one-GPU box: ranks share the device and exchange through the host; measurements use RCCL, one rank per GPU)
     device = int(os.environ.get("DZ_BENCH_DEVICE", local_rank))
     e = setup_engine(_capi.Engine, args, n_global, n_local, rank * n_local, total, device=device)
+    transport_note = None
     if world > 1:
         from pydream_amd.distributed import attach_transport
-        attach_transport(e, rank, world, transport=os.environ.get("DZ_BENCH_TRANSPORT", "rccl"))
+        transport = os.environ.get("DZ_BENCH_TRANSPORT", "rccl")
+        err = ""
+        try:
+            attach_transport(e, rank, world, transport=transport)
+        except Exception as ex:                       # e.g. ncclCommInitRank refused: every rank must learn of it
+            err = "%s" % ex
+        errs = [None] * world
+        dist.all_gather_object(errs, err)
+        if any(errs):
+            # a number over the host-staged all-gather (named as such in the JSON line) beats no number
+            transport_note = "host (rccl unavailable: %s)" % next(x for x in errs if x)
+            attach_transport(e, rank, world, transport="host")
+        else:
+            transport_note = transport
 
     def barrier():
         e.sync()
@@ -247,7 +261,8 @@ def main():
                                % (n_local, args.dim, "correlated MVN" if args.target == "mvn" else "3-Gaussian mixture",
                                   args.mvn_kind if args.target == "mvn" else "identity cov", args.multitry, args.snooker, args.thin),
                    "chains_global": n_global, "chains_per_gpu": n_local, "ndim": args.dim, "multitry": args.multitry,
-                   "parallelism": "chains sharded x%d, Z replicated by RCCL all-gather" % world if world > 1 else "single GPU"},
+                   "parallelism": ("chains sharded x%d, Z appends all-gathered, transport: %s" % (world, transport_note))
+                                  if world > 1 else "single GPU"},
         "logp_points_per_s": n_global * (2 * args.multitry - 1) * args.steps / dt,
         "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps, "spinup_generations": spun,
         "acceptance_rate": acc, "rhat_max": float(np.max(rhat)),

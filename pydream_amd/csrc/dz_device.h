@@ -97,6 +97,21 @@ DZ_DEV void normal32_pair(uint32_t w1, uint32_t w2, float& z0, float& z1)
     z0 = rad * c; z1 = rad * sv;
 }
 
+// 16-byte load through the GLOBAL address space.  A pointer read out of a Params held in memory is generic to the compiler,
+// which then emits flat_load: that counts on lgkmcnt as well as vmcnt, so every later LDS or scalar-memory wait would also
+// wait for archive rows that are requested a whole try ahead on purpose.
+typedef double __attribute__((ext_vector_type(2))) dz_d2v;      // (a native vector: double2's copy constructor takes a generic reference)
+DZ_DEV double2 gload2(const double* q)
+{
+    const dz_d2v v = *(const __attribute__((address_space(1))) dz_d2v*)q;
+    double2 r; r.x = v.x; r.y = v.y; return r;
+}
+DZ_DEV void gstore2(double* q, double2 v)
+{
+    dz_d2v w; w.x = v.x; w.y = v.y;
+    *(__attribute__((address_space(1))) dz_d2v*)q = w;
+}
+
 // ---------------------------------------------------------------- elementary functions
 #define DZ_LN2_HI 6.93147180369123816490e-01
 #define DZ_LN2_LO 1.90821492927058770002e-10

@@ -519,7 +519,10 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
     }
     const int nrt = p.ld / 16;
     const int ch = mega_chains(e);
-    const dim3 grid((p.nl + ch - 1) / ch), block(64 * ch);
+    // waves per chain: 4 when a block holds only 4 chains (fewer than 8 chains per CU) -- the tries of a phase then run side by
+    // side (1024 chains: 238 -> 249 M proposals/s, 512: 120 -> 131); at 8 chains per block two waves per chain lose (405 -> 368)
+    const int wpc = ch == 4 ? 4 : 1;
+    const dim3 grid((p.nl + ch - 1) / ch), block(64 * ch * wpc);
     const bool xlds = mega_xlds(e);
     const size_t lds = mega_lds_bytes(e, xlds);
     if (!e->params_uploaded || memcmp(&e->p_shadow, &p, sizeof(dz::Params)) != 0) {   // the kernel reads Params through a pointer
@@ -528,8 +531,9 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
         e->params_uploaded = true;
     }
     {
-#define DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, CH_) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations<NRT_, TRI_, X_, CH_>), grid, block, lds, (const dz::Params*)e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0)
-#define DZ_MEGA_LAUNCH(NRT_, TRI_, X_) do { if (ch == 16) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 16); else if (ch == 8) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 8); else DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 4); } while (0)
+#define DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, CH_, WPC_) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations<NRT_, TRI_, X_, CH_, WPC_>), grid, block, lds, (const dz::Params*)e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0)
+#define DZ_MEGA_LAUNCH(NRT_, TRI_, X_) do { if (ch == 16) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 16, 1); \
+        else if (ch == 8) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 8, 1); else DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 4, 4); } while (0)
 #define DZ_MEGA_CASE(NRT_)                                                              \
     case NRT_:                                                                          \
         if (p.tri) { if (xlds) DZ_MEGA_LAUNCH(NRT_, true, true); else DZ_MEGA_LAUNCH(NRT_, true, false); }    \

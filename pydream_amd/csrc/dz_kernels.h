@@ -587,8 +587,8 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
                 if (jj < p.ld) { ra[it] = double2{(double)r0, 1.0}; rb[it] = double2{(double)r1, 2.0}; }
 #else
                 if (jj < p.ld) {
-                    ra[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)r0 * p.ld + jj);
-                    rb[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)r1 * p.ld + jj);
+                    ra[it] = gload2(p.Z + (size_t)r0 * p.ld + jj);
+                    rb[it] = gload2(p.Z + (size_t)r1 * p.ld + jj);
                 }
 #endif
             }
@@ -632,9 +632,9 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
             for (int it = 0; it < NCH; ++it) {
                 const int jj = 128 * it + 2 * lane;
                 if (jj < p.ld) {
-                    rz[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)iz * p.ld + jj);
-                    r1[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)i1x * p.ld + jj);
-                    r2[it] = *reinterpret_cast<const double2*>(p.Z + (size_t)i2x * p.ld + jj);
+                    rz[it] = gload2(p.Z + (size_t)iz * p.ld + jj);
+                    r1[it] = gload2(p.Z + (size_t)i1x * p.ld + jj);
+                    r2[it] = gload2(p.Z + (size_t)i2x * p.ld + jj);
                 }
             }
         };

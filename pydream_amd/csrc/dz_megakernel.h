@@ -119,12 +119,16 @@ DZ_DEV void mfma_units(const Params& p, const double* __restrict__ Ms, const dou
     }
 }
 
-template <int NRT, bool TRI, bool XLDS, int CH>
-__global__ __launch_bounds__(64 * CH) void k_generations(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int append_last)
+template <int NRT, bool TRI, bool XLDS, int CH, int WPC>
+__global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int append_last)
 {
     const Params& p = *pp;       // read through the scalar cache on demand: keeps the ~70 fields out of the SGPR file
     constexpr int NCH = 1;
-    constexpr int NT = 64 * CH;                        // one wave per chain
+    // WPC waves per chain (1 at 16 chains per block; 2 / 4 at 8 / 4 chains per block, i.e. when there are fewer than 16 chains
+    // per CU): the tries of a phase are dealt to the chain's waves, all of them share the likelihood units, the chain's
+    // first wave does the Metropolis step.  Every wave of a chain derives the chain's decisions itself (same draws, same
+    // arithmetic); two more barriers per generation keep the base point and the new state consistent between them.
+    constexpr int NT = 64 * CH * WPC;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int d = p.d, k = p.k, ld = p.ld;
     const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, XLDS, CH);
@@ -140,7 +144,8 @@ __global__ __launch_bounds__(64 * CH) void k_generations(const Params* __restric
     double* gts = smem + L.off_gt;
     double* Xs = smem + L.off_X;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int cl = wv;                                                   // chain inside the block
+    const int cl = WPC == 1 ? wv : wv % CH;                              // chain inside the block
+    const int sub = WPC == 1 ? 0 : wv / CH;                              // this wave's number among the chain's waves
     const int cg = blockIdx.x * CH + cl;
     const bool active = cg < p.nl;
     const int c = min(cg, p.nl - 1);
@@ -165,14 +170,14 @@ __global__ __launch_bounds__(64 * CH) void k_generations(const Params* __restric
     if (threadIdx.x < p.ncr) probs[threadIdx.x] = p.cr_probs[threadIdx.x];
     if (threadIdx.x < p.ngamma) probs[p.ncr + threadIdx.x] = p.g_probs[threadIdx.x];
     for (int i = threadIdx.x; i < p.ngamma * d; i += NT) gts[i] = p.gtab[(size_t)(i / d) * p.depairs * d + (i % d)];
-    if (lane == 0) { st[4 * cl] = p.lprior[c]; st[4 * cl + 1] = p.llike[c]; st[4 * cl + 2] = 0.0; }
-    if (XLDS) {
+    if (lane == 0 && sub == 0) { st[4 * cl] = p.lprior[c]; st[4 * cl + 1] = p.llike[c]; st[4 * cl + 2] = 0.0; }
+    if (XLDS && sub == 0) {
         for (int j = lane; j < L.LDP; j += 64) Xs[cl * L.LDP + j] = j < d ? p.X[(size_t)c * ld + j] : 0.0;
     }
     __syncthreads();
 
 #ifdef DZ_EXP_STAMPS
-#define DZ_MSTAMP(i_) do { if (gi == ngen - 1 && lane == 0) p.dbg[((size_t)3 * p.nl + blockIdx.x * CH + wv) * 16 + (i_)] = __builtin_readcyclecounter(); } while (0)
+#define DZ_MSTAMP(i_) do { if (gi == ngen - 1 && lane == 0 && sub == 0) p.dbg[((size_t)3 * p.nl + blockIdx.x * CH + cl) * 16 + (i_)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define DZ_MSTAMP(i_) do { } while (0)
 #endif
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(64 * CH) void k_generations(const Params* __restric
                 u.u_snk = u53(w0.x, w0.y); u.u_cr = u53(w0.z, w0.w); u.u_de = u53(w1.x, w1.y); u.u_glev = u53(w1.z, w1.w);
                 u.u_sel = u53(w2.x, w2.y); u.u_acc = u53(w2.z, w2.w);
                 f = step_flags_from(p, u, probs, probs + p.ncr);                     // Dream.py:246-256
-                if (lane == 0) {
+                if (lane == 0 && sub == 0) {
                     double* dc = dec + 8 * cl;
                     dc[0] = u.u_sel; dc[1] = u.u_acc; dc[2] = f.snk ? 1.0 : 0.0; dc[3] = (double)f.cr_idx; dc[4] = (double)f.glev;
                 }
@@ -215,38 +220,43 @@ __global__ __launch_bounds__(64 * CH) void k_generations(const Params* __restric
                     double Q = 0.0;
                     for (int t = 0; t < NRT; ++t) Q = Q + qb[pt * NRT + t];
                     const double lk = nan_to_ninf(p.logF - 0.5 * Q);
-                    sL[cl * k + lane] = lk;
+                    if (sub == 0) sL[cl * k + lane] = lk;
                     lp = sP[cl * k + lane] + p.T * lk;
                 }
                 bool fin;
                 const int sel = mt_select_vals(k, lp, u_sel, lane, &fin);
-                if (lane == 0) st[4 * cl + 2] = (double)(sel | (fin ? 256 : 0));
+                if (lane == 0 && sub == 0) st[4 * cl + 2] = (double)(sel | (fin ? 256 : 0));
                 const double* row = region + (size_t)sel * tstride;
                 base[0][0] = 2 * lane < d ? row[2 * lane] : 0.0; base[0][1] = 2 * lane + 1 < d ? row[2 * lane + 1] : 0.0;
-                if (2 * lane < d) region[2 * lane] = base[0][0];                     // the selected proposal now sits in tile 0
-                if (2 * lane + 1 < d) region[2 * lane + 1] = base[0][1];
+                if (WPC > 1) __syncthreads();                                        // every wave of the chain holds the base point before any try row is rewritten
+                if (sub == 0) {
+                    if (2 * lane < d) region[2 * lane] = base[0][0];                 // the selected proposal now sits in tile 0
+                    if (2 * lane + 1 < d) region[2 * lane + 1] = base[0][1];
+                }
             }
             double gt[NCH][2];
             load_gamma_row_from<NCH>(gts + (size_t)(f.glev - 1) * d, d, lane, gt);
             const int n = k - phase;
-            propose_set<NCH, false, false, true>(p, phase, g, M, c, gc, 0, n, n, lane, base, gt, f.snk, f.cr_idx, 1, f.glev, ds,
-                                                 region + (size_t)phase * tstride, tstride, (phase ? rS + cl * (k - 1) : sS + cl * k), nullptr,
-                                                 (phase ? rP + cl * (k - 1) : sP + cl * k));
+            const int i0 = WPC == 1 ? 0 : (sub * n) / WPC, i1 = WPC == 1 ? n : ((sub + 1) * n) / WPC;     // this wave's tries
+            if (i0 < i1)
+                propose_set<NCH, false, false, true>(p, phase, g, M, c, gc, i0, i1, n, lane, base, gt, f.snk, f.cr_idx, 1, f.glev, ds,
+                                                     region + (size_t)phase * tstride, tstride, (phase ? rS + cl * (k - 1) : sS + cl * k), nullptr,
+                                                     (phase ? rP + cl * (k - 1) : sP + cl * k));
             DZ_MSTAMP(1 + 4 * phase);
             __syncthreads();                                                         // points visible
             DZ_MSTAMP(2 + 4 * phase);
             // mt_evaluate_logps :278, :302 (x - 0.0 == x bit for bit, so a zero mean skips the subtraction and its LDS read)
             {
                 const int row0 = phase ? CH : 0, ntl = ((k - phase) * CH + 15) / 16;
-                if (p.mu_zero) mfma_units<NRT, TRI, true>(p, Ms, Pt, mus, qb, row0, ntl, wv, CH, lane, L.LDM, L.LDP);
-                else mfma_units<NRT, TRI, false>(p, Ms, Pt, mus, qb, row0, ntl, wv, CH, lane, L.LDM, L.LDP);
+                if (p.mu_zero) mfma_units<NRT, TRI, true>(p, Ms, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, L.LDM, L.LDP);
+                else mfma_units<NRT, TRI, false>(p, Ms, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, L.LDM, L.LDP);
             }
             DZ_MSTAMP(3 + 4 * phase);
             __syncthreads();                                                         // q visible
             DZ_MSTAMP(4 + 4 * phase);
         }
         // ---- Metropolis step (:305-347), trace (core.py:114-116), record_history (:919-938)
-        {
+        if (sub == 0) {
             const double* dc = dec + 8 * cl;
             const double u_acc = dc[1];
             const bool snk = dc[2] != 0.0;
@@ -281,9 +291,9 @@ __global__ __launch_bounds__(64 * CH) void k_generations(const Params* __restric
             if (XLDS && accept) { double* xr = Xs + cl * L.LDP; if (jj < d) xr[jj] = xn.x; if (jj + 1 < d) xr[jj + 1] = xn.y; }
             if (active) {
                 if (jj < ld) {
-                    if (XLDS ? last : accept) *reinterpret_cast<double2*>(p.X + (size_t)c * ld + jj) = xn;
-                    if (trace_slot0 >= 0) *reinterpret_cast<double2*>(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj) = xn;
-                    if (last && append_last) *reinterpret_cast<double2*>(p.Z + ((size_t)M + gc) * ld + jj) = xn;      // record_history :933-936
+                    if (XLDS ? last : accept) gstore2(p.X + (size_t)c * ld + jj, xn);
+                    if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn);
+                    if (last && append_last) gstore2(p.Z + ((size_t)M + gc) * ld + jj, xn);      // record_history :933-936
                 }
                 if (lane == 0) {
                     if (trace_slot0 >= 0) {
@@ -297,8 +307,9 @@ __global__ __launch_bounds__(64 * CH) void k_generations(const Params* __restric
             if (lane == 0) { st[4 * cl] = npri; st[4 * cl + 1] = nlik; }
         }
         DZ_MSTAMP(9);
-        // no barrier here: the next generation's first phase only touches each wave's own chain's rows and scalars,
-        // and the shared q buffer is not written again before the next barrier
+        // one wave per chain: no barrier here -- the next generation's first phase only touches each wave's own chain's rows
+        // and scalars, and the shared q buffer is not written again before the next barrier
+        if (WPC > 1) __syncthreads();                                                // the chain's other waves read the new state
     }
 }
 
@@ -430,8 +441,8 @@ __global__ __launch_bounds__(64 * MIXW) void k_generations_mix(const Params* __r
             if (active) {
                 if (jj < ld) {
                     if (last) *reinterpret_cast<double2*>(p.X + (size_t)c * ld + jj) = xn;
-                    if (trace_slot0 >= 0) *reinterpret_cast<double2*>(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj) = xn;
-                    if (last && append_last) *reinterpret_cast<double2*>(p.Z + ((size_t)M + gc) * ld + jj) = xn;      // record_history :933-936
+                    if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn);
+                    if (last && append_last) gstore2(p.Z + ((size_t)M + gc) * ld + jj, xn);      // record_history :933-936
                 }
                 if (lane == 0) {
                     if (trace_slot0 >= 0) {

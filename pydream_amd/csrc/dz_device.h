@@ -117,6 +117,16 @@ DZ_DEV void gstore2(double* q, double2 v)
 #define DZ_LN2_LO 1.90821492927058770002e-10
 #define DZ_DBL_MAX 1.7976931348623157e308
 
+// A double constant that is rebuilt where it is used (two scalar moves) instead of living in a register pair for the whole
+// kernel: left alone the compiler hoists the polynomial coefficients below out of the generation loop of the persistent
+// kernel and then spills them, and every evaluation waits for a chain of scratch reloads (5 inside one dexp).
+DZ_DEV double kd(double c)
+{
+    unsigned lo = (unsigned)((unsigned long long)__double_as_longlong(c) & 0xffffffffull), hi = (unsigned)((unsigned long long)__double_as_longlong(c) >> 32);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 DZ_DEV double dexp(double x)
 {
     if (x != x) return x;
@@ -125,17 +135,17 @@ DZ_DEV double dexp(double x)
     const double kf = floor(x * 1.4426950408889634 + 0.5);
     double r = fma(-kf, DZ_LN2_HI, x);
     r = fma(-kf, DZ_LN2_LO, r);
-    double p = 1.0 / 6227020800.0;
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
+    double p = kd(1.0 / 6227020800.0);
+    p = fma(p, r, kd(1.0 / 479001600.0));
+    p = fma(p, r, kd(1.0 / 39916800.0));
+    p = fma(p, r, kd(1.0 / 3628800.0));
+    p = fma(p, r, kd(1.0 / 362880.0));
+    p = fma(p, r, kd(1.0 / 40320.0));
+    p = fma(p, r, kd(1.0 / 5040.0));
+    p = fma(p, r, kd(1.0 / 720.0));
+    p = fma(p, r, kd(1.0 / 120.0));
+    p = fma(p, r, kd(1.0 / 24.0));
+    p = fma(p, r, kd(1.0 / 6.0));
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
@@ -159,17 +169,17 @@ DZ_DEV double dlog(double x)
     const double f = m - 1.0;
     const double s = f / (2.0 + f);
     const double z = s * s;
-    double p = 1.0 / 23.0;
-    p = fma(p, z, 1.0 / 21.0);
-    p = fma(p, z, 1.0 / 19.0);
-    p = fma(p, z, 1.0 / 17.0);
-    p = fma(p, z, 1.0 / 15.0);
-    p = fma(p, z, 1.0 / 13.0);
-    p = fma(p, z, 1.0 / 11.0);
-    p = fma(p, z, 1.0 / 9.0);
-    p = fma(p, z, 1.0 / 7.0);
-    p = fma(p, z, 1.0 / 5.0);
-    p = fma(p, z, 1.0 / 3.0);
+    double p = kd(1.0 / 23.0);
+    p = fma(p, z, kd(1.0 / 21.0));
+    p = fma(p, z, kd(1.0 / 19.0));
+    p = fma(p, z, kd(1.0 / 17.0));
+    p = fma(p, z, kd(1.0 / 15.0));
+    p = fma(p, z, kd(1.0 / 13.0));
+    p = fma(p, z, kd(1.0 / 11.0));
+    p = fma(p, z, kd(1.0 / 9.0));
+    p = fma(p, z, kd(1.0 / 7.0));
+    p = fma(p, z, kd(1.0 / 5.0));
+    p = fma(p, z, kd(1.0 / 3.0));
     const double t = 2.0 * s;
     const double lm = fma(t * z, p, t);
     const double ef = (double)e;

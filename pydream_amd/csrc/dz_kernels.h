@@ -86,9 +86,15 @@ DZ_DEV int mt_select_vals(int k, double lp, double u_sel, int lane, bool* anyfin
     double S = 0.0;
     for (int i = 0; i < k; ++i) S = S + readlane_f64(w, i);
     const double pr = w / S;                          // lane i: probability of try i (:907)
-    double cum = 0.0; int sel = k - 1;
-    for (int i = 0; i < k; ++i) { cum = cum + readlane_f64(pr, i); if (u_sel < cum) { sel = i; break; } }
-    return sel;
+    // first i with u_sel < cum_i, else k-1 (:908-913); without a data-dependent branch (the values are wave-uniform, but live
+    // in vector registers: a branch on them costs a compare -> mask -> branch round trip per step)
+    double cum = 0.0; int sel = k - 1; bool found = false;
+    for (int i = 0; i < k; ++i) {
+        cum = cum + readlane_f64(pr, i);
+        const bool hit = !found && (u_sel < cum);
+        sel = hit ? i : sel; found = found || hit;
+    }
+    return __builtin_amdgcn_readfirstlane(sel);
 }
 DZ_DEV int mt_select(const Params& p, int c, double u_sel, int lane, bool* anyfinite)
 {

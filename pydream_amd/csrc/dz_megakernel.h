@@ -191,6 +191,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
             //      (:295-299) take tiles 1..k-1.  One copy of the code serves both (instruction cache).
             DrawSrc ds; ds.have = true; ds.mine = make_uint4(0, 0, 0, 0);
             if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g); ds.mine = make_uint4(w.x, w.y, w.z, w.w); }
+            if (phase) DZ_MSTAMP(10);
             StepFlags f;
             double base[NCH][2];
             if (phase == 0) {
@@ -224,7 +225,9 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                     lp = sP[cl * k + lane] + p.T * lk;
                 }
                 bool fin;
+                DZ_MSTAMP(11);
                 const int sel = mt_select_vals(k, lp, u_sel, lane, &fin);
+                DZ_MSTAMP(12);
                 if (lane == 0 && sub == 0) st[4 * cl + 2] = (double)(sel | (fin ? 256 : 0));
                 const double* row = region + (size_t)sel * tstride;
                 base[0][0] = 2 * lane < d ? row[2 * lane] : 0.0; base[0][1] = 2 * lane + 1 < d ? row[2 * lane + 1] : 0.0;
@@ -236,6 +239,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
             }
             double gt[NCH][2];
             load_gamma_row_from<NCH>(gts + (size_t)(f.glev - 1) * d, d, lane, gt);
+            if (phase) DZ_MSTAMP(13);
             const int n = k - phase;
             const int i0 = WPC == 1 ? 0 : (sub * n) / WPC, i1 = WPC == 1 ? n : ((sub + 1) * n) / WPC;     // this wave's tries
             if (i0 < i1)
@@ -277,9 +281,12 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 } else val = p.T * llik + lpri;                                                          // :877-879
                 if (snk) { const double sr = i < k - 1 ? rS[cl * (k - 1) + i] : 0.0; val = (val + sr) + sS[cl * k + i]; }   // :312-313
             }
+            DZ_MSTAMP(14);
+            const double lu = dlog(u_acc);                                           // (independent of the ratio's chain: the two interleave)
             double ratio = mt_log_ratio(k, val);
             if (!fin) ratio = -__builtin_huge_val();                                 // DESIGN.md deviation D1
-            const bool accept = is_finite(ratio) && (dlog(u_acc) < ratio);           // :993
+            const bool accept = is_finite(ratio) && (lu < ratio);                    // :993
+            DZ_MSTAMP(15);
             const int jj = 2 * lane;
             double2 xo = {0.0, 0.0};
             if (XLDS) { const double* xr = Xs + cl * L.LDP; if (jj < d) xo.x = xr[jj]; if (jj + 1 < d) xo.y = xr[jj + 1]; }

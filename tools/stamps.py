@@ -44,3 +44,9 @@ if len(MG):
     for i, nm in enumerate(names):
         dtt = MG[:, i + 1] - MG[:, i]
         print("   %-34s mean %6d  p5 %6d  p95 %6d" % (nm, dtt.mean(), np.percentile(dtt, 5), np.percentile(dtt, 95)))
+    if MG[:, 10].min() > 0:
+        seq = [(4, 10, "phase 1: slot draws (Philox)"), (10, 11, "  Q sums, lp"), (11, 12, "  mt_select_vals"), (12, 13, "  base row, tile 0, gamma row"),
+               (13, 5, "  k-1 tries"), (8, 14, "Metropolis: operands"), (14, 15, "  mt_log_ratio, dlog(u), decision"), (15, 9, "  state, trace, history rows")]
+        for a, b, nm in seq:
+            dtt = MG[:, b] - MG[:, a]
+            print("   %-34s mean %6d  p5 %6d  p95 %6d" % (nm, dtt.mean(), np.percentile(dtt, 5), np.percentile(dtt, 95)))

@@ -185,12 +185,14 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
         const uint32_t g = g0 + (uint32_t)gi;
         const bool last = gi == ngen - 1;
         DZ_MSTAMP(0);
+        // the generation's wave-uniform draws: lane s holds slot s (both phases read them; four registers across the likelihood pass
+        // are cheaper than a second Philox call)
+        DrawSrc ds; ds.have = true; ds.mine = make_uint4(0, 0, 0, 0);
+        if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g); ds.mine = make_uint4(w.x, w.y, w.z, w.w); }
         for (int phase = 0; phase < 2; ++phase) {
             // ---- phase 0: k proposals around the chain's state (generate_proposal_points :258-264) into the chain's rows
             //      of tiles 0..k-1; phase 1: the selected proposal moves to tile 0 and k-1 reference points around it
             //      (:295-299) take tiles 1..k-1.  One copy of the code serves both (instruction cache).
-            DrawSrc ds; ds.have = true; ds.mine = make_uint4(0, 0, 0, 0);
-            if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g); ds.mine = make_uint4(w.x, w.y, w.z, w.w); }
             if (phase) DZ_MSTAMP(10);
             StepFlags f;
             double base[NCH][2];

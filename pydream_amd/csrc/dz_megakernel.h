@@ -355,9 +355,9 @@ __global__ __launch_bounds__(64 * MIXW) void k_generations_mix(const Params* __r
         const uint32_t g = g0 + (uint32_t)gi;
         const bool last = gi == ngen - 1;
         int sel = 0; bool fin = true;
+        DrawSrc ds; ds.have = true; ds.mine = make_uint4(0, 0, 0, 0);      // the generation's wave-uniform draws, both phases read them
+        if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g); ds.mine = make_uint4(w.x, w.y, w.z, w.w); }
         for (int phase = 0; phase < 2; ++phase) {
-            DrawSrc ds; ds.have = true; ds.mine = make_uint4(0, 0, 0, 0);
-            if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g); ds.mine = make_uint4(w.x, w.y, w.z, w.w); }
             StepFlags f;
             double base[NCH][2];
             if (phase == 0) {

@@ -287,7 +287,7 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
                         hipLaunchKernelGGL(dz::k_logp_mvn_gemm, dim3(nbm * nbn), block, 0, st, e->p, pts, n, e->d_qpart, e->num_cu);
                     } else
                     hipLaunchKernelGGL((dz::k_logp_mvn_mfma_tiled<PT, RTC>), dim3((npg * nrg + 3) / 4), block, 0, st, e->p, pts, n, e->d_qpart);
-                    hipLaunchKernelGGL(dz::k_q_finish, dim3((n + 255) / 256), dim3(256), 0, st, e->p, (const double*)e->d_qpart, n, nrtb, prior, like);
+                    hipLaunchKernelGGL(dz::k_q_finish, dim3((n + 63) / 64), dim3(64), 0, st, e->p, (const double*)e->d_qpart, n, nrtb, prior, like);
                 }
             }
             if (e->p.have_prior) NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_prior_only<NCH>, grid, block, 0, st, e->p, pts, n, prior));

@@ -1083,7 +1083,7 @@ __global__ __launch_bounds__(256) void k_logp_mvn_mfma_tiled(Params p, const dou
                 if (rt0 + t < NRT) {
                     const double y = acc[u][t][e];
                     const double qv = bfly16(r < d ? y * (p.tri ? y : xs[r] - p.mu[r]) : 0.0);
-                    if (pi == 0 && pt < npts) qpart[(size_t)pt * NRT + rt0 + t] = qv;
+                    if (pi == 0 && pt < npts) qpart[(size_t)(rt0 + t) * npts + pt] = qv;          // [row tile][point]: k_q_finish reads it coalesced
                 }
             }
         }
@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
     constexpr int BM = 64, BN = 64, BK = 16, LDA = BM + 2, LDB = BN;
     __shared__ __attribute__((aligned(16))) double As[2][BK * LDA];
     __shared__ __attribute__((aligned(16))) double Bs[2][BK * LDB];
-    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
+    const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
     const int pi = l & 15, kq = l >> 4;
     const int wm = wv >> 1, wn = wv & 1;
     const int ld = p.ld, d = p.d;
@@ -1120,15 +1120,17 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
     const int a_pt = tid >> 2, a_k = 4 * (tid & 3);
     const int b_k = tid >> 4, b_r = 4 * (tid & 15);
     const double* arow = pts + (size_t)min(p0 + a_pt, npts - 1) * ld;
-    double ra[4], rb[4];
-    // rows of pts, mu and Mt are zero padded to ld (a multiple of 16 >= 4*KS), so whole 32-byte groups can be read
+    double ra[4], rm[4], rb[4];
+    // rows of pts, mu and Mt are zero padded to ld (a multiple of 16 >= 4*KS), so whole 32-byte groups can be read.
+    // (The mean is subtracted when the chunk goes to LDS, not here: subtracting at the load made the loop wait for the next
+    //  chunk's rows before this chunk's MFMAs instead of after them.)
     auto gload = [&](int kc) {
         const int k = kc * BK + a_k;
         if (k < ld) {
             const double2 x0 = *reinterpret_cast<const double2*>(arow + k), x1 = *reinterpret_cast<const double2*>(arow + k + 2);
             const double2 m0 = *reinterpret_cast<const double2*>(p.mu + k), m1 = *reinterpret_cast<const double2*>(p.mu + k + 2);
-            ra[0] = x0.x - m0.x; ra[1] = x0.y - m0.y; ra[2] = x1.x - m1.x; ra[3] = x1.y - m1.y;
-        } else { ra[0] = 0.0; ra[1] = 0.0; ra[2] = 0.0; ra[3] = 0.0; }
+            ra[0] = x0.x; ra[1] = x0.y; ra[2] = x1.x; ra[3] = x1.y; rm[0] = m0.x; rm[1] = m0.y; rm[2] = m1.x; rm[3] = m1.y;
+        } else { ra[0] = 0.0; ra[1] = 0.0; ra[2] = 0.0; ra[3] = 0.0; rm[0] = 0.0; rm[1] = 0.0; rm[2] = 0.0; rm[3] = 0.0; }
         const int kb = kc * BK + b_k, r = BN * bn + b_r;
         if (kb < ld && r < ld) {
             const double2 b0 = *reinterpret_cast<const double2*>(p.Mt + (size_t)kb * ld + r), b1 = *reinterpret_cast<const double2*>(p.Mt + (size_t)kb * ld + r + 2);
@@ -1137,7 +1139,7 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) As[buf][(a_k + j) * LDA + a_pt] = ra[j];
+        for (int j = 0; j < 4; ++j) As[buf][(a_k + j) * LDA + a_pt] = ra[j] - rm[j];
         *reinterpret_cast<double2*>(&Bs[buf][b_k * LDB + b_r]) = double2{rb[0], rb[1]};
         *reinterpret_cast<double2*>(&Bs[buf][b_k * LDB + b_r + 2]) = double2{rb[2], rb[3]};
     };
@@ -1152,19 +1154,24 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
     for (int kc = kc0; kc < nkc; ++kc) {
         const int buf = (kc - kc0) & 1;
         if (kc + 1 < nkc) gload(kc + 1);                           // next chunk in flight during this chunk's MFMAs
+        // all operand reads of the chunk first, then its 16 MFMAs back to back (read-then-use per k-step left an LDS round trip
+        // in front of every pair of MFMAs)
+        double a[BK / 4][2], b[BK / 4][2];
+#pragma unroll
+        for (int q = 0; q < BK / 4; ++q) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) a[q][u] = As[buf][(4 * q + kq) * LDA + 32 * wm + 16 * u + pi];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) b[q][t] = Bs[buf][(4 * q + kq) * LDB + 32 * wn + 16 * t + pi];
+        }
 #pragma unroll
         for (int q = 0; q < BK / 4; ++q) {
             const int ks = kc * (BK / 4) + q;
-            double a[2], b[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) a[u] = As[buf][(4 * q + kq) * LDA + 32 * wm + 16 * u + pi];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) b[t] = Bs[buf][(4 * q + kq) * LDB + 32 * wn + 16 * t + pi];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
                 if (ks < KS && rt0 + t < NRT && (!p.tri || ks >= 4 * (rt0 + t))) {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[t], acc[u][t], 0, 0, 0);
+                    for (int u = 0; u < 2; ++u) acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][u], b[q][t], acc[u][t], 0, 0, 0);
                 }
         }
         if (kc + 1 < nkc) lstore(buf ^ 1);
@@ -1182,7 +1189,7 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
                 if (rt0 + t < NRT) {
                     const double y = acc[u][t][e];
                     const double qv = bfly16(r < d ? y * (p.tri ? y : xs[r] - p.mu[r]) : 0.0);
-                    if (pi == 0 && pt < npts) qpart[(size_t)pt * NRT + rt0 + t] = qv;
+                    if (pi == 0 && pt < npts) qpart[(size_t)(rt0 + t) * npts + pt] = qv;          // [row tile][point]: k_q_finish reads it coalesced
                 }
             }
         }
@@ -1200,8 +1207,18 @@ __global__ void k_q_finish(Params p, const double* __restrict__ qpart, int npts,
 {
     const int pt = blockIdx.x * blockDim.x + threadIdx.x;
     if (pt >= npts) return;
+    // ascending t (the contract's order); eight loads in flight at a time -- one load per add left a memory round trip in
+    // front of every term (18 us for 63 terms)
     double Q = 0.0;
-    for (int t = 0; t < nrt; ++t) Q = Q + qpart[(size_t)pt * nrt + t];
+    int t = 0;
+    for (; t + 8 <= nrt; t += 8) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = qpart[(size_t)(t + j) * npts + pt];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Q = Q + v[j];
+    }
+    for (; t < nrt; ++t) Q = Q + qpart[(size_t)t * npts + pt];
     like_out[pt] = nan_to_ninf(p.logF - 0.5 * Q);
     if (!p.have_prior) prior_out[pt] = 0.0;
 }

@@ -1120,28 +1120,29 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
     const int a_pt = tid >> 2, a_k = 4 * (tid & 3);
     const int b_k = tid >> 4, b_r = 4 * (tid & 15);
     const double* arow = pts + (size_t)min(p0 + a_pt, npts - 1) * ld;
-    double ra[4], rm[4], rb[4];
     // rows of pts, mu and Mt are zero padded to ld (a multiple of 16 >= 4*KS), so whole 32-byte groups can be read.
-    // (The mean is subtracted when the chunk goes to LDS, not here: subtracting at the load made the loop wait for the next
-    //  chunk's rows before this chunk's MFMAs instead of after them.)
-    auto gload = [&](int kc) {
+    // Two register sets: a chunk's loads are issued two chunks ahead (one chunk of MFMAs is ~0.4 us, less than a memory
+    // round trip) and always issued (index clamped), so that the wait in front of the LDS store covers exactly the older set.
+    // (The mean is subtracted when the chunk goes to LDS, not at the load: subtracting there made the loop wait for the
+    //  loads before the MFMAs instead of after them.)
+    struct Stage { double ra[4], rm[4], rb[4]; };
+    auto gload = [&](int kc, Stage& R) {
+        // no predicates (a select after a load makes the loop wait for it at once): k < 16 nkc <= ld always; a row group past
+        // ld (last bn only) is read from the last valid group instead -- those output rows are dropped below (rt0 + t < NRT)
+        kc = min(kc, nkc - 1);
         const int k = kc * BK + a_k;
-        if (k < ld) {
-            const double2 x0 = *reinterpret_cast<const double2*>(arow + k), x1 = *reinterpret_cast<const double2*>(arow + k + 2);
-            const double2 m0 = *reinterpret_cast<const double2*>(p.mu + k), m1 = *reinterpret_cast<const double2*>(p.mu + k + 2);
-            ra[0] = x0.x; ra[1] = x0.y; ra[2] = x1.x; ra[3] = x1.y; rm[0] = m0.x; rm[1] = m0.y; rm[2] = m1.x; rm[3] = m1.y;
-        } else { ra[0] = 0.0; ra[1] = 0.0; ra[2] = 0.0; ra[3] = 0.0; rm[0] = 0.0; rm[1] = 0.0; rm[2] = 0.0; rm[3] = 0.0; }
-        const int kb = kc * BK + b_k, r = BN * bn + b_r;
-        if (kb < ld && r < ld) {
-            const double2 b0 = *reinterpret_cast<const double2*>(p.Mt + (size_t)kb * ld + r), b1 = *reinterpret_cast<const double2*>(p.Mt + (size_t)kb * ld + r + 2);
-            rb[0] = b0.x; rb[1] = b0.y; rb[2] = b1.x; rb[3] = b1.y;
-        } else { rb[0] = 0.0; rb[1] = 0.0; rb[2] = 0.0; rb[3] = 0.0; }
+        const double2 x0 = *reinterpret_cast<const double2*>(arow + k), x1 = *reinterpret_cast<const double2*>(arow + k + 2);
+        const double2 m0 = *reinterpret_cast<const double2*>(p.mu + k), m1 = *reinterpret_cast<const double2*>(p.mu + k + 2);
+        R.ra[0] = x0.x; R.ra[1] = x0.y; R.ra[2] = x1.x; R.ra[3] = x1.y; R.rm[0] = m0.x; R.rm[1] = m0.y; R.rm[2] = m1.x; R.rm[3] = m1.y;
+        const int kb = kc * BK + b_k, r = min(BN * bn + b_r, ld - 4);
+        const double2 b0 = *reinterpret_cast<const double2*>(p.Mt + (size_t)kb * ld + r), b1 = *reinterpret_cast<const double2*>(p.Mt + (size_t)kb * ld + r + 2);
+        R.rb[0] = b0.x; R.rb[1] = b0.y; R.rb[2] = b1.x; R.rb[3] = b1.y;
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const Stage& R) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) As[buf][(a_k + j) * LDA + a_pt] = ra[j] - rm[j];
-        *reinterpret_cast<double2*>(&Bs[buf][b_k * LDB + b_r]) = double2{rb[0], rb[1]};
-        *reinterpret_cast<double2*>(&Bs[buf][b_k * LDB + b_r + 2]) = double2{rb[2], rb[3]};
+        for (int j = 0; j < 4; ++j) As[buf][(a_k + j) * LDA + a_pt] = R.ra[j] - R.rm[j];
+        *reinterpret_cast<double2*>(&Bs[buf][b_k * LDB + b_r]) = double2{R.rb[0], R.rb[1]};
+        *reinterpret_cast<double2*>(&Bs[buf][b_k * LDB + b_r + 2]) = double2{R.rb[2], R.rb[3]};
     };
     dz_double4 acc[2][2];
 #pragma unroll
@@ -1149,13 +1150,9 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
 #pragma unroll
         for (int t = 0; t < 2; ++t) acc[u][t] = dz_double4{0.0, 0.0, 0.0, 0.0};
     const int rt0 = (BN / 16) * bn + 2 * wn;                       // this wave's first row tile
-    gload(kc0); lstore(0);
-    __syncthreads();
-    for (int kc = kc0; kc < nkc; ++kc) {
-        const int buf = (kc - kc0) & 1;
-        if (kc + 1 < nkc) gload(kc + 1);                           // next chunk in flight during this chunk's MFMAs
-        // all operand reads of the chunk first, then its 16 MFMAs back to back (read-then-use per k-step left an LDS round trip
-        // in front of every pair of MFMAs)
+    // the chunk's operand reads first, then its 16 MFMAs back to back (read-then-use per k-step left an LDS round trip in
+    // front of every pair of MFMAs)
+    auto compute = [&](int kc, int buf) {
         double a[BK / 4][2], b[BK / 4][2];
 #pragma unroll
         for (int q = 0; q < BK / 4; ++q) {
@@ -1174,7 +1171,20 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
                     for (int u = 0; u < 2; ++u) acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][u], b[q][t], acc[u][t], 0, 0, 0);
                 }
         }
-        if (kc + 1 < nkc) lstore(buf ^ 1);
+    };
+    Stage R0, R1;
+    gload(kc0, R0); lstore(0, R0);
+    gload(kc0 + 1, R0); gload(kc0 + 2, R1);
+    __syncthreads();
+    for (int kc = kc0; kc < nkc; kc += 2) {
+        compute(kc, 0);
+        lstore(1, R0);                                             // chunk kc+1 (loaded two chunks ago)
+        gload(kc + 3, R0);
+        __syncthreads();
+        if (kc + 1 >= nkc) break;
+        compute(kc + 1, 1);
+        lstore(0, R1);                                             // chunk kc+2
+        gload(kc + 4, R1);
         __syncthreads();
     }
 #pragma unroll

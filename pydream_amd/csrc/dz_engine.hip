@@ -477,7 +477,8 @@ bool mega_eligible(const dz_engine* e)
 {
     const dz::Params& p = e->p;
     if (mega_mix_eligible(e)) return true;
-    return e->mega && !p.Tc && e->lk == LK_MVN && !p.hard && !p.have_prior && p.ld <= 128 && p.k >= 3 && p.k <= dz::MAXK && p.depairs == 1 &&
+    if ((p.hard || p.have_prior) && !mega_xlds(e)) return false;
+    return e->mega && !p.Tc && e->lk == LK_MVN && p.ld <= 128 && p.k >= 3 && p.k <= dz::MAXK && p.depairs == 1 &&
            p.nslots <= 64 && (!p.tri || p.Mtp) && mega_lds_bytes(e, false) <= (size_t)160 * 1024;
 }
 // number of generations, starting at g, that one launch may cover: none of them publishes positions
@@ -524,6 +525,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
     const int wpc = ch == 4 ? 4 : 1;
     const dim3 grid((p.nl + ch - 1) / ch), block(64 * ch * wpc);
     const bool xlds = mega_xlds(e);
+    const bool pb = p.hard || p.have_prior;
     const size_t lds = mega_lds_bytes(e, xlds);
     if (!e->params_uploaded || memcmp(&e->p_shadow, &p, sizeof(dz::Params)) != 0) {   // the kernel reads Params through a pointer
         HIPCK(hipMemcpyAsync(e->d_params, &p, sizeof(dz::Params), hipMemcpyHostToDevice, e->stream));
@@ -531,13 +533,15 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
         e->params_uploaded = true;
     }
     {
-#define DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, CH_, WPC_) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations<NRT_, TRI_, X_, CH_, WPC_>), grid, block, lds, (const dz::Params*)e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0)
-#define DZ_MEGA_LAUNCH(NRT_, TRI_, X_) do { if (ch == 16) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 16, 1); \
-        else if (ch == 8) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 8, 1); else DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 4, 4); } while (0)
+#define DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, CH_, WPC_, PB_) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations<NRT_, TRI_, X_, CH_, WPC_, PB_>), grid, block, lds, (const dz::Params*)e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0)
+#define DZ_MEGA_LAUNCH(NRT_, TRI_, X_, PB_) do { if (ch == 16) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 16, 1, PB_); \
+        else if (ch == 8) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 8, 1, PB_); else DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 4, 4, PB_); } while (0)
+    // (priors / boundaries: only with the chain states in LDS -- mega_eligible -- which keeps the number of kernels down)
 #define DZ_MEGA_CASE(NRT_)                                                              \
     case NRT_:                                                                          \
-        if (p.tri) { if (xlds) DZ_MEGA_LAUNCH(NRT_, true, true); else DZ_MEGA_LAUNCH(NRT_, true, false); }    \
-        else { if (xlds) DZ_MEGA_LAUNCH(NRT_, false, true); else DZ_MEGA_LAUNCH(NRT_, false, false); }        \
+        if (pb) { if (p.tri) DZ_MEGA_LAUNCH(NRT_, true, true, true); else DZ_MEGA_LAUNCH(NRT_, false, true, true); }     \
+        else if (p.tri) { if (xlds) DZ_MEGA_LAUNCH(NRT_, true, true, false); else DZ_MEGA_LAUNCH(NRT_, true, false, false); }    \
+        else { if (xlds) DZ_MEGA_LAUNCH(NRT_, false, true, false); else DZ_MEGA_LAUNCH(NRT_, false, false, false); }        \
         break;
         switch (nrt) { DZ_MEGA_CASE(1) DZ_MEGA_CASE(2) DZ_MEGA_CASE(3) DZ_MEGA_CASE(4) DZ_MEGA_CASE(5) DZ_MEGA_CASE(6) DZ_MEGA_CASE(7) DZ_MEGA_CASE(8) }
 #undef DZ_MEGA_CASE

@@ -606,7 +606,7 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
         // dependency chains for the scheduler to interleave (a wave is latency-bound at 4 waves per SIMD)
         auto dimdraw = [&](int i) { return philox(p.k0, p.k1, (uint32_t)lane, stream_id(K_DIM, (uint32_t)i, (uint32_t)phase), gc, g); };
         // (not in the persistent kernel: LEAN -- its 128-register budget has no room for the extra draw; measured -4% there, +1% here)
-        constexpr bool AHEAD = NCH == 1 && !LEAN;
+        constexpr bool AHEAD = NCH == 1 && !LEAN && AL16;     // (AL16: k_propose's global rows; the persistent kernel writes LDS rows)
         u32x4 wn = AHEAD ? dimdraw(i0) : u32x4{0, 0, 0, 0};
         for (int i = i0; i < i1; ++i) {
             const u32x4 wcur = wn;

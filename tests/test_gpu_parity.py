@@ -160,16 +160,20 @@ def test_d1000_stress_shape_against_oracle(G, O):
     assert_traces_identical(out[0], out[1])
 
 
-@pytest.mark.parametrize("N,d,k,tri,burnin,eligible", [(1024, 100, 5, 0, 0, True), (1000, 100, 5, 1, 0, True), (96, 10, 3, 1, 0, True),
-                                                       (64, 64, 4, 0, 0, True), (256, 100, 5, 1, 12, True),
-                                                       (64, 128, 4, 0, 0, True), (64, 128, 4, 1, 0, True)])
-def test_persistent_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, k, tri, burnin, eligible, monkeypatch):
+@pytest.mark.parametrize("N,d,k,tri,burnin,eligible,prior", [(1024, 100, 5, 0, 0, True, None), (1000, 100, 5, 1, 0, True, None), (96, 10, 3, 1, 0, True, None),
+                                                             (64, 64, 4, 0, 0, True, None), (256, 100, 5, 1, 12, True, None),
+                                                             (64, 128, 4, 0, 0, True, None), (64, 128, 4, 1, 0, True, None),
+                                                             (4096, 20, 5, 1, 0, True, "uniform"), (200, 100, 5, 0, 0, True, "uniform"),
+                                                             (96, 10, 3, 1, 0, True, "normal"), (64, 128, 4, 0, 0, True, "normal")])
+def test_persistent_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, k, tri, burnin, eligible, prior, monkeypatch):
     """k_generations (whole thin-cycles in one launch, the default wherever it is eligible) against the
     multi-kernel path (DZ_MEGA=0) and the oracle: 35 generations across three history appends, chain counts that do
     not fill the last block, dense and triangular matrix, and a crossover burn-in in front (multi-kernel during the
     burn-in, persistent afterwards).  Chain counts below 4096 run 8 or 4 chains per block (the 128-D cases only fit that
     way); the multi-kernel run of the dense 128-D case also exercises the likelihood kernel that takes its operands from
-    L2 (its matrix does not fit LDS)."""
+    L2 (its matrix does not fit LDS).  prior: SampledParam-style priors -- "uniform" with hard boundaries narrow enough that
+    proposals are reflected and some are redrawn (Dream.py:733-791), "normal" without boundaries (with priors the persistent
+    kernel keeps the chain states in LDS; at 4 chains per block even the dense 128-D matrix leaves room for that)."""
     n, seed = 35, 77
     P = H.mvn_precision(d)
     M = np.linalg.cholesky((P + P.T) / 2).T if tri else P
@@ -180,6 +184,11 @@ def test_persistent_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, k, tr
         e = Cls(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
                 adapt_crossover=1 if burnin else 0, crossover_burnin=burnin)
         mu = np.linspace(-1.0, 1.0, d) if d in (10, 64) else np.zeros(d)      # (a zero mean takes a shorter code path)
+        if prior == "uniform":                                                # scipy uniform(loc=-6, scale=22): support [-6, 16]
+            e.set_prior(np.full(d, 2, np.int32), np.full(d, -6.0), np.full(d, 22.0))
+            e.set_bounds(np.full(d, -6.0), np.full(d, 16.0))
+        elif prior == "normal":
+            e.set_prior(np.full(d, 1, np.int32), np.linspace(-1.0, 2.0, d), np.full(d, 30.0))
         e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(mu, M, tri, 0.0)
         launches = None
         if Cls is G.Engine:

@@ -95,7 +95,7 @@ struct dz_engine {
     ncclComm_t comm = nullptr; int rank = 0, world = 1;
     // owned device buffers (also referenced from p)
     double *d_mins = nullptr, *d_maxs = nullptr, *d_gtab = nullptr, *d_mu = nullptr, *d_Mt = nullptr, *d_Mtp = nullptr, *d_mixF = nullptr;
-    double *d_pa = nullptr, *d_pb = nullptr; int32_t* d_pkind = nullptr;
+    double *d_pa = nullptr, *d_pb = nullptr, *d_plogb = nullptr; int32_t* d_pkind = nullptr;
     double *d_shared = nullptr;      // cr_probs|cr_delta|cr_n|g_probs|g_delta|g_n
     double *d_partial = nullptr, *d_mean = nullptr, *d_sd = nullptr, *d_sdc = nullptr, *d_dl = nullptr, *d_dlg = nullptr;
     int *d_binc = nullptr, *d_bing = nullptr;
@@ -645,7 +645,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     rc |= ealloc(e, &e->d_mins, ld); rc |= ealloc(e, &e->d_maxs, ld);
     rc |= ealloc(e, &e->d_gtab, (size_t)cfg->ngamma * cfg->depairs * p.d);
     rc |= ealloc(e, &e->d_shared, (size_t)3 * (cfg->ncr + cfg->ngamma));
-    rc |= ealloc(e, &e->d_pkind, ld); rc |= ealloc(e, &e->d_pa, ld); rc |= ealloc(e, &e->d_pb, ld);
+    rc |= ealloc(e, &e->d_pkind, ld); rc |= ealloc(e, &e->d_pa, ld); rc |= ealloc(e, &e->d_pb, ld); rc |= ealloc(e, &e->d_plogb, ld);
     if (e->adapt) {
         rc |= ealloc(e, &p.cp_prev, N * ld); rc |= ealloc(e, &p.cp_new, N * ld);
         rc |= ealloc(e, &e->d_partial, (size_t)((N + 63) / 64) * ld);
@@ -662,7 +662,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     p.mins = e->d_mins; p.maxs = e->d_maxs; p.gtab = e->d_gtab;
     p.cr_probs = e->d_shared; p.cr_delta = p.cr_probs + cfg->ncr; p.cr_n = p.cr_delta + cfg->ncr;
     p.g_probs = p.cr_n + cfg->ncr; p.g_delta = p.g_probs + cfg->ngamma; p.g_n = p.g_delta + cfg->ngamma;
-    p.pkind = e->d_pkind; p.pa = e->d_pa; p.pb = e->d_pb; p.have_prior = 0;
+    p.pkind = e->d_pkind; p.pa = e->d_pa; p.pb = e->d_pb; p.plogb = e->d_plogb; p.have_prior = 0;
     // defaults: unbounded, uniform CR / gamma-level probabilities (Dream.py:134, :143), computed gamma table
     {
         std::vector<double> lo(ld, -HUGE_VAL), hi(ld, HUGE_VAL);
@@ -781,6 +781,8 @@ int dz_set_prior(dz_engine* e, const int32_t* kind, const double* a, const doubl
     HIPCK(hipMemcpy(e->d_pkind, kind, sizeof(int32_t) * d, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(e->d_pa, a, sizeof(double) * d, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(e->d_pb, b, sizeof(double) * d, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(dz::k_prior_consts, dim3((d + 127) / 128), dim3(128), 0, e->stream, (const double*)e->d_pb, d, e->d_plogb);
+    DZCK(launch_check("k_prior_consts"));
     e->p.have_prior = any ? 1 : 0;
     return 0;
 }

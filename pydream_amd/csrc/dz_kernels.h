@@ -32,7 +32,7 @@ struct Params {
     double *tX, *tlogp; uint8_t *tmoved, *tsnk; int32_t *ttry, *tcr;
     long long tcap;      // trace capacity in generations; tX is CHAIN-major [nl][tcap][ld] (a chain's samples are one block, as run_dream returns them)
     // likelihood / prior
-    const int32_t* pkind; const double *pa, *pb; int have_prior;
+    const int32_t* pkind; const double *pa, *pb, *plogb; int have_prior;      // plogb[j] = dlog(pb[j]), made once by k_prior_consts
     const double *mu, *Mt; double logF; int tri; int J; const double* mixF;
     // triangular factor, packed for k_logp_mvn_lds: k-row r keeps its first 16*(r/16+1) columns (the row tiles that
     // use it), rows back to back; mtp_len doubles (even)
@@ -446,8 +446,8 @@ DZ_DEV double prior_of_point(const Params& p, const double (&x)[NCH][2], int lan
             if (j < p.d) {
                 const int kd = p.pkind[j];
                 double t = 0.0;
-                if (kd == 1) { const double z = (x[it][s] - p.pa[j]) / p.pb[j]; t = (-(z * z) / 2.0 - 0.91893853320467274178) - dlog(p.pb[j]); }
-                else if (kd == 2) t = (x[it][s] >= p.pa[j] && x[it][s] <= p.pa[j] + p.pb[j]) ? -dlog(p.pb[j]) : -__builtin_huge_val();
+                if (kd == 1) { const double z = (x[it][s] - p.pa[j]) / p.pb[j]; t = (-(z * z) / 2.0 - 0.91893853320467274178) - p.plogb[j]; }
+                else if (kd == 2) t = (x[it][s] >= p.pa[j] && x[it][s] <= p.pa[j] + p.pb[j]) ? -p.plogb[j] : -__builtin_huge_val();
                 acc = acc + t;
             }
         }
@@ -1234,6 +1234,12 @@ __global__ void k_q_finish(Params p, const double* __restrict__ qpart, int npts,
 }
 
 // prior only (wave per point), used beside the MFMA likelihood kernel when priors are not flat
+// log of the priors' scale parameters (scipy norm / uniform `scale`), evaluated once instead of per point and dimension
+__global__ void k_prior_consts(const double* __restrict__ pb, int n, double* __restrict__ plogb)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) plogb[j] = dlog(pb[j]);
+}
 template <int NCH>
 __global__ __launch_bounds__(256) void k_prior_only(Params p, const double* __restrict__ pts, int npts, double* prior_out)
 {

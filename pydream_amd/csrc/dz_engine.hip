@@ -275,7 +275,6 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
                 if (need > e->qpart_len) {
                     DZCK(sync_all(e));
                     if (e->d_qpart) hipFree(e->d_qpart);
-    if (e->h_pin) hipHostFree(e->h_pin);
                     e->d_qpart = nullptr; e->qpart_len = 0;
                     DZCK(dalloc(&e->d_qpart, need));
                     e->qpart_len = need;
@@ -284,7 +283,7 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
                 else {
                     if (e->logp_gemm && n >= 512) {            // enough points to fill the chip with 64 x 64 block tiles
                         const int nbm = (n + 63) / 64, nbn = (nrtb * 16 + 63) / 64;
-                        hipLaunchKernelGGL(dz::k_logp_mvn_gemm, dim3(nbm * nbn), block, 0, st, e->p, pts, n, e->d_qpart, e->num_cu);
+                        hipLaunchKernelGGL(dz::k_logp_mvn_gemm, dim3(nbm * nbn), block, e->p.mu_zero ? 0 : sizeof(double) * (size_t)e->p.ld, st, e->p, pts, n, e->d_qpart, e->num_cu);
                     } else
                     hipLaunchKernelGGL((dz::k_logp_mvn_mfma_tiled<PT, RTC>), dim3((npg * nrg + 3) / 4), block, 0, st, e->p, pts, n, e->d_qpart);
                     hipLaunchKernelGGL(dz::k_q_finish, dim3((n + 63) / 64), dim3(64), 0, st, e->p, (const double*)e->d_qpart, n, nrtb, prior, like);
@@ -697,6 +696,7 @@ int dz_destroy(dz_engine* e)
     for (void* q : e->to_free) hipFree(q);
     if (e->d_scratch) hipFree(e->d_scratch);
     if (e->d_qpart) hipFree(e->d_qpart);
+    if (e->h_pin) hipHostFree(e->h_pin);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
     return 0;

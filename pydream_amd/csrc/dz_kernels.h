@@ -1098,6 +1098,7 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
     constexpr int BM = 64, BN = 64, BK = 16, LDA = BM + 2, LDB = BN;
     __shared__ __attribute__((aligned(16))) double As[2][BK * LDA];
     __shared__ __attribute__((aligned(16))) double Bs[2][BK * LDB];
+    extern __shared__ __attribute__((aligned(16))) double mus[];      // the mean (ld doubles), staged once -- unless it is all zero
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
     const int pi = l & 15, kq = l >> 4;
     const int wm = wv >> 1, wn = wv & 1;
@@ -1107,6 +1108,8 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
     // All blocks are resident at once and land on the CUs round-robin, so nothing rebalances the triangular factor's
     // uneven blocks (bn = 0 walks all of k, the last bn almost none).  Blocks are therefore numbered from a list sorted
     // heaviest first, taken alternately from its two ends per round of ncu blocks: every CU gets heavy + light.
+    // (Tried: an XCD-aware numbering -- an XCD keeps a fixed set of point blocks, matrix panels shared by neighbours --, wave
+    //  priorities for the long blocks, padded matrix rows in LDS: no change each.  PMC: the waves wait at vmcnt half the time.)
     const int nbm = (int)gridDim.x / nbn;
     int li;
     {
@@ -1125,22 +1128,26 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
     // round trip) and always issued (index clamped), so that the wait in front of the LDS store covers exactly the older set.
     // (The mean is subtracted when the chunk goes to LDS, not at the load: subtracting there made the loop wait for the
     //  loads before the MFMAs instead of after them.)
-    struct Stage { double ra[4], rm[4], rb[4]; };
+    // (PMC: the waves of this kernel spend half their time at s_waitcnt vmcnt -- operand traffic, not latency, so the mean is
+    //  not fetched with every chunk as it once was: a third of the loads.)
+    struct Stage { double ra[4], rb[4]; };
+    const bool mz = p.mu_zero != 0;
+    if (!mz) { for (int i = tid; i < ld; i += 256) mus[i] = p.mu[i]; }
     auto gload = [&](int kc, Stage& R) {
         // no predicates (a select after a load makes the loop wait for it at once): k < 16 nkc <= ld always; a row group past
         // ld (last bn only) is read from the last valid group instead -- those output rows are dropped below (rt0 + t < NRT)
         kc = min(kc, nkc - 1);
         const int k = kc * BK + a_k;
         const double2 x0 = *reinterpret_cast<const double2*>(arow + k), x1 = *reinterpret_cast<const double2*>(arow + k + 2);
-        const double2 m0 = *reinterpret_cast<const double2*>(p.mu + k), m1 = *reinterpret_cast<const double2*>(p.mu + k + 2);
-        R.ra[0] = x0.x; R.ra[1] = x0.y; R.ra[2] = x1.x; R.ra[3] = x1.y; R.rm[0] = m0.x; R.rm[1] = m0.y; R.rm[2] = m1.x; R.rm[3] = m1.y;
+        R.ra[0] = x0.x; R.ra[1] = x0.y; R.ra[2] = x1.x; R.ra[3] = x1.y;
         const int kb = kc * BK + b_k, r = min(BN * bn + b_r, ld - 4);
         const double2 b0 = *reinterpret_cast<const double2*>(p.Mt + (size_t)kb * ld + r), b1 = *reinterpret_cast<const double2*>(p.Mt + (size_t)kb * ld + r + 2);
         R.rb[0] = b0.x; R.rb[1] = b0.y; R.rb[2] = b1.x; R.rb[3] = b1.y;
     };
-    auto lstore = [&](int buf, const Stage& R) {
+    auto lstore = [&](int buf, int kc, const Stage& R) {
+        const int k = min(kc, nkc - 1) * BK + a_k;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) As[buf][(a_k + j) * LDA + a_pt] = R.ra[j] - R.rm[j];
+        for (int j = 0; j < 4; ++j) As[buf][(a_k + j) * LDA + a_pt] = mz ? R.ra[j] : R.ra[j] - mus[k + j];       // (x - 0.0 == x, bit for bit)
         *reinterpret_cast<double2*>(&Bs[buf][b_k * LDB + b_r]) = double2{R.rb[0], R.rb[1]};
         *reinterpret_cast<double2*>(&Bs[buf][b_k * LDB + b_r + 2]) = double2{R.rb[2], R.rb[3]};
     };
@@ -1173,17 +1180,19 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
         }
     };
     Stage R0, R1;
-    gload(kc0, R0); lstore(0, R0);
+    gload(kc0, R0);
+    __syncthreads();                                               // the staged mean
+    lstore(0, kc0, R0);
     gload(kc0 + 1, R0); gload(kc0 + 2, R1);
     __syncthreads();
     for (int kc = kc0; kc < nkc; kc += 2) {
         compute(kc, 0);
-        lstore(1, R0);                                             // chunk kc+1 (loaded two chunks ago)
+        lstore(1, kc + 1, R0);                                     // chunk kc+1 (loaded two chunks ago)
         gload(kc + 3, R0);
         __syncthreads();
         if (kc + 1 >= nkc) break;
         compute(kc + 1, 1);
-        lstore(0, R1);                                             // chunk kc+2
+        lstore(0, kc + 2, R1);                                     // chunk kc+2
         gload(kc + 4, R1);
         __syncthreads();
     }

@@ -80,7 +80,7 @@ struct dz_engine {
     // bounded host run-ahead: a marker every ra_stride generations, the host never gets more than 3 markers ahead
     dz::Params p_shadow; bool params_uploaded = false;    // what d_params holds
     void* h_pin = nullptr;          // page-locked bounce buffer for downloads into pageable memory (d2h_2d)
-    double* d_qpart = nullptr; size_t qpart_len = 0; bool force_big = false; bool logp_gemm = true;    // DZ_LOGP_GEMM=0: no LDS-tiled product; row-tile sums of the tiled large-d likelihood; DZ_LOGP_BIG=1: the one-wave-per-tile kernel
+    double* d_qpart = nullptr; size_t qpart_len = 0; bool force_big = false; bool logp_gemm = true; int logp_bm = 0;    // DZ_LOGP_GEMM=0: no LDS-tiled product; row-tile sums of the tiled large-d likelihood; DZ_LOGP_BIG=1: the one-wave-per-tile kernel
     int logp_waves = 0;      // DZ_LOGP_WAVES: force the block size of k_logp_mvn_lds (tuning)
     int ra_stride = 32; hipEvent_t ra_ev[4] = {nullptr}; bool ra_used[4] = {false, false, false, false}; int64_t ra_n = 0;
     int nch = 1;
@@ -282,8 +282,18 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
                 if (e->force_big) hipLaunchKernelGGL(dz::k_logp_mvn_mfma_big<8>, dim3((n + 63) / 64), block, 0, st, e->p, pts, n, prior, like);
                 else {
                     if (e->logp_gemm && n >= 512) {            // enough points to fill the chip with 64 x 64 block tiles
-                        const int nbm = (n + 63) / 64, nbn = (nrtb * 16 + 63) / 64;
-                        hipLaunchKernelGGL(dz::k_logp_mvn_gemm, dim3(nbm * nbn), block, e->p.mu_zero ? 0 : sizeof(double) * (size_t)e->p.ld, st, e->p, pts, n, e->d_qpart, e->num_cu);
+                        const int nbn = (nrtb * 16 + 63) / 64;
+                        const size_t ldsm = e->p.mu_zero ? 0 : sizeof(double) * (size_t)e->p.ld;
+                        // Points per block (128 / 64 / 32): the kernel is bound by how many blocks a CU has in flight (each one is a
+                        // chain of barrier -> LDS reads -> MFMAs -> LDS store), so the largest tile that still leaves five blocks per
+                        // CU: 2560 points x 1000 rows: 32 points 65 us, 64 points 70 us, 128 points 98 us per launch.
+                        int bmsel = e->logp_bm;
+                        if (bmsel != 32 && bmsel != 64 && bmsel != 128)
+                            bmsel = ((n + 127) / 128) * nbn >= 5 * e->num_cu ? 128 : ((n + 63) / 64) * nbn >= 5 * e->num_cu ? 64 : 32;
+                        const dim3 gridg(((n + bmsel - 1) / bmsel) * nbn);
+                        if (bmsel == 32) hipLaunchKernelGGL(dz::k_logp_mvn_gemm<1>, gridg, block, ldsm, st, e->p, pts, n, e->d_qpart, e->num_cu);
+                        else if (bmsel == 64) hipLaunchKernelGGL(dz::k_logp_mvn_gemm<2>, gridg, block, ldsm, st, e->p, pts, n, e->d_qpart, e->num_cu);
+                        else hipLaunchKernelGGL(dz::k_logp_mvn_gemm<4>, gridg, block, ldsm, st, e->p, pts, n, e->d_qpart, e->num_cu);
                     } else
                     hipLaunchKernelGGL((dz::k_logp_mvn_mfma_tiled<PT, RTC>), dim3((npg * nrg + 3) / 4), block, 0, st, e->p, pts, n, e->d_qpart);
                     hipLaunchKernelGGL(dz::k_q_finish, dim3((n + 63) / 64), dim3(64), 0, st, e->p, (const double*)e->d_qpart, n, nrtb, prior, like);
@@ -594,6 +604,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     if (const char* kv = getenv("DZ_FUSE")) e->fuse = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA")) e->mega = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_MAXGEN")) e->mega_max_gen = std::max(1, atoi(kv));
+    if (const char* kv = getenv("DZ_LOGP_BM")) e->logp_bm = atoi(kv);          // 64 / 128: points per block of k_logp_mvn_gemm (default: by size)
     if (const char* kv = getenv("DZ_MEGA_CHAINS")) { const int v = atoi(kv); e->mega_ch = (v == 16 || v == 8 || v == 4) ? v : 0; }
     if (const char* kv = getenv("DZ_WPB")) e->waves_per_block = atoi(kv);
     if (const char* kv = getenv("DZ_PROPOSE_SPLIT")) e->propose_split = atoi(kv);

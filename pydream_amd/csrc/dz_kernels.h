@@ -1093,9 +1093,10 @@ __global__ __launch_bounds__(256) void k_logp_mvn_mfma_tiled(Params p, const dou
 // ([k][row], as stored) in LDS, double buffered; wave (wm, wn) owns 2 point tiles x 2 row tiles = four accumulators, each
 // summed over k in ascending order by one MFMA chain -- the contract's order.  Row-tile sums go to the scratch array
 // of k_q_finish.  Triangular factor: a block starts at k = 64*bn and a row tile joins at k = 16*rt.
+template <int PT>      // point tiles per wave: the block owns BM = 32 PT points (64 or 128) x 64 rows
 __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* __restrict__ pts, int npts, double* __restrict__ qpart, int ncu)
 {
-    constexpr int BM = 64, BN = 64, BK = 16, LDA = BM + 2, LDB = BN;
+    constexpr int BM = 32 * PT, BN = 64, BK = 16, LDA = BM + 2, LDB = BN, NA = PT >= 2 ? PT / 2 : 1;
     __shared__ __attribute__((aligned(16))) double As[2][BK * LDA];
     __shared__ __attribute__((aligned(16))) double Bs[2][BK * LDB];
     extern __shared__ __attribute__((aligned(16))) double mus[];      // the mean (ld doubles), staged once -- unless it is all zero
@@ -1119,18 +1120,20 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
     const int bn = li / nbm, bm = li - bn * nbm;
     const int p0 = bm * BM;
     const int kc0 = p.tri ? (BN * bn) / BK : 0, nkc = (4 * KS + BK - 1) / BK;       // chunks of 16 k
-    // loader roles: A: thread -> (point = tid / 4, four k's = 4*(tid%4)..+3); B: thread -> (k row = tid / 16, four rows = 4*(tid%16)..+3)
+    // loader roles: A: thread -> (points tid / 4 + 64 a, four k's = 4*(tid%4)..+3); B: thread -> (k row = tid / 16, four rows = 4*(tid%16)..+3)
     const int a_pt = tid >> 2, a_k = 4 * (tid & 3);
     const int b_k = tid >> 4, b_r = 4 * (tid & 15);
-    const double* arow = pts + (size_t)min(p0 + a_pt, npts - 1) * ld;
+    const bool a_on = PT >= 2 || a_pt < BM;                        // 32 points per block: the first two waves load them
+    const double* arow[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) arow[a] = pts + (size_t)min(p0 + a_pt + 64 * a, npts - 1) * ld;
     // rows of pts, mu and Mt are zero padded to ld (a multiple of 16 >= 4*KS), so whole 32-byte groups can be read.
     // Two register sets: a chunk's loads are issued two chunks ahead (one chunk of MFMAs is ~0.4 us, less than a memory
     // round trip) and always issued (index clamped), so that the wait in front of the LDS store covers exactly the older set.
-    // (The mean is subtracted when the chunk goes to LDS, not at the load: subtracting there made the loop wait for the
-    //  loads before the MFMAs instead of after them.)
-    // (PMC: the waves of this kernel spend half their time at s_waitcnt vmcnt -- operand traffic, not latency, so the mean is
-    //  not fetched with every chunk as it once was: a third of the loads.)
-    struct Stage { double ra[4], rb[4]; };
+    // The mean is subtracted when the chunk goes to LDS, not at the load (subtracting there made the loop wait for the loads
+    // before the MFMAs instead of after them), and it comes from LDS, not with every chunk (PMC: the waves of this kernel spend
+    // half their time at s_waitcnt vmcnt -- operand traffic from L2, not latency; 128 points per block halve the matrix's share).
+    struct Stage { double ra[NA][4], rb[4]; };
     const bool mz = p.mu_zero != 0;
     if (!mz) { for (int i = tid; i < ld; i += 256) mus[i] = p.mu[i]; }
     auto gload = [&](int kc, Stage& R) {
@@ -1138,8 +1141,11 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
         // ld (last bn only) is read from the last valid group instead -- those output rows are dropped below (rt0 + t < NRT)
         kc = min(kc, nkc - 1);
         const int k = kc * BK + a_k;
-        const double2 x0 = *reinterpret_cast<const double2*>(arow + k), x1 = *reinterpret_cast<const double2*>(arow + k + 2);
-        R.ra[0] = x0.x; R.ra[1] = x0.y; R.ra[2] = x1.x; R.ra[3] = x1.y;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) if (a_on) {
+            const double2 x0 = *reinterpret_cast<const double2*>(arow[a] + k), x1 = *reinterpret_cast<const double2*>(arow[a] + k + 2);
+            R.ra[a][0] = x0.x; R.ra[a][1] = x0.y; R.ra[a][2] = x1.x; R.ra[a][3] = x1.y;
+        }
         const int kb = kc * BK + b_k, r = min(BN * bn + b_r, ld - 4);
         const double2 b0 = *reinterpret_cast<const double2*>(p.Mt + (size_t)kb * ld + r), b1 = *reinterpret_cast<const double2*>(p.Mt + (size_t)kb * ld + r + 2);
         R.rb[0] = b0.x; R.rb[1] = b0.y; R.rb[2] = b1.x; R.rb[3] = b1.y;
@@ -1147,24 +1153,26 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
     auto lstore = [&](int buf, int kc, const Stage& R) {
         const int k = min(kc, nkc - 1) * BK + a_k;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) As[buf][(a_k + j) * LDA + a_pt] = mz ? R.ra[j] : R.ra[j] - mus[k + j];       // (x - 0.0 == x, bit for bit)
+        for (int a = 0; a < NA; ++a) if (a_on)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) As[buf][(a_k + j) * LDA + a_pt + 64 * a] = mz ? R.ra[a][j] : R.ra[a][j] - mus[k + j];       // (x - 0.0 == x, bit for bit)
         *reinterpret_cast<double2*>(&Bs[buf][b_k * LDB + b_r]) = double2{R.rb[0], R.rb[1]};
         *reinterpret_cast<double2*>(&Bs[buf][b_k * LDB + b_r + 2]) = double2{R.rb[2], R.rb[3]};
     };
-    dz_double4 acc[2][2];
+    dz_double4 acc[PT][2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < PT; ++u)
 #pragma unroll
         for (int t = 0; t < 2; ++t) acc[u][t] = dz_double4{0.0, 0.0, 0.0, 0.0};
     const int rt0 = (BN / 16) * bn + 2 * wn;                       // this wave's first row tile
-    // the chunk's operand reads first, then its 16 MFMAs back to back (read-then-use per k-step left an LDS round trip in
-    // front of every pair of MFMAs)
+    // the chunk's operand reads first, then its MFMAs back to back (read-then-use per k-step left an LDS round trip in
+    // front of every pair of MFMAs); every accumulator is one chain over k in ascending order -- the contract's order
     auto compute = [&](int kc, int buf) {
-        double a[BK / 4][2], b[BK / 4][2];
+        double a[BK / 4][PT], b[BK / 4][2];
 #pragma unroll
         for (int q = 0; q < BK / 4; ++q) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) a[q][u] = As[buf][(4 * q + kq) * LDA + 32 * wm + 16 * u + pi];
+            for (int u = 0; u < PT; ++u) a[q][u] = As[buf][(4 * q + kq) * LDA + 16 * PT * wm + 16 * u + pi];
 #pragma unroll
             for (int t = 0; t < 2; ++t) b[q][t] = Bs[buf][(4 * q + kq) * LDB + 32 * wn + 16 * t + pi];
         }
@@ -1175,7 +1183,7 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
             for (int t = 0; t < 2; ++t)
                 if (ks < KS && rt0 + t < NRT && (!p.tri || ks >= 4 * (rt0 + t))) {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][u], b[q][t], acc[u][t], 0, 0, 0);
+                    for (int u = 0; u < PT; ++u) acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][u], b[q][t], acc[u][t], 0, 0, 0);
                 }
         }
     };
@@ -1197,10 +1205,10 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
         __syncthreads();
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < PT; ++u)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int pt = p0 + 32 * wm + 16 * u + kq + 4 * e;
+            const int pt = p0 + 16 * PT * wm + 16 * u + kq + 4 * e;
             const double* xs = pts + (size_t)min(pt, npts - 1) * ld;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {

@@ -322,19 +322,17 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
 #pragma unroll
         for (int it = 0; it < NCH; ++it) {        // zeta, e, U :694-700 -- one Philox call and one Box-Muller pair per lane
             const int j0 = 128 * it + 2 * lane;    // the lane's two dimensions j0, j0+1 = pair j0/2
-            keep[it][0] = false; keep[it][1] = false; e1[it][0] = 0.0; e1[it][1] = 0.0; zt[it][0] = 0.0; zt[it][1] = 0.0;
-            if (j0 < d) {
+            {   // no lane predicate around the arithmetic (the lanes past d compute on their own, unused draws; `keep` masks them):
+                // a predicated region costs the zero defaults of every value it defines plus the exec-mask round trip
                 const u32x4 w = (NCH == 1 && wpre) ? *wpre : philox(p.k0, p.k1, (uint32_t)(j0 >> 1), s_dim, gc, g);
                 float z0, z1;
                 normal32_pair(w.z, w.w, z0, z1);
-                keep[it][0] = (uint64_t)(w.x & 0xffffu) < thr;               // U_j < CR
+                keep[it][0] = j0 < d && (uint64_t)(w.x & 0xffffu) < thr;     // U_j < CR
                 e1[it][0] = (-p.lamb + (p.lamb - (-p.lamb)) * u16d(w.y)) + 1.0;
                 zt[it][0] = p.zeta * (double)z0;
-                if (j0 + 1 < d) {
-                    keep[it][1] = (uint64_t)(w.x >> 16) < thr;
-                    e1[it][1] = (-p.lamb + (p.lamb - (-p.lamb)) * u16d(w.y >> 16)) + 1.0;
-                    zt[it][1] = p.zeta * (double)z1;
-                }
+                keep[it][1] = j0 + 1 < d && (uint64_t)(w.x >> 16) < thr;
+                e1[it][1] = (-p.lamb + (p.lamb - (-p.lamb)) * u16d(w.y >> 16)) + 1.0;
+                zt[it][1] = p.zeta * (double)z1;
             }
             dprime += __popcll(__ballot(keep[it][0])) + __popcll(__ballot(keep[it][1]));   // d' :704 / :709
         }
@@ -592,10 +590,11 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
 #ifdef DZ_EXP_NOZ        // timing experiment only: no archive gathers
                 if (jj < p.ld) { ra[it] = double2{(double)r0, 1.0}; rb[it] = double2{(double)r1, 2.0}; }
 #else
-                if (jj < p.ld) {
-                    ra[it] = gload2(p.Z + (size_t)r0 * p.ld + jj);
-                    rb[it] = gload2(p.Z + (size_t)r1 * p.ld + jj);
-                }
+                // no lane predicate (it would keep the previous rows alive in the lanes past ld and cost a register copy per row
+                // and try): those lanes re-read the row's last pair, their results are masked where they are used (j < d)
+                const int jc = min(jj, p.ld - 2);
+                ra[it] = gload2(p.Z + (size_t)r0 * p.ld + jc);
+                rb[it] = gload2(p.Z + (size_t)r1 * p.ld + jc);
 #endif
             }
         };
@@ -620,7 +619,9 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
             // (a deeper pipeline -- three buffers, straight-line code, rows of tries i+1..i+3 in flight -- measured
             //  10% SLOWER: during the tries the kernel already moves ~4 TB/s, so latency is not what limits it)
             DZ_STAMP(p, phase, c, 2 + 2 * i);          // rows of try i have arrived
-            if (i + 1 < i1) request(i + 1);
+            // (unconditional: after the last try the same rows are requested again and never used -- a conditional request makes
+            //  the compiler keep the old and the new rows apart and copy one set into the other every try)
+            request(min(i + 1, i1 - 1));
             propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * out_stride, sl + i, csn, false, cr_idx, 1, glev, dsrc,
                                            AHEAD ? &wcur : nullptr);
             DZ_STAMP(p, phase, c, 3 + 2 * i);          // try i's arithmetic issued

@@ -637,12 +637,10 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
             const uint32_t iz = mulhi_idx(w.x, M), i1x = mulhi_idx(w.y, M), i2x = mulhi_idx(w.z, M);
 #pragma unroll
             for (int it = 0; it < NCH; ++it) {
-                const int jj = 128 * it + 2 * lane;
-                if (jj < p.ld) {
-                    rz[it] = gload2(p.Z + (size_t)iz * p.ld + jj);
-                    r1[it] = gload2(p.Z + (size_t)i1x * p.ld + jj);
-                    r2[it] = gload2(p.Z + (size_t)i2x * p.ld + jj);
-                }
+                const int jc = min(128 * it + 2 * lane, p.ld - 2);            // (no lane predicate: see the DE path)
+                rz[it] = gload2(p.Z + (size_t)iz * p.ld + jc);
+                r1[it] = gload2(p.Z + (size_t)i1x * p.ld + jc);
+                r2[it] = gload2(p.Z + (size_t)i2x * p.ld + jc);
             }
         };
 #pragma unroll

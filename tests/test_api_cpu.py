@@ -117,3 +117,35 @@ def test_run_dream_validation_errors():
     with pytest.raises(Exception, match="seeded starting history is insufficient"):
         run_dream(p, l, nchains=30, niterations=10, verbose=False)          # default nseedchains = 40 < 2*30
 
+
+
+def _quad_like(x):
+    return -.5 * float(np.sum(x * x))
+
+
+def test_host_evaluator_pool_equals_in_process_evaluation(monkeypatch):
+    """model.HostEvaluator (worker processes behind the batched host callback; the reference's one process per chain,
+    core.py:250-314): the split over workers returns the same (prior, likelihood) columns as Model.batch_logp, for a batch
+    smaller than, equal to and larger than the number of workers, with and without the host-side prior."""
+    from pydream_amd.model import HostEvaluator, Model
+    from pydream_amd.parameters import SampledParam
+    from scipy.stats import norm
+    model = Model(_quad_like, [SampledParam(norm, loc=np.zeros(3), scale=2.0), FlatParam(np.zeros(2))])
+    rng = np.random.default_rng(5)
+    monkeypatch.setenv("DREAMZS_HOST_WORKERS", "3")
+    for with_prior in (True, False):
+        ev = HostEvaluator(model, with_prior, nchains=8, force=True)
+        try:
+            for n in (1, 2, 3, 11):
+                X = rng.normal(size=(n, 5))
+                p0, l0 = model.batch_logp(X, with_prior)
+                p1, l1 = ev(X)
+                np.testing.assert_array_equal(p0, p1)
+                np.testing.assert_array_equal(l0, l1)
+            assert ev.pool is not None                       # the pool really ran
+        finally:
+            ev.close()
+    monkeypatch.setenv("DREAMZS_HOST_WORKERS", "0")
+    ev = HostEvaluator(model, True, nchains=8, force=True)
+    ev(rng.normal(size=(4, 5)))
+    assert ev.pool is None                                   # disabled: in-process

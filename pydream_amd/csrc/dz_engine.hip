@@ -467,8 +467,19 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
 int mega_chains(const dz_engine* e)
 {
     if (e->mega_ch) return e->mega_ch;
-    for (int ch = dz::MEGA_CHAINS; ch > 4; ch >>= 1) if (e->p.nl / ch >= e->num_cu) return ch;
-    return 4;
+    // One block per CU is resident (LDS), so a launch takes ceil(blocks / CUs) rounds of a block's time; measured at 100-D
+    // a block of 8 chains needs 0.67 and one of 4 chains (four waves per chain) 0.49 of the time of a block of 16.  The
+    // smallest product wins, the larger block on a tie: 4096 chains -> 16, 3072 -> 16 (192 CUs at full speed beat 384 blocks
+    // of 8 in two rounds: 431 vs 333 M proposals/s), 2048 -> 8, 1024 -> 4.
+    const int ncu = e->num_cu > 0 ? e->num_cu : 1;
+    const double cost[3] = {1.0, 0.67, 0.49};
+    int best = dz::MEGA_CHAINS; double tb = 0.0;
+    for (int i = 0, ch = dz::MEGA_CHAINS; i < 3; ++i, ch >>= 1) {
+        const int blocks = (e->p.nl + ch - 1) / ch, rounds = (blocks + ncu - 1) / ncu;
+        const double t = rounds * cost[i];
+        if (i == 0 || t < tb - 1e-9) { best = ch; tb = t; }
+    }
+    return best;
 }
 size_t mega_lds_bytes(const dz_engine* e, bool xlds)
 {

@@ -607,17 +607,15 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
         // (not in the persistent kernel: LEAN -- its 128-register budget has no room for the extra draw; measured -4% there, +1% here)
         constexpr bool AHEAD = NCH == 1 && !LEAN && AL16;     // (AL16: k_propose's global rows; the persistent kernel writes LDS rows)
         u32x4 wn = AHEAD ? dimdraw(i0) : u32x4{0, 0, 0, 0};
-        // The loop carries the difference of try i's rows (formed at the end of try i-1, when they are waited for), not the rows:
-        // the next request can then land in the same registers, with no copy of one row set into another per try.
-        RowTerms<NCH> rt;
-#pragma unroll
-        for (int it = 0; it < NCH; ++it) {
-            rt.a[it][0] = ra[it].x - rb[it].x; rt.a[it][1] = ra[it].y - rb[it].y;       // chain_differences :692
-            rt.b[it][0] = 0.0; rt.b[it][1] = 0.0;
-        }
         for (int i = i0; i < i1; ++i) {
             const u32x4 wcur = wn;
             if (AHEAD) wn = dimdraw(min(i + 1, i1 - 1));
+            RowTerms<NCH> rt;
+#pragma unroll
+            for (int it = 0; it < NCH; ++it) {
+                rt.a[it][0] = ra[it].x - rb[it].x; rt.a[it][1] = ra[it].y - rb[it].y;   // chain_differences :692
+                rt.b[it][0] = 0.0; rt.b[it][1] = 0.0;
+            }
             // (a deeper pipeline -- three buffers, straight-line code, rows of tries i+1..i+3 in flight -- measured
             //  10% SLOWER: during the tries the kernel already moves ~4 TB/s, so latency is not what limits it)
             DZ_STAMP(p, phase, c, 2 + 2 * i);          // rows of try i have arrived
@@ -628,8 +626,6 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
                                            AHEAD ? &wcur : nullptr);
             DZ_STAMP(p, phase, c, 3 + 2 * i);          // try i's arithmetic issued
             if (prior_out) { if (LEAN) { if (lane == 0) prior_out[i] = 0.0; } else point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i); }   // LEAN: flat priors only
-#pragma unroll
-            for (int it = 0; it < NCH; ++it) { rt.a[it][0] = ra[it].x - rb[it].x; rt.a[it][1] = ra[it].y - rb[it].y; }      // the next try's rows
         }
         return;
     }

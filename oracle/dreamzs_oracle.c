@@ -914,6 +914,11 @@ static int generation_s2(orc_engine* e)
             for (int j = 0; j < d; ++j) { double t = e->X[(size_t)a * d + j]; e->X[(size_t)a * d + j] = e->X[(size_t)b * d + j]; e->X[(size_t)b * d + j] = t; }
             double t = e->llike[a]; e->llike[a] = e->llike[b]; e->llike[b] = t;
             t = e->lprior[a]; e->lprior[a] = e->lprior[b]; e->lprior[b] = t;
+            /* the next generation's jumps are measured from the states astep is handed, i.e. after the swap
+             * (Dream.py:371-378: q0 is the post-swap point, core.py:204-215): the published copy that serves as that
+             * baseline follows the exchange; the column statistics of this generation were taken before it */
+            if ((e->c.adapt_crossover || e->c.adapt_gamma) && (int64_t)g < (int64_t)e->c.crossover_burnin + 1)
+                for (int j = 0; j < d; ++j) { double q = e->cp_new[(size_t)a * d + j]; e->cp_new[(size_t)a * d + j] = e->cp_new[(size_t)b * d + j]; e->cp_new[(size_t)b * d + j] = q; }
         }
         if (e->c.trace_capacity) { int32_t* q = e->tswap + 3 * (size_t)(e->ntrace - 1); q[0] = (int32_t)a; q[1] = (int32_t)b; q[2] = acc; }
     }

@@ -32,111 +32,94 @@ class Dream():
                  p_gamma_unity=.20, gamma_levels=1, start_random=True, save_history=True, history_file=False,
                  crossover_file=False, gamma_file=False, multitry=False, parallel=False, verbose=False,
                  model_name=False, hardboundaries=True, mp_context=None, **kwargs):
-        self.mp_context = mp_context
+        # what is sampled
         self.model = model
         self.model_name = model_name
-        if variables is None:
-            self.variables = self.model.sampled_parameters
-        else:
-            self.variables = variables
+        self.mp_context = mp_context
+        self.variables = model.sampled_parameters if variables is None else variables
+        self.total_var_dimension = int(sum(var.dsize for var in self.variables))
+        d = self.total_var_dimension
+        self.logp = model.total_logp
 
-        # total variable dimension and boundaries (Dream.py:79-105)
+        # hard boundaries = the support of every prior (Dream.py:79-105)
         self.boundaries = hardboundaries
-        self.total_var_dimension = 0
-        for var in self.variables:
-            self.total_var_dimension += var.dsize
-        if self.boundaries:
-            if self.total_var_dimension == 1:
-                self.boundary_mask = True
-            else:
-                self.boundary_mask = np.ones((self.total_var_dimension), dtype=bool)
-            self.mins = []
-            self.maxs = []
+        if hardboundaries:
+            self.boundary_mask = True if d == 1 else np.ones(d, dtype=bool)
+            lows, highs = [], []
             for var in self.variables:
-                interval = var.interval(1)
-                if var.dsize > 1:
-                    self.mins += list(interval[0])
-                    self.maxs += list(interval[1])
-                else:
-                    self.mins.append(np.ravel(interval[0])[0])
-                    self.maxs.append(np.ravel(interval[1])[0])
-            self.mins = np.array(self.mins, dtype=float)
-            self.maxs = np.array(self.maxs, dtype=float)
+                lo, hi = var.interval(1)
+                lows.extend(np.ravel(lo)[:var.dsize])
+                highs.extend(np.ravel(hi)[:var.dsize])
+            self.mins = np.asarray(lows, dtype=float)
+            self.maxs = np.asarray(highs, dtype=float)
 
-        self.nseedchains = nseedchains
+        # crossover values and their selection probabilities (Dream.py:107-134, :146)
         self.nCR = nCR
-        if self.nCR > self.total_var_dimension:      # Dream.py:110-113
-            self.nCR = self.total_var_dimension
-            print('Warning: the total number of crossover values specified (' + str(nCR) + ') is less than the total dimension of all variables (' + str(self.total_var_dimension) + ').  Setting the number of crossover values to be equal to the total variable dimension.')
-        if self.total_var_dimension == 1 and adapt_crossover:     # Dream.py:115-118
+        if nCR > d:
+            self.nCR = d
+            print('Warning: the total number of crossover values specified (' + str(nCR) + ') is less than the total dimension of all variables (' + str(d) + ').  Setting the number of crossover values to be equal to the total variable dimension.')
+        if d == 1 and adapt_crossover:
             adapt_crossover = False
             print('Warning: the total variable dimension = 1, so crossover values will not be adapted, even though crossover adaptation was requested.')
-
-        self.ngamma = gamma_levels
-        self.njoint_cr_gamma_probs = nCR * gamma_levels
+        self.adapt_crossover = adapt_crossover
         self.crossover_burnin = crossover_burnin
         self.crossover_file = crossover_file
-        self.adapt_crossover = adapt_crossover
-
-        if crossover_file:                            # Dream.py:127-134
+        if crossover_file:
             self.CR_probabilities = np.load(crossover_file)
             self.nCR = len(self.CR_probabilities)
-            if self.adapt_crossover:
+            if adapt_crossover:
                 print('Warning: Crossover values loaded and adapt_crossover = True.  Crossover values will be further adapted.')
         else:
-            self.CR_probabilities = [1 / float(self.nCR) for i in range(self.nCR)]
+            self.CR_probabilities = [1.0 / self.nCR] * self.nCR
+        self.CR_values = np.arange(1, self.nCR + 1) / float(self.nCR)
 
-        self.adapt_gamma = adapt_gamma                # Dream.py:136-143
+        # gamma levels (Dream.py:120-122, :136-147)
+        self.ngamma = gamma_levels
+        self.njoint_cr_gamma_probs = nCR * gamma_levels
+        self.adapt_gamma = adapt_gamma
         self.gamma_file = gamma_file
         if gamma_file:
             self.gamma_probabilities = np.load(gamma_file)
             if adapt_gamma:
                 print('Warning: Gamma values loaded and adapt gamma = True.  Gamma values will be further adapted.')
         else:
-            self.gamma_probabilities = [1 / float(self.ngamma) for i in range(self.ngamma)]
+            self.gamma_probabilities = [1.0 / gamma_levels] * gamma_levels
+        self.gamma_level_values = np.arange(1, gamma_levels + 1)
 
-        self.CR_values = np.array([m / float(self.nCR) for m in range(1, self.nCR + 1)])
-        self.gamma_level_values = np.array([m for m in range(1, self.ngamma + 1)])
-        self.DEpairs = np.linspace(1, DEpairs, num=DEpairs, dtype=int)
+        # jump parameters
+        self.DEpairs = np.arange(1, DEpairs + 1, dtype=int)           # (the reference keeps the list 1..DEpairs, Dream.py:148)
         self.snooker = snooker
         self.p_gamma_unity = p_gamma_unity
-
-        if multitry == False:                         # noqa: E712  (Dream.py:155-161)
-            self.multitry = 1
-        elif multitry == True:                        # noqa: E712
-            self.multitry = 5
-        else:
-            self.multitry = multitry
+        self.lamb = lamb
+        self.zeta = zeta
+        self.parallel = parallel
+        # multitry: False -> 1 try, True -> 5 tries, a number -> that many (Dream.py:155-161)
+        # (compared by value like the reference does, so 0 counts as False and 1 as True)
+        self.multitry = {False: 1, True: 5}.get(multitry, multitry) if isinstance(multitry, (bool, int, np.integer)) else multitry
         if self.multitry == 2:
             raise Exception('multitry=2 fails inside the reference (Dream.py:867-868); use 1 or >= 3.')
 
-        self.parallel = parallel
-        self.lamb = lamb
-        self.zeta = zeta
-        self.last_logp = None
-        if self.nseedchains is None:                  # Dream.py:168-170
-            self.nseedchains = self.total_var_dimension * 10
-
-        # gamma table, Dream.py:172-179
-        gamma_array = np.zeros((self.ngamma, DEpairs, self.total_var_dimension))
-        gamma_level_decrease = 1
-        for gamma_level in range(1, self.ngamma + 1):
+        # jump scale 2.38 / sqrt(2 delta d') by (gamma level, number of pairs delta, crossed dimensions d'), halved from one
+        # level to the next (Dream.py:172-179)
+        dprime = np.arange(1, d + 1, dtype=float)
+        self.gamma_arr = np.empty((gamma_levels, DEpairs, d))
+        for level in range(gamma_levels):
             for delta in range(1, DEpairs + 1):
-                gamma_array[gamma_level - 1, delta - 1, :] = (2.38 / np.sqrt(2 * delta * np.linspace(1, self.total_var_dimension, num=self.total_var_dimension))) / gamma_level_decrease
-            gamma_level_decrease = gamma_level_decrease * 2
-        self.gamma_arr = gamma_array
+                self.gamma_arr[level, delta - 1, :] = (2.38 / np.sqrt(2 * delta * dprime)) / (2 ** level)
         self.gamma = None
 
-        self.iter = 0
-        self.chain_n = None
-        self.nchains = None
-        self.len_history = 0
+        # history archive and bookkeeping
+        self.nseedchains = 10 * d if nseedchains is None else nseedchains      # Dream.py:168-170
         self.save_history = save_history
         self.history_file = history_file
         self.history_thin = history_thin
         self.start_random = start_random
         self.verbose = verbose
-        self.logp = self.model.total_logp
+        self.len_history = 0
+        self.iter = 0
+        self.chain_n = None
+        self.nchains = None
+        self.last_logp = None
         self.last_prior = None
         self.last_like = None
 

@@ -17,18 +17,17 @@ rng = None                # numpy RandomState used for prior draws (history seed
 
 
 def draw_from_prior(model_vars):
-    """Dream.draw_from_prior (Dream.py:628-644) with this module's RandomState."""
-    draw = np.array([])
+    """One point drawn from the priors of ``model_vars``, as a flat vector (what Dream.draw_from_prior, Dream.py:628-644,
+    returns), using this module's RandomState when there is one so that seeded runs are reproducible."""
+    pieces = []
     for variable in model_vars:
         try:
-            if rng is not None and hasattr(variable, "dist"):
-                var_draw = variable.dist.rvs(random_state=rng)
-            else:
-                var_draw = variable.random()
+            frozen = getattr(variable, "dist", None)
+            value = frozen.rvs(random_state=rng) if (rng is not None and frozen is not None) else variable.random()
         except AttributeError:
             raise Exception('Random draw from distribution for variable %s not implemented yet.' % variable)
-        draw = np.append(draw, var_draw)
-    return draw.flatten()
+        pieces.append(np.ravel(value))
+    return np.concatenate(pieces) if pieces else np.array([])
 
 
 def history():

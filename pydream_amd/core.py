@@ -19,7 +19,9 @@ def run_dream(parameters, likelihood, nchains=5, niterations=50000, start=None, 
     ----------
     parameters: iterable of SampledParam class
     likelihood: function ``f(vec[d]) -> float`` -- or one of ``pydream_amd.likelihoods`` to evaluate it on the device
-    nchains, niterations, start, restart, verbose, nverbose: as in the reference
+    nchains, niterations, start, restart, verbose: as in the reference
+    nverbose: with verbose on, progress (acceptance rates over all chains) is printed every ``nverbose`` iterations
+        rounded up to a multiple that is at least 1000 iterations -- one line per device chunk
     tempering: parallel tempering as in the reference (core.py:131-236): the ladder T_i = 0.001**(i/nchains), one
         temperature-swap attempt per iteration; returns arrays of shape (nchains, 2*niterations, d) and
         (nchains, 2*niterations, 1) with the samples before and after each swap attempt interleaved
@@ -114,6 +116,12 @@ def _sample_dream_batched(eng, step, niterations, verbose, nverbose):
     d = step.total_var_dimension
     nchains = eng.nl                                  # the chains this engine owns (all of them on one GPU)
     chunk = eng.cfg.trace_capacity
+    if verbose and nverbose:
+        # progress lines come per device chunk: with verbose on, a chunk is the smallest multiple of nverbose that is
+        # at least 1000 iterations (the reference prints every nverbose iterations of every chain, core.py:118-126;
+        # a line per 10 iterations would cost a device round trip each)
+        step_it = int(nverbose) * max(1, -(-1000 // int(nverbose)))
+        chunk = max(1, min(chunk, step_it))
     by_chain = hasattr(eng, "get_trace_chains")       # the HIP engine keeps the trace chain by chain: no host transposition
     if by_chain:
         S = np.empty((nchains, niterations, d))

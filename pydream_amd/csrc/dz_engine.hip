@@ -451,7 +451,7 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
     }
     if (e->tempering && full) {      // temperature swap (core.py:185-221): after every chain's step and the updates above
         if (L > 1) { DZCK(join_all(e)); e->need_join = true; }
-        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_pt_swap<NCH>, dim3(1), dim3(64), 0, e->stream, p, g, slot));
+        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_pt_swap<NCH>, dim3(1), dim3(64), 0, e->stream, p, g, slot, publish ? 1 : 0));
         DZCK(launch_check("k_pt_swap"));
     }
     for (int c = c0; c < c0 + nc; ++c) e->gen_c[c] = (int64_t)g + 1;
@@ -637,6 +637,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
         if (const char* ev = getenv("DZ_STREAMS")) nl_req = atoi(ev);
         e->nlanes = std::max(1, std::min(8, nl_req));
         if (cfg->nchains_local < 64 * e->nlanes) e->nlanes = 1;
+        if (p.ld > 128) e->nlanes = 1;      // the large-d likelihood kernels share one row-tile scratch array (d_qpart)
         e->lane_stream[0] = e->stream;
         for (int s = 1; s < e->nlanes; ++s) HIPCK(hipStreamCreateWithFlags(&e->lane_stream[s], hipStreamNonBlocking));
         for (int s = 0; s < e->nlanes; ++s) HIPCK(hipEventCreateWithFlags(&e->lane_ev[s], hipEventDisableTiming));
@@ -1130,7 +1131,6 @@ static int need_scratch(dz_engine* e, size_t rows)
 {
     if (e->scratch_rows >= rows) return 0;
     if (e->d_scratch) hipFree(e->d_scratch);
-    if (e->d_qpart) hipFree(e->d_qpart);
     e->d_scratch = nullptr; e->scratch_rows = 0;
     HIPCK(hipMalloc((void**)&e->d_scratch, sizeof(double) * (rows * e->p.ld + 4 * rows)));
     e->scratch_rows = rows;

@@ -1369,7 +1369,7 @@ __global__ __launch_bounds__(1024) void k_accept(Params p, uint32_t g, int64_t z
 // Temperature swap of parallel tempering (core.py:185-221): one random pair per generation, after every chain's step
 // and the end-of-generation updates.  One wave; lanes share the row exchange.  Stream SWAP (=4) of the random contract.
 template <int NCH>
-__global__ __launch_bounds__(64) void k_pt_swap(Params p, uint32_t g, int64_t trace_slot)
+__global__ __launch_bounds__(64) void k_pt_swap(Params p, uint32_t g, int64_t trace_slot, int published)
 {
     const int lane = threadIdx.x & 63;
     const u32x4 w = philox(p.k0, p.k1, 0u, stream_id(4u, 0u, 0u), 0u, g);
@@ -1388,6 +1388,14 @@ __global__ __launch_bounds__(64) void k_pt_swap(Params p, uint32_t g, int64_t tr
             if (jj < p.ld) {
                 const double2 ta = *reinterpret_cast<const double2*>(xa + jj), tb = *reinterpret_cast<const double2*>(xb + jj);
                 *reinterpret_cast<double2*>(xa + jj) = tb; *reinterpret_cast<double2*>(xb + jj) = ta;
+                if (published) {
+                    // the next generation's jumps are measured from the states astep is handed, i.e. after the swap (Dream.py:371-378,
+                    // core.py:204-215): the published copy that serves as that baseline follows the exchange (the column statistics
+                    // of this generation were taken before it)
+                    double* ca = p.cp_new + (size_t)a * p.ld + jj; double* cb = p.cp_new + (size_t)b * p.ld + jj;
+                    const double2 qa = *reinterpret_cast<const double2*>(ca), qb = *reinterpret_cast<const double2*>(cb);
+                    *reinterpret_cast<double2*>(ca) = qb; *reinterpret_cast<double2*>(cb) = qa;
+                }
             }
         }
         if (lane == 0) {

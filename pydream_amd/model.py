@@ -65,29 +65,26 @@ class HostEvaluator:
 
 
 class Model():
-    """pydream/model.py:8-32"""
+    """The likelihood together with the priors it is sampled under (interface of pydream/model.py:8-32):
+    ``Model(likelihood, sampled_parameters)``, attribute ``sampled_parameters`` (always a list), ``total_logp``."""
 
     def __init__(self, likelihood, sampled_parameters):
         self.likelihood = likelihood
-        if type(sampled_parameters) is list:
-            self.sampled_parameters = sampled_parameters
-        else:
-            self.sampled_parameters = [sampled_parameters]
+        self.sampled_parameters = sampled_parameters if type(sampled_parameters) is list else [sampled_parameters]
 
     def total_logp(self, q0):
-        """(prior_logp, loglike) of one point (model.py:17-32)."""
-        prior_logp = 0
-        var_start = 0
+        """``(log prior, log likelihood)`` of one point.  The point is the concatenation of the parameters' values in
+        order; each parameter's prior sees its own slice, the likelihood the whole vector (model.py:17-32)."""
+        logprior = 0
+        offset = 0
         for param in self.sampled_parameters:
-            var_end = param.dsize + var_start
             try:
-                prior_logp += param.prior(q0[var_start:var_end])
-            except IndexError:
-                # raised if q0 is a single scalar
-                prior_logp += param.prior(q0)
-            var_start += param.dsize
-        loglike = self.likelihood(q0)
-        return prior_logp, loglike
+                piece = q0[offset:offset + param.dsize]
+            except IndexError:          # q0 is a bare scalar (one parameter of one dimension)
+                piece = q0
+            logprior += param.prior(piece)
+            offset += param.dsize
+        return logprior, self.likelihood(q0)
 
     # ---- batched host evaluation used by the engine's host-callback path ----
     def device_prior(self):

@@ -1,4 +1,5 @@
-"""Parameter priors -- same interface as pydream/parameters.py (SampledParam, FlatParam).
+"""Parameter priors -- the interface of pydream/parameters.py (SampledParam, FlatParam): ``dsize``, ``interval``,
+``random``, ``prior``.
 
 Additionally each parameter can describe itself to the device (``device_prior``) so that
 ``scipy.stats.norm`` / ``scipy.stats.uniform`` / flat priors are evaluated inside the HIP kernels
@@ -8,36 +9,31 @@ import numpy as np
 
 
 class SampledParam():
-    """A SciPy-based parameter prior class (pydream/parameters.py:6-47).
+    """A prior given by a frozen SciPy distribution (interface of pydream/parameters.py:6-47).
 
-    Parameters
-    ----------
-    scipy_distribution: SciPy continuous random variable class
-        A SciPy statistical distribution (i.e. scipy.stats.norm)
-    args, kwargs:
-        Arguments for the SciPy distribution
-    """
+    ``SampledParam(scipy.stats.norm, loc=..., scale=...)``: the first argument is the SciPy continuous distribution
+    class, everything after it is handed to that class.  The dimension of the parameter (``dsize``) is the size of
+    one draw from the distribution."""
 
     def __init__(self, scipy_distribution, *args, **kwargs):
         self.dist = scipy_distribution(*args, **kwargs)
-        self.dsize = self.random().size
+        self.dsize = np.size(self.random())
 
     def interval(self, alpha=1):
-        """Return the interval for a given alpha value (parameters.py:23-26)."""
+        """Central interval holding a fraction ``alpha`` of the prior mass; ``alpha = 1`` gives the support, which is
+        what Dream uses as hard boundaries (parameters.py:23-26, Dream.py:86-105)."""
         return self.dist.interval(alpha)
 
     def random(self, reseed=False):
-        """Return a random value drawn from this prior (parameters.py:28-35)."""
-        if reseed:
-            random_seed = np.random.RandomState()
-        else:
-            random_seed = None
-        return self.dist.rvs(random_state=random_seed)
+        """One draw from the prior.  ``reseed=True`` draws from a freshly seeded generator instead of numpy's
+        global one (parameters.py:28-35: forked workers would otherwise all produce the same start)."""
+        state = np.random.RandomState() if reseed else None
+        return self.dist.rvs(random_state=state)
 
     def prior(self, q0):
-        """Return the prior log probability given a point (parameters.py:37-47)."""
-        logp = np.sum(self.dist.logpdf(q0))
-        return logp
+        """Log prior density of the point ``q0``: the log pdf summed over the parameter's dimensions
+        (parameters.py:37-47)."""
+        return np.sum(self.dist.logpdf(q0))
 
     def device_prior(self):
         """(kind[d], a[d], b[d]) for dz_set_prior, or None if this distribution has no device form.
@@ -56,25 +52,18 @@ class SampledParam():
 
 
 class FlatParam(SampledParam):
-    """A Flat parameter class (returns 0 at all locations) (pydream/parameters.py:49-70).
-
-    Parameters
-    ----------
-    test_value: array
-        Representative value for the parameter.  Used to infer the parameter dimension.
-    """
+    """An improper flat prior: log density 0 everywhere, unbounded support (interface of
+    pydream/parameters.py:49-70).  ``test_value`` is any representative value; only its size is used."""
 
     def __init__(self, test_value):
-        self.dsize = np.asarray(test_value).size
+        self.dsize = np.size(test_value)
 
     def prior(self, q0):
         return 0
 
     def interval(self, alpha=1):
-        """Return the interval for a given alpha value."""
-        lower = [-np.inf] * self.dsize
-        upper = [np.inf] * self.dsize
-        return [lower, upper]
+        """(-inf, +inf) in every dimension, whatever ``alpha``."""
+        return [[-np.inf] * self.dsize, [np.inf] * self.dsize]
 
     def device_prior(self):
         return np.zeros(self.dsize, dtype=np.int32), np.zeros(self.dsize), np.ones(self.dsize)

@@ -84,60 +84,73 @@ static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint64_t d2u(double f) { uint64_t u; memcpy(&u, &f, 8); return u; }
 static inline double u2d(uint64_t u) { double f; memcpy(&f, &u, 8); return f; }
 
-/* Two independent standard normals in binary32 from two words: Box-Muller (z0 = r cos, z1 = r sin), with
- * the polynomial log / sin,cos(2 pi u) of DESIGN.md "Elementary functions". */
+/* Two independent standard normals in binary32 from two words (contract v2, DESIGN.md "Random contract"):
+ * Box-Muller in a form made of +, *, fma, one correctly rounded sqrt and integer bit operations only.
+ *   radius  u = n 2^-24 with n = (w1 >> 8) | 1, an odd integer in [1, 2^24): with n = 2^k m, m in [sqrt(1/2), sqrt 2),
+ *           t = -ln u = (24 - k) ln2 - ln m;  ln m = f g(f), f = m - 1, g a degree-8 polynomial (|error| < 2e-8; no
+ *           cancellation as u -> 1, where k = 24);
+ *           r = sqrt(t) (so that r sqrt2 cos = sqrt(-2 ln u) cos);  |z| <= sqrt(2 * 24 ln 2) = 5.77
+ *   angle   theta = pi/4 + phi, phi = (pi/2) y, y = 1.fraction(w2 >> 9) - 1.5 in [-1/2, 1/2):
+ *           sqrt2 cos theta = cos phi - sin phi, sqrt2 sin theta = cos phi + sin phi (polynomials on |phi| <= pi/4);
+ *           the quadrant comes from two independent sign bits (bit 0 of w2 for the cosine branch, bit 0 of w1 for the sine
+ *           branch), which makes the angle uniform on the whole circle.
+ * z0 = +-r (cos phi - sin phi), z1 = +-r (cos phi + sin phi). */
 HOT void orc_normal32_pair(uint32_t w1, uint32_t w2, float* z0, float* z1)
 {
-    float u1 = ((float)(w1 >> 9) + 0.5f) * 1.1920928955078125e-07f; /* 2^-23 */
-    float u2 = ((float)(w2 >> 9) + 0.5f) * 1.1920928955078125e-07f;
-    /* log(u1), u1 in (0,1) */
-    uint32_t b = f2u(u1);
-    int e = (int)(b >> 23) - 127;
-    float m = u2f((b & 0x007fffffu) | 0x3f800000u);
-    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
-    float f = m - 1.0f;
-    float s = f / (2.0f + f);
-    float z = s * s;
-    float p = 1.0f / 11.0f;
-    p = fmaf(p, z, 1.0f / 9.0f);
-    p = fmaf(p, z, 1.0f / 7.0f);
-    p = fmaf(p, z, 1.0f / 5.0f);
-    p = fmaf(p, z, 1.0f / 3.0f);
-    float t = 2.0f * s;
-    float lm = fmaf(t * z, p, t);
-    float ef = (float)e;
-    float lg = fmaf(ef, 0.693145751953125f, fmaf(ef, 1.42860682030941723e-06f, lm));
-    float rad = sqrtf(-2.0f * lg);
-    /* cos, sin(2 pi u2) by octants: angle = (pi/4)(o + r) */
-    float t8 = u2 * 8.0f;
-    float fo = floorf(t8);
-    int o = (int)fo;
-    float r = t8 - fo;
-    if (o & 1) r = 1.0f - r;
-    float y = r * 0.785398163397448309616f;
-    float y2 = y * y;
-    float sp = 1.0f / 362880.0f;
-    sp = fmaf(sp, y2, -1.0f / 5040.0f);
-    sp = fmaf(sp, y2, 1.0f / 120.0f);
-    sp = fmaf(sp, y2, -1.0f / 6.0f);
-    float sn = fmaf(y * y2, sp, y);
-    float cp = -1.0f / 3628800.0f;
-    cp = fmaf(cp, y2, 1.0f / 40320.0f);
-    cp = fmaf(cp, y2, -1.0f / 720.0f);
-    cp = fmaf(cp, y2, 1.0f / 24.0f);
+    const uint32_t n = (w1 >> 8) | 1u;
+    const float nf = (float)n;                                      /* exact: 24 bits */
+    const uint32_t ix = f2u(nf) + 0x004afb0du;                      /* + (bits(1) - bits(sqrt(1/2))): exponent field = that of n / sqrt(1/2) */
+    const float Ef = (float)(151 - (int)(ix >> 23));                /* 24 - k */
+    const float f = u2f((ix & 0x007fffffu) + 0x3f3504f3u) - 1.0f;   /* m - 1, m in [sqrt(1/2), sqrt 2); exact */
+    float g = 0.08743945509195328f;
+    g = fmaf(g, f, -0.14377330243587494f);
+    g = fmaf(g, f, 0.14949095249176025f);
+    g = fmaf(g, f, -0.16560696065425873f);
+    g = fmaf(g, f, 0.19956977665424347f);
+    g = fmaf(g, f, -0.2500215470790863f);
+    g = fmaf(g, f, 0.3333418369293213f);
+    g = fmaf(g, f, -0.49999988079071045f);
+    g = fmaf(g, f, 1.0f);
+    const float t = fmaf(-f, g, Ef * 0.693147182464599609375f);
+    int32_t tb = (int32_t)f2u(t);
+    if (tb < 0) tb = 0;                                             /* a rounding-level negative becomes +0 */
+    const float rad = sqrtf(u2f((uint32_t)tb));                     /* IEEE, correctly rounded */
+    const float y = u2f(0x3f800000u | (w2 >> 9)) - 1.5f;            /* exact */
+    const float ph = y * 1.57079637050628662109375f;
+    const float y2 = ph * ph;
+    float sp = -0.00019598381186369807f;
+    sp = fmaf(sp, y2, 0.008332823403179646f);
+    sp = fmaf(sp, y2, -0.1666666567325592f);
+    const float sn = fmaf(ph * y2, sp, ph);
+    float cp = 2.447330734867137e-05f;
+    cp = fmaf(cp, y2, -0.0013887685490772128f);
+    cp = fmaf(cp, y2, 0.041666653007268906f);
     cp = fmaf(cp, y2, -0.5f);
-    float cs = fmaf(y2, cp, 1.0f);
-    const int swap = ((o + 1) >> 1) & 1;          /* octants 1,2,5,6: cos <-> sin of the reduced angle */
-    float c = swap ? sn : cs;
-    float sv = swap ? cs : sn;
-    if (((o + 2) >> 2) & 1) c = -c;               /* cos < 0 in octants 2..5 */
-    if ((o >> 2) & 1) sv = -sv;                   /* sin < 0 in octants 4..7 */
-    *z0 = rad * c; *z1 = rad * sv;
+    const float cs = fmaf(cp, y2, 1.0f);
+    const float r0 = u2f(f2u(rad) | (w2 << 31)), r1 = u2f(f2u(rad) | (w1 << 31));
+    *z0 = r0 * (cs - sn); *z1 = r1 * (cs + sn);
+}
+/* npairs Box-Muller pairs from consecutive Philox counters (words 2 and 3, as the DIM stream uses them): for the
+ * statistical tests of the generator */
+void orc_normal32_fill(uint64_t seed, int64_t npairs, float* out)
+{
+    for (int64_t i = 0; i < npairs; ++i) {
+        uint32_t w[4];
+        orc_philox4x32_10(seed, (uint32_t)i, (uint32_t)(i >> 32), 7u, 11u, w);
+        orc_normal32_pair(w[2], w[3], out + 2 * i, out + 2 * i + 1);
+    }
 }
 float orc_normal32(uint32_t w1, uint32_t w2) { float a, b; orc_normal32_pair(w1, w2, &a, &b); return a; }
 float orc_normal32_sin(uint32_t w1, uint32_t w2) { float a, b; orc_normal32_pair(w1, w2, &a, &b); return b; }
 /* 16-bit uniform in (0,1): (h + 1/2) 2^-16 */
 double orc_u16(uint32_t h) { return ((double)(h & 0xffffu) + 0.5) * (1.0 / 65536.0); }
+/* np.random.uniform(low, high) (Dream.py:696) from a 16-bit draw h: low + (high - low) (h + 1/2) 2^-16 evaluated as ONE
+ * fused multiply-add, h c1 + c0 with c1 = (high - low) 2^-16 and c0 = low + (high - low) 2^-17 (contract v2) */
+double orc_uniform16(uint32_t h, double low, double high)
+{
+    const double c1 = (high - low) * (1.0 / 65536.0), c0 = low + (high - low) * (1.0 / 131072.0);
+    return fma((double)(h & 0xffffu), c1, c0);
+}
 
 /* ------------------------------------------------------------------ */
 /* Elementary functions (binary64), DESIGN.md "Elementary functions"   */
@@ -444,9 +457,10 @@ int64_t orc_generation(orc_engine* e) { return e->gen; }
  * MVN: examples/ndim_gaussian/dream_ex_ndim_gaussian.py:49-52
  *      logp = log_F - .5 * sum(x * dot(invC, x));  kind 0 takes invC itself,
  *      kind 1 an upper-triangular U with invC = U^T U (Q = |U v|^2).
- *      Order: y_r = sum_c M[r][c] v_c ascending c (fma chain); Q = q_0 + q_1 + ... over row
- *      tiles of 16 in ascending order, q_t = xor butterfly (8,4,2,1) of the 16 products y_r s_r;
- *      s = v (dense) or y (triangular).
+ *      Order (contract v2): y_r = sum_c M[r][c] v_c ascending c (fma chain); Q = q_0 + q_1 + ... over row
+ *      tiles of 16 in ascending order; inside tile t, with r = 16 t + kq + 4 e: four partial sums
+ *      s_kq = fma chain over e = 0..3 of y_r s_r, then q_t = (s_0 + s_2) + (s_1 + s_3) -- the xor butterfly
+ *      (2, 1) over kq.  s = v (dense) or y (triangular).  Rows r >= d contribute y_r s_r = 0.
  * Mixture: examples/mixturemodel/mixturemodel.py:37-48; the squared distances are
  *      summed in the lane/butterfly order of the reduction contract. */
 HOT double orc_loglike(orc_engine* e, const double* x)
@@ -458,23 +472,21 @@ HOT double orc_loglike(orc_engine* e, const double* x)
         for (int j = 0; j < d; ++j) v[j] = x[j] - e->mu[j];
         double Q = 0.0;
         for (int t0 = 0; t0 < d; t0 += 16) {                       /* row tiles of 16, ascending */
-            double acc[16];
-            for (int i = 0; i < 16; ++i) {
-                const int r = t0 + i;
-                acc[i] = 0.0;
-                if (r < d) {
-                    const double* row = e->Mx + (size_t)r * d;
-                    double y = 0.0;
-                    for (int c = tri ? r : 0; c < d; ++c) y = fma(row[c], v[c], y);
-                    acc[i] = y * (tri ? y : v[r]);
+            double sk[4];
+            for (int kq = 0; kq < 4; ++kq) {
+                double sacc = 0.0;
+                for (int el = 0; el < 4; ++el) {
+                    const int r = t0 + kq + 4 * el;
+                    if (r < d) {
+                        const double* row = e->Mx + (size_t)r * d;
+                        double y = 0.0;
+                        for (int c = tri ? r : 0; c < d; ++c) y = fma(row[c], v[c], y);
+                        sacc = fma(y, tri ? y : v[r], sacc);
+                    }
                 }
+                sk[kq] = sacc;
             }
-            for (int off = 8; off >= 1; off >>= 1) {               /* xor butterfly over the tile's 16 products */
-                double t[16];
-                for (int i = 0; i < 16; ++i) t[i] = acc[i] + acc[i ^ off];
-                memcpy(acc, t, sizeof t);
-            }
-            Q = Q + acc[0];
+            Q = Q + ((sk[0] + sk[2]) + (sk[1] + sk[3]));
         }
         return e->logF - 0.5 * Q;
     }
@@ -584,7 +596,7 @@ static int gen_points(orc_engine* e, uint32_t gc, uint32_t g, int phase, int n, 
                 orc_philox4x32_10(seed, (uint32_t)(j >> 1), s_dim, gc, g, w);
                 orc_normal32_pair(w[2], w[3], &z0, &z1);
                 U[j] = orc_u16(w[0] >> (16 * h));
-                e1[j] = (-e->c.lamb + (e->c.lamb - (-e->c.lamb)) * orc_u16(w[1] >> (16 * h))) + 1.0;      /* :696-697 */
+                e1[j] = orc_uniform16(w[1] >> (16 * h), -e->c.lamb, e->c.lamb) + 1.0;                     /* :696-697 */
                 zt[j] = e->c.zeta * (double)(h ? z1 : z0);                                     /* :694 */
                 if (U[j] < CR) dprime++;                                                       /* :704, :709 */
             }

@@ -103,7 +103,9 @@ double   orc_u53(uint32_t hi, uint32_t lo);
 double   orc_u32(uint32_t w);
 float    orc_normal32(uint32_t w1, uint32_t w2);      /* cosine branch of the Box-Muller pair */
 float    orc_normal32_sin(uint32_t w1, uint32_t w2);  /* sine branch */
+void     orc_normal32_fill(uint64_t seed, int64_t npairs, float* out /* [2 npairs] */);
 double   orc_u16(uint32_t h);
+double   orc_uniform16(uint32_t h, double low, double high);   /* uniform(low, high) from a 16-bit draw, one fma */
 double   orc_exp(double x);
 double   orc_log(double x);
 uint32_t orc_stream_id(int kind, int tr, int phase, int round);

@@ -67,6 +67,8 @@ def lib():
         L.orc_normal32_sin.argtypes = [C.c_uint32, C.c_uint32]
         L.orc_u16.restype = C.c_double
         L.orc_u16.argtypes = [C.c_uint32]
+        L.orc_uniform16.restype = C.c_double
+        L.orc_uniform16.argtypes = [C.c_uint32, C.c_double, C.c_double]
         L.orc_exp.restype = C.c_double
         L.orc_exp.argtypes = [C.c_double]
         L.orc_log.restype = C.c_double
@@ -125,6 +127,10 @@ def normal32_sin(w1, w2):
 
 def u16(h):
     return float(lib().orc_u16(int(h) & 0xffff))
+
+
+def uniform16(h, low, high):
+    return float(lib().orc_uniform16(int(h) & 0xffff, float(low), float(high)))
 
 
 def threads():

@@ -17,9 +17,6 @@ struct u32x4 { uint32_t x, y, z, w; };
 // Philox4x32-10, key = 64-bit seed, counter = (idx, stream, chain, generation).
 DZ_DEV u32x4 philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3)
 {
-#ifdef DZ_EXP_NOPHILOX   // timing experiment only (tools/variants.sh): breaks the random contract
-    return u32x4{c0 * 0x9E3779B9u ^ k0, c1 * 0xBB67AE85u ^ c2, c2 * 0xD2511F53u ^ c3, (c3 + c0) * 0xCD9E8D57u ^ k1};
-#endif
     // The round keys are recomputed by every call (20 scalar adds).  Left to itself the compiler hoists the whole key
     // schedule out of the callers' loops into 20 SGPRs, which then spill to VGPR lanes: ~40 v_readlane per try in k_propose.
     asm volatile("" : "+s"(k0), "+s"(k1));
@@ -47,55 +44,57 @@ DZ_DEV double u32d(uint32_t w) { return ((double)w + 0.5) * (1.0 / 4294967296.0)
 
 DZ_DEV double u16d(uint32_t h) { return ((double)(h & 0xffffu) + 0.5) * (1.0 / 65536.0); }
 
-// two independent standard normals (binary32): Box-Muller on two 23-bit uniforms, z0 = r cos, z1 = r sin
+// np.random.uniform(low, high) (Dream.py:696) from a 16-bit draw h: low + (high - low)(h + 1/2) 2^-16 as ONE fused multiply-add
+// h c1 + c0, c1 = (high - low) 2^-16, c0 = low + (high - low) 2^-17 (both made once on the host: Params::ec1, ec0)
+DZ_DEV double uniform16(uint32_t h, double c1, double c0) { return fma((double)(h & 0xffffu), c1, c0); }
+
+// Two independent standard normals (binary32), contract v2 (DESIGN.md "Random contract"; restated in oracle/dreamzs_oracle.c):
+// Box-Muller made of +, *, fma, one correctly rounded square root and integer bit operations.
+//   radius: u = n 2^-24, n = (w1 >> 8) | 1 odd in [1, 2^24); n = 2^k m with m in [sqrt(1/2), sqrt 2): t = -ln u = (24 - k) ln2 - ln m,
+//           ln m = f g(f), f = m - 1; r = sqrt(t)
+//   angle:  theta = pi/4 + phi, phi = (pi/2) y, y in [-1/2, 1/2) from the top 23 bits of w2; sqrt2 cos theta = cos phi - sin phi,
+//           sqrt2 sin theta = cos phi + sin phi; the quadrant comes from two sign bits (bit 0 of w2 / of w1)
 DZ_DEV void normal32_pair(uint32_t w1, uint32_t w2, float& z0, float& z1)
 {
-#ifdef DZ_EXP_NOBM       // timing experiment only
-    z0 = (float)(int)w1 * 4.6e-10f; z1 = (float)(int)w2 * 4.6e-10f; return;
-#endif
-    const float u1 = ((float)(w1 >> 9) + 0.5f) * 1.1920928955078125e-07f;
-    const float u2 = ((float)(w2 >> 9) + 0.5f) * 1.1920928955078125e-07f;
-    const uint32_t b = __float_as_uint(u1);
-    int e = (int)(b >> 23) - 127;
-    float m = __uint_as_float((b & 0x007fffffu) | 0x3f800000u);
-    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
-    const float f = m - 1.0f;
-    const float s = f / (2.0f + f);
-    const float z = s * s;
-    float p = 1.0f / 11.0f;
-    p = fmaf(p, z, 1.0f / 9.0f);
-    p = fmaf(p, z, 1.0f / 7.0f);
-    p = fmaf(p, z, 1.0f / 5.0f);
-    p = fmaf(p, z, 1.0f / 3.0f);
-    const float t = 2.0f * s;
-    const float lm = fmaf(t * z, p, t);
-    const float ef = (float)e;
-    const float lg = fmaf(ef, 0.693145751953125f, fmaf(ef, 1.42860682030941723e-06f, lm));
-    const float rad = sqrtf(-2.0f * lg);
-    const float t8 = u2 * 8.0f;
-    const float fo = floorf(t8);
-    const int o = (int)fo;
-    float r = t8 - fo;
-    if (o & 1) r = 1.0f - r;
-    const float y = r * 0.785398163397448309616f;
-    const float y2 = y * y;
-    float sp = 1.0f / 362880.0f;
-    sp = fmaf(sp, y2, -1.0f / 5040.0f);
-    sp = fmaf(sp, y2, 1.0f / 120.0f);
-    sp = fmaf(sp, y2, -1.0f / 6.0f);
-    const float sn = fmaf(y * y2, sp, y);
-    float cp = -1.0f / 3628800.0f;
-    cp = fmaf(cp, y2, 1.0f / 40320.0f);
-    cp = fmaf(cp, y2, -1.0f / 720.0f);
-    cp = fmaf(cp, y2, 1.0f / 24.0f);
+    const uint32_t n = (w1 >> 8) | 1u;
+    const float nf = (float)n;                                                  // exact (24 bits)
+    const uint32_t ix = __float_as_uint(nf) + 0x004afb0du;                      // exponent field = that of n / sqrt(1/2)
+    const float Ef = (float)(151 - (int)(ix >> 23));                            // 24 - k
+    const float f = __uint_as_float((ix & 0x007fffffu) + 0x3f3504f3u) - 1.0f;
+    float g = 0.08743945509195328f;
+    g = fmaf(g, f, -0.14377330243587494f);
+    g = fmaf(g, f, 0.14949095249176025f);
+    g = fmaf(g, f, -0.16560696065425873f);
+    g = fmaf(g, f, 0.19956977665424347f);
+    g = fmaf(g, f, -0.2500215470790863f);
+    g = fmaf(g, f, 0.3333418369293213f);
+    g = fmaf(g, f, -0.49999988079071045f);
+    g = fmaf(g, f, 1.0f);
+    const float t = fmaf(-f, g, Ef * 0.693147182464599609375f);
+    const float tc = __uint_as_float((uint32_t)max((int)__float_as_uint(t), 0));  // a rounding-level negative becomes +0
+    // correctly rounded sqrt(tc), tc = 0 or in [2^-24, 17): the hardware approximation (within 1 ulp) and the two-sided correction
+    // the compiler's own IEEE expansion uses, without that expansion's scaling of subnormal inputs and its inf / zero cases
+    float r = __builtin_amdgcn_sqrtf(tc);
+    {
+        const float rdn = __uint_as_float(__float_as_uint(r) - 1u), rup = __uint_as_float(__float_as_uint(r) + 1u);
+        const float edn = fmaf(-rdn, r, tc), eup = fmaf(-rup, r, tc);
+        r = edn <= 0.0f ? rdn : r;
+        r = eup > 0.0f ? rup : r;
+    }
+    const float y = __uint_as_float(0x3f800000u | (w2 >> 9)) - 1.5f;            // exact
+    const float ph = y * 1.57079637050628662109375f;
+    const float y2 = ph * ph;
+    float sp = -0.00019598381186369807f;
+    sp = fmaf(sp, y2, 0.008332823403179646f);
+    sp = fmaf(sp, y2, -0.1666666567325592f);
+    const float sn = fmaf(ph * y2, sp, ph);
+    float cp = 2.447330734867137e-05f;
+    cp = fmaf(cp, y2, -0.0013887685490772128f);
+    cp = fmaf(cp, y2, 0.041666653007268906f);
     cp = fmaf(cp, y2, -0.5f);
-    const float cs = fmaf(y2, cp, 1.0f);
-    const bool swap = (((o + 1) >> 1) & 1) != 0;
-    float c = swap ? sn : cs;
-    float sv = swap ? cs : sn;
-    if (((o + 2) >> 2) & 1) c = -c;
-    if ((o >> 2) & 1) sv = -sv;
-    z0 = rad * c; z1 = rad * sv;
+    const float cs = fmaf(cp, y2, 1.0f);
+    const float r0 = __uint_as_float(__float_as_uint(r) | (w2 << 31)), r1 = __uint_as_float(__float_as_uint(r) | (w1 << 31));
+    z0 = r0 * (cs - sn); z1 = r1 * (cs + sn);
 }
 
 // 16-byte load through the GLOBAL address space.  A pointer read out of a Params held in memory is generic to the compiler,

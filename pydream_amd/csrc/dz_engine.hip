@@ -627,6 +627,11 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     p.burnin = cfg->crossover_burnin; p.adapt_cr = cfg->adapt_crossover; p.adapt_g = cfg->adapt_gamma; p.hard = 0;   // set by dz_set_bounds
     p.k0 = (uint32_t)cfg->seed; p.k1 = (uint32_t)(cfg->seed >> 32);
     p.lamb = cfg->lamb; p.zeta = cfg->zeta; p.snooker = cfg->snooker; p.pgu = cfg->p_gamma_unity; p.T = cfg->temperature;
+    {   // contract constants made once (dz_device.h uniform16; dz_kernels.h crossover_threshold)
+        const double low = -cfg->lamb, high = cfg->lamb;
+        p.ec1 = (high - low) * (1.0 / 65536.0); p.ec0 = low + (high - low) * (1.0 / 131072.0);
+        for (int m = 0; m < 32; ++m) p.crthr[m] = m < cfg->ncr ? dz::crossover_threshold((double)(m + 1) / (double)cfg->ncr) : 0u;
+    }
     const int chunks = (p.ld + 127) / 128;
     e->nch = chunks <= 1 ? 1 : chunks <= 2 ? 2 : chunks <= 4 ? 4 : 8;
     e->adapt = cfg->adapt_crossover || cfg->adapt_gamma;
@@ -660,7 +665,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     rc |= ealloc(e, &e->d_draws[0], nl * (size_t)p.nslots); rc |= ealloc(e, &e->d_draws[1], nl * (size_t)p.nslots);
     rc |= ealloc(e, &e->d_ctl[0], nl); rc |= ealloc(e, &e->d_ctl[1], nl);
     rc |= ealloc(e, &p.sel, nl);
-#ifdef DZ_EXP_STAMPS
+#ifdef DZ_EXPERIMENTS
     { void* hp = nullptr; if (hipHostMalloc(&hp, (size_t)4 * nl * 16 * 8, hipHostMallocDefault) == hipSuccess) { memset(hp, 0, (size_t)4 * nl * 16 * 8); p.dbg = (unsigned long long*)hp; } }
 #endif
     rc |= ealloc(e, &e->d_params, 1);
@@ -701,7 +706,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
 
 int dz_destroy(dz_engine* e)
 {
-#ifdef DZ_EXP_STAMPS
+#ifdef DZ_EXPERIMENTS
     if (e && e->p.dbg) {
         hipDeviceSynchronize();
         if (FILE* f = fopen("gpurun_out/stamps.bin", "wb")) { fwrite(e->p.dbg, 8, (size_t)4 * e->p.nl * 16, f); fclose(f); }

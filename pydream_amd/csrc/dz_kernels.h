@@ -45,16 +45,17 @@ struct Params {
     const uint4* draws; uint4* draws_next; int nslots, npt;
     const ChainCtl* ctl; ChainCtl* ctl_next;
     int* sel;      // [nl] selected try | anyfinite<<8, written by the reference-phase proposal wave
-#ifdef DZ_EXP_STAMPS   // timing experiment only: per-wave cycle stamps of the latest proposal launches
-    unsigned long long* dbg;
-#endif
+    double ec1, ec0;          // e ~ U(-lamb, lamb) from a 16-bit draw h as fma(h, ec1, ec0) (dz_device.h uniform16)
+    uint32_t crthr[32];       // crossover_threshold(CR_values[m]), m < ncr: `U_j < CR` as an integer test on the 16-bit draw
+    unsigned long long* dbg;  // cycle-stamp buffer of instrumented builds (-DDZ_EXPERIMENTS, dz_experiments.h); null otherwise
 };
-#ifdef DZ_EXP_STAMPS
-#define DZ_STAMP(p_, phase_, c_, i_) do { if ((threadIdx.x & 63) == 0) (p_).dbg[((size_t)(phase_) * (p_).nl + (c_)) * 16 + (i_)] = __builtin_readcyclecounter(); } while (0)
-#define DZ_LSTAMP(p_, w_, i_) do { if ((threadIdx.x & 63) == 0) (p_).dbg[((size_t)2 * (p_).nl + (w_)) * 16 + (i_)] = __builtin_readcyclecounter(); } while (0)
+// per-phase cycle stamps: defined by dz_experiments.h in instrumented builds only (tools/variants.sh), no-ops in the product
+#ifdef DZ_EXPERIMENTS
+#include "dz_experiments.h"
 #else
 #define DZ_STAMP(p_, phase_, c_, i_) do { } while (0)
 #define DZ_LSTAMP(p_, w_, i_) do { } while (0)
+#define DZ_MSTAMP(i_) do { } while (0)
 #endif
 
 // offset of k-row r in the packed triangular layout: row block b = r/16 has 16*(b+1) columns
@@ -169,11 +170,11 @@ DZ_DEV Ctrl ctrl_from(const Params& p, const uint4* dr, uint32_t gc, uint32_t g)
 // ------------------------------------------------------------------------------------------
 // number of 16-bit values h with (h + 1/2) 2^-16 < CR, so that `U_j < CR` (:704, :723) is the integer test
 // h < crossover_threshold(CR) -- exactly the same predicate as the double comparison
-DZ_DEV uint64_t crossover_threshold(double CR)
-{
+__host__ __device__ inline uint32_t crossover_threshold(double CR)
+{   // evaluated once per crossover value on the host (Params::crthr)
     const double t = CR * 65536.0 - 0.5;               // exact
     const double c = ceil(t);
-    return c <= 0.0 ? 0ull : (uint64_t)c;
+    return c <= 0.0 ? 0u : (uint32_t)c;
 }
 
 template <int NCH>
@@ -311,13 +312,14 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
 {   // wpre: the DIM draw of chunk 0, computed by the caller one try ahead (software pipelining, NCH == 1)
     const int d = p.d, ld = p.ld;
     const uint32_t gc = (uint32_t)(p.off + c);
-    const uint64_t thr = crossover_threshold((double)(cr_idx + 1) / (double)p.ncr);   // CR = CR_values[m], :146
+    const uint32_t thr = p.crthr[__builtin_amdgcn_readfirstlane(cr_idx)];             // CR = CR_values[m], :146 (the decision is wave-uniform)
     const uint32_t s_dim = stream_id(K_DIM, (uint32_t)i, (uint32_t)phase),
                    s_bnd = stream_id(K_BND, (uint32_t)i, (uint32_t)phase);
     double pr[NCH][2];
     double slogp = 0.0;
     if (!snk) {
         bool keep[NCH][2]; double e1[NCH][2], zt[NCH][2];
+        const double ec1 = p.ec1, ec0 = p.ec0;
         int dprime = 0;
 #pragma unroll
         for (int it = 0; it < NCH; ++it) {        // zeta, e, U :694-700 -- one Philox call and one Box-Muller pair per lane
@@ -327,11 +329,11 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
                 const u32x4 w = (NCH == 1 && wpre) ? *wpre : philox(p.k0, p.k1, (uint32_t)(j0 >> 1), s_dim, gc, g);
                 float z0, z1;
                 normal32_pair(w.z, w.w, z0, z1);
-                keep[it][0] = j0 < d && (uint64_t)(w.x & 0xffffu) < thr;     // U_j < CR
-                e1[it][0] = (-p.lamb + (p.lamb - (-p.lamb)) * u16d(w.y)) + 1.0;
+                keep[it][0] = j0 < d && (w.x & 0xffffu) < thr;               // U_j < CR
+                e1[it][0] = uniform16(w.y, ec1, ec0) + 1.0;                  // :696-697
                 zt[it][0] = p.zeta * (double)z0;
-                keep[it][1] = j0 + 1 < d && (uint64_t)(w.x >> 16) < thr;
-                e1[it][1] = (-p.lamb + (p.lamb - (-p.lamb)) * u16d(w.y >> 16)) + 1.0;
+                keep[it][1] = j0 + 1 < d && (w.x >> 16) < thr;
+                e1[it][1] = uniform16(w.y >> 16, ec1, ec0) + 1.0;
                 zt[it][1] = p.zeta * (double)z1;
             }
             dprime += __popcll(__ballot(keep[it][0])) + __popcll(__ballot(keep[it][1]));   // d' :704 / :709
@@ -419,11 +421,7 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
                 }
             }
             double2 o; o.x = (jj < d) ? pr[it][0] : 0.0; o.y = (jj + 1 < d) ? pr[it][1] : 0.0;
-#ifdef DZ_EXP_NOSTORE    // timing experiment only
-            if (AL16) { if (o.x == 1.2345e300) *reinterpret_cast<double2*>(out + jj) = o; }
-#else
             if (AL16) *reinterpret_cast<double2*>(out + jj) = o;
-#endif
             else { if (jj < d) out[jj] = o.x; if (jj + 1 < d) out[jj + 1] = o.y; }     // unpadded, 8-byte aligned row (LDS tile)
         }
     }
@@ -587,15 +585,11 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
 #pragma unroll
             for (int it = 0; it < NCH; ++it) {
                 const int jj = 128 * it + 2 * lane;
-#ifdef DZ_EXP_NOZ        // timing experiment only: no archive gathers
-                if (jj < p.ld) { ra[it] = double2{(double)r0, 1.0}; rb[it] = double2{(double)r1, 2.0}; }
-#else
                 // no lane predicate (it would keep the previous rows alive in the lanes past ld and cost a register copy per row
                 // and try): those lanes re-read the row's last pair, their results are masked where they are used (j < d)
                 const int jc = min(jj, p.ld - 2);
                 ra[it] = gload2(p.Z + (size_t)r0 * p.ld + jc);
                 rb[it] = gload2(p.Z + (size_t)r1 * p.ld + jc);
-#endif
             }
         };
 #pragma unroll
@@ -684,11 +678,7 @@ __global__ __launch_bounds__(NCH >= 4 ? 256 : 1024) void k_propose(Params p, int
     const int c = c0 + wave / split;
     DZ_STAMP(p, phase, c, 0);
     const int per = (n + split - 1) / split;
-#ifdef DZ_EXP_NOTRIES    // timing experiment only: the kernel without its tries
-    const int i0 = 0, i1 = (int)(threadIdx.x >> 12);
-#else
     const int i0 = (wave % split) * per, i1 = min(n, i0 + per);
-#endif
     DrawSrc dsrc; ChainCtl ct;
     double xb[NCH][2];
     double* out; double* sl;
@@ -754,14 +744,32 @@ __global__ __launch_bounds__(64) void k_propose_debug(Params p, int phase, uint3
 // v_mfma_f64_16x16x4_f64 accumulates exactly like an ascending-k fma chain (tools/mfma_f64_layout.hip,
 // measured on gfx950: 0 mismatches in 51200 outputs, 77.6 TFLOP/s), so y[p][r] = sum_c M[r][c] v[p][c]
 // (ascending c) comes out bit-identical to the scalar contract.  One wave = PT tiles of 16 points:
-//   A operand (16 points x 4 cols): lane l supplies v[p0 + l%16][4 ks + l/16]
-//   B operand (4 cols x 16 rows):   lane l supplies Mt[4 ks + l/16][16 t + l%16]   (shared by the PT tiles)
-//   D: lane l, element e holds y[p0 + l/16 + 4 e][16 t + l%16]
-// Q contract: Q = q_0 + q_1 + ... in ascending row tile t, where q_t is the xor butterfly (8,4,2,1) over
-// i = 0..15 of the products y_r * s_r, r = 16 t + i -- exactly the D layout, so the quadratic form never leaves
-// the registers, and row tiles can be produced by different waves.  s = v (dense precision) or y (triangular factor; the k-steps left of
-// a diagonal tile are structural zeros and are skipped).
+//   A operand (16 rows x 4 cols):   lane l supplies Mt[4 ks + l/16][16 t + l%16]   (shared by the PT tiles)
+//   B operand (4 cols x 16 points): lane l supplies v[p0 + l%16][4 ks + l/16]
+//   D: lane l, element e holds y[point p0 + l%16][row 16 t + l/16 + 4 e]      (the transposed tile: Y^T = M V^T)
+// Q contract (v2): Q = q_0 + q_1 + ... in ascending row tile t; inside a tile the lane adds its four rows' products y_r s_r by an
+// fma chain and the four lane groups are combined by two lane-swap steps (tile_q_tri / tile_q above) -- so the quadratic form never
+// leaves the registers, and row tiles can be produced by different waves.  s = v (dense precision) or y (triangular factor; the
+// k-steps left of a diagonal tile are structural zeros and are skipped).
 typedef double dz_double4 __attribute__((ext_vector_type(4)));
+
+// Row-tile sum q_t of the MVN contract (v2) from one MFMA accumulator in the TRANSPOSED tile layout -- matrix = A operand, points =
+// B operand: lane l holds, for point (l & 15), the rows r = 16 t + (l >> 4) + 4 e, e = 0..3, of y.
+//   s_kq = fma chain over e = 0..3 of y_r s_r (rows r >= d contribute nothing), q_t = (s_0 + s_2) + (s_1 + s_3)
+// i.e. two lane-swap steps (lanes ^32, then ^16); every lane of a point ends with q_t.
+DZ_DEV double tile_q_tri(const dz_double4& acc)     // s = y (triangular factor); rows r >= d have y == +0 exactly: fma(+0, +0, s) == s
+{
+    double s = fma(acc[0], acc[0], 0.0);
+    s = fma(acc[1], acc[1], s); s = fma(acc[2], acc[2], s); s = fma(acc[3], acc[3], s);
+    return swap16_sum(swap32_sum(s));
+}
+DZ_DEV double tile_q(const dz_double4& acc, const double (&sv)[4], int r0, int d)     // general: row r0 + 4 e takes part iff it is < d
+{
+    double s = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s = (r0 + 4 * e < d) ? fma(acc[e], sv[e], s) : s;
+    return swap16_sum(swap32_sum(s));
+}
 
 // ld <= 128: NRT = ld/16 row tiles, everything in registers, k loop fully unrolled
 template <int PT, int NRT, bool TRI>
@@ -796,30 +804,31 @@ __global__ __launch_bounds__(256) void k_logp_mvn_mfma(Params p, const double* _
                 if (!TRI || ks >= 4 * t) {
                     const double b = mrow[16 * t];
 #pragma unroll
-                    for (int u = 0; u < PT; ++u) acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[u][ks], b, acc[u][t], 0, 0, 0);
+                    for (int u = 0; u < PT; ++u) acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, A[u][ks], acc[u][t], 0, 0, 0);
                 }
             }
         }
     }
 #pragma unroll
-    for (int u = 0; u < PT; ++u)
+    for (int u = 0; u < PT; ++u) {
+        const int pt = p0 + 16 * u + pi;
+        const double* xs = pts + (size_t)min(pt, npts - 1) * ld;
+        double q = 0.0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int pt = p0 + 16 * u + kq + 4 * e;
-            const double* xs = pts + (size_t)min(pt, npts - 1) * ld;
-            double q = 0.0;
+        for (int t = 0; t < NRT; ++t) {      // Q = q_0 + q_1 + ... (ascending t)
+            if (TRI) q = q + tile_q_tri(acc[u][t]);      // (Mt is zero padded: rows r >= d are exact zeros)
+            else {
+                double sv[4];
 #pragma unroll
-            for (int t = 0; t < NRT; ++t) {      // Q = q_0 + q_1 + ... (ascending t), q_t = butterfly16 of the tile's products
-                const int r = 16 * t + pi;
-                const double y = acc[u][t][e];
-                const double sv = TRI ? y : xs[r] - p.mu[r];
-                q = q + bfly16(r < d ? y * sv : 0.0);
-            }
-            if (pi == 0 && pt < npts) {
-                like_out[pt] = nan_to_ninf(p.logF - 0.5 * q);
-                if (!p.have_prior) prior_out[pt] = 0.0;
+                for (int e = 0; e < 4; ++e) { const int r = 16 * t + kq + 4 * e; sv[e] = xs[r] - p.mu[r]; }
+                q = q + tile_q(acc[u][t], sv, 16 * t + kq, d);
             }
         }
+        if (kq == 0 && pt < npts) {
+            like_out[pt] = nan_to_ninf(p.logF - 0.5 * q);
+            if (!p.have_prior) prior_out[pt] = 0.0;
+        }
+    }
 }
 
 // Persistent variant (ld <= 128): operands through LDS.
@@ -928,22 +937,24 @@ __global__ __launch_bounds__(512) void k_logp_mvn_lds(Params p, const double* __
                 const double* mrow = TRI ? Ms + tri_row_offset(4 * ks) + kq * (16 * (ks / 4 + 1)) + pi : mbase + (size_t)(4 * ks) * LD;
 #pragma unroll
                 for (int t = 0; t < NRT; ++t)
-                    if (!TRI || ks >= 4 * t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ks], mrow[16 * t], acc[t], 0, 0, 0);
+                    if (!TRI || ks >= 4 * t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(mrow[16 * t], A[ks], acc[t], 0, 0, 0);
             }
         }
         DZ_LSTAMP(p, blockIdx.x * nwv + wv, 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int pt = p0 + kq + 4 * e;
+        {
+            const int pt = p0 + pi;
             double q = 0.0;
 #pragma unroll
-            for (int t = 0; t < NRT; ++t) {      // Q = q_0 + q_1 + ... (ascending t), q_t = butterfly16 of the tile's products
-                const int r = 16 * t + pi;
-                const double y = acc[t][e];
-                const double sv = TRI ? y : Vt[(kq + 4 * e) * LDT + r];
-                q = q + bfly16(r < d ? y * sv : 0.0);
+            for (int t = 0; t < NRT; ++t) {      // Q = q_0 + q_1 + ... (ascending t)
+                if (TRI) q = q + tile_q_tri(acc[t]);     // (the packed triangle is zero padded: rows r >= d are exact zeros)
+                else {
+                    double sv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sv[e] = Vt[pi * LDT + 16 * t + kq + 4 * e];
+                    q = q + tile_q(acc[t], sv, 16 * t + kq, d);
+                }
             }
-            if (pi == 0 && pt < npts) {
+            if (kq == 0 && pt < npts) {
                 like_out[pt] = nan_to_ninf(p.logF - 0.5 * q);
                 if (!p.have_prior) prior_out[pt] = 0.0;
             }
@@ -965,7 +976,7 @@ __global__ __launch_bounds__(256) void k_logp_mvn_mfma_big(Params p, const doubl
     const int ld = p.ld, d = p.d;
     const double* xrow = pts + (size_t)min(p0 + pi, npts - 1) * ld;
     const int KS = (d + 3) >> 2, NRT = (d + 15) >> 4;
-    double q[4] = {0.0, 0.0, 0.0, 0.0};
+    double Q = 0.0;
     for (int rt0 = 0; rt0 < NRT; rt0 += RTC) {
         dz_double4 acc[RTC];
 #pragma unroll
@@ -989,24 +1000,22 @@ __global__ __launch_bounds__(256) void k_logp_mvn_mfma_big(Params p, const doubl
 #pragma unroll
             for (int t = 0; t < RTC; ++t) {
                 const int rt = rt0 + t;
-                if (rt < NRT && (!p.tri || ks >= 4 * rt)) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t], acc[t], 0, 0, 0);
+                if (rt < NRT && (!p.tri || ks >= 4 * rt)) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[t], a, acc[t], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const double* xs = pts + (size_t)min(p0 + kq + 4 * e, npts - 1) * ld;
+        for (int t = 0; t < RTC; ++t) {
+            if (rt0 + t < NRT) {
+                double sv[4];
 #pragma unroll
-            for (int t = 0; t < RTC; ++t) {
-                const int r = 16 * (rt0 + t) + pi;
-                if (rt0 + t < NRT) { const double y = acc[t][e]; q[e] = q[e] + bfly16(r < d ? y * (p.tri ? y : xs[r] - p.mu[r]) : 0.0); }
+                for (int e = 0; e < 4; ++e) { const int r = 16 * (rt0 + t) + kq + 4 * e; sv[e] = p.tri ? acc[t][e] : xrow[r] - p.mu[r]; }
+                Q = Q + tile_q(acc[t], sv, 16 * (rt0 + t) + kq, d);
             }
         }
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int pt = p0 + kq + 4 * e;
-        const double Q = q[e];
-        if (pi == 0 && pt < npts) {
+    {
+        const int pt = p0 + pi;
+        if (kq == 0 && pt < npts) {
             like_out[pt] = nan_to_ninf(p.logF - 0.5 * Q);
             if (!p.have_prior) prior_out[pt] = 0.0;
         }
@@ -1066,26 +1075,24 @@ __global__ __launch_bounds__(256) void k_logp_mvn_mfma_tiled(Params p, const dou
             const int rt = rt0 + t;
             if (rt < NRT && (!p.tri || ks >= 4 * rt)) {
 #pragma unroll
-                for (int u = 0; u < PT; ++u) acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[t], acc[u][t], 0, 0, 0);
+                for (int u = 0; u < PT; ++u) acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[t], a[u], acc[u][t], 0, 0, 0);
             }
         }
     }
 #pragma unroll
-    for (int u = 0; u < PT; ++u)
+    for (int u = 0; u < PT; ++u) {
+        const int pt = p0 + 16 * u + pi;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int pt = p0 + 16 * u + kq + 4 * e;
-            const double* xs = pts + (size_t)min(pt, npts - 1) * ld;
+        for (int t = 0; t < RTC; ++t) {
+            if (rt0 + t < NRT) {
+                double sv[4];
 #pragma unroll
-            for (int t = 0; t < RTC; ++t) {
-                const int r = 16 * (rt0 + t) + pi;
-                if (rt0 + t < NRT) {
-                    const double y = acc[u][t][e];
-                    const double qv = bfly16(r < d ? y * (p.tri ? y : xs[r] - p.mu[r]) : 0.0);
-                    if (pi == 0 && pt < npts) qpart[(size_t)(rt0 + t) * npts + pt] = qv;          // [row tile][point]: k_q_finish reads it coalesced
-                }
+                for (int e = 0; e < 4; ++e) { const int r = 16 * (rt0 + t) + kq + 4 * e; sv[e] = p.tri ? acc[u][t][e] : xrow[u][r] - p.mu[r]; }
+                const double qv = tile_q(acc[u][t], sv, 16 * (rt0 + t) + kq, d);
+                if (kq == 0 && pt < npts) qpart[(size_t)(rt0 + t) * npts + pt] = qv;          // [row tile][point]: k_q_finish reads it coalesced
             }
         }
+    }
 }
 // Large d, many points: the quadratic form as an LDS-tiled product.  A block of 4 waves owns 64 points x 64 rows; it
 // walks k in chunks of 16, staging the point chunk (transposed to [k][point], mean subtracted) and the matrix chunk
@@ -1182,7 +1189,7 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
             for (int t = 0; t < 2; ++t)
                 if (ks < KS && rt0 + t < NRT && (!p.tri || ks >= 4 * (rt0 + t))) {
 #pragma unroll
-                    for (int u = 0; u < PT; ++u) acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][u], b[q][t], acc[u][t], 0, 0, 0);
+                    for (int u = 0; u < PT; ++u) acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[q][t], a[q][u], acc[u][t], 0, 0, 0);
                 }
         }
     };
@@ -1204,21 +1211,20 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
         __syncthreads();
     }
 #pragma unroll
-    for (int u = 0; u < PT; ++u)
+    for (int u = 0; u < PT; ++u) {
+        const int pt = p0 + 16 * PT * wm + 16 * u + pi;
+        const double* xs = pts + (size_t)min(pt, npts - 1) * ld;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int pt = p0 + 16 * PT * wm + 16 * u + kq + 4 * e;
-            const double* xs = pts + (size_t)min(pt, npts - 1) * ld;
+        for (int t = 0; t < 2; ++t) {
+            if (rt0 + t < NRT) {
+                double sv[4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int r = 16 * (rt0 + t) + pi;
-                if (rt0 + t < NRT) {
-                    const double y = acc[u][t][e];
-                    const double qv = bfly16(r < d ? y * (p.tri ? y : xs[r] - p.mu[r]) : 0.0);
-                    if (pi == 0 && pt < npts) qpart[(size_t)(rt0 + t) * npts + pt] = qv;          // [row tile][point]: k_q_finish reads it coalesced
-                }
+                for (int e = 0; e < 4; ++e) { const int r = 16 * (rt0 + t) + kq + 4 * e; sv[e] = p.tri ? acc[u][t][e] : xs[r] - p.mu[r]; }
+                const double qv = tile_q(acc[u][t], sv, 16 * (rt0 + t) + kq, d);
+                if (kq == 0 && pt < npts) qpart[(size_t)(rt0 + t) * npts + pt] = qv;          // [row tile][point]: k_q_finish reads it coalesced
             }
         }
+    }
 }
 
 // tlogp [generation][chain] -> [chain][generation] for the chain-by-chain download (dz_get_trace_chains)

@@ -66,56 +66,64 @@ __host__ __device__ inline MegaLayout mega_layout(int d, int k, int nrt, int ncr
 // Wave w of tw takes the units w, 2tw-1-w, 2tw+w, ... (snake), which evens out the k-steps per wave and per SIMD.
 DZ_DEV int mega_unit(int j, int wv, int tw) { return (j & 1) ? tw * j + (tw - 1 - wv) : tw * j + wv; }
 
-// The (point tile, row tile) units of Y = V M^T for the ntl point tiles of 16 rows starting at row row0 of the LDS point area; writes
-// q[point][t] = butterfly16 over i of y_{16t+i} s_{16t+i}  (MVN contract, dz_kernels.h).
+// The (point tile, row tile) units of Y^T = M V^T for the ntl point tiles of 16 rows starting at row row0 of the LDS point area; writes
+// q[point][t], the row-tile sum of the MVN contract (dz_kernels.h tile_q_*).  Transposed tile: the matrix is the MFMA's A operand
+// (lane l: row 16 t + l%16, k = 4 ks + l/16), the points are its B operand (lane l: point l%16, same k), so a lane ends up with four
+// rows of ONE point and the row-tile sum needs two lane-swap steps instead of four butterfly stages per accumulator element.
+// wv, tw, ntl and row0 are wave-uniform (the kernel passes its wave number through readfirstlane): the unit index, the row tile and
+// every loop bound live in scalar registers, and with the block index b16 unrolled the LDS addresses are one lane offset per unit plus
+// immediates.
 template <int NRT, bool TRI, bool MZ>
 DZ_DEV void mfma_units(const Params& p, const double* __restrict__ Ms, const double* __restrict__ Pt, const double* __restrict__ mus,
                        double* __restrict__ qb, int row0, int ntl, int wv, int tw, int l, int LDM, int LDP)
 {
-    const int d = p.d, KS = (d + 3) >> 2;
+    const int d = p.d, KS = (d + 3) >> 2, KB = KS >> 2;            // KB whole batches of four k-steps (one 16-row block of the matrix)
     const int pi = l & 15, kq = l >> 4;
-    for (int j = 0;; ++j) {
+    const int nun = ntl * NRT;
+    const int rcp = ((1 << 20) + ntl - 1) / ntl;                  // u / ntl == (u * rcp) >> 20 for every u < 2^10
+    for (int j = 0; tw * j < nun; ++j) {
         const int u = mega_unit(j, wv, tw);
-        if (tw * j >= ntl * NRT) break;
-        if (u >= ntl * NRT) continue;
-        const int t = u / ntl, trow = row0 + 16 * (u - t * ntl);           // the tile's first point row
-        const double* ap = Pt + (size_t)(trow + pi) * LDP + kq;
+        if (u >= nun) continue;
+        const int t = (u * rcp) >> 20, trow = row0 + 16 * (u - t * ntl);           // the tile's first point row
+        const double* bp = Pt + (size_t)(trow + pi) * LDP + kq;                    // B operand: point trow + pi, k = 4 ks + kq
         const double* mp = mus + kq;
-        const int r = 16 * t + pi;
-        const bool rok = r < d;
+        // A operand: matrix row r = 16 t + pi of k-row c = 4 ks + kq; packed triangle: k-row c of block b = c / 16 starts at
+        // tri_row_offset(c) = 128 b (b + 1) + (c - 16 b) 16 (b + 1)
+        const double* ap = Ms + 16 * t + pi;
         dz_double4 acc = dz_double4{0.0, 0.0, 0.0, 0.0};
-        int ks = TRI ? 4 * t : 0;
-        // four k-steps (one 16-row block of the matrix) per trip: the LDS reads are issued together, then the four
-        // MFMAs (ascending k).  No predicates: point rows and mu are zero padded to the k-steps and the matrix rows
-        // c >= d are zero, so out-of-range k terms add exact zeros; output rows r >= d read whatever sits there, stay
-        // inside their own accumulator rows and are dropped below (rok).
-        for (; ks + 4 <= KS; ks += 4) {
-            const int b16 = ks >> 2;
-            const double* bp = TRI ? Ms + 128 * b16 * (b16 + 1) + kq * 16 * (b16 + 1) + r : Ms + (size_t)(4 * ks + kq) * LDM + r;
-            const int bstep = TRI ? 64 * (b16 + 1) : 4 * LDM;
+        // No predicates: point rows and mu are zero padded to the k-steps and the matrix rows c >= d are zero, so out-of-range k
+        // terms add exact zeros; output rows r >= d of the packed triangle are exact zeros, those of the dense square read whatever
+        // sits there, stay inside their own accumulator rows and are dropped by tile_q.
+#pragma unroll
+        for (int b16 = 0; b16 < NRT; ++b16) {
+            if ((TRI && b16 < t) || b16 >= KB) continue;
             double a[4], b[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c4 = 4 * (ks + q);
-                a[q] = MZ ? ap[c4] : ap[c4] - mp[c4];
-                b[q] = bp[(size_t)q * bstep];
+            for (int q = 0; q < 4; ++q) {                          // the batch's LDS reads are issued together, then its four MFMAs (ascending k)
+                const int c = 16 * b16 + 4 * q;
+                b[q] = MZ ? bp[c] : bp[c] - mp[c];
+                a[q] = TRI ? ap[128 * b16 * (b16 + 1) + (4 * q + kq) * 16 * (b16 + 1)] : ap[(size_t)(c + kq) * LDM];
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
         }
-        for (; ks < KS; ++ks) {
-            const int c = 4 * ks + kq;
-            const double* bp = TRI ? Ms + tri_row_offset(c) + r : Ms + (size_t)c * LDM + r;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(MZ ? ap[4 * ks] : ap[4 * ks] - mp[4 * ks], *bp, acc, 0, 0, 0);
+        for (int ks = 4 * KB; ks < KS; ++ks) {                     // the last, partial block: every row tile takes part (ks >= 4 (NRT - 1) >= 4 t)
+            const int c = 4 * ks;
+            const double av = TRI ? ap[128 * KB * (KB + 1) + (c - 16 * KB + kq) * 16 * (KB + 1)] : ap[(size_t)(c + kq) * LDM];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, MZ ? bp[c] : bp[c] - mp[c], acc, 0, 0, 0);
         }
+        double qv;
+        if (TRI) qv = tile_q_tri(acc);
+        else {
+            double sv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int pt = trow + kq + 4 * e;
-            const double y = acc[e];
-            const double sv = TRI ? y : (rok ? Pt[(size_t)pt * LDP + r] - mus[r] : 0.0);
-            const double q = bfly16(rok ? y * sv : 0.0);
-            if (pi == 0) qb[pt * NRT + t] = q;
+            for (int e = 0; e < 4; ++e) {
+                const int r = min(16 * t + kq + 4 * e, d - 1);
+                sv[e] = MZ ? Pt[(size_t)(trow + pi) * LDP + r] : Pt[(size_t)(trow + pi) * LDP + r] - mus[r];
+            }
+            qv = tile_q(acc, sv, 16 * t + kq, d);
         }
+        if (kq == 0) qb[(trow + pi) * NRT + t] = qv;
     }
 }
 
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     double* dec = smem + L.off_dec;
     double* gts = smem + L.off_gt;
     double* Xs = smem + L.off_X;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;       // (scalar: everything derived from the wave number stays on the scalar unit)
     const int cl = WPC == 1 ? wv : wv % CH;                              // chain inside the block
     const int sub = WPC == 1 ? 0 : wv / CH;                              // this wave's number among the chain's waves
     const int cg = blockIdx.x * CH + cl;
@@ -178,11 +186,6 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     }
     __syncthreads();
 
-#ifdef DZ_EXP_STAMPS
-#define DZ_MSTAMP(i_) do { if (gi == ngen - 1 && lane == 0 && sub == 0) p.dbg[((size_t)3 * p.nl + blockIdx.x * CH + cl) * 16 + (i_)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define DZ_MSTAMP(i_) do { } while (0)
-#endif
     for (int gi = 0; gi < ngen; ++gi) {
         const uint32_t g = g0 + (uint32_t)gi;
         const bool last = gi == ngen - 1;

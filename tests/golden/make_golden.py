@@ -95,7 +95,7 @@ class ContractRandom:
             for h in (0, 1):
                 j = 2 * q + h
                 if j < d:
-                    U[j] = O.u16(int(w[0]) >> (16 * h)); ue[j] = O.u16(int(w[1]) >> (16 * h)); z[j] = zz[h]
+                    U[j] = O.u16(int(w[0]) >> (16 * h)); ue[j] = (int(w[1]) >> (16 * h)) & 0xffff; z[j] = zz[h]     # ue: the raw 16-bit draw
         return U, ue, z
 
     @staticmethod
@@ -150,8 +150,8 @@ class ContractRandom:
         if isinstance(size, tuple):                                          # U, Dream.py:700
             n, d = size
             return np.array([self._dim(tr, d)[0] for tr in range(n)])
-        tr = self._next("e")                                                 # e, Dream.py:696
-        return low + (high - low) * self._dim(tr, size)[1]
+        tr = self._next("e")                                                 # e, Dream.py:696: uniform(low, high) from the 16-bit draws, one fma each
+        return np.array([O.uniform16(int(h), low, high) for h in self._dim(tr, size)[1]])
 
     def rand(self, n):                                                       # bounds redraw, Dream.py:749-751, 773-775
         fr = sys._getframe(1).f_locals
@@ -380,6 +380,7 @@ class InProcessPool:
 
     def __init__(self, rnd, step, N, burnin):
         self.rnd, self.step, self.N, self.g, self.chains, self.swaps, self.log, self.burnin = rnd, step, N, 0, None, [], [], burnin
+        self.probs = []
 
     def map(self, fn, args):
         args = list(args)
@@ -405,7 +406,13 @@ class InProcessPool:
                         c.iter += 1
         for c in self.chains:
             c.queue = []
+            if self.g <= self.step.crossover_burnin:                  # as in run_reference: the chains adopt the shared probabilities
+                if self.step.adapt_crossover:
+                    c.CR_probabilities = list(SV.cross_probs[0:self.step.nCR])
+                if self.step.adapt_gamma:
+                    c.gamma_probabilities = list(SV.gamma_level_probs[0:self.step.ngamma])
         self.log.append(row)
+        self.probs.append(np.array(SV.cross_probs[0:self.step.nCR]))
         self.g += 1
         return out
 
@@ -432,13 +439,15 @@ def run_reference_pt(params, likelihood, Z0, starts, N, G, seed, dream_kwargs, w
         T = np.array([np.power(.001, (float(i) / N)) for i in range(N)])           # core.py:133-136
         return dict(pt_sampled=np.asarray(sampled), pt_log_ps=np.asarray(log_ps), pt_swaps=np.array(fake.swaps, np.int32),
                     try_idx=dec[:, :, 0], cr_idx=dec[:, :, 1], snooker=dec[:, :, 2].astype(np.uint8), T=T,
-                    Z_tail=np.array(SV.history[0:M * d]).reshape(M, d)[len(Z0):])
+                    Z_tail=np.array(SV.history[0:M * d]).reshape(M, d)[len(Z0):],
+                    cross_probs=np.array(fake.probs), delta_m=np.array(SV.delta_m[:]), ncr_updates=np.array(SV.ncr_updates[:]),
+                    burnin=step.crossover_burnin)
     finally:
         RC.np = np
         uninstall()
 
 
-def pt_case(name, *, d, N, G, k, seed, rng_seed=0):
+def pt_case(name, *, d, N, G, k, seed, rng_seed=0, dream_kwargs=None):
     rng = np.random.default_rng(rng_seed)
     params = [FlatParam(test_value=np.zeros(d))]
     nseed = max(10 * d, 2 * N)
@@ -446,6 +455,7 @@ def pt_case(name, *, d, N, G, k, seed, rng_seed=0):
     invC, log_F, like = mvn_target(d)
     starts = Z0[:N].copy()
     kw = dict(multitry=k, adapt_crossover=False)
+    kw.update(dream_kwargs or {})
     with tempfile.TemporaryDirectory() as wd:
         cwd = os.getcwd()
         os.chdir(wd)
@@ -453,7 +463,8 @@ def pt_case(name, *, d, N, G, k, seed, rng_seed=0):
             out = run_reference_pt(params, like, Z0, starts, N, G, seed, kw, wd)
         finally:
             os.chdir(cwd)
-    save(name, Z0=Z0, starts=starts, invC=invC, log_F=log_F, cfg_d=d, cfg_N=N, cfg_G=G, cfg_k=k, cfg_seed=seed, **out)
+    save(name, Z0=Z0, starts=starts, invC=invC, log_F=log_F, cfg_d=d, cfg_N=N, cfg_G=G, cfg_k=k, cfg_seed=seed,
+         cfg_adapt_crossover=int(bool(kw["adapt_crossover"])), **out)
     sw = out["pt_swaps"]
     acc = [(not np.array_equal(out["pt_sampled"][sw[g, 0], 2 * g], out["pt_sampled"][sw[g, 0], 2 * g + 1])) for g in range(G)]
     print("   ", name, "swap acceptance", np.mean(acc), "move acceptance (coldest chain)",
@@ -507,7 +518,10 @@ def save(name, **arrs):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
-def trace_case(name, *, d, N, G, k, schedule, seed, target, dream_kwargs=None, prior="flat", rng_seed=0, nseed=None):
+def trace_case(name, *, d, N, G, k, schedule, seed, target, dream_kwargs=None, prior="flat", rng_seed=0, nseed=None, restart_from=None):
+    """restart_from: name of an earlier trace fixture -- this run then restarts it the way run_dream(restart=True) does
+    (core.py:46-62, 255-263; Dream.py:128-141): seed history = everything that run left in its history file (seed rows + appended
+    rows), crossover probabilities loaded from its crossover file through Dream's `crossover_file`, starts = its last states."""
     from scipy.stats import norm, uniform
     dream_kwargs = dict(dream_kwargs or {})
     rng = np.random.default_rng(rng_seed)
@@ -545,7 +559,15 @@ def trace_case(name, *, d, N, G, k, schedule, seed, target, dream_kwargs=None, p
         cwd = os.getcwd()
         os.chdir(wd)
         try:
+            if restart_from is not None:
+                prev = np.load(os.path.join(HERE, restart_from + ".npz"))
+                Z0 = np.concatenate([prev["Z0"], prev["Z_tail"]])           # what save_history_to_disc writes (Dream.py:947-959)
+                starts = prev["X"][-1].copy()
+                np.save(os.path.join(wd, "prev_crossoverprob.npy"), prev["cross_probs"][-1])      # Dream.py:961-964
+                dream_kwargs["crossover_file"] = os.path.join(wd, "prev_crossoverprob.npy")
+                extra.update(restart_cr_probs=prev["cross_probs"][-1])
             out = run_reference(params, like, Z0, starts, N, G, seed, schedule, dict(multitry=mt, **dream_kwargs), wd)
+            dream_kwargs.pop("crossover_file", None)
         finally:
             os.chdir(cwd)
     kw = dict(nCR=3, adapt_crossover=True, adapt_gamma=False, DEpairs=1, lamb=.05, zeta=1e-12, history_thin=10,
@@ -670,7 +692,9 @@ def main():
     trace_case("trace_s2_adapt", d=10, N=4, G=120, k=5, schedule=2, seed=11, target=("mvn",),
                dream_kwargs=dict(adapt_crossover=True, crossover_burnin=40))
     # T3: single-try, uniform prior + hard boundaries (pydream/tests/test_models.py:35-50)
-    trace_case("trace_s2_k1_bounds", d=4, N=5, G=150, k=1, schedule=2, seed=3, target=("simple",), prior="uniform",
+    # (100 generations: the reference sums the snooker projection in BLAS order, a 1e-15 difference per snooker step that the
+    #  coupled chains amplify from generation to generation -- 4e-10 on log p after 125 generations at snooker = 0.3)
+    trace_case("trace_s2_k1_bounds", d=4, N=5, G=100, k=1, schedule=2, seed=3, target=("simple",), prior="uniform",
                dream_kwargs=dict(adapt_crossover=True, crossover_burnin=50, snooker=.3))
     # T3b: multi-try with uniform prior + boundaries
     trace_case("trace_s2_k3_bounds", d=4, N=5, G=100, k=3, schedule=2, seed=5, target=("simple",), prior="uniform",
@@ -686,6 +710,13 @@ def main():
                dream_kwargs=dict(adapt_crossover=True, crossover_burnin=30))
     # T7: parallel tempering (core.py:131-248): temperature ladder, one swap attempt per iteration
     pt_case("trace_pt_mvn10", d=10, N=6, G=150, k=5, seed=23)
+    # T7b: parallel tempering WITH crossover adaptation (run_dream's default), burn-in inside the run: after an accepted swap
+    # the next jump is measured from the swapped state (Dream.py:371-378)
+    pt_case("trace_pt_adapt", d=10, N=6, G=100, k=5, seed=29, dream_kwargs=dict(adapt_crossover=True, crossover_burnin=60))
+    # T8: restart (core.py:46-62, 255-263; Dream.py:128-141): continues trace_s2_adapt from its history and adapted
+    # crossover probabilities, adaptation on again
+    trace_case("trace_s2_restart", d=10, N=4, G=60, k=5, schedule=2, seed=12, target=("mvn",), restart_from="trace_s2_adapt",
+               dream_kwargs=dict(adapt_crossover=True, crossover_burnin=30))
 
 
 if __name__ == "__main__":

@@ -34,6 +34,8 @@ def engine_from_trace_fixture(EngineCls, fx, schedule=None, trace=True, **over):
     e.set_gamma_table(fx["gamma_arr"])
     e.set_history(Z0)
     e.set_prior(fx["prior_kind"], fx["prior_a"], fx["prior_b"])
+    if "restart_cr_probs" in fx:                       # a restarted run: Dream's `crossover_file` (Dream.py:128-134)
+        e.set_cr_probs(fx["restart_cr_probs"])
     lk = str(fx["lk_kind"])
     if lk == "mvn":
         e.set_likelihood_mvn(np.zeros(d), fx["invC"], 0, float(fx["log_F"]))
@@ -81,7 +83,8 @@ def pt_engine_from_fixture(EngineCls, fx, **over):
     d, N, G, k = int(fx["cfg_d"]), int(fx["cfg_N"]), int(fx["cfg_G"]), int(fx["cfg_k"])
     Z0 = fx["Z0"]
     kw = dict(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (G // 10 + 2), trace_capacity=G, seed=int(fx["cfg_seed"]),
-              adapt_crossover=0, crossover_burnin=G // 10)
+              adapt_crossover=int(fx["cfg_adapt_crossover"]) if "cfg_adapt_crossover" in fx else 0,
+              crossover_burnin=int(fx["burnin"]) if "burnin" in fx else G // 10)
     kw.update(over)
     e = EngineCls(**kw)
     e.set_history(Z0)
@@ -121,4 +124,9 @@ def compare_pt_with_reference(e, fx, x_rtol=1e-9, logp_atol=1e-10):
     np.testing.assert_allclose(S, fx["pt_sampled"], rtol=x_rtol, atol=1e-11)
     np.testing.assert_allclose(L, fx["pt_log_ps"], rtol=0, atol=logp_atol)
     np.testing.assert_allclose(e.get_history()[len(fx["Z0"]):], fx["Z_tail"], rtol=x_rtol, atol=1e-11)
+    if "cfg_adapt_crossover" in fx and int(fx["cfg_adapt_crossover"]):
+        pr, dm, nu = e.get_cr_state()
+        np.testing.assert_allclose(pr, fx["cross_probs"][-1], rtol=1e-11)
+        np.testing.assert_allclose(dm, fx["delta_m"], rtol=1e-11)
+        np.testing.assert_array_equal(nu, fx["ncr_updates"])
     return tr, sw

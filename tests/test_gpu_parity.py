@@ -8,7 +8,7 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 S2_TRACES = ["trace_s2_adapt", "trace_s2_k1_bounds", "trace_s2_k3_bounds", "trace_s2_depairs_gamma",
-             "trace_s2_mvn100", "trace_s2_mix3"]
+             "trace_s2_mvn100", "trace_s2_mix3", "trace_s2_restart"]
 
 
 @pytest.fixture(scope="module")
@@ -239,16 +239,24 @@ def test_full_size_run_recovers_the_target_moments(G):
     e.close()
 
 
-def test_parallel_tempering_reference_and_oracle(G, O):
+@pytest.mark.parametrize("name", ["trace_pt_mvn10", "trace_pt_adapt"])
+def test_parallel_tempering_fixtures(G, O, name):
     """parallel tempering (core.py:131-236): HIP == reference fixture (both interleaved sample streams, swap pairs,
-    accepted-swap sequence, history) and HIP == oracle bit for bit, also at a size the fixture does not cover."""
-    fx = H.load("trace_pt_mvn10")
+    accepted-swap sequence, history; trace_pt_adapt: with crossover adaptation on, run_dream's default, where the jump after
+    an accepted swap is measured from the swapped state, Dream.py:371-378) and HIP == oracle bit for bit."""
+    fx = H.load(name)
     n = int(fx["cfg_G"])
     e, o = H.pt_engine_from_fixture(G.Engine, fx), H.pt_engine_from_fixture(O.Engine, fx)
     e.step(n); o.step(n)
     H.compare_pt_with_reference(e, fx)
     assert_traces_identical(e.get_trace(0, n), o.get_trace(0, n))
     np.testing.assert_array_equal(e.get_swaps(0, n), o.get_swaps(0, n))
+    for a, b in zip(e.get_cr_state(), o.get_cr_state()):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_parallel_tempering_reference_and_oracle(G, O):
+    """parallel tempering at a size the fixtures do not cover, with crossover adaptation on: HIP == oracle bit for bit."""
     # 256 chains x 100-D, 60 generations
     N, d, n, seed = 256, 100, 60, 31
     P = H.mvn_precision(d)
@@ -256,16 +264,19 @@ def test_parallel_tempering_reference_and_oracle(G, O):
     T = np.array([np.power(.001, float(i) / N) for i in range(N)])
     out = []
     for Cls in (G.Engine, O.Engine):
-        en = Cls(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed)
+        en = Cls(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
+                 adapt_crossover=1, crossover_burnin=40)
         en.set_history(Z0); en.set_state(Z0[:N]); en.set_likelihood_mvn(np.zeros(d), P, 0, 0.0); en.set_temperatures(T)
         en.step(n)
-        out.append((en.get_trace(0, n), en.get_swaps(0, n), en.get_history(), en.get_state()))
+        out.append((en.get_trace(0, n), en.get_swaps(0, n), en.get_history(), en.get_state(), en.get_cr_state()))
     assert_traces_identical(out[0][0], out[1][0])
     np.testing.assert_array_equal(out[0][1], out[1][1])
     np.testing.assert_array_equal(out[0][2], out[1][2])
     for a, b in zip(out[0][3], out[1][3]):
         np.testing.assert_array_equal(a, b)
-    assert out[0][1][:, 2].sum() > 0                    # some swaps were accepted
+    for a, b in zip(out[0][4], out[1][4]):
+        np.testing.assert_array_equal(a, b)
+    assert out[0][1][11:40, 2].sum() > 0                # swaps were accepted inside the adaptation window
 
 
 @pytest.mark.parametrize("N,d,tri,gemm,zero_mean", [(160, 333, 1, 1, 0), (200, 200, 0, 1, 0), (160, 333, 1, 0, 0), (128, 1000, 1, 1, 0),
@@ -319,3 +330,27 @@ def test_persistent_mixture_kernel_equals_multi_kernel_path_and_oracle(G, O, N, 
         assert_traces_identical(a[0], other[0])
         np.testing.assert_array_equal(a[1], other[1])
         np.testing.assert_array_equal(a[2], other[2])
+
+
+def test_eval_logp_scratch_buffers_survive_growth(G, O):
+    """dz_eval_logp with a growing number of points at d = 200 (the large-d likelihood path with its row-tile scratch array),
+    a trace download that uses the same array, then dz_step: the staging buffer and the row-tile array are separate allocations and
+    growing one must not release the other (round-1 advisor finding: a dangling d_qpart after need_scratch)."""
+    d, N, seed = 200, 64, 3
+    P = H.mvn_precision(d)
+    Z0 = H.seed_history(10 * d, d, seed)
+    e = G.Engine(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * 3, trace_capacity=8, seed=seed)
+    o = O.Engine(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * 3, trace_capacity=8, seed=seed)
+    for x in (e, o):
+        x.set_history(Z0); x.set_state(Z0[:N]); x.set_likelihood_mvn(np.linspace(-1, 1, d), P, 0, 0.0)
+    for n in (40, 700, 90, 1500):
+        got = e.eval_logp(Z0[:n])[1]
+        np.testing.assert_array_equal(got, np.array([o.loglike(x) for x in Z0[:n]]))
+    e.step(4); o.step(4)
+    S = np.empty((N, 4, d)); LP = np.empty((N, 4, 1))
+    e.get_trace_chains(0, 4, S, row0=0, logp_out=LP)
+    got = e.eval_logp(Z0[:1800])[1]
+    np.testing.assert_array_equal(got, np.array([o.loglike(x) for x in Z0[:1800]]))
+    e.step(4); o.step(4)
+    assert_traces_identical(e.get_trace(0, 8), o.get_trace(0, 8))
+    np.testing.assert_array_equal(S, e.get_trace(0, 4)["X"].transpose(1, 0, 2))

@@ -7,7 +7,7 @@ from oracle import oracle as O
 from tests import helpers as H
 
 TRACES = ["trace_s1_c1", "trace_s1_adapt", "trace_s2_adapt", "trace_s2_k1_bounds", "trace_s2_k3_bounds",
-          "trace_s2_depairs_gamma", "trace_s2_mvn100", "trace_s2_mix3"]
+          "trace_s2_depairs_gamma", "trace_s2_mvn100", "trace_s2_mix3", "trace_s2_restart"]
 
 
 @pytest.mark.parametrize("name", TRACES)
@@ -104,12 +104,26 @@ def test_gelman_rubin_matches_reference():
     np.testing.assert_allclose(O.gelman_rubin(fx["gr_traces"]), fx["gr_rhat"], rtol=1e-12)
 
 
-def test_parallel_tempering_matches_reference():
+def test_restart_fixture_continues_the_earlier_run():
+    """trace_s2_restart restarts trace_s2_adapt the way run_dream(restart=True) does (core.py:46-62, 255-263; Dream.py:128-141):
+    its seed history is everything the first run left (seed rows + appended rows), its starts are the first run's last states and
+    its crossover probabilities the adapted ones -- checked here on the fixtures themselves; the replay is in TRACES above."""
+    a, b = H.load("trace_s2_adapt"), H.load("trace_s2_restart")
+    np.testing.assert_array_equal(b["Z0"], np.concatenate([a["Z0"], a["Z_tail"]]))
+    np.testing.assert_array_equal(b["starts"], a["X"][-1])
+    np.testing.assert_array_equal(b["restart_cr_probs"], a["cross_probs"][-1])
+    assert not np.allclose(b["restart_cr_probs"], 1. / 3)                      # the loaded probabilities really are adapted ones
+
+
+@pytest.mark.parametrize("name", ["trace_pt_mvn10", "trace_pt_adapt"])
+def test_parallel_tempering_matches_reference(name):
     """core._sample_dream_pt (core.py:131-236) itself, run in one process by tests/golden/make_golden.py: temperature
     ladder, per-chain T inside astep, one swap attempt per iteration -- oracle == reference on both interleaved sample
     streams, the swap pairs, the accepted-swap sequence and the history."""
-    fx = H.load("trace_pt_mvn10")
+    fx = H.load(name)
     e = H.pt_engine_from_fixture(O.Engine, fx)
     e.step(int(fx["cfg_G"]))
     tr, sw = H.compare_pt_with_reference(e, fx)
     assert 3 <= sw[:, 2].sum() <= 60
+    if name == "trace_pt_adapt":        # accepted swaps inside the adaptation window: the case the jump baseline matters for
+        assert sw[11:int(fx["burnin"]), 2].sum() >= 2

@@ -631,6 +631,10 @@ int dz_create(const dz_config* cfg, dz_engine** out)
         const double low = -cfg->lamb, high = cfg->lamb;
         p.ec1 = (high - low) * (1.0 / 65536.0); p.ec0 = low + (high - low) * (1.0 / 131072.0);
         for (int m = 0; m < 32; ++m) p.crthr[m] = m < cfg->ncr ? dz::crossover_threshold((double)(m + 1) / (double)cfg->ncr) : 0u;
+        const double q = std::min(1.0, std::max(0.0, cfg->p_gamma_unity));
+        p.pgu_thr = (unsigned long long)std::ceil(std::ldexp(q, 53));
+        const double sn = std::min(1.0, std::max(0.0, cfg->snooker));
+        p.snk_thr = (unsigned long long)std::ceil(std::ldexp(sn, 53));
     }
     const int chunks = (p.ld + 127) / 128;
     e->nch = chunks <= 1 ? 1 : chunks <= 2 ? 2 : chunks <= 4 ? 4 : 8;

@@ -47,6 +47,8 @@ struct Params {
     int* sel;      // [nl] selected try | anyfinite<<8, written by the reference-phase proposal wave
     double ec1, ec0;          // e ~ U(-lamb, lamb) from a 16-bit draw h as fma(h, ec1, ec0) (dz_device.h uniform16)
     uint32_t crthr[32];       // crossover_threshold(CR_values[m]), m < ncr: `U_j < CR` as an integer test on the 16-bit draw
+    unsigned long long pgu_thr;   // ceil(p_gamma_unity 2^53): u53(hi, lo) < p_gamma_unity as an integer test on the 53-bit draw (u53_below)
+    unsigned long long snk_thr;   // ceil(snooker 2^53): the same for set_snooker's draw (0 when snooker == 0)
     unsigned long long* dbg;  // cycle-stamp buffer of instrumented builds (-DDZ_EXPERIMENTS, dz_experiments.h); null otherwise
 };
 // per-phase cycle stamps: defined by dz_experiments.h in instrumented builds only (tools/variants.sh), no-ops in the product
@@ -116,6 +118,14 @@ DZ_DEV double mt_log_ratio(int k, double val)
     for (int i = 0; i < k; ++i) SA = SA + readlane_f64(ev, i);
     for (int i = 0; i < k; ++i) SB = SB + readlane_f64(ev, 16 + i);
     return nan_to_num(dlog(SA / SB));                                                                // :323
+}
+
+// u53(hi, lo) < q for q in [0, 1], as an integer test: u53 = k 2^-53 with k = (hi >> 5) 2^26 + (lo >> 6), so the test is
+// k < ceil(q 2^53) =: thr (made once on the host).  Wave-uniform operands stay on the scalar unit.
+DZ_DEV bool u53_below(uint32_t hi, uint32_t lo, unsigned long long thr)
+{
+    const unsigned long long k = ((unsigned long long)(hi >> 5) << 26) | (unsigned long long)(lo >> 6);
+    return k < thr;
 }
 
 DZ_DEV uint32_t mulhi_idx(uint32_t w, uint32_t M) { return (uint32_t)(((uint64_t)w * (uint64_t)M) >> 32); }
@@ -251,40 +261,10 @@ DZ_DEV void fetch_rows(const Params& p, int phase, uint32_t g, uint32_t M, uint3
     }
 }
 
-// gamma_arr[level-1][delta-1][:] (Dream.py:172-179) in the lanes' registers, same dimension->lane layout as a
-// data row: the look-up gamma_arr[..][d'-1] (:624) becomes a v_readlane instead of a dependent global load
-// at the very end of every try.
-template <int NCH>
-DZ_DEV void load_gamma_row(const Params& p, int glev, int delta, int lane, double (&gt)[NCH][2])
+// gamma_arr[level-1][delta-1][:] (Dream.py:172-179): the row the look-up gamma_arr[..][d'-1] (:624) reads from
+DZ_DEV const double* gamma_row(const Params& p, int glev, int delta)
 {
-    const double* row = p.gtab + ((size_t)(glev - 1) * p.depairs + (delta - 1)) * p.d;
-    const double zero = (double)(threadIdx.x >> 12);
-#pragma unroll
-    for (int it = 0; it < NCH; ++it)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) { const int j = 128 * it + 2 * lane + s; gt[it][s] = (j < p.d ? row[j] : 0.0) + zero; }
-}
-// the same from any copy of the row (the persistent kernel keeps the table in LDS)
-template <int NCH>
-DZ_DEV void load_gamma_row_from(const double* row, int d, int lane, double (&gt)[NCH][2])
-{
-    const double zero = (double)(threadIdx.x >> 12);
-#pragma unroll
-    for (int it = 0; it < NCH; ++it)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) { const int j = 128 * it + 2 * lane + s; gt[it][s] = (j < d ? row[j] : 0.0) + zero; }
-}
-template <int NCH>
-DZ_DEV double gamma_lookup(const double (&gt)[NCH][2], int idx)      // idx wave-uniform
-{
-    const int u = __builtin_amdgcn_readfirstlane(idx);
-    const int it = u >> 7, ln = (u & 127) >> 1, sb = u & 1;
-    double v = 0.0;
-#pragma unroll
-    for (int q = 0; q < NCH; ++q) if (q == it) v = sb ? gt[q][1] : gt[q][0];
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), ln), hi = __builtin_amdgcn_readlane((int)(b >> 32), ln);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    return p.gtab + ((size_t)(__builtin_amdgcn_readfirstlane(glev) - 1) * p.depairs + (__builtin_amdgcn_readfirstlane(delta) - 1)) * p.d;
 }
 
 // What propose_point needs from the fetched rows, reduced to VALU-defined registers as soon as the loads land
@@ -305,9 +285,13 @@ DZ_DEV void reduce_rows(const ZRows<NCH>& zr, bool snk, RowTerms<NCH>& rt)
 
 // LEAN drops what the persistent kernel's fast path never needs (hard-boundary handling, the single-try snooker
 // variant) so that the whole generation fits the register budget of a 16-wave block.
+// Returns, for a snooker try, the squared distance |proposal - z|^2 (wave-uniform): the caller turns the tries' distances into
+// snooker_logp = (d - 1) log sqrt(.) (:823-824 / :834-835) in ONE pass of the logarithm (snooker_logps below) instead of one per
+// try; 0 for a DE try (snooker_logp = 0).  grow: gamma_arr[level-1][delta-1][:] (any address space; the look-up address is
+// wave-uniform).
 template <int NCH, bool AL16 = true, bool LEAN = false>
-DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, int c, int i, int n, int lane,
-                          const double (&xb)[NCH][2], const double (&gt)[NCH][2], const RowTerms<NCH>& zr, double* __restrict__ out, double* slogp_out,
+DZ_DEV double propose_point(const Params& p, int phase, uint32_t g, uint32_t M, int c, int i, int n, int lane,
+                          const double (&xb)[NCH][2], const double* __restrict__ grow, const RowTerms<NCH>& zr, double* __restrict__ out,
                           double* cur_snk_out, bool snk, int cr_idx, int delta, int glev, const DrawSrc& dr, const u32x4* wpre = nullptr)
 {   // wpre: the DIM draw of chunk 0, computed by the caller one try ahead (software pipelining, NCH == 1)
     const int d = p.d, ld = p.ld;
@@ -316,7 +300,7 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
     const uint32_t s_dim = stream_id(K_DIM, (uint32_t)i, (uint32_t)phase),
                    s_bnd = stream_id(K_BND, (uint32_t)i, (uint32_t)phase);
     double pr[NCH][2];
-    double slogp = 0.0;
+    double sqdist = 0.0;
     if (!snk) {
         bool keep[NCH][2]; double e1[NCH][2], zt[NCH][2];
         const double ec1 = p.ec1, ec0 = p.ec0;
@@ -336,12 +320,12 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
                 e1[it][1] = uniform16(w.y >> 16, ec1, ec0) + 1.0;
                 zt[it][1] = p.zeta * (double)z1;
             }
-            dprime += __popcll(__ballot(keep[it][0])) + __popcll(__ballot(keep[it][1]));   // d' :704 / :709
+            dprime += __popcll(__builtin_amdgcn_ballot_w64(keep[it][0])) + __popcll(__builtin_amdgcn_ballot_w64(keep[it][1]));   // d' :704 / :709
         }
         const u32x4 wg = uniform_draw(p, dr, pt_slot(p, phase, i, 0), gc, g);  // set_gamma :615
         double gamma = 1.0;
-        if (!(u53(wg.x, wg.y) < p.pgu))
-            gamma = gamma_lookup<NCH>(gt, (dprime == 0 ? d : dprime) - 1);      // gamma_arr[level-1][delta-1][d'-1], :624
+        if (!u53_below(wg.x, wg.y, p.pgu_thr))                                 // u53(wg.x, wg.y) < p_gamma_unity
+            gamma = grow[(dprime == 0 ? d : dprime) - 1];                      // gamma_arr[level-1][delta-1][d'-1], :624 (one address for the whole wave)
 #pragma unroll
         for (int it = 0; it < NCH; ++it)
 #pragma unroll
@@ -394,8 +378,7 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
         for (int it = 0; it < NCH; ++it)
 #pragma unroll
             for (int s = 0; s < 2; ++s) if (128 * it + 2 * lane + s < d) { const double t = pr[it][s] - zz[it][s]; accN = fma(t, t, accN); }
-        const double norm = sqrt(wave_bfly(accN));                             // :823 / :834
-        slogp = norm != 0.0 ? dlog(norm) * (double)(d - 1) : 0.0;              // :824 / :835
+        sqdist = wave_bfly(accN);                                              // :823 / :834 (the norm's square; snooker_logps finishes it)
         if (cur_snk_out && i == 0) { const double nc = sqrt(D); *cur_snk_out = nc != 0.0 ? dlog(nc) * (double)(d - 1) : 0.0; }   // :328-329
     }
     // hard boundaries :733-791
@@ -425,7 +408,17 @@ DZ_DEV void propose_point(const Params& p, int phase, uint32_t g, uint32_t M, in
             else { if (jj < d) out[jj] = o.x; if (jj + 1 < d) out[jj + 1] = o.y; }     // unpadded, 8-byte aligned row (LDS tile)
         }
     }
-    if (lane == 0) *slogp_out = slogp;
+    return sqdist;
+}
+
+// snooker_logp of the tries of one set (:823-824 / :834-835): lane j holds the squared distance of try j (propose_point's return
+// value), j < cnt; sl[j] = (d - 1) log sqrt(.), or 0 where the distance is 0 (np.log(..., where = norm != 0)).  One
+// pass of sqrt / dlog for all tries.
+DZ_DEV void snooker_logps(const Params& p, double sq, int cnt, int lane, double* __restrict__ sl)
+{
+    const double norm = sqrt(lane < cnt ? sq : 1.0);
+    const double v = norm != 0.0 ? dlog(norm) * (double)(p.d - 1) : 0.0;
+    if (lane < cnt) sl[lane] = v;
 }
 
 // sum over dims of the per-dimension prior log densities (parameters.py:37-47), lane/butterfly order
@@ -566,7 +559,7 @@ DZ_DEV void point_prior(const Params& p, const double* row, int lane, double* pr
 // around the selected proposal).  out / sl / prior_out address try 0's row and scalars.
 template <int NCH, bool AL16, bool GENERIC = true, bool LEAN = false>
 DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int c, uint32_t gc, int i0, int i1, int n, int lane,
-                        const double (&xb)[NCH][2], const double (&gt)[NCH][2], bool snk, int cr_idx, int delta, int glev, const DrawSrc& dsrc,
+                        const double (&xb)[NCH][2], const double* __restrict__ grow, bool snk, int cr_idx, int delta, int glev, const DrawSrc& dsrc,
                         double* out, int out_stride, double* sl, double* csn, double* prior_out)
 {
     // software pipeline over the tries: the Z rows of try i+1 are requested before try i's arithmetic starts,
@@ -616,8 +609,9 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
             // (unconditional: after the last try the same rows are requested again and never used -- a conditional request makes
             //  the compiler keep the old and the new rows apart and copy one set into the other every try)
             request(min(i + 1, i1 - 1));
-            propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * out_stride, sl + i, csn, false, cr_idx, 1, glev, dsrc,
+            propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, grow, rt, out + (size_t)i * out_stride, csn, false, cr_idx, 1, glev, dsrc,
                                            AHEAD ? &wcur : nullptr);
+            if (lane == 0) sl[i] = 0.0;
             DZ_STAMP(p, phase, c, 3 + 2 * i);          // try i's arithmetic issued
             if (prior_out) { if (LEAN) { if (lane == 0) prior_out[i] = 0.0; } else point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i); }   // LEAN: flat priors only
         }
@@ -639,6 +633,7 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
         };
 #pragma unroll
         for (int it = 0; it < NCH; ++it) { rz[it] = double2{0.0, 0.0}; r1[it] = rz[it]; r2[it] = rz[it]; }
+        double sqv = 1.0;                             // lane j: squared distance |proposal - z|^2 of try i0 + j
         request(i0);
         for (int i = i0; i < i1; ++i) {
             RowTerms<NCH> rt;
@@ -648,9 +643,11 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
                 rt.b[it][0] = r1[it].x - r2[it].x; rt.b[it][1] = r1[it].y - r2[it].y;          // :819
             }
             if (i + 1 < i1) request(i + 1);
-            propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * out_stride, sl + i, csn, true, cr_idx, delta, glev, dsrc);
+            const double sq = propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, grow, rt, out + (size_t)i * out_stride, csn, true, cr_idx, delta, glev, dsrc);
+            sqv = (lane == i - i0) ? sq : sqv;
             if (prior_out) { if (LEAN) { if (lane == 0) prior_out[i] = 0.0; } else point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i); }
         }
+        snooker_logps(p, sqv, i1 - i0, lane, sl + i0);
         return;
     }
     if (GENERIC) for (int i = i0; i < i1; ++i) {     // DEpairs > 1
@@ -658,7 +655,8 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
         RowTerms<NCH> rt;
         fetch_rows<NCH>(p, phase, g, M, gc, i, lane, false, delta, dsrc, raw);
         reduce_rows<NCH>(raw, false, rt);
-        propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * out_stride, sl + i, csn, false, cr_idx, delta, glev, dsrc);
+        propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, grow, rt, out + (size_t)i * out_stride, csn, false, cr_idx, delta, glev, dsrc);
+        if (lane == 0) sl[i] = 0.0;
         if (prior_out) point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i);
     }
 }
@@ -706,13 +704,12 @@ __global__ __launch_bounds__(NCH >= 4 ? 256 : 1024) void k_propose(Params p, int
 #pragma unroll
         for (int it = 0; it < NCH; ++it) { xb[it][0] = xb[it][0] + zero; xb[it][1] = xb[it][1] + zero; }   // VALU-defined (see load_draws)
     }
-    double gt[NCH][2];
-    load_gamma_row<NCH>(p, ct.glev, ct.delta, lane, gt);
+    const double* grow = gamma_row(p, ct.glev, ct.delta);
     const uint32_t gc = (uint32_t)(p.off + c);
     const bool snk = ct.snk != 0;
     double* csn = (phase == 0 && p.k == 1) ? p.cur_snk + c : nullptr;
     DZ_STAMP(p, phase, c, 1);
-    propose_set<NCH, true>(p, phase, g, M, c, gc, i0, i1, n, lane, xb, gt, snk, ct.cr_idx, ct.delta, ct.glev, dsrc, out, p.ld, sl, csn, nullptr);
+    propose_set<NCH, true>(p, phase, g, M, c, gc, i0, i1, n, lane, xb, grow, snk, ct.cr_idx, ct.delta, ct.glev, dsrc, out, p.ld, sl, csn, nullptr);
     DZ_STAMP(p, phase, c, 15);
 }
 
@@ -725,15 +722,18 @@ __global__ __launch_bounds__(64) void k_propose_debug(Params p, int phase, uint3
     double xb[NCH][2];
     load_row<NCH>(base, p.ld, lane, xb);
     ZRows<NCH> zr;
-    double gt[NCH][2];
-    load_gamma_row<NCH>(p, glev, delta, lane, gt);
+    const double* grow = gamma_row(p, glev, delta);
     const DrawSrc none = load_draws(p, nullptr, lane);
+    double sqv = 1.0;
     for (int i = 0; i < n; ++i) {
         fetch_rows<NCH>(p, phase, g, M, (uint32_t)(p.off + c), i, lane, snk != 0, delta, none, zr);
         RowTerms<NCH> rt;
         reduce_rows<NCH>(zr, snk != 0, rt);
-        propose_point<NCH>(p, phase, g, M, c, i, n, lane, xb, gt, rt, out + (size_t)i * p.ld, sl + i, nullptr, snk != 0, cr_idx, delta, glev, none);
+        const double sq = propose_point<NCH>(p, phase, g, M, c, i, n, lane, xb, grow, rt, out + (size_t)i * p.ld, nullptr, snk != 0, cr_idx, delta, glev, none);
+        sqv = (lane == i) ? sq : sqv;
+        if (!snk && lane == 0) sl[i] = 0.0;
     }
+    if (snk) snooker_logps(p, sqv, n, lane, sl);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -127,6 +127,51 @@ DZ_DEV void mfma_units(const Params& p, const double* __restrict__ Ms, const dou
     }
 }
 
+// ---- archive-row prefetch of the persistent kernels.  Measured with cycle stamps (tools/stamps.py): with the rows of try i + 1
+// requested at the start of try i, a try of ~2.8 k cycles still waited 1-2 k cycles for them -- the gathers are latency-bound (two
+// 1-KB requests in flight per wave), not bandwidth-bound.  So three row buffers rotate (the rows of tries i + 1 and i + 2 are in
+// flight during try i; the loop is unrolled by three so that no buffer is ever copied -- a copy would wait for its load), and the
+// first two tries of a phase are requested before the PREVIOUS phase's barrier and likelihood pass: row indices depend on
+// (chain, generation, phase, try) only, never on the selected point.
+struct RowPair { double2 a, b; };
+
+DZ_DEV void request_pair(const Params& p, const DrawSrc& ds, int phase, int i, uint32_t gc, uint32_t g, uint32_t M, int lane, RowPair& R)
+{
+    const u32x4 w = uniform_draw(p, ds, pt_slot(p, phase, i, 1), gc, g);
+    const uint32_t r0 = __builtin_amdgcn_readfirstlane(mulhi_idx(w.x, M));
+    uint32_t r1 = __builtin_amdgcn_readfirstlane(mulhi_idx(w.y, M - 1u));
+    if (r1 >= r0) r1++;                                   // random.sample(range(M), 2) :662  (wave-uniform: kept on the scalar unit)
+    const uint32_t uld = (uint32_t)p.ld;
+    const int jc = min(2 * lane, p.ld - 2);               // (no lane predicate: lanes past ld re-read the row's last pair, masked where used)
+    R.a = gload2(p.Z + (uint64_t)r0 * uld + jc);
+    R.b = gload2(p.Z + (uint64_t)r1 * uld + jc);
+}
+
+// DE tries i0..i1-1 of one chain's set (one pair, the common case); A and B already hold the rows of tries i0 and i0 + 1.
+template <bool LEAN>
+DZ_DEV void propose_de_pf(const Params& p, int phase, uint32_t g, uint32_t M, int c, uint32_t gc, int i0, int i1, int n, int lane,
+                          const double (&xb)[1][2], const double* __restrict__ grow, int cr_idx, int glev, const DrawSrc& ds,
+                          double* out, int out_stride, double* sl, double* prior_out, RowPair& A, RowPair& B, RowPair& C)
+{
+    auto body = [&](int i, const RowPair& R) {
+        RowTerms<1> rt;
+        rt.a[0][0] = R.a.x - R.b.x; rt.a[0][1] = R.a.y - R.b.y; rt.b[0][0] = 0.0; rt.b[0][1] = 0.0;       // chain_differences :692
+        propose_point<1, false, LEAN>(p, phase, g, M, c, i, n, lane, xb, grow, rt, out + (size_t)i * out_stride, nullptr, false, cr_idx, 1, glev, ds);
+        if (!LEAN && prior_out) point_prior<1>(p, out + (size_t)i * out_stride, lane, prior_out + i);
+    };
+    for (int i = i0; i < i1; i += 3) {
+        if (i + 2 < i1) request_pair(p, ds, phase, i + 2, gc, g, M, lane, C);
+        body(i, A);
+        if (i + 1 >= i1) break;
+        if (i + 3 < i1) request_pair(p, ds, phase, i + 3, gc, g, M, lane, A);
+        body(i + 1, B);
+        if (i + 2 >= i1) break;
+        if (i + 4 < i1) request_pair(p, ds, phase, i + 4, gc, g, M, lane, B);
+        body(i + 2, C);
+    }
+    if (lane >= i0 && lane < i1) { sl[lane] = 0.0; if (LEAN && prior_out) prior_out[lane] = 0.0; }            // snooker_logp = 0 (flat priors: 0)
+}
+
 // PB: per-dimension priors and/or hard boundaries (SampledParam priors, parameters.py:37-47; Dream.py:733-791) -- the full
 // propose_point with its prior evaluation; the flat, unbounded case keeps the lean code (2.4 % faster at the headline size).
 template <int NRT, bool TRI, bool XLDS, int CH, int WPC, bool PB>
@@ -186,14 +231,34 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     }
     __syncthreads();
 
+    // A generation's wave-uniform draws: lane s holds slot s (both phases read them; four registers across the likelihood pass are
+    // cheaper than a second Philox call).  They are made at the end of the PREVIOUS generation's second proposal phase, together
+    // with the requests for the first archive rows the generation will need.
+    auto generation_draws = [&](uint32_t g_) {
+        DrawSrc q; q.have = true; q.mine = make_uint4(0, 0, 0, 0);
+        if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g_); q.mine = make_uint4(w.x, w.y, w.z, w.w); }
+        return q;
+    };
+    RowPair RA, RB, RC;
+    RA.a = double2{0.0, 0.0}; RA.b = RA.a; RB = RA; RC = RA;
+    auto prefetch_first = [&](const DrawSrc& q, int phase_, uint32_t g_) {          // rows of this wave's first two tries of (g_, phase_)
+        const int n_ = k - phase_;
+        const int a0 = WPC == 1 ? 0 : (sub * n_) / WPC, a1 = WPC == 1 ? n_ : ((sub + 1) * n_) / WPC;
+        if (a0 < a1) request_pair(p, q, phase_, a0, gc, g_, M, lane, RA);
+        if (a0 + 1 < a1) request_pair(p, q, phase_, a0 + 1, gc, g_, M, lane, RB);
+    };
+    auto draws_say_snooker = [&](const DrawSrc& q, uint32_t g_) {                   // set_snooker :542-554 on the integer form of the draw
+        const u32x4 w0 = uniform_draw(p, q, 0, gc, g_);
+        return u53_below(w0.x, w0.y, p.snk_thr);
+    };
+    DrawSrc dsn = generation_draws(g0);
+    if (!draws_say_snooker(dsn, g0)) prefetch_first(dsn, 0, g0);
+
     for (int gi = 0; gi < ngen; ++gi) {
         const uint32_t g = g0 + (uint32_t)gi;
         const bool last = gi == ngen - 1;
         DZ_MSTAMP(0);
-        // the generation's wave-uniform draws: lane s holds slot s (both phases read them; four registers across the likelihood pass
-        // are cheaper than a second Philox call)
-        DrawSrc ds; ds.have = true; ds.mine = make_uint4(0, 0, 0, 0);
-        if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g); ds.mine = make_uint4(w.x, w.y, w.z, w.w); }
+        const DrawSrc ds = dsn;
         for (int phase = 0; phase < 2; ++phase) {
             // ---- phase 0: k proposals around the chain's state (generate_proposal_points :258-264) into the chain's rows
             //      of tiles 0..k-1; phase 1: the selected proposal moves to tile 0 and k-1 reference points around it
@@ -244,15 +309,24 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                     if (2 * lane + 1 < d) region[2 * lane + 1] = base[0][1];
                 }
             }
-            double gt[NCH][2];
-            load_gamma_row_from<NCH>(gts + (size_t)(f.glev - 1) * d, d, lane, gt);
+            const bool snk_s = __builtin_amdgcn_readfirstlane((int)f.snk) != 0;      // (the decision is wave-uniform: branch on the scalar unit)
+            const double* grow = gts + (size_t)(__builtin_amdgcn_readfirstlane(f.glev) - 1) * d;
             if (phase) DZ_MSTAMP(13);
             const int n = k - phase;
             const int i0 = WPC == 1 ? 0 : (sub * n) / WPC, i1 = WPC == 1 ? n : ((sub + 1) * n) / WPC;     // this wave's tries
-            if (i0 < i1)
-                propose_set<NCH, false, false, !PB>(p, phase, g, M, c, gc, i0, i1, n, lane, base, gt, f.snk, f.cr_idx, 1, f.glev, ds,
-                                                     region + (size_t)phase * tstride, tstride, (phase ? rS + cl * (k - 1) : sS + cl * k), nullptr,
-                                                     (phase ? rP + cl * (k - 1) : sP + cl * k));
+            double* slp = phase ? rS + cl * (k - 1) : sS + cl * k;
+            double* prp = phase ? rP + cl * (k - 1) : sP + cl * k;
+            if (!snk_s) {
+                propose_de_pf<!PB>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, f.cr_idx, f.glev, ds,
+                                   region + (size_t)phase * tstride, tstride, slp, prp, RA, RB, RC);
+                if (phase == 0) prefetch_first(ds, 1, g);                            // the reference set's first rows, ahead of the likelihood pass
+            } else if (i0 < i1)
+                propose_set<NCH, false, false, !PB>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, true, f.cr_idx, 1, f.glev, ds,
+                                                     region + (size_t)phase * tstride, tstride, slp, nullptr, prp);
+            if (phase == 1 && !last) {                                               // the next generation's draws and first rows
+                dsn = generation_draws(g + 1u);
+                if (!draws_say_snooker(dsn, g + 1u)) prefetch_first(dsn, 0, g + 1u);
+            }
             DZ_MSTAMP(1 + 4 * phase);
             __syncthreads();                                                         // points visible
             DZ_MSTAMP(2 + 4 * phase);
@@ -383,11 +457,10 @@ __global__ __launch_bounds__(64 * MIXW) void k_generations_mix(const Params* __r
                 if (2 * lane < d) region[2 * lane] = base[0][0];                    // the selected proposal now sits in row 0
                 if (2 * lane + 1 < d) region[2 * lane + 1] = base[0][1];
             }
-            double gt[NCH][2];
-            load_gamma_row<NCH>(p, f.glev, 1, lane, gt);
+            const double* grow = gamma_row(p, f.glev, 1);
             const int n = k - phase;
             double* rows = region + (size_t)phase * LDP;
-            propose_set<NCH, false, false, true>(p, phase, g, M, c, gc, 0, n, n, lane, base, gt, f.snk, f.cr_idx, 1, f.glev, ds,
+            propose_set<NCH, false, false, true>(p, phase, g, M, c, gc, 0, n, n, lane, base, grow, f.snk, f.cr_idx, 1, f.glev, ds,
                                                  rows, LDP, (phase ? rS : sS), nullptr, (phase ? lh : sP));   // (flat priors: in phase 1 the prior slot is scratch)
             // mt_evaluate_logps :278, :302 -- by this wave, for its own points.  The squared distances to the J means need the
             // whole wave (one butterfly each); the log-sum-exp of a point is scalar work, so lane i does it for point i and

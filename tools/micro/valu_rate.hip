@@ -99,6 +99,42 @@ K64(k_add_f64, "v_add_f64 %0, %0, %1")
 K64(k_pk_fma_f32, "v_pk_fma_f32 %0, %0, %1, %1")
 K64(k_pk_mul_f32, "v_pk_mul_f32 %0, %0, %1")
 K64(k_lshlrev_b64, "v_lshlrev_b64 %0, 1, %0")
+__global__ void k_mad_u64_u32(unsigned* out, long long* cyc, int iters)
+{
+    unsigned long long r[8]; unsigned b = threadIdx.x * 2654435761u + 12345u;
+    for (int i = 0; i < 8; ++i) r[i] = threadIdx.x * 40503u + i * 7919u + 1u;
+    __syncthreads();
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, 0" : "=v"(r[i]) : "v"((unsigned)r[i]), "v"(b) : "s20", "s21");
+        }
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    unsigned long long s = 0; for (int i = 0; i < 8; ++i) s ^= r[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+__global__ void k_mul_lo_hi(unsigned* out, long long* cyc, int iters)
+{   // the 32 x 32 -> 64 product as two instructions
+    unsigned lo[8], hi[8]; unsigned b = threadIdx.x * 2654435761u + 12345u;
+    for (int i = 0; i < 8; ++i) { lo[i] = threadIdx.x * 40503u + i * 7919u + 1u; hi[i] = 0; }
+    __syncthreads();
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_mul_hi_u32 %1, %0, %2\n v_mul_lo_u32 %0, %0, %2" : "+v"(lo[i]), "=v"(hi[i]) : "v"(b));
+        }
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    unsigned s = 0; for (int i = 0; i < 8; ++i) s ^= lo[i] ^ hi[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
 K64(k_rcp_f64, "v_rcp_f64 %0, %0")
 K64(k_sqrt_f64, "v_sqrt_f64 %0, %0")
 KCVT(k_cvt_f64_u32, "v_cvt_f64_u32 %0, %1", double, unsigned)
@@ -131,7 +167,7 @@ int main()
         {"v_add_u32", k_add_u32, 1}, {"v_xor_b32", k_xor_b32, 1}, {"v_lshlrev_b32", k_lshlrev, 1}, {"v_alignbit_b32", k_alignbit, 1},
         {"v_bitop3_b32", k_bitop3, 1}, {"v_add3_u32", k_add3_u32, 1}, {"v_xad_u32", k_xad_u32, 1},
         {"v_mul_lo_u32", k_mul_lo_u32, 1}, {"v_mul_hi_u32", k_mul_hi_u32, 1}, {"v_mul_u32_u24", k_mul_u32_u24, 1},
-        {"v_lshlrev_b64", k_lshlrev_b64, 1},
+        {"v_lshlrev_b64", k_lshlrev_b64, 1}, {"v_mad_u64_u32", k_mad_u64_u32, 1}, {"v_mul_hi+v_mul_lo", k_mul_lo_hi, 2},
         {"v_mul_f32", k_mul_f32, 1}, {"v_fma_f32", k_fma_f32, 1}, {"v_pk_fma_f32", k_pk_fma_f32, 1}, {"v_pk_mul_f32", k_pk_mul_f32, 1},
         {"v_fma_f64", k_fma_f64, 1}, {"v_mul_f64", k_mul_f64, 1}, {"v_add_f64", k_add_f64, 1}, {"v_rcp_f64", k_rcp_f64, 1}, {"v_sqrt_f64", k_sqrt_f64, 1},
         {"v_cvt_f64_u32", k_cvt_f64_u32, 1}, {"v_cvt_f64_f32", k_cvt_f64_f32, 1}, {"v_cvt_f32_u32", k_cvt_f32_u32, 1}, {"v_cvt_u32_f32", k_cvt_u32_f32, 1},

@@ -109,7 +109,8 @@ DZ_DEV int mt_select(const Params& p, int c, double u_sel, int lane, bool* anyfi
 
 // log of the multi-try ratio (:305-323).  val: lane i < k holds proposal term A_i, lane 16+i reference term B_i,
 // every other lane -inf.
-DZ_DEV double mt_log_ratio(int k, double val)
+// u_acc: the Metropolis uniform (:993); its logarithm is evaluated in lane 1 of the same dlog pass (one pass instead of two).
+DZ_DEV double mt_log_ratio(int k, double val, double u_acc, int lane, double* log_u)
 {
     const double rm = rowmax16(val);
     const double m2 = fmax(readlane_f64(rm, 0), readlane_f64(rm, 16));                                 // :320
@@ -117,8 +118,11 @@ DZ_DEV double mt_log_ratio(int k, double val)
     double SA = 0.0, SB = 0.0;
     for (int i = 0; i < k; ++i) SA = SA + readlane_f64(ev, i);
     for (int i = 0; i < k; ++i) SB = SB + readlane_f64(ev, 16 + i);
-    return nan_to_num(dlog(SA / SB));                                                                // :323
+    const double lg = dlog(lane == 1 ? u_acc : SA / SB);
+    *log_u = readlane_f64(lg, 1);
+    return nan_to_num(readlane_f64(lg, 0));                                                          // :323
 }
+DZ_DEV double mt_log_ratio(int k, double val) { double lu; return mt_log_ratio(k, val, 0.5, 0, &lu); }
 
 // u53(hi, lo) < q for q in [0, 1], as an integer test: u53 = k 2^-53 with k = (hi >> 5) 2^26 + (lo >> 6), so the test is
 // k < ceil(q 2^53) =: thr (made once on the host).  Wave-uniform operands stay on the scalar unit.

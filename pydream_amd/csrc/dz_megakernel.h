@@ -290,8 +290,12 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 double lp = -__builtin_huge_val();
                 if (lane < k) {
                     const int pt = lane * CH + cl;
+                    double qt[NRT];
+#pragma unroll
+                    for (int t = 0; t < NRT; ++t) qt[t] = qb[pt * NRT + t];          // (all reads in flight, then the ordered sum)
                     double Q = 0.0;
-                    for (int t = 0; t < NRT; ++t) Q = Q + qb[pt * NRT + t];
+#pragma unroll
+                    for (int t = 0; t < NRT; ++t) Q = Q + qt[t];
                     const double lk = nan_to_ninf(p.logF - 0.5 * Q);
                     if (sub == 0) sL[cl * k + lane] = lk;
                     lp = sP[cl * k + lane] + p.T * lk;
@@ -320,9 +324,14 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 propose_de_pf<!PB>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, f.cr_idx, f.glev, ds,
                                    region + (size_t)phase * tstride, tstride, slp, prp, RA, RB, RC);
                 if (phase == 0) prefetch_first(ds, 1, g);                            // the reference set's first rows, ahead of the likelihood pass
-            } else if (i0 < i1)
+            } else if (i0 < i1) {
+                // a snooker set is the longest path to the block's barrier (three rows and three reductions per try, one chain in
+                // ten): its wave gets issue priority over the three DE waves it shares a SIMD with
+                __builtin_amdgcn_s_setprio(3);
                 propose_set<NCH, false, false, !PB>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, true, f.cr_idx, 1, f.glev, ds,
                                                      region + (size_t)phase * tstride, tstride, slp, nullptr, prp);
+                __builtin_amdgcn_s_setprio(0);
+            }
             if (phase == 1 && !last) {                                               // the next generation's draws and first rows
                 dsn = generation_draws(g + 1u);
                 if (!draws_say_snooker(dsn, g + 1u)) prefetch_first(dsn, 0, g + 1u);
@@ -356,15 +365,19 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 const int i = lane - 16;
                 if (i < k - 1) {
                     const int pt = (1 + i) * CH + cl;
+                    double qt[NRT];
+#pragma unroll
+                    for (int t = 0; t < NRT; ++t) qt[t] = qb[pt * NRT + t];
                     double Q = 0.0;
-                    for (int t = 0; t < NRT; ++t) Q = Q + qb[pt * NRT + t];
+#pragma unroll
+                    for (int t = 0; t < NRT; ++t) Q = Q + qt[t];
                     val = p.T * nan_to_ninf(p.logF - 0.5 * Q) + rP[cl * (k - 1) + i];                     // :303
                 } else val = p.T * llik + lpri;                                                          // :877-879
                 if (snk) { const double sr = i < k - 1 ? rS[cl * (k - 1) + i] : 0.0; val = (val + sr) + sS[cl * k + i]; }   // :312-313
             }
             DZ_MSTAMP(14);
-            const double lu = dlog(u_acc);                                           // (independent of the ratio's chain: the two interleave)
-            double ratio = mt_log_ratio(k, val);
+            double lu;
+            double ratio = mt_log_ratio(k, val, u_acc, lane, &lu);                   // log(u) of :993 rides in the ratio's logarithm pass
             if (!fin) ratio = -__builtin_huge_val();                                 // DESIGN.md deviation D1
             const bool accept = is_finite(ratio) && (lu < ratio);                    // :993
             DZ_MSTAMP(15);
@@ -515,9 +528,10 @@ __global__ __launch_bounds__(64 * MIXW) void k_generations_mix(const Params* __r
                 val = i < k - 1 ? p.T * rL[i] + 0.0 : p.T * llik + lpri;            // :303, :877-879 (flat priors)
                 if (snk) { const double sr = i < k - 1 ? rS[i] : 0.0; val = (val + sr) + sS[i]; }   // :312-313
             }
-            double ratio = mt_log_ratio(k, val);
+            double lu;
+            double ratio = mt_log_ratio(k, val, u_acc, lane, &lu);
             if (!fin) ratio = -__builtin_huge_val();                                // DESIGN.md deviation D1
-            const bool accept = is_finite(ratio) && (dlog(u_acc) < ratio);          // :993
+            const bool accept = is_finite(ratio) && (lu < ratio);                   // :993
             const int jj = 2 * lane;
             const double2 xo = {xs[0][0], xs[0][1]};
             double2 xn = xo;

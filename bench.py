@@ -9,6 +9,19 @@ scaling, BASELINE.json north_star / configs[3]): 4096 chains per GPU on the 100-
 pydream/examples/ndim_gaussian, multitry=5, DE+snooker, reference defaults otherwise.  Inputs
 (seed archive, start states, precision matrix) are resident in HBM before the timed region.
 
+Sequence (every part but the timed blocks is untimed):
+  1. convergence run from the over-dispersed starts, in chunks, with the whole run traced on the device: after every
+     chunk R-hat (pydream/convergence.py:3-20: second half of the run so far) over all chains; reports the first
+     generation count at which max R-hat < 1.2 (the reference example's stopping rule, dream_ex_ndim_gaussian.py:80)
+     -- this also takes the GPU out of its idle clock state;
+  2. R-hat over a fixed window of --rhat-window generations after that (independent of --steps);
+  3. W warm-up generations, then blocks of EXACTLY K generations, each bracketed by barrier + device sync on both sides
+     and timed on its own (max over ranks), repeated until at least --min-timed-ms have been timed:
+     value = N k K / median block time (a single block at the default K lasts 30 ms, at K = 20 0.6 ms);
+  4. a pass of K generations with HIP events on every launch (per-kernel durations for the roofline);
+  5. (one GPU) the same timed blocks with the reference example's own formula, the dense precision matrix: `dense_value`;
+  6. (rank 0) the CPU restatement on the host cores.
+
 For N>1 the driver launches one rank per GPU with torch.distributed.run; torch is used ONLY for the
 rendezvous (gloo: barrier, max-reduce of the time, broadcast of the RCCL unique id) -- the engine
 itself is libdreamzs.so (HIP + RCCL), loaded through ctypes.
@@ -27,6 +40,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_MFMA_PEAK_TFLOPS = 78.6 # v_mfma_f64_16x16x4_f64: 64 cycles per instruction and SIMD (tools/micro/mfma_f64_rate.hip measured 77.4 TFLOP/s);
+                             # equal to the FP64 vector rate -- the guide's table has no FP64 row
+PROFILE_TAG = "r02"          # profiles/<tag>_traffic.json, profiles/<tag>_pmc_summary.json (tools/collect_profiles.sh)
 
 
 def mvn_precision(d):
@@ -82,8 +98,8 @@ def algorithmic_bytes(args, n_local):
 
 def measured_traffic(args, n_local, kernel_class, gens_per_launch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same workload
-    (profiles/r01_traffic.json, made by tools/collect_profiles.sh + tools/traffic_from_pmc.py), or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+    (profiles/<tag>_traffic.json, made by tools/collect_profiles.sh + tools/traffic_from_pmc.py), or None."""
+    path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_traffic.json")
     default = (n_local == 4096 and args.dim == 100 and args.multitry == 5 and args.target == "mvn" and args.mvn_kind == "tri"
                and args.snooker == 0.1 and args.thin == 10)
     if not (default and kernel_class == "generations" and os.path.exists(path)):
@@ -91,7 +107,7 @@ def measured_traffic(args, n_local, kernel_class, gens_per_launch):
     t = json.load(open(path))
     if "k_generations" not in t["kernel"]:
         return None, None
-    return t["bytes_per_generation"] * gens_per_launch, "profiles/r01_traffic.json"
+    return t["bytes_per_generation"] * gens_per_launch, "profiles/%s_traffic.json" % PROFILE_TAG
 
 
 def cpu_baseline(args):
@@ -116,16 +132,66 @@ def cpu_baseline(args):
                       "thread(s) over the chains, %.1f s" % (nc, g, args.dim, args.target, args.multitry, cores, dt)}
 
 
+def measured_pmc(args, n_local):
+    """VALU / matrix-pipe busy fractions of the dominant kernel from the committed PMC summary, or None."""
+    path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_summary.json")
+    default = (n_local == 4096 and args.dim == 100 and args.multitry == 5 and args.target == "mvn" and args.mvn_kind == "tri")
+    if not (default and os.path.exists(path)):
+        return None
+    summ = json.load(open(path))
+    cand = {k: v for k, v in summ.items() if "k_generations" in k and "SQ_BUSY_CYCLES" in v}
+    if not cand:
+        return None
+    v = max(cand.values(), key=lambda x: x.get("SQ_WAVE_CYCLES", 0))
+    out = {"source": "profiles/%s_pmc_summary.json" % PROFILE_TAG}
+    # units (checked against the instruction counts): SQ_WAVE_CYCLES and SQ_ACTIVE_INST_VALU count quad-cycles summed over waves,
+    # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 SIMDs
+    if v.get("SQ_WAVES") and v.get("SQ_INSTS_VALU") is not None:
+        out["valu_insts_per_wave_generation"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"] / args.thin
+    if v.get("SQ_WAVE_CYCLES") and v.get("SQ_WAVES"):
+        nsimd = 1024.0
+        waves_per_simd = v["SQ_WAVES"] / nsimd
+        if "SQ_ACTIVE_INST_VALU" in v:
+            out["valu_busy"] = v["SQ_ACTIVE_INST_VALU"] * waves_per_simd / v["SQ_WAVE_CYCLES"]
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+            out["mfma_busy"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (nsimd * 4.0 * v["SQ_WAVE_CYCLES"] / v["SQ_WAVES"])
+    return out
+
+
+def timed_blocks(e, K, min_ms, barrier, dist, max_blocks=400):
+    """Blocks of exactly K generations, each bracketed by barrier + sync on both sides; returns the block times (s, max over ranks)."""
+    times = []
+    while True:
+        e.trace_reset()
+        barrier()
+        t0 = time.perf_counter()
+        e.step(K)
+        e.sync()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            t = torch.tensor([dt, float(sum(times) + dt)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        times.append(dt)
+        if 1e3 * sum(times) >= min_ms or len(times) >= max_blocks:      # (the times are rank-maxima: every rank stops at the same block)
+            return times
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--spinup", type=int, default=2000,
-                    help="untimed generations run before the W warm-up steps so that the GPU leaves its idle clock "
-                         "state (a cold MI355X needs ~0.1 s of load; without it short runs vary 3x); more are added, up "
-                         "to 4x, until --spinup-seconds of load have passed (small workloads finish 2000 generations sooner)")
-    ap.add_argument("--spinup-seconds", type=float, default=0.15)
+    ap.add_argument("--min-timed-ms", type=float, default=50.0, help="the block of K timed generations is repeated until this much has been timed")
+    ap.add_argument("--rhat-chunk", type=int, default=500, help="generations between R-hat evaluations of the convergence run")
+    ap.add_argument("--rhat-max-generations", type=int, default=10000, help="the convergence run stops here if R-hat has not passed 1.2")
+    ap.add_argument("--rhat-min-generations", type=int, default=2000,
+                    help="the convergence run lasts at least this long (it doubles as the clock spin-up: a cold MI355X needs ~0.1 s of load)")
+    ap.add_argument("--rhat-window", type=int, default=4000, help="generations of the fixed R-hat window after the convergence run")
+    ap.add_argument("--spinup", type=int, default=None, help="(deprecated) alias of --rhat-min-generations")
     ap.add_argument("--chains-per-gpu", type=int, default=4096)
     ap.add_argument("--dim", type=int, default=100)
     ap.add_argument("--multitry", type=int, default=5)
@@ -140,8 +206,12 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=0, help="generations of the CPU baseline (0: as many as fit --cpu-seconds)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense", action="store_true", help="skip the dense-matrix (reference formula) pass")
     ap.add_argument("--no-events", action="store_true", help="do not time individual kernels with HIP events")
     args = ap.parse_args()
+    if args.spinup is not None:
+        args.rhat_min_generations = args.spinup
+        args.rhat_max_generations = max(args.spinup, min(args.rhat_max_generations, 4 * args.spinup))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -160,14 +230,19 @@ def main():
 
     n_local = args.chains_per_gpu
     n_global = n_local * world
-    # spin-up (single GPU: extended by time up to 4x) + warm-up + timed pass + HIP-event pass: sizes the replicated archive
-    total = (4 if world == 1 else 1) * args.spinup + 2 * args.steps + args.warmup
+    K = args.steps
+    chunk = max(1, args.rhat_chunk)
+    conv_cap = max(chunk, args.rhat_max_generations)
+    est_block_s = max(K * 15e-6 * max(1.0, (args.dim / 100.0) ** 2) * max(1.0, n_local / 4096.0), 1e-5)
+    max_blocks = int(min(400, max(2, args.min_timed_ms * 1e-3 / est_block_s + 2)))
+    total = conv_cap + args.rhat_window + args.warmup + K * (max_blocks + 2)
     # (DZ_BENCH_TRANSPORT=host and DZ_BENCH_DEVICE exist so that the multi-rank control flow can be rehearsed on a
     #  one-GPU box: ranks share the device and exchange through the host; measurements use RCCL, one rank per GPU)
     device = int(os.environ.get("DZ_BENCH_DEVICE", local_rank))
-    e = setup_engine(_capi.Engine, args, n_global, n_local, rank * n_local, total, device=device)
-    transport_note = None
-    if world > 1:
+
+    def attach(e):
+        if world == 1:
+            return None
         from pydream_amd.distributed import attach_transport
         transport = os.environ.get("DZ_BENCH_TRANSPORT", "rccl")
         err = ""
@@ -179,65 +254,76 @@ def main():
         dist.all_gather_object(errs, err)
         if any(errs):
             # a number over the host-staged all-gather (named as such in the JSON line) beats no number
-            transport_note = "host (rccl unavailable: %s)" % next(x for x in errs if x)
             attach_transport(e, rank, world, transport="host")
-        else:
-            transport_note = transport
+            return "host (rccl unavailable: %s)" % next(x for x in errs if x)
+        return transport
 
-    def barrier():
-        e.sync()
-        if dist is not None:
-            dist.barrier()
-
-    chunk = max(1, min(args.spinup, max(args.steps, args.warmup, 2)))
-    spun, t_spin = 0, time.perf_counter()
-    # (with several ranks every e.step is a collective sequence, so the count must not depend on a local clock)
-    extend = lambda: world == 1 and spun < 4 * args.spinup and time.perf_counter() - t_spin < args.spinup_seconds
-    while spun < args.spinup or extend():
-        n = min(chunk, (args.spinup if spun < args.spinup else 4 * args.spinup) - spun)      # clock spin-up (untimed, not part of W or K)
-        e.trace_reset()
-        e.step(n)
-        e.sync()
-        spun += n
-    barrier()
-    e.trace_reset()
-    e.step(args.warmup)
-    barrier()
-    e.trace_reset()
-    barrier()
-    # ---- timed region: exactly K generations, nothing else on the stream ----
-    t0 = time.perf_counter()
-    e.step(args.steps)
-    t_enqueued = time.perf_counter() - t0
-    e.sync()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-    tr = e.get_trace(0, args.steps, with_X=False)
-    acc = float(tr["moved"].mean())
-    rhat = e.get_rhat() if world == 1 else None
-    if world > 1:
+    def rhat_now(e, nsamples):
+        if world == 1:
+            return e.get_rhat()
         from pydream_amd.distributed import gelman_rubin_sharded
-        rhat = gelman_rubin_sharded(e, args.steps)
+        return gelman_rubin_sharded(e, nsamples)
 
-    # ---- second pass of K generations with HIP events around every kernel launch (per-kernel durations
-    #      for the roofline; kept out of the timed region because each event record costs a few us) ----
+    def converge_and_time(e, with_rhat):
+        """parts 1-3 of the sequence on engine e; returns (block times, convergence record, acceptance of the last block)"""
+        def barrier():
+            e.sync()
+            if dist is not None:
+                dist.barrier()
+        conv = {"chunk": chunk, "criterion": "max R-hat < 1.2 (reference rule: second half of the run so far, all %d chains)" % n_global,
+                "generations_to_rhat_below_1p2": None, "history": []}
+        done = 0
+        e.trace_reset()
+        while done < conv_cap:
+            n = min(chunk, conv_cap - done)
+            if not with_rhat:
+                e.trace_reset()                       # (no diagnostic on this engine: its trace buffer holds one chunk)
+            e.step(n)
+            done += n
+            if with_rhat:
+                r = float(np.max(rhat_now(e, done)))
+                conv["history"].append([done, r])
+                if r < 1.2 and conv["generations_to_rhat_below_1p2"] is None:
+                    conv["generations_to_rhat_below_1p2"] = done
+                    conv["rhat_at_that_point"] = r
+            else:
+                e.sync()
+            if done >= args.rhat_min_generations and (not with_rhat or conv["generations_to_rhat_below_1p2"] is not None):
+                break
+        conv["generations_run"] = done
+        if with_rhat:
+            e.trace_reset()
+            e.step(args.rhat_window)
+            conv["rhat_window_generations"] = args.rhat_window
+            conv["rhat_window_max"] = float(np.max(rhat_now(e, args.rhat_window)))
+        barrier()
+        e.trace_reset()
+        e.step(args.warmup)
+        barrier()
+        times = timed_blocks(e, K, args.min_timed_ms, barrier, dist, max_blocks)
+        acc = float(e.get_trace(0, K, with_X=False)["moved"].mean())
+        return times, conv, acc
+
+    trace_cap = max(conv_cap, args.rhat_window, K, args.warmup, 2)
+    e = setup_engine(_capi.Engine, args, n_global, n_local, rank * n_local, total, device=device, trace_capacity=trace_cap)
+    transport_note = attach(e)
+    t_enq0 = time.perf_counter()
+    times, conv, acc = converge_and_time(e, True)
+    med = float(np.median(times))
+
+    # ---- a pass of K generations with HIP events around every kernel launch (per-kernel durations
+    #      for the roofline; kept out of the timed blocks because each event record costs a few us) ----
     prof = {}
     if not args.no_events:
         e.trace_reset()
-        e.profile_enable(True, prealloc_pairs=8 * args.steps)
+        e.profile_enable(True, prealloc_pairs=8 * K)
         e.profile_reset()
-        e.step(args.steps)
+        e.step(K)
         e.sync()
         e.profile_enable(False)
-        # propose / logp / accept launches carry their own start/stop events (hipExtLaunchKernelGGL: the dispatch's
-        # begin/end timestamps, the same figures rocprofv3's kernel trace reports); adapt / exchange / generations
-        # are bracketed by event records, which adds about `event_bracket_us` to each of those
+        # propose / logp / accept / generations launches carry their own start/stop events (hipExtLaunchKernelGGL: the
+        # dispatch's begin/end timestamps, the same figures rocprofv3's kernel trace reports); adapt / exchange are
+        # bracketed by event records, which adds about `event_bracket_us` to each of those
         for name in ("generations", "propose", "logp", "accept", "adapt", "exchange"):
             ms, n = e.profile_get(name)
             prof[name] = {"total_ms": ms, "launches": n, "avg_us": (1e3 * ms / n) if n else None}
@@ -245,16 +331,30 @@ def main():
         prof["event_bracket_us"] = (1e3 * ms0 / n0) if n0 else None
         if dist is not None:
             dist.barrier()
+    e.close()
+
+    dense = None
+    if world == 1 and args.target == "mvn" and args.mvn_kind == "tri" and not args.no_dense:
+        import copy
+        a2 = copy.copy(args)
+        a2.mvn_kind = "dense"
+        e2 = setup_engine(_capi.Engine, a2, n_global, n_local, 0, total, device=device, trace_capacity=max(K, args.warmup, chunk, 2))
+        t2, _, acc2 = converge_and_time(e2, False)
+        e2.close()
+        m2 = float(np.median(t2))
+        dense = {"value": n_global * args.multitry * K / m2, "ms_per_step": 1e3 * m2 / K, "timed_blocks": len(t2),
+                 "formula": "log_F - x.(invC.x)/2 with the dense precision matrix (dream_ex_ndim_gaussian.py:49-52)", "acceptance_rate": acc2}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    value = n_global * args.multitry * args.steps / dt
+    value = n_global * args.multitry * K / med
+    flops_gen = n_local * (2 * args.multitry - 1) * (1.0 if args.mvn_kind == "tri" else 2.0) * float(args.dim) ** 2 if args.target == "mvn" else None
     out = {
         "metric": "proposals/sec (all chains), 100D MVN logpdf, MT-DREAM(ZS) multitry=%d" % args.multitry,
-        "value": value, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": value, "unit": "proposals/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "ms_per_step": 1e3 * med / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%d chains/GPU x %d-D %s target (%s), multitry=%d, DE+snooker(%g), nCR=3, history_thin=%d, "
                                "seed archive max(10d,2N) rows U(-5,15); BASELINE north_star target / configs[3] per-GPU shard"
@@ -263,33 +363,63 @@ def main():
                    "chains_global": n_global, "chains_per_gpu": n_local, "ndim": args.dim, "multitry": args.multitry,
                    "parallelism": ("chains sharded x%d, Z appends all-gathered, transport: %s" % (world, transport_note))
                                   if world > 1 else "single GPU"},
-        "logp_points_per_s": n_global * (2 * args.multitry - 1) * args.steps / dt,
-        "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps, "spinup_generations": spun,
-        "acceptance_rate": acc, "rhat_max": float(np.max(rhat)),
+        "timing": {"timed_blocks": len(times), "block_generations": K, "block_ms_median": 1e3 * med, "block_ms_min": 1e3 * min(times),
+                   "block_ms_max": 1e3 * max(times), "timed_ms_total": 1e3 * sum(times),
+                   "value_from": "median block", "value_best_block": n_global * args.multitry * K / min(times),
+                   "value_worst_block": n_global * args.multitry * K / max(times)},
+        "logp_points_per_s": n_global * (2 * args.multitry - 1) * K / med,
+        "acceptance_rate": acc,
+        "generations_executed": conv["generations_run"] + args.rhat_window + args.warmup + K * (len(times) + (0 if args.no_events else 1)),
+        "rhat_max": conv.get("rhat_window_max"),
+        "convergence": conv,
     }
+    if dense is not None:
+        out["dense_value"] = dense["value"]
+        out["dense"] = dense
     if prof:
         ab = algorithmic_bytes(args, n_local)
         if prof.get("generations", {}).get("launches"):
             # the persistent kernel covers whole generations: SURVEY.md section 8(d) B = 176 d + 152 bytes per chain-generation
-            ab["generations"] = n_local * (176.0 * args.dim + 152.0) * args.steps / prof["generations"]["launches"]
+            ab["generations"] = n_local * (176.0 * args.dim + 152.0) * K / prof["generations"]["launches"]
         cand = {k: v for k, v in prof.items() if k in ab and v["launches"]}
         dom = max(cand, key=lambda k: cand[k]["total_ms"])
         avg_s = cand[dom]["avg_us"] * 1e-6
-        achieved = ab[dom] / avg_s / 1e9
-        traffic, tsrc = measured_traffic(args, n_local, dom, args.steps / cand[dom]["launches"])
-        out["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
-                           "algorithmic_bytes_per_launch": ab[dom], "avg_launch_us": avg_s * 1e6}
+        gens_per_launch = K / cand[dom]["launches"] if dom == "generations" else 1.0
+        compute_bound = args.dim > 128 and args.target == "mvn" and dom in ("logp", "generations")
+        if compute_bound:
+            # d > 128: the batched quadratic form dominates and is FP64-matrix-bound (~100 flop/B at d = 1000)
+            fl = flops_gen * (gens_per_launch if dom == "generations" else 0.5)          # logp: two launches per generation
+            achieved = fl / avg_s / 1e12
+            out["roofline"] = {"bound": "fp64_mfma", "kernel": "k_" + dom, "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "algorithmic_flops_per_launch": fl, "avg_launch_us": avg_s * 1e6}
+        else:
+            achieved = ab[dom] / avg_s / 1e9
+            traffic, tsrc = measured_traffic(args, n_local, dom, gens_per_launch)
+            out["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                               "algorithmic_bytes_per_launch": ab[dom], "avg_launch_us": avg_s * 1e6}
+            pm = measured_pmc(args, n_local)
+            if pm:
+                out["roofline"].update({k: v for k, v in pm.items() if k != "source"})
+                out["roofline"]["pmc_source"] = pm["source"]
+            if flops_gen:
+                out["roofline"]["fp64_matrix_tflops"] = flops_gen * K / sum_or(prof, dom, med * 1e3) / 1e9
         out["kernel_times"] = prof
         gen_bytes = n_local * (176.0 * args.dim + 152.0)        # B = 176 d + 152 per chain-generation
         out["generation_hbm"] = {"algorithmic_bytes_per_generation": gen_bytes,
-                                 "achieved_GBps": gen_bytes * args.steps / dt / 1e9,
-                                 "frac_of_8TBps": gen_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBS}
+                                 "achieved_GBps": gen_bytes * K / med / 1e9,
+                                 "frac_of_8TBps": gen_bytes * K / med / 1e9 / HBM_PEAK_GBS}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def sum_or(prof, dom, fallback_ms):
+    """total milliseconds of the dominant class in the event pass (K generations)"""
+    return prof[dom]["total_ms"] if prof.get(dom, {}).get("total_ms") else fallback_ms
 
 
 if __name__ == "__main__":

@@ -246,3 +246,61 @@ def test_python_likelihood_over_worker_processes():
     np.testing.assert_array_equal(np.array(out["1"][0]), np.array(out["8"][0]))
     np.testing.assert_array_equal(np.array(out["1"][1]), np.array(out["8"][1]))
     assert out["8t"] < 0.6 * out["1t"], (out["1t"], out["8t"])
+
+
+def _oracle_run_dream(params, like, nchains, niterations, start, seed, **kwargs):
+    """run_dream's own sequence (core.py) with the CPU oracle as the engine: the checker for API-level runs."""
+    from oracle import oracle as O
+    from pydream_amd.core import _sample_dream_batched
+    restart = kwargs.pop("restart", False)
+    if restart:
+        mn = kwargs["model_name"]
+        kwargs.update(history_file=mn + '_DREAM_chain_history.npy', crossover_file=mn + '_DREAM_chain_adapted_crossoverprob.npy',
+                      gamma_file=mn + '_DREAM_chain_adapted_gammalevelprob.npy')
+    step = Dream(model=Model(like, params), variables=params, verbose=False, **kwargs)
+    pool = _setup_mp_dream_pool(nchains, niterations, step, start_pt=start, seed=seed, engine_cls=O.Engine)
+    try:
+        pool._initializer(*pool._initargs)
+        step.save_history = False
+        return _sample_dream_batched(pool.engine, step, niterations, False, 10)
+    finally:
+        pool.close(); pool.join()
+
+
+def test_restart_continues_bit_for_bit_like_the_oracle(tmp_path):
+    """restart=True (core.py:46-62, 255-263; Dream.py:128-141, 947-969): a first run saves its history and adapted crossover /
+    gamma-level probabilities; the restarted run seeds its archive with the WHOLE saved history, loads the probabilities and
+    starts where the first run stopped.  The restarted GPU run equals the oracle started from the same three .npy files, bit for
+    bit, and really did read them (its archive starts with the saved rows, its first proposals come from the adapted
+    probabilities: a run restarted from the files differs from one that ignores them)."""
+    os.chdir(tmp_path)
+    d, N, G1, G2 = 12, 8, 60, 45
+    P = H.mvn_precision(d)
+    like = MVNormalLogLike(P, factorize=False)
+    params = [FlatParam(np.zeros(d))]
+    Z0 = H.seed_history(10 * d, d, 21)
+    np.save("seed.npy", Z0)
+    kw = dict(multitry=5, adapt_crossover=True, crossover_burnin=30, adapt_gamma=True, gamma_levels=2, history_thin=5)
+    s1, _ = run_dream(params, like, nchains=N, niterations=G1, verbose=False, start=[Z0[i] for i in range(N)], history_file="seed.npy",
+                      model_name="rs", save_history=True, seed=101, **kw)
+    hist = np.load("rs_DREAM_chain_history.npy").reshape(-1, d)
+    crp = np.load("rs_DREAM_chain_adapted_crossoverprob.npy")
+    assert len(hist) == len(Z0) + N * (G1 // 5) and not np.allclose(crp, 1 / 3.)
+    np.testing.assert_array_equal(hist[:len(Z0)], Z0)
+    starts = [s[-1] for s in s1]
+    # the restarted run: GPU through run_dream, oracle through the same host code
+    s2, l2 = run_dream(params, like, nchains=N, niterations=G2, verbose=False, restart=True, start=starts, model_name="rs",
+                       save_history=False, seed=202, **kw)
+    o2, ol2 = _oracle_run_dream(params, like, N, G2, starts, 202, restart=True, model_name="rs", save_history=False, **kw)
+    np.testing.assert_array_equal(np.array(s2), np.array(o2))
+    np.testing.assert_array_equal(np.array(l2), np.array(ol2))
+    # ... and the files mattered: the same run from the original seed history with uniform probabilities goes elsewhere
+    s3, _ = run_dream(params, like, nchains=N, niterations=G2, verbose=False, start=starts, history_file="seed.npy",
+                      save_history=False, seed=202, **kw)
+    assert not np.array_equal(np.array(s2), np.array(s3))
+    # saving again after the restart appends to the loaded history (Dream.py:947-959)
+    run_dream(params, like, nchains=N, niterations=10, verbose=False, restart=True, start=starts, model_name="rs", save_history=True,
+              seed=303, **kw)
+    hist2 = np.load("rs_DREAM_chain_history.npy").reshape(-1, d)
+    assert len(hist2) == len(hist) + N * 2
+    np.testing.assert_array_equal(hist2[:len(hist)], hist)

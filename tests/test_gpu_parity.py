@@ -354,3 +354,71 @@ def test_eval_logp_scratch_buffers_survive_growth(G, O):
     e.step(4); o.step(4)
     assert_traces_identical(e.get_trace(0, 8), o.get_trace(0, 8))
     np.testing.assert_array_equal(S, e.get_trace(0, 4)["X"].transpose(1, 0, 2))
+
+
+def test_c3_full_size_mixture_with_adaptation(G, O):
+    """BASELINE configs[2] at full size: 4096 chains x 100-D mixture of three Gaussians (examples/mixturemodel/mixturemodel.py:18-48
+    generalised: weights 1/6, 1/3, 1/2, means -5, 0, +5 in every dimension), crossover adaptation on.
+    (a) the first 30 generations (all inside the crossover burn-in: multi-kernel path with the adaptation kernels) equal the
+        oracle bit for bit, adapted probabilities included;
+    (b) size-independent properties of the long run (burn-in ends inside it, the persistent mixture kernel takes over): the
+        chains end up in the modes in the proportions of the mixture weights -- the archive lets a chain jump between modes 50
+        standard deviations apart --, every chain sits within a mode's shell (|x - mu_j|^2 / d ~ 1), and inside each mode the
+        pooled sample has unit variance per dimension."""
+    N, d, seed = 4096, 100, 5
+    means = (-5.0, 0.0, 5.0)
+    w = np.array([1 / 6., 1 / 3., 1 / 2.])
+    mu = np.array([np.full(d, m) for m in means])
+    logF = np.log(w) - (d / 2.) * np.log(2 * np.pi)
+    Z0 = H.seed_history(2 * N, d, seed, lo=-8, hi=8)
+    n = 30
+    out = []
+    for Cls in (G.Engine, O.Engine):
+        e = Cls(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
+                adapt_crossover=1, crossover_burnin=300)
+        e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mixture(mu, logF)
+        e.step(n)
+        out.append((e.get_trace(0, n), e.get_cr_state(), e.get_history()))
+    assert_traces_identical(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    # (b) the long run
+    total, burn = 6000, 300
+    e = G.Engine(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * (total // 10 + 2), trace_capacity=1000, seed=seed,
+                 adapt_crossover=1, crossover_burnin=burn)
+    e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mixture(mu, logF)
+    e.profile_enable(True); e.profile_reset()
+    for _ in range(total // 1000):
+        e.trace_reset(); e.step(1000)
+    assert e.profile_get("generations")[1] > 0          # the persistent mixture kernel ran after the burn-in
+    e.profile_enable(False)
+    X = e.get_state()[0]
+    d2 = ((X[:, None, :] - mu[None, :, :]) ** 2).sum(axis=2) / d            # [chain, mode]
+    mode = d2.argmin(axis=1)
+    assert np.all(d2.min(axis=1) < 1.6) and np.all(d2.min(axis=1) > 0.55)   # chi^2_100 / 100 lies in (0.55, 1.6) with overwhelming probability
+    frac = np.bincount(mode, minlength=3) / float(N)
+    np.testing.assert_allclose(frac, w, atol=0.04)
+    for j in range(3):
+        sel = X[mode == j]
+        np.testing.assert_allclose(sel.var(axis=0).mean(), 1.0, atol=0.08)
+        assert np.abs(sel.mean(axis=0) - means[j]).max() < 0.25
+    assert not np.allclose(e.get_cr_state()[0], 1 / 3.)
+    e.close()
+
+
+def test_c5_shard_512_chains_1000d_against_oracle(G, O):
+    """BASELINE configs[4] per-GPU shard at full size: 512 chains x 1000-D correlated MVN, triangular-factor likelihood,
+    12 generations across two history appends: everything bit-exact against the oracle."""
+    N, d, n, seed = 512, 1000, 12, 9
+    P = H.mvn_precision(d)
+    U = np.linalg.cholesky((P + P.T) / 2).T
+    Z0 = H.seed_history(10 * d, d, seed)
+    out = []
+    for Cls in (G.Engine, O.Engine):
+        e = Cls(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * 4, trace_capacity=n, seed=seed)
+        e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), U, 1, 0.0)
+        e.step(n)
+        out.append((e.get_trace(0, n), e.get_history()))
+    assert_traces_identical(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])

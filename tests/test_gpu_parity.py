@@ -361,16 +361,20 @@ def test_c3_full_size_mixture_with_adaptation(G, O):
     generalised: weights 1/6, 1/3, 1/2, means -5, 0, +5 in every dimension), crossover adaptation on.
     (a) the first 30 generations (all inside the crossover burn-in: multi-kernel path with the adaptation kernels) equal the
         oracle bit for bit, adapted probabilities included;
-    (b) size-independent properties of the long run (burn-in ends inside it, the persistent mixture kernel takes over): the
-        chains end up in the modes in the proportions of the mixture weights -- the archive lets a chain jump between modes 50
-        standard deviations apart --, every chain sits within a mode's shell (|x - mu_j|^2 / d ~ 1), and inside each mode the
-        pooled sample has unit variance per dimension."""
+    (b) size-independent properties of the long run (burn-in ends inside it, the persistent mixture kernel takes over), from a
+        seed archive and starts spread over all three modes: every chain ends inside a mode's shell (|x - mu_j|^2 / d ~ 1) and
+        inside each mode the pooled sample has the component's moments (mean mu_j, unit variance per dimension).
+    (The mode OCCUPANCIES are not asserted: at d = 100 the modes are 50 standard deviations apart, a differential-evolution jump
+    between them lands with three times the component's variance in every dimension and is rejected with overwhelming
+    probability -- in the reference as here --, so the occupancies stay those of the starts.)"""
     N, d, seed = 4096, 100, 5
     means = (-5.0, 0.0, 5.0)
     w = np.array([1 / 6., 1 / 3., 1 / 2.])
     mu = np.array([np.full(d, m) for m in means])
     logF = np.log(w) - (d / 2.) * np.log(2 * np.pi)
-    Z0 = H.seed_history(2 * N, d, seed, lo=-8, hi=8)
+    rng = np.random.default_rng(seed)
+    comp = rng.integers(0, 3, 2 * N)
+    Z0 = mu[comp] + 2.0 * rng.standard_normal((2 * N, d))                  # over-dispersed around every mode
     n = 30
     out = []
     for Cls in (G.Engine, O.Engine):
@@ -396,14 +400,18 @@ def test_c3_full_size_mixture_with_adaptation(G, O):
     X = e.get_state()[0]
     d2 = ((X[:, None, :] - mu[None, :, :]) ** 2).sum(axis=2) / d            # [chain, mode]
     mode = d2.argmin(axis=1)
-    assert np.all(d2.min(axis=1) < 1.6) and np.all(d2.min(axis=1) > 0.55)   # chi^2_100 / 100 lies in (0.55, 1.6) with overwhelming probability
+    shell = (d2.min(axis=1) < 1.6) & (d2.min(axis=1) > 0.55)                # chi^2_100 / 100 lies in (0.55, 1.6) with overwhelming probability
+    print("chains inside a mode's shell after %d generations: %.4f; largest |x - mu|^2 / d: %.2f" % (total, shell.mean(), d2.min(axis=1).max()))
+    assert shell.mean() > 0.97 and d2.min(axis=1).max() < 4.0               # (the starts sit at 4: a few chains are still on their way in)
     frac = np.bincount(mode, minlength=3) / float(N)
-    np.testing.assert_allclose(frac, w, atol=0.04)
+    assert frac.min() > 0.25                                                # all three modes stay populated (the starts' thirds)
     for j in range(3):
-        sel = X[mode == j]
+        sel = X[(mode == j) & shell]
         np.testing.assert_allclose(sel.var(axis=0).mean(), 1.0, atol=0.08)
         assert np.abs(sel.mean(axis=0) - means[j]).max() < 0.25
     assert not np.allclose(e.get_cr_state()[0], 1 / 3.)
+    acc = e.get_trace(900, 100, with_X=False)["moved"].mean()
+    assert 0.05 < acc < 0.7
     e.close()
 
 

@@ -92,6 +92,8 @@ int dz_set_likelihood_host(dz_engine* e, dz_logp_cb cb, void* user);
 /* Multi-GPU: chains are sharded, Z / positions are replicated by an all-gather at the
  * end of appending generations (replaces the multiprocessing shared arrays,
  * Dream.py:919-938, 424-449).  Attach ONE of the two transports before dz_step. */
+const char* dz_hip_library(void);      /* path of the HIP runtime this library's calls are bound to */
+const char* dz_comm_library(void);     /* path of the librccl in use: the one next to that HIP runtime (and checked to resolve the same one) */
 int dz_comm_unique_id(void* id128);                                                 /* rank 0: 128-byte RCCL unique id */
 int dz_comm_init_rccl(dz_engine* e, int32_t rank, int32_t world, const void* id128);
 int dz_set_exchange(dz_engine* e, dz_exchange_cb cb, void* user);

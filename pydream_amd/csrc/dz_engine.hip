@@ -43,18 +43,44 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string path, hip_path;
+    // RCCL must sit on the SAME HIP runtime as this library: device pointers and streams of one runtime instance mean nothing to
+    // another.  A process that also imports PyTorch holds a second ROCm stack (torch/lib/librccl.so + its own libamdhip64), and a
+    // bare dlopen("librccl.so.1") hands back whichever copy was loaded first.  So the library is opened by path, next to the
+    // libamdhip64 this engine is linked against (DZ_RCCL_LIB overrides), and the HIP runtime it resolves is checked against ours.
     int load()
     {
         if (lib) return 0;
-        lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!lib) return fail(std::string("cannot load librccl: ") + dlerror());
+        Dl_info hi;
+        if (!dladdr((void*)&hipGetDeviceCount, &hi) || !hi.dli_fname) return fail("cannot locate the HIP runtime this library is linked against");
+        hip_path = hi.dli_fname;
+        const std::string dir = hip_path.substr(0, hip_path.find_last_of('/'));
+        std::vector<std::string> cand;
+        if (const char* ov = getenv("DZ_RCCL_LIB")) cand.push_back(ov);
+        cand.push_back(dir + "/librccl.so.1");
+        cand.push_back(dir + "/librccl.so");
+        std::string tried;
+        for (const std::string& c : cand) {
+            lib = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (lib) { path = c; break; }
+            tried += c + " (" + dlerror() + "); ";
+        }
+        if (!lib) return fail("cannot load librccl next to " + hip_path + ": " + tried);
         GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
         CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
         AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
         CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
         GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
-        if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy) return fail("librccl lacks required symbols");
+        if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy) { dlclose(lib); lib = nullptr; return fail("librccl lacks required symbols: " + path); }
+        Dl_info ri, rh;
+        if (dladdr((void*)GetUniqueId, &ri) && ri.dli_fname) path = ri.dli_fname;
+        void* their_hip = dlsym(lib, "hipGetDeviceCount");         // (searches librccl and its dependencies: the runtime it was built against)
+        if (their_hip && dladdr(their_hip, &rh) && rh.dli_fname && hip_path != rh.dli_fname && !getenv("DZ_RCCL_ALLOW_MISMATCH")) {
+            const std::string theirs = rh.dli_fname;
+            dlclose(lib); lib = nullptr;
+            return fail("librccl " + path + " uses the HIP runtime " + theirs + " but this engine uses " + hip_path +
+                        ": two ROCm stacks in one process (set DZ_RCCL_LIB to the matching librccl)");
+        }
         return 0;
     }
 };
@@ -866,6 +892,21 @@ int dz_set_likelihood_host(dz_engine* e, dz_logp_cb cb, void* user)
     if (!cb) return fail("null callback");
     e->cb = cb; e->cb_user = user; e->lk = LK_HOST;
     return 0;
+}
+
+const char* dz_comm_library(void)
+{   // path of the librccl the engine uses (loads it if necessary); NULL with dz_last_error set if it cannot be loaded
+    if (g_rccl.load()) return nullptr;
+    return g_rccl.path.c_str();
+}
+
+const char* dz_hip_library(void)
+{   // path of the HIP runtime this library's calls are bound to (in a process that imported PyTorch first that is torch's copy)
+    static std::string path;
+    Dl_info hi;
+    if (!dladdr((void*)&hipGetDeviceCount, &hi) || !hi.dli_fname) { fail("cannot locate the HIP runtime"); return nullptr; }
+    path = hi.dli_fname;
+    return path.c_str();
 }
 
 int dz_comm_unique_id(void* id128)

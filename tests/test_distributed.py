@@ -114,8 +114,14 @@ def test_two_ranks_one_gpu_hip_engine(tmp_path):
 @pytest.mark.gpu
 def test_rccl_single_rank_comm(tmp_path):
     """RCCL bootstrap + in-place ncclAllGather with world size 1 (all the 1-GPU box can run)."""
+    import torch            # noqa: F401  (brings its own bundled ROCm stack, torch/lib/librccl.so included, into the process first)
     from pydream_amd import _capi
     from tests import helpers as H
+    # One ROCm stack for the engine AND its RCCL, whatever else the process holds: librccl is opened next to the HIP runtime the
+    # engine's calls are bound to (here torch's copy, because torch was imported first; in bench.py, which loads libdreamzs.so
+    # first, /opt/rocm's) and is checked to resolve that same runtime.
+    lib, hip = _capi.comm_library(), _capi.hip_library()
+    assert os.path.dirname(os.path.realpath(lib)) == os.path.dirname(os.path.realpath(hip)), (lib, hip)
     d, N, n = 16, 8, 25
     P = H.mvn_precision(d); Z0 = H.seed_history(40, d, 4)
     res = []
@@ -128,3 +134,28 @@ def test_rccl_single_rank_comm(tmp_path):
         res.append((e.get_trace(0, n)["X"], e.get_history()))
     np.testing.assert_array_equal(res[0][0], res[1][0])
     np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.gpu
+def test_bench_eight_rank_control_flow_on_one_gpu(tmp_path):
+    """bench.py as the driver launches it for N = 8 (torch.distributed.run, one rank per process), rehearsed on the one GPU of
+    the test box: the eight ranks share device 0 and exchange through the host (DZ_BENCH_DEVICE / DZ_BENCH_TRANSPORT; RCCL needs
+    one GPU per rank).  Proves the control flow the 8-GPU run takes: rendezvous, sharded engines, the convergence run with the
+    sharded R-hat, timed blocks with the rank-maximum, one JSON line from rank 0 with whole-job throughput."""
+    import json
+    import subprocess
+    env = dict(os.environ, DZ_BENCH_DEVICE="0", DZ_BENCH_TRANSPORT="host", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5",
+           "--chains-per-gpu", "128", "--rhat-max-generations", "400", "--rhat-min-generations", "200", "--rhat-chunk", "100",
+           "--rhat-window", "200", "--min-timed-ms", "20", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 20 and d["scaling"] == "weak"
+    assert d["config"]["chains_global"] == 8 * 128 and "host" in d["config"]["parallelism"]
+    assert d["value"] > 0 and abs(d["value"] - 8 * 128 * 5 * 20 / (d["timing"]["block_ms_median"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["convergence"]["generations_run"] >= 200 and np.isfinite(d["rhat_max"])
+    assert d["kernel_times"]["exchange"]["launches"] > 0            # the Z appends were all-gathered

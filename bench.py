@@ -299,6 +299,13 @@ def main():
         barrier()
         e.trace_reset()
         e.step(args.warmup)
+        # the timed blocks start right after a history append (the W warm-up generations are followed by the 0..thin-1 more that
+        # complete the current thin-cycle), so that a block of K generations is K / thin whole launches of the persistent kernel
+        g_now = e.generation() if callable(e.generation) else e.generation
+        align = (-(g_now - 1)) % args.thin
+        if align:
+            e.trace_reset()
+            e.step(align)
         barrier()
         times = timed_blocks(e, K, args.min_timed_ms, barrier, dist, max_blocks)
         acc = float(e.get_trace(0, K, with_X=False)["moved"].mean())

@@ -90,6 +90,10 @@ template <class T> int dalloc(T** p, size_t n)
 {
     HIPCK(hipMalloc((void**)p, sizeof(T) * (n ? n : 1)));
     HIPCK(hipMemset(*p, 0, sizeof(T) * (n ? n : 1)));
+    // hipMemset on device memory may return before the fill has run, and the fill is queued on the NULL stream, which the engine's
+    // non-blocking streams do not wait for: without this wait a late fill can wipe what the first kernels wrote (seen as zeroed
+    // log_ps of a short run_dream call right after another engine's work)
+    HIPCK(hipStreamSynchronize(nullptr));
     return 0;
 }
 

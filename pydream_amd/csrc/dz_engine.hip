@@ -137,6 +137,7 @@ struct dz_engine {
     int num_cu = 256;
     int waves_per_block = 0;        // DZ_WPB
     bool fuse = true;               // DZ_FUSE=0 disables the accept+propose fusion
+    bool stream_propose = true;     // ld > 256: the streaming proposal kernel (k_propose_stream); DZ_STREAM=0 keeps k_propose<4|8>
     bool mega = true;               // the persistent generation kernel serves every eligible configuration (mega_eligible); DZ_MEGA=0 forces the multi-kernel path
     int mega_max_gen = 1 << 20;     // DZ_MEGA_MAXGEN: generations per launch cap (measurement)
     int mega_ch = 0;                // DZ_MEGA_CHAINS: force 16 / 8 / 4 chains per block (0: by chain count)
@@ -442,7 +443,9 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
     const int64_t slot = (traced && e->c.trace_capacity) ? e->ntrace : -1;
     // the Metropolis step of this generation can ride in front of the next generation's proposal kernel when
     // nothing shared changes in between (no history append, no published positions) and a generation follows
-    const bool defer = full && e->fuse && more_follow && !append && !publish && split == 1 && e->lk != LK_HOST && !e->tempering;
+    // ld > 256, one DE pair, multi-try: one wave per (chain, try) streaming over the dimension chunks (dz_kernels.h)
+    const bool streamed = e->stream_propose && e->nch >= 4 && p.depairs == 1 && k >= 3;
+    const bool defer = full && e->fuse && more_follow && !append && !publish && split == 1 && e->lk != LK_HOST && !e->tempering && !streamed;
     const int64_t zbase = full ? e->M : e->M - (int64_t)(p.off + c0);
     for (int s = 0; s < L; ++s) {
         const int lc0 = c0 + (int)((int64_t)nc * s / L), lc1 = c0 + (int)((int64_t)nc * (s + 1) / L), lnc = lc1 - lc0;
@@ -450,14 +453,16 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
         hipStream_t st = e->lane_stream[s];
         if (need_draws)
             hipLaunchKernelGGL(dz::k_draws, dim3((lnc * p.nslots + 255) / 256), dim3(256), 0, st, p, g, lc0, lnc, e->d_draws[g & 1], e->d_ctl[g & 1]);
-        {
+        if (streamed && !fused_in) DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose_stream, dim3((lnc * k + 3) / 4), dim3(256), 0, p, 0, g, (uint32_t)e->M, lc0, lnc);
+        else {
             if (fused_in) { NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc + wpb - 1) / wpb), dim3(64 * wpb), 0, p, 0, g, (uint32_t)e->M, lc0, lnc, 1, 1, e->pending_slot)); }
             else { NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc * sp0 + wpb - 1) / wpb), dim3(64 * wpb), 0, p, 0, g, (uint32_t)e->M, lc0, lnc, sp0, 0, (int64_t)-1)); }
         }
         DZCK(launch_check("propose"));
         DZCK(eval_logp(e, p.P + (size_t)lc0 * k * p.ld, lnc * k, p.p_prior + (size_t)lc0 * k, p.p_like + (size_t)lc0 * k, st));
         if (k > 1) {
-            {
+            if (streamed) DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose_stream, dim3((lnc * (k - 1) + 3) / 4), dim3(256), 0, p, 1, g, (uint32_t)e->M, lc0, lnc);
+            else {
                 NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc * sp1 + wpb - 1) / wpb), dim3(64 * wpb), 0, p, 1, g, (uint32_t)e->M, lc0, lnc, sp1, 0, (int64_t)-1));
             }
             DZCK(launch_check("propose(ref)"));
@@ -643,6 +648,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     e->c = *cfg;
     e->gen_c.assign((size_t)cfg->nchains_local, 0);
     if (const char* kv = getenv("DZ_FUSE")) e->fuse = atoi(kv) != 0;
+    if (const char* kv = getenv("DZ_STREAM")) e->stream_propose = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA")) e->mega = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_MAXGEN")) e->mega_max_gen = std::max(1, atoi(kv));
     if (const char* kv = getenv("DZ_LOGP_BM")) e->logp_bm = atoi(kv);          // 64 / 128: points per block of k_logp_mvn_gemm (default: by size)

@@ -717,6 +717,117 @@ __global__ __launch_bounds__(NCH >= 4 ? 256 : 1024) void k_propose(Params p, int
     DZ_STAMP(p, phase, c, 15);
 }
 
+// Large d (ld > 256): one wave per (chain, try) STREAMS over the 128-dimension chunks instead of holding all of them in registers
+// (k_propose<8> needs 344 registers: one wave per SIMD, every latency exposed).  Two passes, each a chunk at a time with the next
+// chunk's base and archive rows in flight: DE -- pass 1 counts the crossed-over dimensions d' (the crossover uniforms are the
+// first word of the pair's Philox call, which pass 2 makes again), then gamma, pass 2 makes the proposal; snooker -- pass 1 the two
+// dot products, pass 2 the proposal and its distance to z.  Same arithmetic and summation order as propose_point (a lane adds its
+// dimensions chunk by chunk in increasing order, then the butterfly): bit-identical to it.  DEpairs = 1, multitry >= 3.
+__global__ __launch_bounds__(256) void k_propose_stream(Params p, int phase, uint32_t g, uint32_t M, int c0, int nc)
+{
+    const int k = p.k, n = phase == 0 ? k : k - 1;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (wave >= nc * n) return;
+    const int lane = threadIdx.x & 63;
+    const int c = c0 + wave / n, i = wave % n;
+    const int d = p.d, ld = p.ld, nchunk = (ld + 127) >> 7;
+    const uint32_t gc = (uint32_t)(p.off + c);
+    const DrawSrc dsrc = load_draws(p, p.draws + (size_t)c * p.nslots, lane);
+    const ChainCtl ct = p.ctl[c];
+    const double* base; double* out; double* sl;
+    if (phase == 0) { base = p.X + (size_t)c * ld; out = p.P + ((size_t)c * k + i) * ld; sl = p.p_slogp + (size_t)c * k; }
+    else {
+        bool fin; const int sel = mt_select(p, c, ct.u_sel, lane, &fin);
+        if (lane == 0 && i == 0) p.sel[c] = sel | (fin ? 256 : 0);
+        base = p.P + ((size_t)c * k + sel) * ld; out = p.R + ((size_t)c * (k - 1) + i) * ld; sl = p.r_slogp + (size_t)c * (k - 1);
+    }
+    const bool snk = __builtin_amdgcn_readfirstlane(ct.snk) != 0;
+    const uint32_t s_dim = stream_id(K_DIM, (uint32_t)i, (uint32_t)phase), s_bnd = stream_id(K_BND, (uint32_t)i, (uint32_t)phase);
+    auto off = [&](int it) { return min(128 * it + 2 * lane, ld - 2); };            // (lanes past ld re-read the row's last pair; masked where used)
+    auto bounded = [&](double x, int j) {                                           // hard boundaries :733-791
+        const double lo = p.mins[j], hi = p.maxs[j];
+        const bool bl = x < lo, bh = x > hi;
+        if (bl) x = 2 * lo - x;
+        if (bh) x = 2 * hi - x;
+        if (x < lo || x > hi) { const u32x4 w = philox(p.k0, p.k1, (uint32_t)j, s_bnd, gc, g); x = lo + u32d(w.x) * (hi - lo); }
+        return x;
+    };
+    auto store = [&](int it, double p0, double p1) {
+        const int jj = 128 * it + 2 * lane;
+        if (jj < ld) {
+            if (p.hard) { if (jj < d) p0 = bounded(p0, jj); if (jj + 1 < d) p1 = bounded(p1, jj + 1); }
+            double2 o; o.x = jj < d ? p0 : 0.0; o.y = jj + 1 < d ? p1 : 0.0;
+            *reinterpret_cast<double2*>(out + jj) = o;
+        }
+    };
+    if (!snk) {
+        const u32x4 wr = uniform_draw(p, dsrc, pt_slot(p, phase, i, 1), gc, g);
+        const uint32_t r0 = __builtin_amdgcn_readfirstlane(mulhi_idx(wr.x, M));
+        uint32_t r1 = __builtin_amdgcn_readfirstlane(mulhi_idx(wr.y, M - 1u));
+        if (r1 >= r0) r1++;                                                         // random.sample(range(M), 2) :662
+        const double* za = p.Z + (size_t)r0 * ld; const double* zb = p.Z + (size_t)r1 * ld;
+        double2 xn = gload2(base + off(0)), an = gload2(za + off(0)), bn = gload2(zb + off(0));      // chunk 0 travels during pass 1
+        const uint32_t thr = p.crthr[__builtin_amdgcn_readfirstlane(ct.cr_idx)];
+        int dprime = 0;
+        for (int it = 0; it < nchunk; ++it) {                                       // pass 1: d' :704 / :709
+            const int j0 = 128 * it + 2 * lane;
+            const u32x4 w = philox(p.k0, p.k1, (uint32_t)(j0 >> 1), s_dim, gc, g);
+            const bool k0b = j0 < d && (w.x & 0xffffu) < thr, k1b = j0 + 1 < d && (w.x >> 16) < thr;
+            dprime += __popcll(__builtin_amdgcn_ballot_w64(k0b)) + __popcll(__builtin_amdgcn_ballot_w64(k1b));
+        }
+        const u32x4 wg = uniform_draw(p, dsrc, pt_slot(p, phase, i, 0), gc, g);     // set_gamma :615
+        double gamma = 1.0;
+        if (!u53_below(wg.x, wg.y, p.pgu_thr)) gamma = gamma_row(p, ct.glev, 1)[(dprime == 0 ? d : dprime) - 1];   // :624
+        const double ec1 = p.ec1, ec0 = p.ec0;
+        for (int it = 0; it < nchunk; ++it) {                                       // pass 2: the proposal :714-726
+            const double2 x = xn, a = an, b = bn;
+            if (it + 1 < nchunk) { xn = gload2(base + off(it + 1)); an = gload2(za + off(it + 1)); bn = gload2(zb + off(it + 1)); }
+            const int j0 = 128 * it + 2 * lane;
+            const u32x4 w = philox(p.k0, p.k1, (uint32_t)(j0 >> 1), s_dim, gc, g);
+            float z0, z1;
+            normal32_pair(w.z, w.w, z0, z1);
+            const bool k0b = j0 < d && (w.x & 0xffffu) < thr, k1b = j0 + 1 < d && (w.x >> 16) < thr;
+            double t0 = (uniform16(w.y, ec1, ec0) + 1.0) * gamma; t0 = t0 * (a.x - b.x);              // :696-697, chain_differences :692
+            double t1 = (uniform16(w.y >> 16, ec1, ec0) + 1.0) * gamma; t1 = t1 * (a.y - b.y);
+            double q0 = x.x + t0; q0 = q0 + p.zeta * (double)z0;
+            double q1 = x.y + t1; q1 = q1 + p.zeta * (double)z1;
+            store(it, k0b ? q0 : x.x, k1b ? q1 : x.y);
+        }
+        if (lane == 0) sl[i] = 0.0;
+    } else {
+        const u32x4 wi = uniform_draw(p, dsrc, pt_slot(p, phase, i, 1), gc, g);     // :808-810
+        const double* zz = p.Z + (size_t)mulhi_idx(wi.x, M) * ld;
+        const double* q1r = p.Z + (size_t)mulhi_idx(wi.y, M) * ld;
+        const double* q2r = p.Z + (size_t)mulhi_idx(wi.z, M) * ld;
+        const u32x4 wg = uniform_draw(p, dsrc, pt_slot(p, phase, 0, 0), gc, g);
+        const double gamma_s = 1.2 + (2.2 - 1.2) * u53(wg.z, wg.w);                 // :618
+        double accD = 0.0, accS = 0.0;
+        double2 xn = gload2(base + off(0)), zn = gload2(zz + off(0)), an = gload2(q1r + off(0)), bn = gload2(q2r + off(0));
+        for (int it = 0; it < nchunk; ++it) {                                       // pass 1: |x - z|^2 and (zR1 - zR2).(x - z) :813-819
+            const double2 x = xn, z = zn, a = an, b = bn;
+            if (it + 1 < nchunk) { xn = gload2(base + off(it + 1)); zn = gload2(zz + off(it + 1)); an = gload2(q1r + off(it + 1)); bn = gload2(q2r + off(it + 1)); }
+            const int jj = 128 * it + 2 * lane;
+            const double v0 = x.x - z.x, v1 = x.y - z.y;
+            if (jj < d) { accD = fma(v0, v0, accD); accS = fma(a.x - b.x, v0, accS); }
+            if (jj + 1 < d) { accD = fma(v1, v1, accD); accS = fma(a.y - b.y, v1, accS); }
+        }
+        const double D = wave_bfly(accD);                                           // :816
+        const double cc = wave_bfly(accS) / D;                                      // :820
+        double accN = 0.0;
+        xn = gload2(base + off(0)); zn = gload2(zz + off(0));
+        for (int it = 0; it < nchunk; ++it) {                                       // pass 2: the proposal :820-822 and its distance to z :823
+            const double2 x = xn, z = zn;
+            if (it + 1 < nchunk) { xn = gload2(base + off(it + 1)); zn = gload2(zz + off(it + 1)); }
+            const int jj = 128 * it + 2 * lane;
+            const double p0 = x.x + gamma_s * nan_to_num(cc * (x.x - z.x)), p1 = x.y + gamma_s * nan_to_num(cc * (x.y - z.y));
+            if (jj < d) { const double t = p0 - z.x; accN = fma(t, t, accN); }
+            if (jj + 1 < d) { const double t = p1 - z.y; accN = fma(t, t, accN); }
+            store(it, p0, p1);
+        }
+        snooker_logps(p, wave_bfly(accN), 1, lane, sl + i);                         // :823-824
+    }
+}
+
 // debug entry: flags supplied by the host (function-level parity tests); one wave, all tries
 template <int NCH>
 __global__ __launch_bounds__(64) void k_propose_debug(Params p, int phase, uint32_t g, uint32_t M, int c, int n,

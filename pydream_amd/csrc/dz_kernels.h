@@ -289,6 +289,18 @@ DZ_DEV void reduce_rows(const ZRows<NCH>& zr, bool snk, RowTerms<NCH>& rt)
 
 // LEAN drops what the persistent kernel's fast path never needs (hard-boundary handling, the single-try snooker
 // variant) so that the whole generation fits the register budget of a 16-wave block.
+// What a set of tries reads from Params, fetched ONCE per set by the persistent kernel (Params lives in memory there: every p.x inside
+// the try loop is a scalar load plus a wait, and scalar instructions cost nearly as much issue time as vector ones -- measured: 200 extra
+// s_add per generation = -3 %).  slot(i, idx) = slot0 + i npt + idx is pt_slot() of the set's phase.
+struct SetConsts { uint32_t thr; unsigned long long pgu_thr; double zeta, ec1, ec0; int npt, slot0; };
+DZ_DEV SetConsts set_consts(const Params& p, int phase, int cr_idx)
+{
+    SetConsts s;
+    s.thr = p.crthr[__builtin_amdgcn_readfirstlane(cr_idx)]; s.pgu_thr = p.pgu_thr; s.zeta = p.zeta; s.ec1 = p.ec1; s.ec0 = p.ec0;
+    s.npt = p.npt; s.slot0 = 3 + (phase ? p.k : 0) * p.npt;
+    return s;
+}
+
 // Returns, for a snooker try, the squared distance |proposal - z|^2 (wave-uniform): the caller turns the tries' distances into
 // snooker_logp = (d - 1) log sqrt(.) (:823-824 / :834-835) in ONE pass of the logarithm (snooker_logps below) instead of one per
 // try; 0 for a DE try (snooker_logp = 0).  grow: gamma_arr[level-1][delta-1][:] (any address space; the look-up address is
@@ -296,18 +308,19 @@ DZ_DEV void reduce_rows(const ZRows<NCH>& zr, bool snk, RowTerms<NCH>& rt)
 template <int NCH, bool AL16 = true, bool LEAN = false>
 DZ_DEV double propose_point(const Params& p, int phase, uint32_t g, uint32_t M, int c, int i, int n, int lane,
                           const double (&xb)[NCH][2], const double* __restrict__ grow, const RowTerms<NCH>& zr, double* __restrict__ out,
-                          double* cur_snk_out, bool snk, int cr_idx, int delta, int glev, const DrawSrc& dr, const u32x4* wpre = nullptr)
+                          double* cur_snk_out, bool snk, int cr_idx, int delta, int glev, const DrawSrc& dr, const u32x4* wpre = nullptr,
+                          const SetConsts* sc = nullptr)
 {   // wpre: the DIM draw of chunk 0, computed by the caller one try ahead (software pipelining, NCH == 1)
     const int d = p.d, ld = p.ld;
     const uint32_t gc = (uint32_t)(p.off + c);
-    const uint32_t thr = p.crthr[__builtin_amdgcn_readfirstlane(cr_idx)];             // CR = CR_values[m], :146 (the decision is wave-uniform)
+    const uint32_t thr = sc ? sc->thr : p.crthr[__builtin_amdgcn_readfirstlane(cr_idx)];   // CR = CR_values[m], :146 (the decision is wave-uniform)
     const uint32_t s_dim = stream_id(K_DIM, (uint32_t)i, (uint32_t)phase),
                    s_bnd = stream_id(K_BND, (uint32_t)i, (uint32_t)phase);
     double pr[NCH][2];
     double sqdist = 0.0;
     if (!snk) {
         bool keep[NCH][2]; double e1[NCH][2], zt[NCH][2];
-        const double ec1 = p.ec1, ec0 = p.ec0;
+        const double ec1 = sc ? sc->ec1 : p.ec1, ec0 = sc ? sc->ec0 : p.ec0, zeta = sc ? sc->zeta : p.zeta;
         int dprime = 0;
 #pragma unroll
         for (int it = 0; it < NCH; ++it) {        // zeta, e, U :694-700 -- one Philox call and one Box-Muller pair per lane
@@ -319,16 +332,16 @@ DZ_DEV double propose_point(const Params& p, int phase, uint32_t g, uint32_t M, 
                 normal32_pair(w.z, w.w, z0, z1);
                 keep[it][0] = j0 < d && (w.x & 0xffffu) < thr;               // U_j < CR
                 e1[it][0] = uniform16(w.y, ec1, ec0) + 1.0;                  // :696-697
-                zt[it][0] = p.zeta * (double)z0;
+                zt[it][0] = zeta * (double)z0;
                 keep[it][1] = j0 + 1 < d && (w.x >> 16) < thr;
                 e1[it][1] = uniform16(w.y >> 16, ec1, ec0) + 1.0;
-                zt[it][1] = p.zeta * (double)z1;
+                zt[it][1] = zeta * (double)z1;
             }
             dprime += __popcll(__builtin_amdgcn_ballot_w64(keep[it][0])) + __popcll(__builtin_amdgcn_ballot_w64(keep[it][1]));   // d' :704 / :709
         }
-        const u32x4 wg = uniform_draw(p, dr, pt_slot(p, phase, i, 0), gc, g);  // set_gamma :615
+        const u32x4 wg = uniform_draw(p, dr, sc ? sc->slot0 + i * sc->npt : pt_slot(p, phase, i, 0), gc, g);  // set_gamma :615
         double gamma = 1.0;
-        if (!u53_below(wg.x, wg.y, p.pgu_thr))                                 // u53(wg.x, wg.y) < p_gamma_unity
+        if (!u53_below(wg.x, wg.y, sc ? sc->pgu_thr : p.pgu_thr))              // u53(wg.x, wg.y) < p_gamma_unity
             gamma = grow[(dprime == 0 ? d : dprime) - 1];                      // gamma_arr[level-1][delta-1][d'-1], :624 (one address for the whole wave)
 #pragma unroll
         for (int it = 0; it < NCH; ++it)

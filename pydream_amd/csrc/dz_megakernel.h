@@ -135,9 +135,9 @@ DZ_DEV void mfma_units(const Params& p, const double* __restrict__ Ms, const dou
 // (chain, generation, phase, try) only, never on the selected point.
 struct RowPair { double2 a, b; };
 
-DZ_DEV void request_pair(const Params& p, const DrawSrc& ds, int phase, int i, uint32_t gc, uint32_t g, uint32_t M, int lane, RowPair& R)
-{
-    const u32x4 w = uniform_draw(p, ds, pt_slot(p, phase, i, 1), gc, g);
+DZ_DEV void request_pair(const Params& p, const DrawSrc& ds, int slot, uint32_t gc, uint32_t g, uint32_t M, int lane, RowPair& R)
+{   // slot = pt_slot(p, phase, i, 1)
+    const u32x4 w = uniform_draw(p, ds, slot, gc, g);
     const uint32_t r0 = __builtin_amdgcn_readfirstlane(mulhi_idx(w.x, M));
     uint32_t r1 = __builtin_amdgcn_readfirstlane(mulhi_idx(w.y, M - 1u));
     if (r1 >= r0) r1++;                                   // random.sample(range(M), 2) :662  (wave-uniform: kept on the scalar unit)
@@ -153,20 +153,22 @@ DZ_DEV void propose_de_pf(const Params& p, int phase, uint32_t g, uint32_t M, in
                           const double (&xb)[1][2], const double* __restrict__ grow, int cr_idx, int glev, const DrawSrc& ds,
                           double* out, int out_stride, double* sl, double* prior_out, RowPair& A, RowPair& B, RowPair& C)
 {
+    const SetConsts sc = set_consts(p, phase, cr_idx);
     auto body = [&](int i, const RowPair& R) {
         RowTerms<1> rt;
         rt.a[0][0] = R.a.x - R.b.x; rt.a[0][1] = R.a.y - R.b.y; rt.b[0][0] = 0.0; rt.b[0][1] = 0.0;       // chain_differences :692
-        propose_point<1, false, LEAN>(p, phase, g, M, c, i, n, lane, xb, grow, rt, out + (size_t)i * out_stride, nullptr, false, cr_idx, 1, glev, ds);
+        propose_point<1, false, LEAN>(p, phase, g, M, c, i, n, lane, xb, grow, rt, out + (size_t)i * out_stride, nullptr, false, cr_idx, 1, glev, ds, nullptr, &sc);
         if (!LEAN && prior_out) point_prior<1>(p, out + (size_t)i * out_stride, lane, prior_out + i);
     };
+    const int rs = sc.slot0 + 1;                          // pt_slot(phase, i, 1) = rs + i npt
     for (int i = i0; i < i1; i += 3) {
-        if (i + 2 < i1) request_pair(p, ds, phase, i + 2, gc, g, M, lane, C);
+        if (i + 2 < i1) request_pair(p, ds, rs + (i + 2) * sc.npt, gc, g, M, lane, C);
         body(i, A);
         if (i + 1 >= i1) break;
-        if (i + 3 < i1) request_pair(p, ds, phase, i + 3, gc, g, M, lane, A);
+        if (i + 3 < i1) request_pair(p, ds, rs + (i + 3) * sc.npt, gc, g, M, lane, A);
         body(i + 1, B);
         if (i + 2 >= i1) break;
-        if (i + 4 < i1) request_pair(p, ds, phase, i + 4, gc, g, M, lane, B);
+        if (i + 4 < i1) request_pair(p, ds, rs + (i + 4) * sc.npt, gc, g, M, lane, B);
         body(i + 2, C);
     }
     if (lane >= i0 && lane < i1) { sl[lane] = 0.0; if (LEAN && prior_out) prior_out[lane] = 0.0; }            // snooker_logp = 0 (flat priors: 0)
@@ -244,8 +246,8 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     auto prefetch_first = [&](const DrawSrc& q, int phase_, uint32_t g_) {          // rows of this wave's first two tries of (g_, phase_)
         const int n_ = k - phase_;
         const int a0 = WPC == 1 ? 0 : (sub * n_) / WPC, a1 = WPC == 1 ? n_ : ((sub + 1) * n_) / WPC;
-        if (a0 < a1) request_pair(p, q, phase_, a0, gc, g_, M, lane, RA);
-        if (a0 + 1 < a1) request_pair(p, q, phase_, a0 + 1, gc, g_, M, lane, RB);
+        if (a0 < a1) request_pair(p, q, pt_slot(p, phase_, a0, 1), gc, g_, M, lane, RA);
+        if (a0 + 1 < a1) request_pair(p, q, pt_slot(p, phase_, a0 + 1, 1), gc, g_, M, lane, RB);
     };
     auto draws_say_snooker = [&](const DrawSrc& q, uint32_t g_) {                   // set_snooker :542-554 on the integer form of the draw
         const u32x4 w0 = uniform_draw(p, q, 0, gc, g_);

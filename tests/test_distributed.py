@@ -159,3 +159,17 @@ def test_bench_eight_rank_control_flow_on_one_gpu(tmp_path):
     assert d["value"] > 0 and abs(d["value"] - 8 * 128 * 5 * 20 / (d["timing"]["block_ms_median"] * 1e-3)) < 1e-6 * d["value"]
     assert d["convergence"]["generations_run"] >= 200 and np.isfinite(d["rhat_max"])
     assert d["kernel_times"]["exchange"]["launches"] > 0            # the Z appends were all-gathered
+
+
+@pytest.mark.gpu
+def test_rccl_next_to_the_engines_hip_runtime_in_bench_load_order():
+    """bench.py's load order for N > 1 -- libdreamzs.so first (binds the system ROCm's HIP runtime), torch afterwards --, in a fresh
+    process (tools/rccl_rocm_check.py): the engine opens the librccl NEXT TO THAT runtime, not the copy torch bundles, and an
+    all-gather through it (world size 1) leaves the run unchanged."""
+    import subprocess
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_rocm_check.py")], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("hip:")][0].split()
+    hip, rccl = line[1], line[3]
+    assert os.path.dirname(os.path.realpath(hip)) == os.path.dirname(os.path.realpath(rccl)) and "torch" not in rccl, line
+    assert "equal: True" in res.stdout

@@ -302,14 +302,18 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
                 // tiled product: waves = point-tile groups x row-tile groups; per-row-tile sums through a scratch array
                 constexpr int PT = 2, RTC = 4;
                 const int nrtb = (e->p.d + 15) / 16, nrg = (nrtb + RTC - 1) / RTC, npg = (n + 16 * PT - 1) / (16 * PT);
+                // every chain-group stream has its own slice of the row-tile scratch array
+                int sl = 0;
+                for (int s2 = 1; s2 < e->nlanes; ++s2) if (e->lane_stream[s2] == st) sl = s2;
                 const size_t need = (size_t)n * nrtb;
-                if (need > e->qpart_len) {
+                if (need * e->nlanes > e->qpart_len) {
                     DZCK(sync_all(e));
                     if (e->d_qpart) hipFree(e->d_qpart);
                     e->d_qpart = nullptr; e->qpart_len = 0;
-                    DZCK(dalloc(&e->d_qpart, need));
-                    e->qpart_len = need;
+                    DZCK(dalloc(&e->d_qpart, need * e->nlanes));
+                    e->qpart_len = need * e->nlanes;
                 }
+                double* qpart = e->d_qpart + (size_t)sl * (e->qpart_len / e->nlanes);
                 if (e->force_big) hipLaunchKernelGGL(dz::k_logp_mvn_mfma_big<8>, dim3((n + 63) / 64), block, 0, st, e->p, pts, n, prior, like);
                 else {
                     if (e->logp_gemm && n >= 512) {            // enough points to fill the chip with 64 x 64 block tiles
@@ -322,12 +326,12 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
                         if (bmsel != 32 && bmsel != 64 && bmsel != 128)
                             bmsel = ((n + 127) / 128) * nbn >= 5 * e->num_cu ? 128 : ((n + 63) / 64) * nbn >= 5 * e->num_cu ? 64 : 32;
                         const dim3 gridg(((n + bmsel - 1) / bmsel) * nbn);
-                        if (bmsel == 32) hipLaunchKernelGGL(dz::k_logp_mvn_gemm<1>, gridg, block, ldsm, st, e->p, pts, n, e->d_qpart, e->num_cu);
-                        else if (bmsel == 64) hipLaunchKernelGGL(dz::k_logp_mvn_gemm<2>, gridg, block, ldsm, st, e->p, pts, n, e->d_qpart, e->num_cu);
-                        else hipLaunchKernelGGL(dz::k_logp_mvn_gemm<4>, gridg, block, ldsm, st, e->p, pts, n, e->d_qpart, e->num_cu);
+                        if (bmsel == 32) hipLaunchKernelGGL(dz::k_logp_mvn_gemm<1>, gridg, block, ldsm, st, e->p, pts, n, qpart, e->num_cu);
+                        else if (bmsel == 64) hipLaunchKernelGGL(dz::k_logp_mvn_gemm<2>, gridg, block, ldsm, st, e->p, pts, n, qpart, e->num_cu);
+                        else hipLaunchKernelGGL(dz::k_logp_mvn_gemm<4>, gridg, block, ldsm, st, e->p, pts, n, qpart, e->num_cu);
                     } else
-                    hipLaunchKernelGGL((dz::k_logp_mvn_mfma_tiled<PT, RTC>), dim3((npg * nrg + 3) / 4), block, 0, st, e->p, pts, n, e->d_qpart);
-                    hipLaunchKernelGGL(dz::k_q_finish, dim3((n + 63) / 64), dim3(64), 0, st, e->p, (const double*)e->d_qpart, n, nrtb, prior, like);
+                    hipLaunchKernelGGL((dz::k_logp_mvn_mfma_tiled<PT, RTC>), dim3((npg * nrg + 3) / 4), block, 0, st, e->p, pts, n, qpart);
+                    hipLaunchKernelGGL(dz::k_q_finish, dim3((n + 63) / 64), dim3(64), 0, st, e->p, (const double*)qpart, n, nrtb, prior, like);
                 }
             }
             if (e->p.have_prior) NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_prior_only<NCH>, grid, block, 0, st, e->p, pts, n, prior));
@@ -682,7 +686,6 @@ int dz_create(const dz_config* cfg, dz_engine** out)
         if (const char* ev = getenv("DZ_STREAMS")) nl_req = atoi(ev);
         e->nlanes = std::max(1, std::min(8, nl_req));
         if (cfg->nchains_local < 64 * e->nlanes) e->nlanes = 1;
-        if (p.ld > 128) e->nlanes = 1;      // the large-d likelihood kernels share one row-tile scratch array (d_qpart)
         e->lane_stream[0] = e->stream;
         for (int s = 1; s < e->nlanes; ++s) HIPCK(hipStreamCreateWithFlags(&e->lane_stream[s], hipStreamNonBlocking));
         for (int s = 0; s < e->nlanes; ++s) HIPCK(hipEventCreateWithFlags(&e->lane_ev[s], hipEventDisableTiming));

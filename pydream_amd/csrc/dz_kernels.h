@@ -1230,7 +1230,7 @@ __global__ __launch_bounds__(256) void k_logp_mvn_mfma_tiled(Params p, const dou
 template <int PT>      // point tiles per wave: the block owns BM = 32 PT points (64 or 128) x 64 rows
 __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* __restrict__ pts, int npts, double* __restrict__ qpart, int ncu)
 {
-    constexpr int BM = 32 * PT, BN = 64, BK = 16, LDA = BM + 2, LDB = BN, NA = PT >= 2 ? PT / 2 : 1;
+    constexpr int BM = 32 * PT, BN = 64, BK = 16, LDA = BM + 2, LDB = BN;
     __shared__ __attribute__((aligned(16))) double As[2][BK * LDA];
     __shared__ __attribute__((aligned(16))) double Bs[2][BK * LDB];
     extern __shared__ __attribute__((aligned(16))) double mus[];      // the mean (ld doubles), staged once -- unless it is all zero
@@ -1243,8 +1243,14 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
     // All blocks are resident at once and land on the CUs round-robin, so nothing rebalances the triangular factor's
     // uneven blocks (bn = 0 walks all of k, the last bn almost none).  Blocks are therefore numbered from a list sorted
     // heaviest first, taken alternately from its two ends per round of ncu blocks: every CU gets heavy + light.
-    // (Tried: an XCD-aware numbering -- an XCD keeps a fixed set of point blocks, matrix panels shared by neighbours --, wave
-    //  priorities for the long blocks, padded matrix rows in LDS: no change each.  PMC: the waves wait at vmcnt half the time.)
+    // (Tried, no gain each: an XCD-aware numbering -- an XCD keeps a fixed set of point blocks, matrix panels shared by neighbours --;
+    //  wave priorities for the long blocks; padded matrix rows in LDS; the per-MFMA predicates hoisted out of the steady state; three
+    //  LDS stages with the next chunk's operands read during the MFMAs (+3 us); blocks numbered heaviest first with 3..6 resident per
+    //  CU so that the dispatcher balances (+3..5 us); resident blocks pulling units from an atomic counter (+16 us: 2.5 k atomics on
+    //  one address).  What bounds it -- tools/micro/mfma_mem_overlap.hip: while a SIMD's FP64 matrix pipe is busy, data returning to
+    //  its registers (LDS reads, global loads, LDS-direct loads alike) makes no progress, so a chunk's operand traffic adds to its
+    //  MFMA time instead of hiding behind it: knocking out the global loads saves 16 us, the LDS reads 10, the LDS stores 7, the MFMAs
+    //  19 of the launch's 55; at 20 k points, where balance no longer matters, the three tile heights reach 46 / 50 / 46 TFLOP/s.)
     const int nbm = (int)gridDim.x / nbn;
     int li;
     {
@@ -1254,20 +1260,20 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
     const int bn = li / nbm, bm = li - bn * nbm;
     const int p0 = bm * BM;
     const int kc0 = p.tri ? (BN * bn) / BK : 0, nkc = (4 * KS + BK - 1) / BK;       // chunks of 16 k
-    // loader roles: A: thread -> (points tid / 4 + 64 a, four k's = 4*(tid%4)..+3); B: thread -> (k row = tid / 16, four rows = 4*(tid%16)..+3)
-    const int a_pt = tid >> 2, a_k = 4 * (tid & 3);
-    const int b_k = tid >> 4, b_r = 4 * (tid & 15);
-    const bool a_on = PT >= 2 || a_pt < BM;                        // 32 points per block: the first two waves load them
-    const double* arow[NA];
+    // loader roles -- every wave-wide load covers whole 128-byte lines (eight lanes x 16 bytes per line).  A: a point's chunk of
+    // 16 k is one line: thread -> (point tid / 8 + 32 a, k's 2 (tid % 8), +1); B: a k row of the block's 64 matrix rows is four
+    // lines: thread -> (k row tid / 32 + 8 h, rows 2 (tid % 32), +1)
+    const int a_pt = tid >> 3, a_k = 2 * (tid & 7);
+    const int b_k = tid >> 5, b_r = 2 * (tid & 31);
+    const double* arow[PT];
 #pragma unroll
-    for (int a = 0; a < NA; ++a) arow[a] = pts + (size_t)min(p0 + a_pt + 64 * a, npts - 1) * ld;
-    // rows of pts, mu and Mt are zero padded to ld (a multiple of 16 >= 4*KS), so whole 32-byte groups can be read.
+    for (int a = 0; a < PT; ++a) arow[a] = pts + (size_t)min(p0 + a_pt + 32 * a, npts - 1) * ld;
+    // rows of pts, mu and Mt are zero padded to ld (a multiple of 16 >= 4*KS), so whole 16-byte groups can be read.
     // Two register sets: a chunk's loads are issued two chunks ahead (one chunk of MFMAs is ~0.4 us, less than a memory
     // round trip) and always issued (index clamped), so that the wait in front of the LDS store covers exactly the older set.
     // The mean is subtracted when the chunk goes to LDS, not at the load (subtracting there made the loop wait for the loads
-    // before the MFMAs instead of after them), and it comes from LDS, not with every chunk (PMC: the waves of this kernel spend
-    // half their time at s_waitcnt vmcnt -- operand traffic from L2, not latency; 128 points per block halve the matrix's share).
-    struct Stage { double ra[NA][4], rb[4]; };
+    // before the MFMAs instead of after them), and it comes from LDS, not with every chunk.
+    struct Stage { double2 ra[PT], rb[2]; };
     const bool mz = p.mu_zero != 0;
     if (!mz) { for (int i = tid; i < ld; i += 256) mus[i] = p.mu[i]; }
     auto gload = [&](int kc, Stage& R) {
@@ -1276,22 +1282,20 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
         kc = min(kc, nkc - 1);
         const int k = kc * BK + a_k;
 #pragma unroll
-        for (int a = 0; a < NA; ++a) if (a_on) {
-            const double2 x0 = *reinterpret_cast<const double2*>(arow[a] + k), x1 = *reinterpret_cast<const double2*>(arow[a] + k + 2);
-            R.ra[a][0] = x0.x; R.ra[a][1] = x0.y; R.ra[a][2] = x1.x; R.ra[a][3] = x1.y;
-        }
-        const int kb = kc * BK + b_k, r = min(BN * bn + b_r, ld - 4);
-        const double2 b0 = *reinterpret_cast<const double2*>(p.Mt + (size_t)kb * ld + r), b1 = *reinterpret_cast<const double2*>(p.Mt + (size_t)kb * ld + r + 2);
-        R.rb[0] = b0.x; R.rb[1] = b0.y; R.rb[2] = b1.x; R.rb[3] = b1.y;
+        for (int a = 0; a < PT; ++a) R.ra[a] = *reinterpret_cast<const double2*>(arow[a] + k);
+        const int r = min(BN * bn + b_r, ld - 2);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) R.rb[h] = *reinterpret_cast<const double2*>(p.Mt + (size_t)(kc * BK + b_k + 8 * h) * ld + r);
     };
     auto lstore = [&](int buf, int kc, const Stage& R) {
         const int k = min(kc, nkc - 1) * BK + a_k;
 #pragma unroll
-        for (int a = 0; a < NA; ++a) if (a_on)
+        for (int a = 0; a < PT; ++a) {                             // (x - 0.0 == x, bit for bit)
+            As[buf][a_k * LDA + a_pt + 32 * a] = mz ? R.ra[a].x : R.ra[a].x - mus[k];
+            As[buf][(a_k + 1) * LDA + a_pt + 32 * a] = mz ? R.ra[a].y : R.ra[a].y - mus[k + 1];
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) As[buf][(a_k + j) * LDA + a_pt + 64 * a] = mz ? R.ra[a][j] : R.ra[a][j] - mus[k + j];       // (x - 0.0 == x, bit for bit)
-        *reinterpret_cast<double2*>(&Bs[buf][b_k * LDB + b_r]) = double2{R.rb[0], R.rb[1]};
-        *reinterpret_cast<double2*>(&Bs[buf][b_k * LDB + b_r + 2]) = double2{R.rb[2], R.rb[3]};
+        for (int h = 0; h < 2; ++h) *reinterpret_cast<double2*>(&Bs[buf][(b_k + 8 * h) * LDB + b_r]) = R.rb[h];
     };
     dz_double4 acc[PT][2];
 #pragma unroll

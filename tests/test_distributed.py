@@ -6,6 +6,7 @@ GPU (marked gpu): the same with the HIP engine, two ranks sharing the one GPU of
 through the host-staged transport.  The RCCL transport itself needs >= 2 GPUs (driver's 8-GPU run).
 """
 import os
+import time
 import socket
 import sys
 
@@ -36,6 +37,8 @@ KW = dict(nchains=8, niterations=45, multitry=5, adapt_crossover=True, crossover
 
 def _worker(rank, world, port, backend_engine, outdir):
     sys.path.insert(0, ROOT)
+    import faulthandler
+    faulthandler.dump_traceback_later(150, exit=True)           # a rank that is stuck says where and leaves
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     from pydream_amd.distributed import run_dream_sharded
@@ -86,7 +89,14 @@ def _single(backend_engine, outdir):
 def _run_two_ranks(backend_engine, tmp_path):
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, backend_engine, str(tmp_path)), nprocs=2, join=True)
+    ctx = mp.spawn(_worker, args=(2, port, backend_engine, str(tmp_path)), nprocs=2, join=False)
+    deadline = time.time() + 180                     # (a rank that never returns fails the test instead of hanging the suite)
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for pr in ctx.processes:
+                if pr.is_alive():
+                    pr.kill()
+            raise AssertionError("the two-rank run did not finish in time")
     r0 = np.load(tmp_path / "rank0.npz"); r1 = np.load(tmp_path / "rank1.npz")
     X = np.concatenate([r0["X"], r1["X"]]); lp = np.concatenate([r0["lp"], r1["lp"]])
     Xs, lps, _, cr = _single(backend_engine, str(tmp_path))
@@ -111,29 +121,52 @@ def test_two_ranks_one_gpu_hip_engine(tmp_path):
     _run_two_ranks("hip", tmp_path)
 
 
+_RCCL_SINGLE_RANK = r"""
+import faulthandler, os, sys
+faulthandler.dump_traceback_later(90, exit=True)       # a bootstrap that never comes up: say where, then leave
+import numpy as np
+import torch            # noqa: F401  (brings its own bundled ROCm stack, torch/lib/librccl.so included, into the process first)
+sys.path.insert(0, sys.argv[1])
+from pydream_amd import _capi
+from tests import helpers as H
+# One ROCm stack for the engine AND its RCCL, whatever else the process holds: librccl is opened next to the HIP runtime the
+# engine's calls are bound to (here torch's copy, because torch was imported first; in bench.py, which loads libdreamzs.so
+# first, /opt/rocm's) and is checked to resolve that same runtime.
+lib, hip = _capi.comm_library(), _capi.hip_library()
+assert os.path.dirname(os.path.realpath(lib)) == os.path.dirname(os.path.realpath(hip)), (lib, hip)
+d, N, n = 16, 8, 25
+P = H.mvn_precision(d); Z0 = H.seed_history(40, d, 4)
+res = []
+for use_comm in (False, True):
+    e = _capi.Engine(nchains=N, ndim=d, multitry=5, history_capacity=40 + N * 8, trace_capacity=n, seed=5, history_thin=5)
+    if use_comm:
+        e.comm_init_rccl(0, 1, _capi.comm_unique_id())
+    e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), P, 0, 0.0)
+    e.step(n)
+    res.append((e.get_trace(0, n)["X"], e.get_history()))
+np.testing.assert_array_equal(res[0][0], res[1][0])
+np.testing.assert_array_equal(res[0][1], res[1][1])
+print("rccl single rank: equal")
+"""
+
+
 @pytest.mark.gpu
 def test_rccl_single_rank_comm(tmp_path):
-    """RCCL bootstrap + in-place ncclAllGather with world size 1 (all the 1-GPU box can run)."""
-    import torch            # noqa: F401  (brings its own bundled ROCm stack, torch/lib/librccl.so included, into the process first)
-    from pydream_amd import _capi
-    from tests import helpers as H
-    # One ROCm stack for the engine AND its RCCL, whatever else the process holds: librccl is opened next to the HIP runtime the
-    # engine's calls are bound to (here torch's copy, because torch was imported first; in bench.py, which loads libdreamzs.so
-    # first, /opt/rocm's) and is checked to resolve that same runtime.
-    lib, hip = _capi.comm_library(), _capi.hip_library()
-    assert os.path.dirname(os.path.realpath(lib)) == os.path.dirname(os.path.realpath(hip)), (lib, hip)
-    d, N, n = 16, 8, 25
-    P = H.mvn_precision(d); Z0 = H.seed_history(40, d, 4)
-    res = []
-    for use_comm in (False, True):
-        e = _capi.Engine(nchains=N, ndim=d, multitry=5, history_capacity=40 + N * 8, trace_capacity=n, seed=5, history_thin=5)
-        if use_comm:
-            e.comm_init_rccl(0, 1, _capi.comm_unique_id())
-        e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), P, 0, 0.0)
-        e.step(n)
-        res.append((e.get_trace(0, n)["X"], e.get_history()))
-    np.testing.assert_array_equal(res[0][0], res[1][0])
-    np.testing.assert_array_equal(res[0][1], res[1][1])
+    """RCCL bootstrap + in-place ncclAllGather with world size 1 (all the 1-GPU box can run).  In a process of its own with a
+    deadline (and one second attempt): RCCL's bootstrap opens sockets and probes the box's topology, and once in some sixty suite
+    runs it did not return on a fresh box -- a stuck bootstrap must cost this test, not hang the whole suite."""
+    import subprocess
+    last = None
+    for attempt in range(2):
+        try:
+            last = subprocess.run([sys.executable, "-c", _RCCL_SINGLE_RANK, ROOT], capture_output=True, text=True, timeout=120, cwd=str(tmp_path),
+                                  env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        except subprocess.TimeoutExpired as exc:
+            last = exc
+            continue
+        if last.returncode == 0 and "rccl single rank: equal" in last.stdout:
+            return
+    raise AssertionError("RCCL single-rank run failed twice: %r" % (getattr(last, "stderr", last),))
 
 
 @pytest.mark.gpu

@@ -415,18 +415,23 @@ def test_c3_full_size_mixture_with_adaptation(G, O):
     e.close()
 
 
-def test_c5_shard_512_chains_1000d_against_oracle(G, O):
+def test_c5_shard_512_chains_1000d_against_oracle(G, O, monkeypatch):
     """BASELINE configs[4] per-GPU shard at full size: 512 chains x 1000-D correlated MVN, triangular-factor likelihood,
-    12 generations across two history appends: everything bit-exact against the oracle."""
+    12 generations across two history appends: everything bit-exact against the oracle -- on one stream and with the chains
+    split into three chain-group streams (DZ_STREAMS; each stream's likelihood launches use their own slice of the row-tile
+    scratch array)."""
     N, d, n, seed = 512, 1000, 12, 9
     P = H.mvn_precision(d)
     U = np.linalg.cholesky((P + P.T) / 2).T
     Z0 = H.seed_history(10 * d, d, seed)
     out = []
-    for Cls in (G.Engine, O.Engine):
+    for Cls, streams in ((G.Engine, "1"), (G.Engine, "3"), (O.Engine, None)):
+        if streams:
+            monkeypatch.setenv("DZ_STREAMS", streams)
         e = Cls(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * 4, trace_capacity=n, seed=seed)
         e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), U, 1, 0.0)
         e.step(n)
         out.append((e.get_trace(0, n), e.get_history()))
-    assert_traces_identical(out[0][0], out[1][0])
-    np.testing.assert_array_equal(out[0][1], out[1][1])
+    for other in out[:2]:
+        assert_traces_identical(other[0], out[2][0])
+        np.testing.assert_array_equal(other[1], out[2][1])

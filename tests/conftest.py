@@ -19,7 +19,15 @@ def golden_dir():
 
 def pytest_collection_modifyitems(config, items):
     """On a machine without an AMD GPU (no /dev/kfd) the `gpu` tests are skipped instead of failing at dz_create.
-    On a GPU box nothing is skipped: a missing libdreamzs.so must fail loudly there, there is no CPU fallback."""
+    On a GPU box nothing is skipped: a missing libdreamzs.so must fail loudly there, there is no CPU fallback.
+
+    The GPU tests that put several processes on the one device (tests/test_distributed.py: two ranks, eight ranks, RCCL bootstrap)
+    run after all single-process ones: on one box in several, such a process stalled while the pytest process held the device
+    (those tests have deadlines), and under `-x` a stall there must not keep the parity tests from running."""
+    multi = [it for it in items if "gpu" in it.keywords and it.nodeid.startswith("tests/test_distributed.py")]
+    if multi:
+        rest = [it for it in items if it not in multi]
+        items[:] = rest + multi
     if os.path.exists("/dev/kfd"):
         return
     skip = pytest.mark.skip(reason="no AMD GPU on this machine (/dev/kfd absent); run `pytest -m gpu` on the MI355X box")

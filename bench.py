@@ -96,6 +96,14 @@ def algorithmic_bytes(args, n_local):
     }
 
 
+def generation_bytes(args):
+    """algorithmic HBM bytes per chain-generation,
+    B = 8d (2k-1)(2(1-s)+3s) [Z gathers] + 16d [state read + write] + 8d + 8 [trace] + 8d/thin [append] + 16(2k-1) [logp scalars];
+    k = 5, s = 0.1, thin = 10: 176 d + 152."""
+    d, k, s = float(args.dim), args.multitry, args.snooker
+    return 8.0 * d * ((2 * k - 1) * (2.0 * (1.0 - s) + 3.0 * s) + 2.0 + 1.0 + 1.0 / args.thin) + 8.0 + 16.0 * (2 * k - 1)
+
+
 def measured_traffic(args, n_local, kernel_class, gens_per_launch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same workload
     (profiles/<tag>_traffic.json, made by tools/collect_profiles.sh + tools/traffic_from_pmc.py), or None."""
@@ -387,7 +395,7 @@ def main():
         ab = algorithmic_bytes(args, n_local)
         if prof.get("generations", {}).get("launches"):
             # the persistent kernel covers whole generations: SURVEY.md section 8(d) B = 176 d + 152 bytes per chain-generation
-            ab["generations"] = n_local * (176.0 * args.dim + 152.0) * K / prof["generations"]["launches"]
+            ab["generations"] = n_local * generation_bytes(args) * K / prof["generations"]["launches"]
         cand = {k: v for k, v in prof.items() if k in ab and v["launches"]}
         dom = max(cand, key=lambda k: cand[k]["total_ms"])
         avg_s = cand[dom]["avg_us"] * 1e-6
@@ -413,7 +421,7 @@ def main():
             if flops_gen:
                 out["roofline"]["fp64_matrix_tflops"] = flops_gen * K / sum_or(prof, dom, med * 1e3) / 1e9
         out["kernel_times"] = prof
-        gen_bytes = n_local * (176.0 * args.dim + 152.0)        # B = 176 d + 152 per chain-generation
+        gen_bytes = n_local * generation_bytes(args)             # B = 176 d + 152 per chain-generation at k = 5, s = 0.1
         out["generation_hbm"] = {"algorithmic_bytes_per_generation": gen_bytes,
                                  "achieved_GBps": gen_bytes * K / med / 1e9,
                                  "frac_of_8TBps": gen_bytes * K / med / 1e9 / HBM_PEAK_GBS}

@@ -537,7 +537,7 @@ bool mega_eligible(const dz_engine* e)
     const dz::Params& p = e->p;
     if (mega_mix_eligible(e)) return true;
     if ((p.hard || p.have_prior) && !mega_xlds(e)) return false;
-    return e->mega && !p.Tc && e->lk == LK_MVN && p.ld <= 128 && p.k >= 3 && p.k <= dz::MAXK && p.depairs == 1 &&
+    return e->mega && !p.Tc && e->lk == LK_MVN && p.ld <= 128 && (p.k == 1 || p.k >= 3) && p.k <= dz::MAXK && p.depairs == 1 &&
            p.nslots <= 64 && (!p.tri || p.Mtp) && mega_lds_bytes(e, false) <= (size_t)160 * 1024;
 }
 // number of generations, starting at g, that one launch may cover: none of them publishes positions
@@ -580,8 +580,10 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
     const int nrt = p.ld / 16;
     const int ch = mega_chains(e);
     // waves per chain: 4 when a block holds only 4 chains (fewer than 8 chains per CU) -- the tries of a phase then run side by
-    // side (1024 chains: 238 -> 249 M proposals/s, 512: 120 -> 131); at 8 chains per block two waves per chain lose (405 -> 368)
-    const int wpc = ch == 4 ? 4 : 1;
+    // side (1024 chains: 238 -> 249 M proposals/s, 512: 120 -> 131); at 8 chains per block two waves per chain lose (405 -> 368).
+    // multitry off: one try, one wave per chain whatever the block size
+    const bool k1 = p.k == 1;
+    const int wpc = (ch == 4 && !k1) ? 4 : 1;
     const dim3 grid((p.nl + ch - 1) / ch), block(64 * ch * wpc);
     const bool xlds = mega_xlds(e);
     const bool pb = p.hard || p.have_prior;
@@ -592,9 +594,11 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
         e->params_uploaded = true;
     }
     {
-#define DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, CH_, WPC_, PB_) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations<NRT_, TRI_, X_, CH_, WPC_, PB_>), grid, block, lds, (const dz::Params*)e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0)
-#define DZ_MEGA_LAUNCH(NRT_, TRI_, X_, PB_) do { if (ch == 16) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 16, 1, PB_); \
-        else if (ch == 8) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 8, 1, PB_); else DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 4, 4, PB_); } while (0)
+#define DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, CH_, WPC_, PB_, K1_) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations<NRT_, TRI_, X_, CH_, WPC_, PB_, K1_>), grid, block, lds, (const dz::Params*)e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0)
+#define DZ_MEGA_LAUNCH(NRT_, TRI_, X_, PB_) do { \
+        if (k1) { if (ch == 16) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 16, 1, PB_, true); else if (ch == 8) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 8, 1, PB_, true); else DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 4, 1, PB_, true); } \
+        else if (ch == 16) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 16, 1, PB_, false); \
+        else if (ch == 8) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 8, 1, PB_, false); else DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 4, 4, PB_, false); } while (0)
     // (priors / boundaries: only with the chain states in LDS -- mega_eligible -- which keeps the number of kernels down)
 #define DZ_MEGA_CASE(NRT_)                                                              \
     case NRT_:                                                                          \

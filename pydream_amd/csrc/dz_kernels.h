@@ -305,7 +305,7 @@ DZ_DEV SetConsts set_consts(const Params& p, int phase, int cr_idx)
 // snooker_logp = (d - 1) log sqrt(.) (:823-824 / :834-835) in ONE pass of the logarithm (snooker_logps below) instead of one per
 // try; 0 for a DE try (snooker_logp = 0).  grow: gamma_arr[level-1][delta-1][:] (any address space; the look-up address is
 // wave-uniform).
-template <int NCH, bool AL16 = true, bool LEAN = false>
+template <int NCH, bool AL16 = true, int LEAN = 0>      // LEAN: 0 full, 1 lean (multi-try sets only), 2 lean with the single-try snooker formula
 DZ_DEV double propose_point(const Params& p, int phase, uint32_t g, uint32_t M, int c, int i, int n, int lane,
                           const double (&xb)[NCH][2], const double* __restrict__ grow, const RowTerms<NCH>& zr, double* __restrict__ out,
                           double* cur_snk_out, bool snk, int cr_idx, int delta, int glev, const DrawSrc& dr, const u32x4* wpre = nullptr,
@@ -368,7 +368,7 @@ DZ_DEV double propose_point(const Params& p, int phase, uint32_t g, uint32_t M, 
             }
         }
         const double D = wave_bfly(accD);                                      // :816 / :827
-        if (LEAN || n > 1) {
+        if (LEAN == 1 || n > 1) {
             const double cc = wave_bfly(accS) / D;                             // :820
 #pragma unroll
             for (int it = 0; it < NCH; ++it)
@@ -574,7 +574,7 @@ DZ_DEV void point_prior(const Params& p, const double* row, int lane, double* pr
 
 // Tries i0..i1-1 of one chain's proposal set (phase 0: around the current state; phase 1: the reference set
 // around the selected proposal).  out / sl / prior_out address try 0's row and scalars.
-template <int NCH, bool AL16, bool GENERIC = true, bool LEAN = false>
+template <int NCH, bool AL16, bool GENERIC = true, int LEAN = 0>
 DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int c, uint32_t gc, int i0, int i1, int n, int lane,
                         const double (&xb)[NCH][2], const double* __restrict__ grow, bool snk, int cr_idx, int delta, int glev, const DrawSrc& dsrc,
                         double* out, int out_stride, double* sl, double* csn, double* prior_out)

@@ -19,7 +19,7 @@
 // the MFMA contract), so results are bit-identical to it and to the oracle.
 //
 // Eligibility (checked on the host, everything else runs the multi-kernel path): MVN likelihood, ld <= 128,
-// multitry >= 3, DEpairs = 1, draw slots <= 64 (priors / hard boundaries: the PB instantiation), no position publishing (i.e. outside
+// multitry 1 or >= 3, DEpairs = 1, draw slots <= 64 (priors / hard boundaries: the PB instantiation), no position publishing (i.e. outside
 // the crossover burn-in), LDS budget met.
 #pragma once
 #include "dz_kernels.h"
@@ -148,7 +148,7 @@ DZ_DEV void request_pair(const Params& p, const DrawSrc& ds, int slot, uint32_t 
 }
 
 // DE tries i0..i1-1 of one chain's set (one pair, the common case); A and B already hold the rows of tries i0 and i0 + 1.
-template <bool LEAN>
+template <int LEAN>
 DZ_DEV void propose_de_pf(const Params& p, int phase, uint32_t g, uint32_t M, int c, uint32_t gc, int i0, int i1, int n, int lane,
                           const double (&xb)[1][2], const double* __restrict__ grow, int cr_idx, int glev, const DrawSrc& ds,
                           double* out, int out_stride, double* sl, double* prior_out, RowPair& A, RowPair& B, RowPair& C)
@@ -176,7 +176,9 @@ DZ_DEV void propose_de_pf(const Params& p, int phase, uint32_t g, uint32_t M, in
 
 // PB: per-dimension priors and/or hard boundaries (SampledParam priors, parameters.py:37-47; Dream.py:733-791) -- the full
 // propose_point with its prior evaluation; the flat, unbounded case keeps the lean code (2.4 % faster at the headline size).
-template <int NRT, bool TRI, bool XLDS, int CH, int WPC, bool PB>
+// K1: multitry off (the reference's default, Dream.py:271-275 and :326-334) -- one proposal per generation, no reference set, the
+// snooker move's current-point term; a template flag so that the multi-try kernels carry none of it (it cost them a register spill).
+template <int NRT, bool TRI, bool XLDS, int CH, int WPC, bool PB, bool K1 = false>
 __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int append_last)
 {
     const Params& p = *pp;       // read through the scalar cache on demand: keeps the ~70 fields out of the SGPR file
@@ -186,8 +188,9 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     // first wave does the Metropolis step.  Every wave of a chain derives the chain's decisions itself (same draws, same
     // arithmetic); two more barriers per generation keep the base point and the new state consistent between them.
     constexpr int NT = 64 * CH * WPC;
+    constexpr int LEANV = PB ? 0 : (K1 ? 2 : 1);
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int d = p.d, k = p.k, ld = p.ld;
+    const int d = p.d, k = K1 ? 1 : p.k, ld = p.ld;
     const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, XLDS, CH);
     double* Ms = smem;
     double* Pt = smem + L.off_P;
@@ -261,7 +264,8 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
         const bool last = gi == ngen - 1;
         DZ_MSTAMP(0);
         const DrawSrc ds = dsn;
-        for (int phase = 0; phase < 2; ++phase) {
+        constexpr int nph = K1 ? 1 : 2;                                              // multitry off: no reference set
+        for (int phase = 0; phase < nph; ++phase) {
             // ---- phase 0: k proposals around the chain's state (generate_proposal_points :258-264) into the chain's rows
             //      of tiles 0..k-1; phase 1: the selected proposal moves to tile 0 and k-1 reference points around it
             //      (:295-299) take tiles 1..k-1.  One copy of the code serves both (instruction cache).
@@ -323,18 +327,18 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
             double* slp = phase ? rS + cl * (k - 1) : sS + cl * k;
             double* prp = phase ? rP + cl * (k - 1) : sP + cl * k;
             if (!snk_s) {
-                propose_de_pf<!PB>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, f.cr_idx, f.glev, ds,
+                propose_de_pf<LEANV>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, f.cr_idx, f.glev, ds,
                                    region + (size_t)phase * tstride, tstride, slp, prp, RA, RB, RC);
                 if (phase == 0) prefetch_first(ds, 1, g);                            // the reference set's first rows, ahead of the likelihood pass
             } else if (i0 < i1) {
                 // a snooker set is the longest path to the block's barrier (three rows and three reductions per try, one chain in
                 // ten): its wave gets issue priority over the three DE waves it shares a SIMD with
                 __builtin_amdgcn_s_setprio(3);
-                propose_set<NCH, false, false, !PB>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, true, f.cr_idx, 1, f.glev, ds,
-                                                     region + (size_t)phase * tstride, tstride, slp, nullptr, prp);
+                propose_set<NCH, false, false, LEANV>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, true, f.cr_idx, 1, f.glev, ds,
+                                                     region + (size_t)phase * tstride, tstride, slp, K1 ? st + 4 * cl + 3 : nullptr, prp);   // (k = 1: log |x - z|^(d-1) of the current point, :328-329)
                 __builtin_amdgcn_s_setprio(0);
             }
-            if (phase == 1 && !last) {                                               // the next generation's draws and first rows
+            if (phase == nph - 1 && !last) {                                         // the next generation's draws and first rows
                 dsn = generation_draws(g + 1u);
                 if (!draws_say_snooker(dsn, g + 1u)) prefetch_first(dsn, 0, g + 1u);
             }
@@ -360,7 +364,16 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
             const double lpri = st[4 * cl], llik = st[4 * cl + 1];
             const int sf = (int)st[4 * cl + 2]; const int sel = sf & 255; const bool fin = (sf & 256) != 0;
             double val = -__builtin_huge_val();
-            if (lane < k) {
+            if (K1) {                                                                // single try: the proposal's density straight from the q sums (:271-275)
+                double qt[NRT];
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) qt[t] = qb[cl * NRT + t];
+                double Q = 0.0;
+#pragma unroll
+                for (int t = 0; t < NRT; ++t) Q = Q + qt[t];
+                val = nan_to_ninf(p.logF - 0.5 * Q);                                 // (every lane: the same sums)
+                sL[cl] = val;
+            } else if (lane < k) {
                 val = sP[cl * k + lane] + p.T * sL[cl * k + lane];                                       // :279
                 if (snk) val = val + sS[cl * k + lane];                                                  // :307
             } else if (lane >= 16 && lane < 16 + k) {
@@ -378,9 +391,16 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 if (snk) { const double sr = i < k - 1 ? rS[cl * (k - 1) + i] : 0.0; val = (val + sr) + sS[cl * k + i]; }   // :312-313
             }
             DZ_MSTAMP(14);
-            double lu;
-            double ratio = mt_log_ratio(k, val, u_acc, lane, &lu);                   // log(u) of :993 rides in the ratio's logarithm pass
-            if (!fin) ratio = -__builtin_huge_val();                                 // DESIGN.md deviation D1
+            double lu, ratio;
+            if (K1) {
+                const double q_logp = p.T * val + sP[cl], last_logp = p.T * llik + lpri;                 // :274, :243
+                if (snk) ratio = nan_to_num((q_logp + sS[cl]) - (last_logp + st[4 * cl + 3]));           // :326-332
+                else ratio = nan_to_num(q_logp) - nan_to_num(last_logp);                                 // :334
+                lu = dlog(u_acc);
+            } else {
+                ratio = mt_log_ratio(k, val, u_acc, lane, &lu);                      // log(u) of :993 rides in the ratio's logarithm pass
+                if (!fin) ratio = -__builtin_huge_val();                             // DESIGN.md deviation D1
+            }
             const bool accept = is_finite(ratio) && (lu < ratio);                    // :993
             DZ_MSTAMP(15);
             const int jj = 2 * lane;

@@ -164,7 +164,9 @@ def test_d1000_stress_shape_against_oracle(G, O):
                                                              (64, 64, 4, 0, 0, True, None), (256, 100, 5, 1, 12, True, None),
                                                              (64, 128, 4, 0, 0, True, None), (64, 128, 4, 1, 0, True, None),
                                                              (4096, 20, 5, 1, 0, True, "uniform"), (200, 100, 5, 0, 0, True, "uniform"),
-                                                             (96, 10, 3, 1, 0, True, "normal"), (64, 128, 4, 0, 0, True, "normal")])
+                                                             (96, 10, 3, 1, 0, True, "normal"), (64, 128, 4, 0, 0, True, "normal"),
+                                                             (4096, 100, 1, 1, 0, True, None), (1000, 100, 1, 0, 0, True, None), (96, 10, 1, 1, 0, True, "uniform"),
+                                                             (256, 100, 1, 1, 12, True, None), (64, 128, 1, 0, 0, True, "normal"), (4096, 20, 1, 1, 0, True, "uniform")])
 def test_persistent_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, k, tri, burnin, eligible, prior, monkeypatch):
     """k_generations (whole thin-cycles in one launch, the default wherever it is eligible) against the
     multi-kernel path (DZ_MEGA=0) and the oracle: 35 generations across three history appends, chain counts that do
@@ -173,7 +175,9 @@ def test_persistent_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, k, tr
     way); the multi-kernel run of the dense 128-D case also exercises the likelihood kernel that takes its operands from
     L2 (its matrix does not fit LDS).  prior: SampledParam-style priors -- "uniform" with hard boundaries narrow enough that
     proposals are reflected and some are redrawn (Dream.py:733-791), "normal" without boundaries (with priors the persistent
-    kernel keeps the chain states in LDS; at 4 chains per block even the dense 128-D matrix leaves room for that)."""
+    kernel keeps the chain states in LDS; at 4 chains per block even the dense 128-D matrix leaves room for that).
+    multitry = 1 (the reference's default, Dream.py:271-275 and :326-334): one proposal per generation, no reference set, the
+    snooker move's current-point term."""
     n, seed = 35, 77
     P = H.mvn_precision(d)
     M = np.linalg.cholesky((P + P.T) / 2).T if tri else P

@@ -529,7 +529,7 @@ bool mega_xlds(const dz_engine* e) { return mega_lds_bytes(e, true) <= (size_t)1
 bool mega_mix_eligible(const dz_engine* e)
 {
     const dz::Params& p = e->p;
-    return e->mega && !p.Tc && e->lk == LK_MIX && !p.hard && !p.have_prior && p.ld <= 128 && p.k >= 3 && p.k <= dz::MAXK && p.depairs == 1 &&
+    return e->mega && !p.Tc && e->lk == LK_MIX && !p.hard && !p.have_prior && p.ld <= 128 && (p.k == 1 || p.k >= 3) && p.k <= dz::MAXK && p.depairs == 1 &&
            p.nslots <= 64 && p.J <= 32;
 }
 bool mega_eligible(const dz_engine* e)

@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
 // The same persistent scheme for a likelihood a single wave evaluates on its own (Gaussian mixture): nothing is shared
 // between the chains of a block, so there are no tiles and no barriers at all -- every wave carries its chain through the
 // generations of the launch independently (its k points in an LDS region it alone touches, its state in registers).
-// Eligibility: flat priors, no bounds, DEpairs = 1, ld <= 128, outside the crossover burn-in.
+// Eligibility: flat priors, no bounds, DEpairs = 1, multitry 1 or >= 3, ld <= 128, outside the crossover burn-in.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int MIXW = 4;       // waves (= chains) per block
 
@@ -471,7 +471,8 @@ __global__ __launch_bounds__(64 * MIXW) void k_generations_mix(const Params* __r
         int sel = 0; bool fin = true;
         DrawSrc ds; ds.have = true; ds.mine = make_uint4(0, 0, 0, 0);      // the generation's wave-uniform draws, both phases read them
         if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g); ds.mine = make_uint4(w.x, w.y, w.z, w.w); }
-        for (int phase = 0; phase < 2; ++phase) {
+        const int nph = k == 1 ? 1 : 2;                                    // multitry off: one proposal, no reference set
+        for (int phase = 0; phase < nph; ++phase) {
             StepFlags f;
             double base[NCH][2];
             if (phase == 0) {
@@ -495,8 +496,8 @@ __global__ __launch_bounds__(64 * MIXW) void k_generations_mix(const Params* __r
             const double* grow = gamma_row(p, f.glev, 1);
             const int n = k - phase;
             double* rows = region + (size_t)phase * LDP;
-            propose_set<NCH, false, false, true>(p, phase, g, M, c, gc, 0, n, n, lane, base, grow, f.snk, f.cr_idx, 1, f.glev, ds,
-                                                 rows, LDP, (phase ? rS : sS), nullptr, (phase ? lh : sP));   // (flat priors: in phase 1 the prior slot is scratch)
+            propose_set<NCH, false, false, 2>(p, phase, g, M, c, gc, 0, n, n, lane, base, grow, f.snk, f.cr_idx, 1, f.glev, ds,
+                                              rows, LDP, (phase ? rS : sS), (k == 1 ? dec + 5 : nullptr), (phase ? lh : sP));   // (flat priors: in phase 1 the prior slot is scratch)
             // mt_evaluate_logps :278, :302 -- by this wave, for its own points.  The squared distances to the J means need the
             // whole wave (one butterfly each); the log-sum-exp of a point is scalar work, so lane i does it for point i and
             // the n points cost one pass of exp / log instead of n (same operations per point as k_logp_mix).
@@ -550,9 +551,16 @@ __global__ __launch_bounds__(64 * MIXW) void k_generations_mix(const Params* __r
                 val = i < k - 1 ? p.T * rL[i] + 0.0 : p.T * llik + lpri;            // :303, :877-879 (flat priors)
                 if (snk) { const double sr = i < k - 1 ? rS[i] : 0.0; val = (val + sr) + sS[i]; }   // :312-313
             }
-            double lu;
-            double ratio = mt_log_ratio(k, val, u_acc, lane, &lu);
-            if (!fin) ratio = -__builtin_huge_val();                                // DESIGN.md deviation D1
+            double lu, ratio;
+            if (k == 1) {
+                const double q_logp = p.T * sL[0] + sP[0], last_logp = p.T * llik + lpri;                // :274, :243
+                if (snk) ratio = nan_to_num((q_logp + sS[0]) - (last_logp + dec[5]));                    // :326-332
+                else ratio = nan_to_num(q_logp) - nan_to_num(last_logp);                                 // :334
+                lu = dlog(u_acc);
+            } else {
+                ratio = mt_log_ratio(k, val, u_acc, lane, &lu);
+                if (!fin) ratio = -__builtin_huge_val();                            // DESIGN.md deviation D1
+            }
             const bool accept = is_finite(ratio) && (lu < ratio);                   // :993
             const int jj = 2 * lane;
             const double2 xo = {xs[0][0], xs[0][1]};

@@ -304,11 +304,11 @@ def test_large_d_likelihood_kernels_against_oracle(G, O, N, d, tri, gemm, zero_m
     assert_traces_identical(out[0], out[1])
 
 
-@pytest.mark.parametrize("N,d,J,burnin", [(512, 100, 3, 0), (70, 20, 2, 0), (256, 100, 3, 15)])
-def test_persistent_mixture_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, J, burnin, monkeypatch):
+@pytest.mark.parametrize("N,d,J,burnin,k", [(512, 100, 3, 0, 5), (70, 20, 2, 0, 5), (256, 100, 3, 15, 5), (512, 100, 3, 0, 1), (70, 20, 2, 12, 1), (64, 10, 2, 0, 3)])
+def test_persistent_mixture_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, J, burnin, k, monkeypatch):
     """k_generations_mix (mixture likelihood: every wave carries its chain on its own, no barriers) against the
     multi-kernel path and the oracle, bit for bit: across history appends, a ragged last block, and with a crossover
-    burn-in in front (configs[2] shape)."""
+    burn-in in front (configs[2] shape); multitry 5, 3 and off (one proposal per generation)."""
     n, seed = 36, 41
     mu = np.array([np.full(d, m) for m in np.linspace(-5.0, 5.0, J)])
     logF = np.log(np.arange(1, J + 1) / np.arange(1, J + 1).sum()) - (d / 2.) * np.log(2 * np.pi)
@@ -316,7 +316,7 @@ def test_persistent_mixture_kernel_equals_multi_kernel_path_and_oracle(G, O, N, 
 
     def run(Cls, mega):
         monkeypatch.setenv("DZ_MEGA", "1" if mega else "0")
-        e = Cls(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
+        e = Cls(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
                 adapt_crossover=1 if burnin else 0, crossover_burnin=burnin)
         e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mixture(mu, logF)
         launches = None

@@ -536,8 +536,8 @@ bool mega_eligible(const dz_engine* e)
 {
     const dz::Params& p = e->p;
     if (mega_mix_eligible(e)) return true;
-    if ((p.hard || p.have_prior) && !mega_xlds(e)) return false;
-    return e->mega && !p.Tc && e->lk == LK_MVN && p.ld <= 128 && (p.k == 1 || p.k >= 3) && p.k <= dz::MAXK && p.depairs == 1 &&
+    if ((p.hard || p.have_prior || p.depairs > 1) && !mega_xlds(e)) return false;      // (the full-code instantiations keep the states in LDS)
+    return e->mega && !p.Tc && e->lk == LK_MVN && p.ld <= 128 && (p.k == 1 || p.k >= 3) && p.k <= dz::MAXK &&
            p.nslots <= 64 && (!p.tri || p.Mtp) && mega_lds_bytes(e, false) <= (size_t)160 * 1024;
 }
 // number of generations, starting at g, that one launch may cover: none of them publishes positions
@@ -586,7 +586,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
     const int wpc = (ch == 4 && !k1) ? 4 : 1;
     const dim3 grid((p.nl + ch - 1) / ch), block(64 * ch * wpc);
     const bool xlds = mega_xlds(e);
-    const bool pb = p.hard || p.have_prior;
+    const bool pb = p.hard || p.have_prior || p.depairs > 1;      // the instantiations with the full proposal code
     const size_t lds = mega_lds_bytes(e, xlds);
     if (!e->params_uploaded || memcmp(&e->p_shadow, &p, sizeof(dz::Params)) != 0) {   // the kernel reads Params through a pointer
         HIPCK(hipMemcpyAsync(e->d_params, &p, sizeof(dz::Params), hipMemcpyHostToDevice, e->stream));

@@ -19,7 +19,7 @@
 // the MFMA contract), so results are bit-identical to it and to the oracle.
 //
 // Eligibility (checked on the host, everything else runs the multi-kernel path): MVN likelihood, ld <= 128,
-// multitry 1 or >= 3, DEpairs = 1, draw slots <= 64 (priors / hard boundaries: the PB instantiation), no position publishing (i.e. outside
+// multitry 1 or >= 3, draw slots <= 64 (priors / hard boundaries / DEpairs > 1: the PB instantiation), no position publishing (i.e. outside
 // the crossover burn-in), LDS budget met.
 #pragma once
 #include "dz_kernels.h"
@@ -211,6 +211,9 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     const int c = min(cg, p.nl - 1);
     const uint32_t gc = (uint32_t)(p.off + c);
     const int tstride = CH * L.LDP;                                      // try i of chain cl: Pt + (CH i + cl) LDP
+    // DEpairs > 1 (set_DEpair :571-583, several archive-row pairs per try): served by the PB instantiations, which carry the full
+    // proposal code -- the general propose_set fetches its own rows, so the one-pair row prefetch is off
+    const bool multipair = PB && p.depairs > 1;
     double* region = Pt + (size_t)cl * L.LDP;
 
     // ---- stage the matrix, mu, the selection probabilities, the gamma table, the chains' logp (and states)
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
         return u53_below(w0.x, w0.y, p.snk_thr);
     };
     DrawSrc dsn = generation_draws(g0);
-    if (!draws_say_snooker(dsn, g0)) prefetch_first(dsn, 0, g0);
+    if (!multipair && !draws_say_snooker(dsn, g0)) prefetch_first(dsn, 0, g0);
 
     for (int gi = 0; gi < ngen; ++gi) {
         const uint32_t g = g0 + (uint32_t)gi;
@@ -281,6 +284,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 if (lane == 0 && sub == 0) {
                     double* dc = dec + 8 * cl;
                     dc[0] = u.u_sel; dc[1] = u.u_acc; dc[2] = f.snk ? 1.0 : 0.0; dc[3] = (double)f.cr_idx; dc[4] = (double)f.glev;
+                    if (PB) dc[5] = (double)f.delta;
                 }
                 if (XLDS) {
                     const double* xr = Xs + cl * L.LDP;
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
             } else {
                 const double* dc = dec + 8 * cl;
                 const double u_sel = dc[0];
-                f.snk = dc[2] != 0.0; f.cr_idx = (int)dc[3]; f.delta = 1; f.glev = (int)dc[4];
+                f.snk = dc[2] != 0.0; f.cr_idx = (int)dc[3]; f.delta = PB ? (int)dc[5] : 1; f.glev = (int)dc[4];
                 // likelihoods of the chain's k points, mt_choose_proposal_pt (:291)
                 double lp = -__builtin_huge_val();
                 if (lane < k) {
@@ -320,13 +324,18 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 }
             }
             const bool snk_s = __builtin_amdgcn_readfirstlane((int)f.snk) != 0;      // (the decision is wave-uniform: branch on the scalar unit)
-            const double* grow = gts + (size_t)(__builtin_amdgcn_readfirstlane(f.glev) - 1) * d;
+            const double* grow = multipair ? gamma_row(p, __builtin_amdgcn_readfirstlane(f.glev), __builtin_amdgcn_readfirstlane(f.delta))
+                                           : gts + (size_t)(__builtin_amdgcn_readfirstlane(f.glev) - 1) * d;
             if (phase) DZ_MSTAMP(13);
             const int n = k - phase;
             const int i0 = WPC == 1 ? 0 : (sub * n) / WPC, i1 = WPC == 1 ? n : ((sub + 1) * n) / WPC;     // this wave's tries
             double* slp = phase ? rS + cl * (k - 1) : sS + cl * k;
             double* prp = phase ? rP + cl * (k - 1) : sP + cl * k;
-            if (!snk_s) {
+            if (!snk_s && multipair) {
+                if (i0 < i1)
+                    propose_set<NCH, false, true, 0>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, false, f.cr_idx, f.delta, f.glev, ds,
+                                                      region + (size_t)phase * tstride, tstride, slp, nullptr, prp);
+            } else if (!snk_s) {
                 propose_de_pf<LEANV>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, f.cr_idx, f.glev, ds,
                                    region + (size_t)phase * tstride, tstride, slp, prp, RA, RB, RC);
                 if (phase == 0) prefetch_first(ds, 1, g);                            // the reference set's first rows, ahead of the likelihood pass
@@ -340,7 +349,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
             }
             if (phase == nph - 1 && !last) {                                         // the next generation's draws and first rows
                 dsn = generation_draws(g + 1u);
-                if (!draws_say_snooker(dsn, g + 1u)) prefetch_first(dsn, 0, g + 1u);
+                if (!multipair && !draws_say_snooker(dsn, g + 1u)) prefetch_first(dsn, 0, g + 1u);
             }
             DZ_MSTAMP(1 + 4 * phase);
             __syncthreads();                                                         // points visible

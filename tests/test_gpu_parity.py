@@ -211,6 +211,42 @@ def test_persistent_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, k, tr
         np.testing.assert_array_equal(a[2], other[2])
 
 
+@pytest.mark.parametrize("N,d,k,depairs,ngamma,prior", [(1000, 100, 5, 3, 2, None), (96, 10, 3, 2, 1, "uniform"), (256, 100, 1, 2, 3, None),
+                                                        (64, 128, 4, 3, 1, None)])
+def test_persistent_kernel_with_several_pairs_and_gamma_levels(G, O, N, d, k, depairs, ngamma, prior, monkeypatch):
+    """DEpairs > 1 and several gamma levels (set_DEpair Dream.py:571-583, set_gamma_level :585-599, the gamma table :692) inside
+    k_generations -- the instantiations with the full proposal code -- against the multi-kernel path and the oracle, bit for bit."""
+    n, seed = 35, 19
+    P = H.mvn_precision(d)
+    U = np.linalg.cholesky((P + P.T) / 2).T
+    Z0 = H.seed_history(max(10 * d, 2 * N * depairs), d, seed)
+    table = np.array([[2.38 / np.sqrt(2.0 * (dl + 1) * np.arange(1, d + 1)) / (lv + 1) for dl in range(depairs)] for lv in range(ngamma)])
+    gp = np.arange(1, ngamma + 1, dtype=float); gp /= gp.sum()
+
+    def run(Cls, mega):
+        monkeypatch.setenv("DZ_MEGA", "1" if mega else "0")
+        e = Cls(nchains=N, ndim=d, multitry=k, depairs=depairs, ngamma=ngamma, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed)
+        e.set_gamma_table(table); e.set_gamma_probs(gp)
+        if prior == "uniform":
+            e.set_prior(np.full(d, 2, np.int32), np.full(d, -6.0), np.full(d, 22.0))
+            e.set_bounds(np.full(d, -6.0), np.full(d, 16.0))
+        e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), U, 1, 0.0)
+        launches = None
+        if Cls is G.Engine:
+            e.profile_enable(True); e.profile_reset()
+        e.step(n)
+        if Cls is G.Engine:
+            launches = e.profile_get("generations")[1]
+            e.profile_enable(False)
+        return e.get_trace(0, n), e.get_history(), launches
+
+    a, b, o = run(G.Engine, True), run(G.Engine, False), run(O.Engine, False)
+    assert a[2] > 0 and b[2] == 0
+    for other in (b, o):
+        assert_traces_identical(a[0], other[0])
+        np.testing.assert_array_equal(a[1], other[1])
+
+
 def test_full_size_run_recovers_the_target_moments(G):
     """BASELINE headline size (4096 chains x 100-D MVN, multitry 5) through properties that do not depend on the size:
     after burn-in the pooled samples have the target's analytic moments (mean 0, Var(x_i) = i, all correlations 0.5;

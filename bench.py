@@ -175,9 +175,9 @@ def timed_blocks(e, K, min_ms, barrier, dist, max_blocks=400):
         t0 = time.perf_counter()
         e.step(K)
         e.sync()
+        dt = time.perf_counter() - t0              # this rank's K generations (its all-gathers waited for every other rank's)
         if dist is not None:
-            dist.barrier()
-        dt = time.perf_counter() - t0
+            dist.barrier()                         # the far side's barrier; the block's time is the slowest rank's
         if dist is not None:
             import torch
             t = torch.tensor([dt, float(sum(times) + dt)], dtype=torch.float64)
@@ -278,6 +278,7 @@ def main():
             e.sync()
             if dist is not None:
                 dist.barrier()
+                e.comm_barrier()                   # the ranks leave a device collective closer together than a host barrier
         conv = {"chunk": chunk, "criterion": "max R-hat < 1.2 (reference rule: second half of the run so far, all %d chains)" % n_global,
                 "generations_to_rhat_below_1p2": None, "history": []}
         done = 0

@@ -97,6 +97,7 @@ const char* dz_comm_library(void);     /* path of the librccl in use: the one ne
 int dz_comm_unique_id(void* id128);                                                 /* rank 0: 128-byte RCCL unique id */
 int dz_comm_init_rccl(dz_engine* e, int32_t rank, int32_t world, const void* id128);
 int dz_set_exchange(dz_engine* e, dz_exchange_cb cb, void* user);
+int dz_comm_barrier(dz_engine* e);     /* device-side rendezvous of the ranks (one-element RCCL all-gather + stream sync; replaces the mp.Barrier-like role of a host barrier in front of a timed region); without a communicator: a sync */
 
 /* Parallel tempering (core.py:131-236).  T[nchains]: the temperature of every (global) chain -- Dream.astep's T argument
  * (Dream.py:193), the ladder of core.py:133-136 is computed by the caller.  swaps != 0 adds the swap step of

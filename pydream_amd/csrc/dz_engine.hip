@@ -110,6 +110,7 @@ struct dz_engine {
     // bounded host run-ahead: a marker every ra_stride generations, the host never gets more than 3 markers ahead
     dz::Params p_shadow; bool params_uploaded = false;    // what d_params holds
     void* h_pin = nullptr;          // page-locked bounce buffer for downloads into pageable memory (d2h_2d)
+    double* d_bar = nullptr;                // dz_comm_barrier's all-gather buffer (one element per rank)
     double* d_qpart = nullptr; size_t qpart_len = 0; bool force_big = false; bool logp_gemm = true; int logp_bm = 0;    // DZ_LOGP_GEMM=0: no LDS-tiled product; row-tile sums of the tiled large-d likelihood; DZ_LOGP_BIG=1: the one-wave-per-tile kernel
     int logp_waves = 0;      // DZ_LOGP_WAVES: force the block size of k_logp_mvn_lds (tuning)
     int ra_stride = 32; hipEvent_t ra_ev[4] = {nullptr}; bool ra_used[4] = {false, false, false, false}; int64_t ra_n = 0;
@@ -949,6 +950,21 @@ int dz_comm_init_rccl(dz_engine* e, int32_t rank, int32_t world, const void* id1
 }
 
 int dz_set_exchange(dz_engine* e, dz_exchange_cb cb, void* user) { e->xcb = cb; e->xcb_user = user; return 0; }
+
+// A rendezvous of the ranks on the device: a one-element all-gather on the engine's stream, then a stream synchronise.  Ranks leave
+// an RCCL collective within microseconds of each other (a host barrier's exits are spread by tens of microseconds), which is what a
+// timed region over a few hundred microseconds wants in front of it.  No communicator (one GPU, or the host transport): just the sync.
+int dz_comm_barrier(dz_engine* e)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    DZCK(sync_all(e));
+    if (!e->comm) return 0;
+    if (!e->d_bar) DZCK(ealloc(e, &e->d_bar, (size_t)std::max(1, e->world)));
+    ncclResult_t r = g_rccl.AllGather(e->d_bar + e->rank, e->d_bar, 1, ncclDouble, e->comm, e->stream);
+    if (r != ncclSuccess) return fail(std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+    HIPCK(hipStreamSynchronize(e->stream));
+    return 0;
+}
 
 int dz_set_temperatures(dz_engine* e, const double* T, int32_t swaps)
 {   // core.py:133-136 (the ladder is the host's), :185-221 (swaps != 0: one swap attempt per generation)

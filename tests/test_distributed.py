@@ -141,6 +141,7 @@ for use_comm in (False, True):
     e = _capi.Engine(nchains=N, ndim=d, multitry=5, history_capacity=40 + N * 8, trace_capacity=n, seed=5, history_thin=5)
     if use_comm:
         e.comm_init_rccl(0, 1, _capi.comm_unique_id())
+        e.comm_barrier()
     e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), P, 0, 0.0)
     e.step(n)
     res.append((e.get_trace(0, n)["X"], e.get_history()))

@@ -162,19 +162,19 @@ struct ProfScope {
         if (on) {
             for (hipEvent_t* x : {&a, &b}) {
                 if (!e->ev_pool.empty()) { *x = e->ev_pool.back(); e->ev_pool.pop_back(); }
-                else hipEventCreate(x);
+                else (void)hipEventCreate(x);
             }
-            hipEventRecord(a, st);
+            (void)hipEventRecord(a, st);
         }
     }
-    ~ProfScope() { if (on) { hipEventRecord(b, st); e->ev[which].emplace_back(a, b); } }
+    ~ProfScope() { if (on) { (void)hipEventRecord(b, st); e->ev[which].emplace_back(a, b); } }
 };
 
 hipEvent_t prof_event(dz_engine* e)
 {
     hipEvent_t x = nullptr;
     if (!e->ev_pool.empty()) { x = e->ev_pool.back(); e->ev_pool.pop_back(); }
-    else hipEventCreate(&x);
+    else (void)hipEventCreate(&x);
     return x;
 }
 // One kernel launch of profile class CLS.  While profiling, the launch carries its own start/stop events
@@ -309,7 +309,7 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
                 const size_t need = (size_t)n * nrtb;
                 if (need * e->nlanes > e->qpart_len) {
                     DZCK(sync_all(e));
-                    if (e->d_qpart) hipFree(e->d_qpart);
+                    if (e->d_qpart) (void)hipFree(e->d_qpart);
                     e->d_qpart = nullptr; e->qpart_len = 0;
                     DZCK(dalloc(&e->d_qpart, need * e->nlanes));
                     e->qpart_len = need * e->nlanes;
@@ -761,19 +761,19 @@ int dz_destroy(dz_engine* e)
     }
 #endif
     if (!e) return 0;
-    hipSetDevice(e->c.device);
-    for (int s2 = 0; s2 < e->nlanes; ++s2) if (e->lane_stream[s2]) hipStreamSynchronize(e->lane_stream[s2]);
-    for (int s2 = 1; s2 < e->nlanes; ++s2) if (e->lane_stream[s2]) hipStreamDestroy(e->lane_stream[s2]);
-    for (int s2 = 0; s2 < e->nlanes; ++s2) if (e->lane_ev[s2]) hipEventDestroy(e->lane_ev[s2]);
-    for (int s2 = 0; s2 < 4; ++s2) if (e->ra_ev[s2]) hipEventDestroy(e->ra_ev[s2]);
-    for (auto& v : e->ev) for (auto& pr : v) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-    for (hipEvent_t x : e->ev_pool) hipEventDestroy(x);
+    (void)hipSetDevice(e->c.device);
+    for (int s2 = 0; s2 < e->nlanes; ++s2) if (e->lane_stream[s2]) (void)hipStreamSynchronize(e->lane_stream[s2]);
+    for (int s2 = 1; s2 < e->nlanes; ++s2) if (e->lane_stream[s2]) (void)hipStreamDestroy(e->lane_stream[s2]);
+    for (int s2 = 0; s2 < e->nlanes; ++s2) if (e->lane_ev[s2]) (void)hipEventDestroy(e->lane_ev[s2]);
+    for (int s2 = 0; s2 < 4; ++s2) if (e->ra_ev[s2]) (void)hipEventDestroy(e->ra_ev[s2]);
+    for (auto& v : e->ev) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (hipEvent_t x : e->ev_pool) (void)hipEventDestroy(x);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
-    for (void* q : e->to_free) hipFree(q);
-    if (e->d_scratch) hipFree(e->d_scratch);
-    if (e->d_qpart) hipFree(e->d_qpart);
-    if (e->h_pin) hipHostFree(e->h_pin);
-    if (e->stream) hipStreamDestroy(e->stream);
+    for (void* q : e->to_free) (void)hipFree(q);
+    if (e->d_scratch) (void)hipFree(e->d_scratch);
+    if (e->d_qpart) (void)hipFree(e->d_qpart);
+    if (e->h_pin) (void)hipHostFree(e->h_pin);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return 0;
 }
@@ -1097,7 +1097,7 @@ static int download_trace_rows(dz_engine* e, double* X, int64_t g0, int64_t ng, 
                        sizeof(double) * d, (size_t)ng) != hipSuccess) rc = -1;
     }
     if (hipStreamSynchronize(e->stream) != hipSuccess) rc = -1;
-    if (pinned) hipHostUnregister(X);
+    if (pinned) (void)hipHostUnregister(X);
     return rc ? fail(std::string("trace download: ") + hipGetErrorString(hipGetLastError())) : 0;
 }
 
@@ -1131,7 +1131,7 @@ int dz_get_trace_chains(dz_engine* e, int64_t g0, int64_t ng, double* X, int64_t
         const size_t nl = e->p.nl, need = nl * (size_t)ng;
         if (need > e->qpart_len) {
             DZCK(sync_all(e));
-            if (e->d_qpart) hipFree(e->d_qpart);
+            if (e->d_qpart) (void)hipFree(e->d_qpart);
             e->d_qpart = nullptr; e->qpart_len = 0;
             DZCK(dalloc(&e->d_qpart, need));
             e->qpart_len = need;
@@ -1213,7 +1213,7 @@ int dz_get_rhat(dz_engine* e, double* rhat)
 static int need_scratch(dz_engine* e, size_t rows)
 {
     if (e->scratch_rows >= rows) return 0;
-    if (e->d_scratch) hipFree(e->d_scratch);
+    if (e->d_scratch) (void)hipFree(e->d_scratch);
     e->d_scratch = nullptr; e->scratch_rows = 0;
     HIPCK(hipMalloc((void**)&e->d_scratch, sizeof(double) * (rows * e->p.ld + 4 * rows)));
     e->scratch_rows = rows;

@@ -671,7 +671,7 @@ int orc_debug_propose(orc_engine* e, int32_t chain_local, int64_t gen, int phase
 /* One chain transition, Dream.py:238-347                              */
 /* ------------------------------------------------------------------ */
 typedef struct {
-    int snk, cr_idx, delta, glev, sel, accept, moved, gamma_unity;
+    int snk, cr_idx, delta, glev, sel, accept, moved, gamma_unity, redraws;
     double prior_new, like_new;
 } step_res;
 
@@ -688,6 +688,7 @@ static int chain_step(orc_engine* e, int c, uint32_t g, int64_t M, const double*
     R->glev = 1 + orc_invcdf(g_probs, e->c.ngamma, u.u_glev);                      /* set_gamma_level :585-599 */
     double slp[64], slr[64], gam[64], cur_snk = 0.0;
     double pri[64], lik[64], rpri[64], rlik[64];
+    R->redraws = 0;
     if (k > 63) return fail("multitry too large");
     if (gen_points(e, gc, g, 0, k, q0, M, R->snk, R->cr_idx, R->delta, R->glev, e->pts, slp, gam, &cur_snk, NULL)) return -1;   /* :258-264 */
     R->gamma_unity = 0;
@@ -703,6 +704,20 @@ static int chain_step(orc_engine* e, int c, uint32_t g, int64_t M, const double*
     } else {
         double lp[64] = {0}; int anyfinite = 0;
         for (int i = 0; i < k; ++i) { lp[i] = pri[i] + T * lik[i]; if (isfinite(lp[i])) anyfinite = 1; }            /* :279, :900 */
+        /* "all logps are -inf ... generate more proposal points" (:281-289): the whole proposal set is drawn again, same
+         * decisions (snooker, CR, DE pairs, gamma level), until one try is finite.  Redraw round r >= 1 takes its point and
+         * dimension streams from the Philox key seed + r * ORC_REDRAW_KEY_STEP; the reference's loop is
+         * unbounded, here it gives up after ORC_MAX_REDRAWS rounds and the step is a forced reject (deviation D1). */
+        for (int round = 1; !anyfinite && round <= ORC_MAX_REDRAWS; ++round) {
+            const uint64_t seed0 = e->c.seed;
+            e->c.seed = seed0 + (uint64_t)round * ORC_REDRAW_KEY_STEP;
+            int grc = gen_points(e, gc, g, 0, k, q0, M, R->snk, R->cr_idx, R->delta, R->glev, e->pts, slp, gam, &cur_snk, NULL);
+            e->c.seed = seed0;
+            if (grc) return -1;
+            if (eval_points(e, e->pts, k, pri, lik)) return -1;
+            for (int i = 0; i < k; ++i) { lp[i] = pri[i] + T * lik[i]; if (isfinite(lp[i])) anyfinite = 1; }
+            R->redraws = round;
+        }
         /* mt_choose_proposal_pt :883-917 */
         double mx = lp[0]; for (int i = 1; i < k; ++i) if (lp[i] > mx) mx = lp[i];
         double wgt[64], S = 0.0;
@@ -727,7 +742,7 @@ static int chain_step(orc_engine* e, int c, uint32_t g, int64_t M, const double*
         for (int i = 0; i < k; ++i) SA = SA + orc_exp(A[i] - m2);                                                   /* :321 */
         for (int i = 0; i < k; ++i) SB = SB + orc_exp(B[i] - m2);                                                   /* :322 */
         ratio = nan_to_num(orc_log(SA / SB));                                                                       /* :323 */
-        if (!anyfinite) ratio = -INFINITY;   /* DESIGN.md deviation D1: the reference's unbounded regenerate loop (:282-289) is a forced reject */
+        if (!anyfinite) ratio = -INFINITY;   /* DESIGN.md deviation D1: after ORC_MAX_REDRAWS redraw rounds the reference's unbounded loop (:282-289) ends in a forced reject */
     }
     /* metrop_select :980-998 */
     R->accept = isfinite(ratio) && (orc_log(u.u_acc) < ratio);

@@ -58,6 +58,11 @@ typedef struct orc_config {
 
 typedef struct orc_engine orc_engine;
 
+/* Redraw of a proposal set whose tries are all impossible (Dream.py:281-289): round r >= 1 uses the Philox key
+ * seed + r * ORC_REDRAW_KEY_STEP (mod 2^64); after ORC_MAX_REDRAWS rounds the step is a forced reject. */
+#define ORC_REDRAW_KEY_STEP 0x9E3779B97F4A7C15ull
+#define ORC_MAX_REDRAWS 64
+
 /* batch log-density callback: X is [n,d] row-major; fill prior[n], like[n]. */
 typedef int (*orc_logp_cb)(const double* X, int64_t n, int32_t d, double* prior, double* like, void* user);
 /* all-gather hook for rank-sharded runs: send = this rank's block, recv = all

@@ -61,10 +61,11 @@ class ContractRandom:
         self.gc, self.g = gc, g
         self.pgu = p_gamma_unity
         self.phase = 0
+        self.round = 0
         self.n_ctrl = 0
         self.cnt = {}
         self.snk = False
-        self.log = dict(snooker=0, cr_idx=-1, sel=0, glev=1, delta=1)
+        self.log = dict(snooker=0, cr_idx=-1, sel=0, glev=1, delta=1, redraws=0)
         s = O.stream_id(O.K_CTRL)
         w0 = O.philox(self.seed, 0, s, gc, g)
         w1 = O.philox(self.seed, 1, s, gc, g)
@@ -82,15 +83,29 @@ class ContractRandom:
     def _ntries(self):
         return self.k if self.phase == 0 else self.k - 1
 
+    # Redraw rounds (Dream.py:281-289: the proposal set is generated again while every try is impossible): the calls of round r
+    # follow those of round r-1 in the same phase, so a per-phase call count c splits into (round, try) = divmod(c, tries per
+    # call); round r >= 1 draws from the Philox key seed + r * REDRAW_KEY_STEP (oracle/dreamzs_oracle.h).
+    REDRAW_KEY_STEP = 0x9E3779B97F4A7C15
+
+    def _key(self):
+        return (self.seed + self.round * self.REDRAW_KEY_STEP) & 0xFFFFFFFFFFFFFFFF
+
+    def _split(self, c, per_call=None):
+        rnd, tr = divmod(c, per_call or self._ntries())
+        self.round = rnd
+        self.log["redraws"] = max(self.log.get("redraws", 0), rnd if self.phase == 0 else 0)
+        return tr
+
     def _pt(self, tr, idx):
-        return O.philox(self.seed, idx, O.stream_id(O.K_PT, tr, self.phase), self.gc, self.g)
+        return O.philox(self._key(), idx, O.stream_id(O.K_PT, tr, self.phase), self.gc, self.g)
 
     def _dim(self, tr, d):
         """per-dimension draws of one try: arrays (U, u_e, z); one Philox call per PAIR of dimensions."""
         s = O.stream_id(O.K_DIM, tr, self.phase)
         U, ue, z = np.zeros(d), np.zeros(d), np.zeros(d)
         for q in range((d + 1) // 2):
-            w = O.philox(self.seed, q, s, self.gc, self.g)
+            w = O.philox(self._key(), q, s, self.gc, self.g)
             zz = (O.normal32(w[2], w[3]), O.normal32_sin(w[2], w[3]))
             for h in (0, 1):
                 j = 2 * q + h
@@ -123,13 +138,14 @@ class ContractRandom:
                 self.log["glev"] = m + 1
             return self._onehot(len(pvals), m)
         if len(pvals) == 2 and pvals[0] == self.pgu and self.k != 2:      # set_gamma, Dream.py:615
-            tr = self._next("gu")
+            tr = self._split(self._next("gu"))
             w = self._pt(tr, 0)
             return self._onehot(2, O.invcdf(pvals, O.u53(w[0], w[1])))
         # mt_choose_proposal_pt, Dream.py:908
         m = O.invcdf(pvals, self.u_sel)
         self.log["sel"] = m
         self.phase = 1
+        self.round = 0
         return self._onehot(len(pvals), m)
 
     def randint(self, lo, hi, size=None):                                    # set_DEpair, Dream.py:580
@@ -138,43 +154,45 @@ class ContractRandom:
         return np.array([v])
 
     def normal(self, loc, scale, size):                                      # Dream.py:694
-        tr = self._next("normal")
+        tr = self._split(self._next("normal"))
         return loc + scale * self._dim(tr, size)[2]
 
     def uniform(self, low=None, high=None, size=None):
         if low is None:                                                      # metrop_select, Dream.py:993
             return self.u_acc
         if size is None:                                                     # snooker gamma, Dream.py:618
+            self._split(self._next("sgamma"), 1)
             w = self._pt(0, 0)
             return low + (high - low) * O.u53(w[2], w[3])
         if isinstance(size, tuple):                                          # U, Dream.py:700
             n, d = size
+            self._split(self._next("U"), 1)
             return np.array([self._dim(tr, d)[0] for tr in range(n)])
-        tr = self._next("e")                                                 # e, Dream.py:696: uniform(low, high) from the 16-bit draws, one fma each
+        tr = self._split(self._next("e"))                                           # e, Dream.py:696: uniform(low, high) from the 16-bit draws, one fma each
         return np.array([O.uniform16(int(h), low, high) for h in self._dim(tr, size)[1]])
 
     def rand(self, n):                                                       # bounds redraw, Dream.py:749-751, 773-775
         fr = sys._getframe(1).f_locals
         tr = int(fr.get("pt_num", 0)) if self._ntries() > 1 else 0
         masks = [m for m in (fr["x_lower"], fr["x_upper"]) if np.any(m)]
-        key = ("bnd", self.phase, tr)
+        key = ("bnd", self.phase, self.round, tr)
         c = self.cnt.get(key, 0)
         self.cnt[key] = c + 1
         mask = np.atleast_1d(masks[c])
         dims = np.where(mask)[0]
         assert len(dims) == n
         s = O.stream_id(O.K_BND, tr, self.phase)
-        return np.array([O.u32(O.philox(self.seed, int(j), s, self.gc, self.g)[0]) for j in dims])
+        return np.array([O.u32(O.philox(self._key(), int(j), s, self.gc, self.g)[0]) for j in dims])
 
     # ---- random.sample used by sample_from_history, Dream.py:662-664 ----
     def sample(self, rng, n):
         M = len(rng)
         if not self.snk:
-            tr = self._next("sample")
+            tr = self._split(self._next("sample"))
             words = np.concatenate([self._pt(tr, 1 + q) for q in range((n + 3) // 4)])[:n]
             return [int(x) for x in O.sample_distinct(words, M)]
-        c = self._next("sample")
         nt = self._ntries()
+        c = self._split(self._next("sample"), 3 * nt)
         if c < nt:
             tr, word = c, 0
         else:
@@ -285,6 +303,7 @@ def run_reference(params, likelihood, Z0, starts, N, G, seed, schedule, dream_kw
         out = dict(X=np.zeros((G, N, d)), logp=np.zeros((G, N)), prior=np.zeros((G, N)), like=np.zeros((G, N)),
                    moved=np.zeros((G, N), np.uint8), try_idx=np.zeros((G, N), np.int32),
                    cr_idx=np.zeros((G, N), np.int32), snooker=np.zeros((G, N), np.uint8),
+                   redraws=np.zeros((G, N), np.int32),
                    cross_probs=np.zeros((G, step.nCR)), gamma_probs=np.zeros((G, step.ngamma)),
                    hist_rows=np.zeros(G, np.int64))
         for g in range(G):
@@ -301,6 +320,7 @@ def run_reference(params, likelihood, Z0, starts, N, G, seed, schedule, dream_kw
                 out["try_idx"][g, ci] = rnd.log["sel"]
                 out["cr_idx"][g, ci] = rnd.log["cr_idx"]
                 out["snooker"][g, ci] = rnd.log["snooker"]
+                out["redraws"][g, ci] = rnd.log.get("redraws", 0)
                 x[ci] = xn
             if schedule == 2:
                 for kind in ("pos", "cr", "gam", "hist"):
@@ -538,6 +558,13 @@ def trace_case(name, *, d, N, G, k, schedule, seed, target, dream_kwargs=None, p
         params = [SampledParam(uniform, loc=lower, scale=upper - lower)]
         Z0 = lower + rng.uniform(0, 1, (nseed, d)) * (upper - lower)
         pk, pa, pb = np.full(d, 2, np.int32), lower, upper - lower
+    elif prior == "uniform_wide_history":      # the same uniform prior, but an archive three times as wide as its support and no
+        lower = np.array([-5., -9., 5., 3.])[:d]   # hard boundaries: most jumps leave the support, whole proposal sets are impossible
+        upper = np.array([10., 2., 7., 8.])[:d]    # (log prior -inf) and the reference draws them again (Dream.py:281-289)
+        params = [SampledParam(uniform, loc=lower, scale=upper - lower)]
+        Z0 = lower + (3 * rng.uniform(0, 1, (nseed, d)) - 1) * (upper - lower)
+        Z0[:N] = lower + rng.uniform(0, 1, (N, d)) * (upper - lower)            # the starts lie inside
+        pk, pa, pb = np.full(d, 2, np.int32), lower, upper - lower
     elif prior == "normal":            # pydream/tests/test_models.py:24-33
         mu = np.resize(np.array([-6.6, 3, 1.0, -.12]), d)
         sd = np.resize(np.array([.13, 5, .9, 1.0]), d)
@@ -699,6 +726,12 @@ def main():
     # T3b: multi-try with uniform prior + boundaries
     trace_case("trace_s2_k3_bounds", d=4, N=5, G=100, k=3, schedule=2, seed=5, target=("simple",), prior="uniform",
                dream_kwargs=dict(adapt_crossover=False, crossover_burnin=10 ** 9, lamb=.3))
+    # T3c/T3d: multi-try, uniform prior WITHOUT hard boundaries and an archive wider than the support: proposal sets whose tries are
+    # all impossible are drawn again (Dream.py:281-289); host likelihood (T3c) and the device MVN likelihood with snooker moves (T3d)
+    trace_case("trace_s2_k3_redraw", d=4, N=5, G=100, k=3, schedule=2, seed=31, target=("simple",), prior="uniform_wide_history",
+               dream_kwargs=dict(adapt_crossover=False, crossover_burnin=10 ** 9, hardboundaries=False))
+    trace_case("trace_s2_k5_redraw_mvn", d=4, N=6, G=100, k=5, schedule=2, seed=37, target=("mvn",), prior="uniform_wide_history",
+               dream_kwargs=dict(adapt_crossover=True, crossover_burnin=40, hardboundaries=False, snooker=.3))
     # T4: DEpairs=2, 3 gamma levels with gamma adaptation, normal prior
     trace_case("trace_s2_depairs_gamma", d=6, N=6, G=120, k=5, schedule=2, seed=13, target=("mvn",), prior="normal",
                dream_kwargs=dict(adapt_crossover=True, adapt_gamma=True, gamma_levels=3, DEpairs=2, crossover_burnin=50))

@@ -7,7 +7,7 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-S2_TRACES = ["trace_s2_adapt", "trace_s2_k1_bounds", "trace_s2_k3_bounds", "trace_s2_depairs_gamma",
+S2_TRACES = ["trace_s2_adapt", "trace_s2_k1_bounds", "trace_s2_k3_bounds", "trace_s2_k3_redraw", "trace_s2_k5_redraw_mvn", "trace_s2_depairs_gamma",
              "trace_s2_mvn100", "trace_s2_mix3", "trace_s2_restart"]
 
 

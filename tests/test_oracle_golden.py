@@ -7,6 +7,7 @@ from oracle import oracle as O
 from tests import helpers as H
 
 TRACES = ["trace_s1_c1", "trace_s1_adapt", "trace_s2_adapt", "trace_s2_k1_bounds", "trace_s2_k3_bounds",
+          "trace_s2_k3_redraw", "trace_s2_k5_redraw_mvn",
           "trace_s2_depairs_gamma", "trace_s2_mvn100", "trace_s2_mix3", "trace_s2_restart"]
 
 
@@ -14,6 +15,8 @@ TRACES = ["trace_s1_c1", "trace_s1_adapt", "trace_s2_adapt", "trace_s2_k1_bounds
 def test_astep_traces_match_reference(name):
     """Accept/selection/CR/snooker sequences exact; states to 1e-9 relative (snooker projections cancel; the reference sums them in BLAS order); logp to 1e-10 (north_star)."""
     fx = H.load(name)
+    if "redraw" in name:       # the case is only worth its name if the reference did draw whole proposal sets again (Dream.py:281-289)
+        assert (fx["redraws"] > 0).mean() > 0.3 and fx["redraws"].max() < 64
     e = H.engine_from_trace_fixture(O.Engine, fx)
     G = int(fx["cfg_G"])
     e.step(G)

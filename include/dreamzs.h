@@ -119,6 +119,13 @@ int     dz_get_chain_state(dz_engine* e, int32_t chain, double* x, double* prior
 int     dz_sync(dz_engine* e);
 int     dz_trace_reset(dz_engine* e);
 int64_t dz_generation(dz_engine* e);
+/* Dream.py:281-289: a multi-try proposal set whose tries are all impossible (log density -inf or nan) is generated again, with the
+ * same decisions, until one try is finite.  Redraw round r >= 1 takes its draws from the Philox key seed + r * DZ_REDRAW_KEY_STEP
+ * (mod 2^64); the reference's loop is unbounded, the engine gives up after DZ_MAX_REDRAWS rounds (the step is then a rejection).
+ * dz_redraw_rounds: number of redraw launches since dz_create (0 for targets and priors that cannot produce such a set). */
+#define DZ_REDRAW_KEY_STEP 0x9E3779B97F4A7C15ull
+#define DZ_MAX_REDRAWS 64
+int64_t dz_redraw_rounds(dz_engine* e);
 
 int dz_get_state(dz_engine* e, double* X, double* prior, double* like);             /* [nl,d],[nl],[nl] */
 /* trace of generations [g0,g0+ng) since the last reset: sampled_params / log_ps of

@@ -143,6 +143,10 @@ struct dz_engine {
     int mega_max_gen = 1 << 20;     // DZ_MEGA_MAXGEN: generations per launch cap (measurement)
     int mega_ch = 0;                // DZ_MEGA_CHAINS: force 16 / 8 / 4 chains per block (0: by chain count)
     bool tempering = false; double* d_Tc = nullptr; int32_t* d_tswap = nullptr;    // parallel tempering (dz_set_temperatures)
+    // Dream.py:281-289: a proposal set whose tries are all impossible is drawn again (redo_possible / one_generation)
+    uint8_t* d_redo = nullptr; int* d_redo_count = nullptr;
+    std::vector<int32_t> h_pkind; std::vector<double> h_pa, h_pb, h_mins, h_maxs;     // host copies: is the uniform priors' support covered by the hard boundaries?
+    int64_t redraw_rounds = 0;      // redraw launches so far (dz_redraw_rounds)
     bool pending_accept = false;    // generation gen-1's Metropolis step has been deferred into the next proposal kernel
     int64_t pending_slot = -1;
     int propose_split = 0;          // waves per chain in k_propose (DZ_PROPOSE_SPLIT); 0 = by problem shape
@@ -397,6 +401,21 @@ int adapt_generation(dz_engine* e, uint32_t g, int gc0, int ngc)
     return launch_check("adaptation kernels");
 }
 
+// Can every try of a multi-try proposal set be impossible (log density -inf or nan)?  Not with the built-in likelihoods under flat or
+// normal priors; yes with a host likelihood, and with a uniform prior unless hard boundaries keep every proposal inside its support.
+// Those configurations take the multi-kernel path, which checks after the proposal set's evaluation and draws again (Dream.py:281-289).
+bool redo_possible(const dz_engine* e)
+{
+    const dz::Params& p = e->p;
+    if (p.k <= 1) return false;
+    if (e->lk == LK_HOST) return true;
+    for (size_t j = 0; j < e->h_pkind.size(); ++j) {
+        if (e->h_pkind[j] != 2) continue;
+        const bool covered = p.hard && j < e->h_mins.size() && e->h_mins[j] >= e->h_pa[j] && e->h_maxs[j] <= e->h_pa[j] + e->h_pb[j];
+        if (!covered) return true;
+    }
+    return false;
+}
 // every lane waits for everything queued so far on every other lane
 int join_all(dz_engine* e)
 {
@@ -406,6 +425,36 @@ int join_all(dz_engine* e)
         for (int t = 0; t < e->nlanes; ++t) if (t != s) HIPCK(hipStreamWaitEvent(e->lane_stream[s], e->lane_ev[t], 0));
     return 0;
 }
+// Dream.py:281-289: while every try of a chain's proposal set is impossible, the set is generated again with the same decisions
+// (snooker, CR, DE pairs, gamma level) and evaluated again.  Redraw round r >= 1 takes its point and dimension streams from the Philox
+// key seed + r * DZ_REDRAW_KEY_STEP, evaluated in place (the precomputed draw table holds round 0); only the
+// flagged chains' waves run, every point is evaluated again (the others' values are reproduced).  The reference's loop is unbounded;
+// after DZ_MAX_REDRAWS rounds the step is a forced reject (k_accept: no finite try), deviation D1.
+int redraw_impossible_sets(dz_engine* e, uint32_t g, int lc0, int lnc, int sp0, int wpb, hipStream_t st)
+{
+    dz::Params& p = e->p;
+    const int k = p.k;
+    if (!e->d_redo) { DZCK(ealloc(e, &e->d_redo, (size_t)p.nl)); DZCK(ealloc(e, &e->d_redo_count, 1)); }
+    for (int round = 1; round <= DZ_MAX_REDRAWS; ++round) {
+        int n = 0;
+        HIPCK(hipMemsetAsync(e->d_redo_count, 0, sizeof(int), st));
+        hipLaunchKernelGGL(dz::k_redo_flags, dim3((lnc + 255) / 256), dim3(256), 0, st, p, lc0, lnc, e->d_redo, e->d_redo_count);
+        DZCK(launch_check("k_redo_flags"));
+        HIPCK(hipMemcpyAsync(&n, e->d_redo_count, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCK(hipStreamSynchronize(st));
+        if (n == 0) break;
+        dz::Params pr = p;
+        const uint64_t key = e->c.seed + (uint64_t)round * DZ_REDRAW_KEY_STEP;
+        pr.k0 = (uint32_t)key; pr.k1 = (uint32_t)(key >> 32);
+        pr.draws = nullptr; pr.redo = e->d_redo;
+        NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc * sp0 + wpb - 1) / wpb), dim3(64 * wpb), 0, pr, 0, g, (uint32_t)e->M, lc0, lnc, sp0, 0, (int64_t)-1));
+        DZCK(launch_check("propose(redraw)"));
+        DZCK(eval_logp(e, p.P + (size_t)lc0 * k * p.ld, lnc * k, p.p_prior + (size_t)lc0 * k, p.p_like + (size_t)lc0 * k, st));
+        e->redraw_rounds++;
+    }
+    return 0;
+}
+
 // one transition of local chains [c0, c0+nc) at generation g.  Full range = a lockstep generation
 // (schedule S2); a sub-range is the single-chain view used by Dream.astep: its end-of-generation
 // updates (append, publish, adaptation) take effect immediately, as when the reference is driven
@@ -449,8 +498,9 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
     // the Metropolis step of this generation can ride in front of the next generation's proposal kernel when
     // nothing shared changes in between (no history append, no published positions) and a generation follows
     // ld > 256, one DE pair, multi-try: one wave per (chain, try) streaming over the dimension chunks (dz_kernels.h)
-    const bool streamed = e->stream_propose && e->nch >= 4 && p.depairs == 1 && k >= 3;
-    const bool defer = full && e->fuse && more_follow && !append && !publish && split == 1 && e->lk != LK_HOST && !e->tempering && !streamed;
+    const bool streamed = e->stream_propose && e->nch >= 4 && p.depairs == 1 && k >= 3 && !redo_possible(e);     // (redraw rounds go through k_propose)
+    const bool redo = redo_possible(e);         // (then the proposal set's evaluation is followed by a check on the host: nothing is deferred)
+    const bool defer = full && e->fuse && more_follow && !append && !publish && split == 1 && e->lk != LK_HOST && !e->tempering && !streamed && !redo;
     const int64_t zbase = full ? e->M : e->M - (int64_t)(p.off + c0);
     for (int s = 0; s < L; ++s) {
         const int lc0 = c0 + (int)((int64_t)nc * s / L), lc1 = c0 + (int)((int64_t)nc * (s + 1) / L), lnc = lc1 - lc0;
@@ -465,6 +515,7 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
         }
         DZCK(launch_check("propose"));
         DZCK(eval_logp(e, p.P + (size_t)lc0 * k * p.ld, lnc * k, p.p_prior + (size_t)lc0 * k, p.p_like + (size_t)lc0 * k, st));
+        if (redo) DZCK(redraw_impossible_sets(e, g, lc0, lnc, sp0, wpb, st));
         if (k > 1) {
             if (streamed) DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose_stream, dim3((lnc * (k - 1) + 3) / 4), dim3(256), 0, p, 1, g, (uint32_t)e->M, lc0, lnc);
             else {
@@ -536,6 +587,7 @@ bool mega_mix_eligible(const dz_engine* e)
 bool mega_eligible(const dz_engine* e)
 {
     const dz::Params& p = e->p;
+    if (redo_possible(e)) return false;
     if (mega_mix_eligible(e)) return true;
     if ((p.hard || p.have_prior || p.depairs > 1) && !mega_xlds(e)) return false;      // (the full-code instantiations keep the states in LDS)
     return e->mega && !p.Tc && e->lk == LK_MVN && p.ld <= 128 && (p.k == 1 || p.k >= 3) && p.k <= dz::MAXK &&
@@ -784,6 +836,7 @@ int dz_set_bounds(dz_engine* e, const double* mins, const double* maxs)
     bool any_finite = false;
     for (int j = 0; j < e->p.d; ++j) any_finite = any_finite || std::isfinite(mins[j]) || std::isfinite(maxs[j]);
     e->p.hard = (e->c.hardboundaries && any_finite) ? 1 : 0;     // with all bounds infinite the reflection code can never trigger
+    e->h_mins.assign(mins, mins + e->p.d); e->h_maxs.assign(maxs, maxs + e->p.d);
     DZCK(upload_padded(e, e->d_mins, mins, 1, -HUGE_VAL));
     return upload_padded(e, e->d_maxs, maxs, 1, HUGE_VAL);
 }
@@ -860,6 +913,7 @@ int dz_set_prior(dz_engine* e, const int32_t* kind, const double* a, const doubl
     hipLaunchKernelGGL(dz::k_prior_consts, dim3((d + 127) / 128), dim3(128), 0, e->stream, (const double*)e->d_pb, d, e->d_plogb);
     DZCK(launch_check("k_prior_consts"));
     e->p.have_prior = any ? 1 : 0;
+    e->h_pkind.assign(kind, kind + d); e->h_pa.assign(a, a + d); e->h_pb.assign(b, b + d);
     return 0;
 }
 
@@ -1062,6 +1116,7 @@ int dz_sync(dz_engine* e)
 }
 int dz_trace_reset(dz_engine* e) { e->ntrace = 0; return 0; }
 int64_t dz_generation(dz_engine* e) { return e->gen; }
+int64_t dz_redraw_rounds(dz_engine* e) { return e->redraw_rounds; }
 
 int dz_get_state(dz_engine* e, double* X, double* prior, double* like)
 {

@@ -49,6 +49,7 @@ struct Params {
     uint32_t crthr[32];       // crossover_threshold(CR_values[m]), m < ncr: `U_j < CR` as an integer test on the 16-bit draw
     unsigned long long pgu_thr;   // ceil(p_gamma_unity 2^53): u53(hi, lo) < p_gamma_unity as an integer test on the 53-bit draw (u53_below)
     unsigned long long snk_thr;   // ceil(snooker 2^53): the same for set_snooker's draw (0 when snooker == 0)
+    const uint8_t* redo;      // [nl] redraw round only (Dream.py:281-289; one_generation): chains whose proposal set is drawn again; null otherwise
     unsigned long long* dbg;  // cycle-stamp buffer of instrumented builds (-DDZ_EXPERIMENTS, dz_experiments.h); null otherwise
 };
 // per-phase cycle stamps: defined by dz_experiments.h in instrumented builds only (tools/variants.sh), no-ops in the product
@@ -691,6 +692,7 @@ __global__ __launch_bounds__(NCH >= 4 ? 256 : 1024) void k_propose(Params p, int
     if (wave >= nc * split) return;
     const int lane = threadIdx.x & 63;
     const int c = c0 + wave / split;
+    if (p.redo && !p.redo[c]) return;      // redraw round: only the chains whose tries were all impossible
     DZ_STAMP(p, phase, c, 0);
     const int per = (n + split - 1) / split;
     const int i0 = (wave % split) * per, i1 = min(n, i0 + per);
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(NCH >= 4 ? 256 : 1024) void k_propose(Params p, int
         if (!dsrc.have) dsrc = load_draws(p, nullptr, lane);
         out = p.P + (size_t)c * p.k * p.ld; sl = p.p_slogp + (size_t)c * p.k;
     } else {
-        dsrc = load_draws(p, p.draws + (size_t)c * p.nslots, lane);
+        dsrc = load_draws(p, p.draws ? p.draws + (size_t)c * p.nslots : nullptr, lane);      // (no table in a redraw round: its key differs)
         ct = p.ctl[c];
         const double* base;
         if (phase == 0) { base = p.X + (size_t)c * p.ld; out = p.P + (size_t)c * p.k * p.ld; sl = p.p_slogp + (size_t)c * p.k; }
@@ -1542,6 +1544,19 @@ __global__ __launch_bounds__(64) void k_pt_swap(Params p, uint32_t g, int64_t tr
         }
     }
     if (lane == 0 && trace_slot >= 0) { int32_t* q = p.tswap + 3 * trace_slot; q[0] = (int32_t)a; q[1] = (int32_t)b; q[2] = acc ? 1 : 0; }
+}
+
+// Dream.py:281-282: `while np.all(np.isfinite(np.array(log_ps))==False)` -- marks the chains whose k tries are all impossible
+// (log_ps = T log_likes + log_priors, :279) and counts them; the host draws their proposal sets again (one_generation).
+__global__ void k_redo_flags(Params p, int c0, int nc, uint8_t* __restrict__ redo, int* __restrict__ count)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nc) return;
+    const int c = c0 + t;
+    bool any = false;
+    for (int i = 0; i < p.k; ++i) any = any || is_finite(p.p_prior[c * p.k + i] + chain_T(p, c) * p.p_like[c * p.k + i]);
+    redo[c] = any ? 0 : 1;
+    if (!any) atomicAdd(count, 1);
 }
 
 __global__ void k_draws(Params p, uint32_t g, int c0, int nc, uint4* __restrict__ out, ChainCtl* __restrict__ ctl)

@@ -38,6 +38,7 @@ def test_golden_traces(name, G, O):
     tr = e.get_trace(0, n)
     gp = e.get_gamma_state()[0] if int(fx["cfg_adapt_gamma"]) else None
     H.compare_with_reference(tr, fx, e.get_history(), e.get_cr_state()[0], gp)
+    assert (e.redraw_rounds() > 0) == ("redraw" in name)      # Dream.py:281-289 taken exactly where the reference took it
     o = H.engine_from_trace_fixture(O.Engine, fx)
     o.step(n)
     assert_traces_identical(tr, o.get_trace(0, n))
@@ -245,6 +246,41 @@ def test_persistent_kernel_with_several_pairs_and_gamma_levels(G, O, N, d, k, de
     for other in (b, o):
         assert_traces_identical(a[0], other[0])
         np.testing.assert_array_equal(a[1], other[1])
+
+
+@pytest.mark.parametrize("N,d,k,snooker,split", [(256, 10, 3, 0.1, None), (200, 6, 5, 0.3, "5"), (32, 140, 4, 0.1, None)])
+def test_impossible_proposal_sets_are_drawn_again(G, O, N, d, k, snooker, split, monkeypatch):
+    """Dream.py:281-289 at sizes the fixtures do not reach: a uniform prior without hard boundaries and an archive wider than its
+    support, so that whole proposal sets are impossible and are generated again (round r from the key seed + r*step).  Such a
+    configuration takes the multi-kernel path with its host-side check (never the persistent kernel); states, decisions and the
+    archive equal the oracle's bit for bit, one wave per chain or per (chain, try), one or two 128-dimension chunks per lane."""
+    n, seed = (25 if d < 100 else 12), 41
+    rng = np.random.default_rng(seed)
+    P = H.mvn_precision(d)
+    lo, width = np.full(d, -2.0), np.full(d, 6.0)
+    Z0 = lo + (3 * rng.uniform(0, 1, (max(10 * d, 2 * N), d)) - 1) * width
+    Z0[:N] = lo + rng.uniform(0, 1, (N, d)) * width
+    if split:
+        monkeypatch.setenv("DZ_PROPOSE_SPLIT", split)
+
+    def run(Cls):
+        e = Cls(nchains=N, ndim=d, multitry=k, hardboundaries=0, snooker=snooker, crossover_burnin=12, adapt_crossover=1,
+                history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed)
+        e.set_prior(np.full(d, 2, np.int32), lo, width)
+        e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), P, 0, 0.0)
+        if Cls is G.Engine:
+            e.profile_enable(True); e.profile_reset()
+        e.step(n)
+        extra = (e.profile_get("generations")[1], e.redraw_rounds()) if Cls is G.Engine else None
+        return e.get_trace(0, n), e.get_history(), e.get_cr_state(), extra
+
+    a, o = run(G.Engine), run(O.Engine)
+    assert a[3][0] == 0 and a[3][1] > n          # no persistent launch; more redraw rounds than generations
+    assert np.isfinite(a[0]["logp"]).all()
+    assert_traces_identical(a[0], o[0])
+    np.testing.assert_array_equal(a[1], o[1])
+    for x, y in zip(a[2], o[2]):
+        np.testing.assert_array_equal(x, y)
 
 
 def test_full_size_run_recovers_the_target_moments(G):

@@ -144,7 +144,7 @@ struct dz_engine {
     int mega_ch = 0;                // DZ_MEGA_CHAINS: force 16 / 8 / 4 chains per block (0: by chain count)
     bool tempering = false; double* d_Tc = nullptr; int32_t* d_tswap = nullptr;    // parallel tempering (dz_set_temperatures)
     // Dream.py:281-289: a proposal set whose tries are all impossible is drawn again (redo_possible / one_generation)
-    uint8_t* d_redo = nullptr; int* d_redo_count = nullptr;
+    uint8_t* d_redo = nullptr; int32_t* d_redo_list = nullptr; uint8_t* h_redo = nullptr; int32_t* h_redo_list = nullptr;     // (host side: page-locked)
     std::vector<int32_t> h_pkind; std::vector<double> h_pa, h_pb, h_mins, h_maxs;     // host copies: is the uniform priors' support covered by the hard boundaries?
     int64_t redraw_rounds = 0;      // redraw launches so far (dz_redraw_rounds)
     bool pending_accept = false;    // generation gen-1's Metropolis step has been deferred into the next proposal kernel
@@ -427,30 +427,47 @@ int join_all(dz_engine* e)
 }
 // Dream.py:281-289: while every try of a chain's proposal set is impossible, the set is generated again with the same decisions
 // (snooker, CR, DE pairs, gamma level) and evaluated again.  Redraw round r >= 1 takes its point and dimension streams from the Philox
-// key seed + r * DZ_REDRAW_KEY_STEP, evaluated in place (the precomputed draw table holds round 0); only the
-// flagged chains' waves run, every point is evaluated again (the others' values are reproduced).  The reference's loop is unbounded;
-// after DZ_MAX_REDRAWS rounds the step is a forced reject (k_accept: no finite try), deviation D1.
+// key seed + r * DZ_REDRAW_KEY_STEP, evaluated in place (the precomputed draw table holds round 0).  A round:
+// k_redo_flags, k_propose over the listed chains whose flag is still set, the listed sets packed into the (not yet used)
+// reference-set buffers, evaluated there -- a host likelihood sees only those points -- and their log densities scattered back.
+// The list comes from one read-back of the flags; up to four rounds are queued per read-back (chains that succeed in between drop
+// out by their flag: same result as a round-by-round loop, fewer host round trips).  The reference's loop is unbounded; after
+// DZ_MAX_REDRAWS rounds the step is a rejection (k_accept: no finite try), deviation D1.
 int redraw_impossible_sets(dz_engine* e, uint32_t g, int lc0, int lnc, int sp0, int wpb, hipStream_t st)
 {
     dz::Params& p = e->p;
     const int k = p.k;
-    if (!e->d_redo) { DZCK(ealloc(e, &e->d_redo, (size_t)p.nl)); DZCK(ealloc(e, &e->d_redo_count, 1)); }
-    for (int round = 1; round <= DZ_MAX_REDRAWS; ++round) {
-        int n = 0;
-        HIPCK(hipMemsetAsync(e->d_redo_count, 0, sizeof(int), st));
-        hipLaunchKernelGGL(dz::k_redo_flags, dim3((lnc + 255) / 256), dim3(256), 0, st, p, lc0, lnc, e->d_redo, e->d_redo_count);
+    if (!e->d_redo) {
+        DZCK(ealloc(e, &e->d_redo, (size_t)p.nl)); DZCK(ealloc(e, &e->d_redo_list, (size_t)p.nl));
+        HIPCK(hipHostMalloc((void**)&e->h_redo, (size_t)p.nl, hipHostMallocDefault));
+        HIPCK(hipHostMalloc((void**)&e->h_redo_list, sizeof(int32_t) * (size_t)p.nl, hipHostMallocDefault));
+    }
+    for (int round = 1; round <= DZ_MAX_REDRAWS;) {
+        hipLaunchKernelGGL(dz::k_redo_flags, dim3((lnc + 255) / 256), dim3(256), 0, st, p, lc0, lnc, e->d_redo);
         DZCK(launch_check("k_redo_flags"));
-        HIPCK(hipMemcpyAsync(&n, e->d_redo_count, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCK(hipMemcpyAsync(e->h_redo, e->d_redo + lc0, (size_t)lnc, hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
+        int n = 0;
+        for (int t = 0; t < lnc; ++t) if (e->h_redo[t]) e->h_redo_list[n++] = lc0 + t;
         if (n == 0) break;
-        dz::Params pr = p;
-        const uint64_t key = e->c.seed + (uint64_t)round * DZ_REDRAW_KEY_STEP;
-        pr.k0 = (uint32_t)key; pr.k1 = (uint32_t)(key >> 32);
-        pr.draws = nullptr; pr.redo = e->d_redo;
-        NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc * sp0 + wpb - 1) / wpb), dim3(64 * wpb), 0, pr, 0, g, (uint32_t)e->M, lc0, lnc, sp0, 0, (int64_t)-1));
-        DZCK(launch_check("propose(redraw)"));
-        DZCK(eval_logp(e, p.P + (size_t)lc0 * k * p.ld, lnc * k, p.p_prior + (size_t)lc0 * k, p.p_like + (size_t)lc0 * k, st));
-        e->redraw_rounds++;
+        HIPCK(hipMemcpyAsync(e->d_redo_list, e->h_redo_list, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+        // (a host likelihood costs more than a round trip: one round per read-back, no point is evaluated that did not have to be)
+        const int batch = e->lk == LK_HOST ? 1 : std::min(DZ_MAX_REDRAWS - round + 1, n >= 16 ? 4 : (n >= 4 ? 3 : 2));
+        for (int b = 0; b < batch; ++b, ++round) {
+            if (b) hipLaunchKernelGGL(dz::k_redo_flags, dim3((lnc + 255) / 256), dim3(256), 0, st, p, lc0, lnc, e->d_redo);
+            dz::Params pr = p;
+            const uint64_t key = e->c.seed + (uint64_t)round * DZ_REDRAW_KEY_STEP;
+            pr.k0 = (uint32_t)key; pr.k1 = (uint32_t)(key >> 32);
+            pr.draws = nullptr; pr.redo_list = e->d_redo_list; pr.redo = e->d_redo;
+            NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((n * sp0 + wpb - 1) / wpb), dim3(64 * wpb), 0, pr, 0, g, (uint32_t)e->M, 0, n, sp0, 0, (int64_t)-1));
+            DZCK(launch_check("propose(redraw)"));
+            const size_t nd2 = (size_t)n * k * p.ld / 2;
+            hipLaunchKernelGGL(dz::k_gather_sets, dim3((unsigned)((nd2 + 255) / 256)), dim3(256), 0, st, p, (const int32_t*)e->d_redo_list, n, p.R);
+            DZCK(eval_logp(e, p.R, n * k, p.r_prior, p.r_like, st));
+            hipLaunchKernelGGL(dz::k_scatter_logp, dim3((n * k + 255) / 256), dim3(256), 0, st, p, (const int32_t*)e->d_redo_list, n, (const double*)p.r_prior, (const double*)p.r_like);
+            DZCK(launch_check("redraw gather/scatter"));
+            e->redraw_rounds++;
+        }
     }
     return 0;
 }
@@ -465,7 +482,7 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
     const int k = p.k;
     const bool full = (c0 == 0 && nc == p.nl);
     if (!full && e->world > 1) return fail("single-chain stepping is not available on a sharded engine");
-    const int L = (full && e->lk != LK_HOST) ? e->nlanes : 1;     // the host-callback likelihood is synchronous anyway
+    const int L = (full && e->lk != LK_HOST && !redo_possible(e)) ? e->nlanes : 1;     // the host-callback likelihood is synchronous anyway; redraw rounds use shared buffers
     if (e->need_join || !full) { DZCK(join_all(e)); e->need_join = false; }
     if (full && g == 0 && e->adapt) {   // publish the start positions (Dream_shared_vars.current_positions)
         const size_t n = (size_t)p.nl * p.ld;
@@ -825,6 +842,8 @@ int dz_destroy(dz_engine* e)
     if (e->d_scratch) (void)hipFree(e->d_scratch);
     if (e->d_qpart) (void)hipFree(e->d_qpart);
     if (e->h_pin) (void)hipHostFree(e->h_pin);
+    if (e->h_redo) (void)hipHostFree(e->h_redo);
+    if (e->h_redo_list) (void)hipHostFree(e->h_redo_list);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return 0;

@@ -49,7 +49,8 @@ struct Params {
     uint32_t crthr[32];       // crossover_threshold(CR_values[m]), m < ncr: `U_j < CR` as an integer test on the 16-bit draw
     unsigned long long pgu_thr;   // ceil(p_gamma_unity 2^53): u53(hi, lo) < p_gamma_unity as an integer test on the 53-bit draw (u53_below)
     unsigned long long snk_thr;   // ceil(snooker 2^53): the same for set_snooker's draw (0 when snooker == 0)
-    const uint8_t* redo;      // [nl] redraw round only (Dream.py:281-289; one_generation): chains whose proposal set is drawn again; null otherwise
+    const uint8_t* redo;      // redraw round only: [nl] 1 = every try of the chain's current set is impossible (k_redo_flags); a listed chain whose flag has cleared is left alone
+    const int32_t* redo_list; // redraw round only (Dream.py:281-289; redraw_impossible_sets): the local chains whose proposal set is drawn again -- wave w works on chain redo_list[w / split]; null otherwise
     unsigned long long* dbg;  // cycle-stamp buffer of instrumented builds (-DDZ_EXPERIMENTS, dz_experiments.h); null otherwise
 };
 // per-phase cycle stamps: defined by dz_experiments.h in instrumented builds only (tools/variants.sh), no-ops in the product
@@ -691,8 +692,8 @@ __global__ __launch_bounds__(NCH >= 4 ? 256 : 1024) void k_propose(Params p, int
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (wave >= nc * split) return;
     const int lane = threadIdx.x & 63;
-    const int c = c0 + wave / split;
-    if (p.redo && !p.redo[c]) return;      // redraw round: only the chains whose tries were all impossible
+    const int c = p.redo_list ? p.redo_list[wave / split] : c0 + wave / split;      // (redraw round: only the chains whose tries were all impossible)
+    if (p.redo_list && !p.redo[c]) return;                                          // (... and still are: several rounds are queued per read-back)
     DZ_STAMP(p, phase, c, 0);
     const int per = (n + split - 1) / split;
     const int i0 = (wave % split) * per, i1 = min(n, i0 + per);
@@ -1547,8 +1548,8 @@ __global__ __launch_bounds__(64) void k_pt_swap(Params p, uint32_t g, int64_t tr
 }
 
 // Dream.py:281-282: `while np.all(np.isfinite(np.array(log_ps))==False)` -- marks the chains whose k tries are all impossible
-// (log_ps = T log_likes + log_priors, :279) and counts them; the host draws their proposal sets again (one_generation).
-__global__ void k_redo_flags(Params p, int c0, int nc, uint8_t* __restrict__ redo, int* __restrict__ count)
+// (log_ps = T log_likes + log_priors, :279); the host draws their proposal sets again (redraw_impossible_sets).
+__global__ void k_redo_flags(Params p, int c0, int nc, uint8_t* __restrict__ redo)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nc) return;
@@ -1556,7 +1557,22 @@ __global__ void k_redo_flags(Params p, int c0, int nc, uint8_t* __restrict__ red
     bool any = false;
     for (int i = 0; i < p.k; ++i) any = any || is_finite(p.p_prior[c * p.k + i] + chain_T(p, c) * p.p_like[c * p.k + i]);
     redo[c] = any ? 0 : 1;
-    if (!any) atomicAdd(count, 1);
+}
+// the redrawn sets, packed: set j (k rows of ld doubles) of chain list[j] -> dst + j k ld, so that only they are evaluated again
+__global__ void k_gather_sets(Params p, const int32_t* __restrict__ list, int n, double* __restrict__ dst)
+{
+    const size_t per = (size_t)p.k * p.ld / 2, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= per * n) return;
+    const size_t j = t / per, r = t % per;
+    reinterpret_cast<double2*>(dst + j * 2 * per)[r] = reinterpret_cast<const double2*>(p.P + (size_t)list[j] * 2 * per)[r];
+}
+// ... and their log densities back to the chains' slots
+__global__ void k_scatter_logp(Params p, const int32_t* __restrict__ list, int n, const double* __restrict__ prior, const double* __restrict__ like)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * p.k) return;
+    const int j = t / p.k, i = t % p.k, c = list[j];
+    p.p_prior[c * p.k + i] = prior[t]; p.p_like[c * p.k + i] = like[t];
 }
 
 __global__ void k_draws(Params p, uint32_t g, int c0, int nc, uint4* __restrict__ out, ChainCtl* __restrict__ ctl)

@@ -105,6 +105,18 @@ def test_hard_boundaries_never_violated():
     assert len(np.unique(S[:, 0])) > 50           # the chains do move
 
 
+def test_open_uniform_prior_without_hard_boundaries_stays_inside_its_support():
+    """The same uniform-prior model with hardboundaries=False and multitry: a proposal outside the support has log prior -inf, a set
+    of such proposals is generated again (Dream.py:281-289) instead of costing the step, and no sample ever leaves the support."""
+    params, like = multidmodel_uniform()
+    lower = np.array([-5, -9, 5, 3]); upper = np.array([10, 2, 7, 8])
+    sampled, log_ps = run_dream(params, like, nchains=5, niterations=600, verbose=False, save_history=False, hardboundaries=False,
+                                multitry=3, seed=6, lamb=0.5)
+    S = np.concatenate(sampled)
+    assert np.all(S >= lower) and np.all(S <= upper) and np.all(np.isfinite(np.concatenate(log_ps)))
+    assert len(np.unique(S[:, 0])) > 50
+
+
 def test_host_likelihood_equals_device_likelihood():
     """The same model through the host callback (arbitrary Python likelihood) and through the device
     descriptor gives the same chain decisions; logp agree to 1e-10."""

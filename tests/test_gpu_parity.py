@@ -283,6 +283,28 @@ def test_impossible_proposal_sets_are_drawn_again(G, O, N, d, k, snooker, split,
         np.testing.assert_array_equal(x, y)
 
 
+def test_a_host_likelihood_sees_only_the_redrawn_sets(G, monkeypatch):
+    """Redraw rounds (Dream.py:281-289) with a host likelihood: the callback is handed the k points of the chains whose sets were drawn
+    again and nothing else -- as the reference evaluates only that chain's new proposals -- one batch per round."""
+    fx = H.load("trace_s2_k3_redraw")
+    N, k, n = int(fx["cfg_N"]), int(fx["cfg_k"]), int(fx["cfg_G"])
+    sizes, plain = [], H.simple_logp
+
+    def counted(X):
+        sizes.append(len(X))
+        return plain(X)
+
+    monkeypatch.setattr(H, "simple_logp", counted)
+    e = H.engine_from_trace_fixture(G.Engine, fx)
+    e.step(n)
+    tr = e.get_trace(0, n)
+    np.testing.assert_array_equal(tr["moved"], fx["moved"])
+    regular = [s for s in sizes if s in (N * k, N * (k - 1), N)]           # proposal sets, reference sets, the start states
+    redrawn = [s for s in sizes if s not in (N * k, N * (k - 1), N)]
+    assert len(regular) >= 2 * n and all(s % k == 0 and 0 < s < N * k for s in redrawn)
+    assert len(redrawn) > n // 2 and len(redrawn) <= e.redraw_rounds() <= len(redrawn) + sizes.count(N * k) - n
+
+
 def test_full_size_run_recovers_the_target_moments(G):
     """BASELINE headline size (4096 chains x 100-D MVN, multitry 5) through properties that do not depend on the size:
     after burn-in the pooled samples have the target's analytic moments (mean 0, Var(x_i) = i, all correlations 0.5;

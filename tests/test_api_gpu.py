@@ -279,6 +279,64 @@ def _oracle_run_dream(params, like, nchains, niterations, start, seed, **kwargs)
         pool.close(); pool.join()
 
 
+# ---- the shipped Robertson example without PySB (examples/robertson_nopysb/example_sample_robertson_nopysb_with_dream.py:58-118):
+# a stiff three-species ODE solved by scipy inside a Python likelihood, log10 rate constants under a uniform prior six decades wide,
+# "-inf when the integrator fails".  The experimental data file is replaced by data simulated from the example's own nominal constants.
+_ROB_T = np.linspace(0.0, 40.0, 12)
+_ROB_TRUE = np.log10([.04, 3.0e7, 1.0e4])
+
+
+def _rob_rhs(y, t, p1, p2, p3):
+    return [-p1 * y[0] + p3 * y[1] * y[2], p1 * y[0] - p3 * y[1] * y[2] - p2 * y[1] ** 2, p2 * y[1] ** 2]
+
+
+def _rob_ctot(logk):
+    from scipy.integrate import odeint
+    return odeint(_rob_rhs, [1.0, 0.0, 0.0], _ROB_T, args=tuple(10 ** np.asarray(logk, dtype=float)))[:, 2]
+
+
+_ROB_DATA = None
+
+
+def _rob_like(logk):
+    global _ROB_DATA
+    if _ROB_DATA is None:
+        _ROB_DATA = _rob_ctot(_ROB_TRUE)
+    if logk[2] > _ROB_TRUE[2] + 2.0:             # stands in for "simulation failed due to integrator errors" (:90-92)
+        return -np.inf
+    r = (_rob_ctot(logk) - _ROB_DATA) / (0.05 * _ROB_DATA + 1e-3)
+    lp = -0.5 * float(np.sum(r * r))
+    return lp if np.isfinite(lp) else -np.inf
+
+
+@pytest.mark.parametrize("multitry,hard", [(False, True), (3, False)])
+def test_robertson_example_with_a_python_ode_likelihood(tmp_path, multitry, hard):
+    """The example's call (uniform SampledParam, gamma_levels=4, adapt_gamma=True, history_thin=1; run_dream :105-118) on the GPU engine
+    with the likelihood behind the host callback equals the same sequence on the oracle bit for bit; as shipped (multitry off, hard
+    boundaries) and with multitry 3 and open boundaries, where tries outside the prior's support or in the region the likelihood
+    calls failed are impossible and whole sets are drawn again (Dream.py:281-289)."""
+    os.chdir(tmp_path)
+    N, G = 5, 50
+    lower = _ROB_TRUE - 3
+    params = [SampledParam(uniform, loc=lower, scale=6)]
+    rng = np.random.default_rng(77)
+    Z0 = lower + 6 * rng.uniform(0, 1, (40, 3))
+    np.save("rob_seed.npy", Z0)
+    starts = [_ROB_TRUE + 0.3 * rng.uniform(-1, 1, 3) for _ in range(N)]
+    kw = dict(multitry=multitry, gamma_levels=4, adapt_gamma=True, history_thin=1, hardboundaries=hard, history_file="rob_seed.npy")
+    os.environ["DREAMZS_HOST_WORKERS"] = "1"
+    try:
+        sampled, log_ps = run_dream(params, _rob_like, nchains=N, niterations=G, verbose=False, start=starts, save_history=False, seed=55, **kw)
+        o_s, o_l = _oracle_run_dream(params, _rob_like, N, G, starts, 55, **kw)
+    finally:
+        del os.environ["DREAMZS_HOST_WORKERS"]
+    S = np.concatenate(sampled)
+    assert np.all(S >= lower) and np.all(S <= lower + 6) and np.all(np.isfinite(np.concatenate(log_ps)))
+    assert len(np.unique(S[:, 0])) > N
+    np.testing.assert_array_equal(np.array(sampled), np.array(o_s))
+    np.testing.assert_array_equal(np.array(log_ps), np.array(o_l))
+
+
 def test_restart_continues_bit_for_bit_like_the_oracle(tmp_path):
     """restart=True (core.py:46-62, 255-263; Dream.py:128-141, 947-969): a first run saves its history and adapted crossover /
     gamma-level probabilities; the restarted run seeds its archive with the WHOLE saved history, loads the probabilities and

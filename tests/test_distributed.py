@@ -24,18 +24,31 @@ def _free_port():
     return p
 
 
-def _model(d):
+def _model(d, variant="flat"):
     from tests import helpers as H
     from pydream_amd.likelihoods import MVNormalLogLike
-    from pydream_amd.parameters import FlatParam
-    return [FlatParam(np.zeros(d))], MVNormalLogLike(H.mvn_precision(d), factorize=False)
+    from pydream_amd.parameters import FlatParam, SampledParam
+    like = MVNormalLogLike(H.mvn_precision(d), factorize=False)
+    if variant == "redraw":      # a uniform prior narrower than the seed archive, no hard boundaries: impossible proposal sets are
+        from scipy.stats import uniform                      # drawn again (Dream.py:281-289), on each rank for its own chains
+        return [SampledParam(uniform, loc=np.full(d, -3.0), scale=np.full(d, 8.0))], like
+    return [FlatParam(np.zeros(d))], like
+
+
+def _starts(Z0, variant):
+    X = Z0[:8]
+    return [(-3.0 + 8.0 * (x + 5.0) / 20.0) if variant == "redraw" else x for x in X]      # (inside the prior's support)
+
+
+def _kw(variant):
+    return dict(KW, hardboundaries=False) if variant == "redraw" else dict(KW)
 
 
 KW = dict(nchains=8, niterations=45, multitry=5, adapt_crossover=True, crossover_burnin=20, save_history=False, seed=77,
           nseedchains=40, history_thin=5)
 
 
-def _worker(rank, world, port, backend_engine, outdir):
+def _worker(rank, world, port, backend_engine, outdir, variant="flat"):
     sys.path.insert(0, ROOT)
     import faulthandler
     faulthandler.dump_traceback_later(150, exit=True)           # a rank that is stuck says where and leaves
@@ -44,7 +57,7 @@ def _worker(rank, world, port, backend_engine, outdir):
     from pydream_amd.distributed import run_dream_sharded
     from tests import helpers as H
     d = 12
-    params, like = _model(d)
+    params, like = _model(d, variant)
     if backend_engine == "oracle":
         from oracle import oracle as O
         cls = O.Engine
@@ -53,43 +66,44 @@ def _worker(rank, world, port, backend_engine, outdir):
     Z0 = H.seed_history(40, d, 3)
     hist = os.path.join(outdir, "seed_%d.npy" % rank)
     np.save(hist, Z0)
-    sampled, log_ps = run_dream_sharded(params, like, start=[Z0[i] for i in range(8)], history_file=hist, transport="host",
-                                        engine_cls=cls, device=0, **KW)
+    sampled, log_ps = run_dream_sharded(params, like, start=_starts(Z0, variant), history_file=hist, transport="host",
+                                        engine_cls=cls, device=0, **_kw(variant))
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), X=np.array(sampled), lp=np.array(log_ps))
     dist.destroy_process_group()
 
 
-def _single(backend_engine, outdir):
+def _single(backend_engine, outdir, variant="flat"):
     from pydream_amd import core
     from pydream_amd.Dream import Dream
     from pydream_amd.model import Model
     from tests import helpers as H
     d = 12
-    params, like = _model(d)
+    params, like = _model(d, variant)
     Z0 = H.seed_history(40, d, 3)
     hist = os.path.join(outdir, "seed_single.npy")
     np.save(hist, Z0)
-    kw = dict(KW)
+    kw = _kw(variant)
     n, it, seed = kw.pop("nchains"), kw.pop("niterations"), kw.pop("seed")
     step = Dream(model=Model(like, params), history_file=hist, **kw)
     cls = None
     if backend_engine == "oracle":
         from oracle import oracle as O
         cls = O.Engine
-    pool = core._setup_mp_dream_pool(n, it, step, start_pt=[Z0[i] for i in range(8)], seed=seed, engine_cls=cls)
+    pool = core._setup_mp_dream_pool(n, it, step, start_pt=_starts(Z0, variant), seed=seed, engine_cls=cls)
     try:
         s, l = core._sample_dream_batched(pool.engine, step, it, False, 10)
         Z = pool.engine.get_history()
         cr = pool.engine.get_cr_state()[0]
+        redraws = pool.engine.redraw_rounds() if hasattr(pool.engine, "redraw_rounds") else None
     finally:
         pool.close(); pool.join()
-    return np.array(s), np.array(l), Z, cr
+    return np.array(s), np.array(l), Z, cr, redraws
 
 
-def _run_two_ranks(backend_engine, tmp_path):
+def _run_two_ranks(backend_engine, tmp_path, variant="flat"):
     import torch.multiprocessing as mp
     port = _free_port()
-    ctx = mp.spawn(_worker, args=(2, port, backend_engine, str(tmp_path)), nprocs=2, join=False)
+    ctx = mp.spawn(_worker, args=(2, port, backend_engine, str(tmp_path), variant), nprocs=2, join=False)
     deadline = time.time() + 180                     # (a rank that never returns fails the test instead of hanging the suite)
     while not ctx.join(timeout=5):
         if time.time() > deadline:
@@ -99,10 +113,13 @@ def _run_two_ranks(backend_engine, tmp_path):
             raise AssertionError("the two-rank run did not finish in time")
     r0 = np.load(tmp_path / "rank0.npz"); r1 = np.load(tmp_path / "rank1.npz")
     X = np.concatenate([r0["X"], r1["X"]]); lp = np.concatenate([r0["lp"], r1["lp"]])
-    Xs, lps, _, cr = _single(backend_engine, str(tmp_path))
+    Xs, lps, _, cr, redraws = _single(backend_engine, str(tmp_path), variant)
     np.testing.assert_array_equal(X, Xs)
     np.testing.assert_array_equal(lp, lps)
     assert not np.allclose(cr, 1 / 3.)            # adaptation ran (and was identical on both ranks, or the traces would differ)
+    if variant == "redraw":
+        assert np.all(np.isfinite(lps)) and np.all(Xs >= -3.0) and np.all(Xs <= 5.0)
+        assert redraws is None or redraws > 0     # (the HIP engine counts its redraw launches)
 
 
 def test_shard_arithmetic():
@@ -112,13 +129,15 @@ def test_shard_arithmetic():
         shard(10, 0, 4)
 
 
-def test_two_ranks_gloo_oracle_backend(tmp_path):
-    _run_two_ranks("oracle", tmp_path)
+@pytest.mark.parametrize("variant", ["flat", "redraw"])
+def test_two_ranks_gloo_oracle_backend(tmp_path, variant):
+    _run_two_ranks("oracle", tmp_path, variant)
 
 
 @pytest.mark.gpu
-def test_two_ranks_one_gpu_hip_engine(tmp_path):
-    _run_two_ranks("hip", tmp_path)
+@pytest.mark.parametrize("variant", ["flat", "redraw"])
+def test_two_ranks_one_gpu_hip_engine(tmp_path, variant):
+    _run_two_ranks("hip", tmp_path, variant)
 
 
 _RCCL_SINGLE_RANK = r"""

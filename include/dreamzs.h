@@ -136,6 +136,11 @@ int dz_get_trace(dz_engine* e, int64_t g0, int64_t ng, double* X, double* logp,
  * chain): sample g0+i of local chain c goes to X[(c*chain_stride_rows + i)*d ...].  The device keeps the trace in
  * this order, so a whole-buffer request is a single strided copy. */
 int dz_get_trace_chains(dz_engine* e, int64_t g0, int64_t ng, double* X, int64_t chain_stride_rows, double* logp /* [nl][chain_stride_rows] or NULL */);
+/* the same for X without stopping the engine: the copy is queued behind the generations stepped so far, the call returns, and
+ * generations stepped afterwards run while the rows leave (replaces nothing in the reference: its chains write their samples into
+ * host arrays as they go, core.py:114).  X must be page-locked (dz_host_register) and untouched until dz_trace_download_wait. */
+int dz_trace_download_begin(dz_engine* e, int64_t g0, int64_t ng, double* X, int64_t chain_stride_rows);
+int dz_trace_download_wait(dz_engine* e);
 /* optional: page-lock the destination beforehand (e.g. from a second thread while dz_step runs) */
 int dz_host_register(void* ptr, int64_t bytes);
 int dz_host_unregister(void* ptr);

@@ -37,7 +37,7 @@ SYMBOLS = [
     "dz_version", "dz_last_error", "dz_device_count", "dz_create", "dz_destroy", "dz_set_bounds", "dz_set_gamma_table",
     "dz_set_history", "dz_set_state", "dz_set_cr_probs", "dz_set_gamma_probs", "dz_set_prior", "dz_set_likelihood_mvn",
     "dz_set_likelihood_mixture", "dz_set_likelihood_host", "dz_hip_library", "dz_comm_library", "dz_comm_unique_id", "dz_comm_init_rccl", "dz_comm_barrier", "dz_set_exchange", "dz_set_temperatures", "dz_get_swaps",
-    "dz_step", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_sync", "dz_trace_reset", "dz_generation", "dz_redraw_rounds", "dz_get_state", "dz_get_trace", "dz_get_trace_chains", "dz_host_register", "dz_host_unregister", "dz_get_history",
+    "dz_step", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_sync", "dz_trace_reset", "dz_generation", "dz_redraw_rounds", "dz_get_state", "dz_get_trace", "dz_get_trace_chains", "dz_trace_download_begin", "dz_trace_download_wait", "dz_host_register", "dz_host_unregister", "dz_get_history",
     "dz_get_cr_state", "dz_get_gamma_state", "dz_get_rhat", "dz_get_chain_moments", "dz_eval_logp", "dz_debug_propose",
     "dz_profile_enable", "dz_profile_get", "dz_profile_reset",
 ]
@@ -320,13 +320,24 @@ class Engine:
     def get_trace_chains(self, g0, ng, out, row0=0, logp_out=None):
         """samples [g0, g0+ng) of every local chain into out[c, row0:row0+ng, :] (out: C-contiguous [nl, rows, d]) and,
         optionally, their log probabilities into logp_out[c, row0:row0+ng] (C-contiguous [nl, rows] or [nl, rows, 1])."""
-        assert out.flags.c_contiguous and out.dtype == np.float64 and out.shape[0] == self.nl and out.shape[2] == self.d
-        base = out.ctypes.data + row0 * self.d * 8
+        base, rows = None, None
+        if out is not None:                     # (out=None: the log probabilities only)
+            assert out.flags.c_contiguous and out.dtype == np.float64 and out.shape[0] == self.nl and out.shape[2] == self.d
+            base, rows = C.c_void_p(out.ctypes.data + row0 * self.d * 8), out.shape[1]
         lp = None
         if logp_out is not None:
-            assert logp_out.flags.c_contiguous and logp_out.dtype == np.float64 and logp_out.shape[:2] == out.shape[:2]
-            lp = C.c_void_p(logp_out.ctypes.data + row0 * 8)
-        self._chk(self.L.dz_get_trace_chains(self.h, C.c_int64(g0), C.c_int64(ng), C.c_void_p(base), C.c_int64(out.shape[1]), lp))
+            assert logp_out.flags.c_contiguous and logp_out.dtype == np.float64 and logp_out.shape[0] == self.nl and logp_out.shape[1] == (rows or logp_out.shape[1])
+            lp, rows = C.c_void_p(logp_out.ctypes.data + row0 * 8), logp_out.shape[1]
+        self._chk(self.L.dz_get_trace_chains(self.h, C.c_int64(g0), C.c_int64(ng), base, C.c_int64(rows), lp))
+
+    def trace_download_begin(self, g0, ng, out, row0=0):
+        """as get_trace_chains for the samples, but queued behind the generations stepped so far and returning at once; `out` must be
+        page-locked (host_register) and left alone until trace_download_wait()."""
+        assert out.flags.c_contiguous and out.dtype == np.float64 and out.shape[0] == self.nl and out.shape[2] == self.d
+        self._chk(self.L.dz_trace_download_begin(self.h, C.c_int64(g0), C.c_int64(ng), C.c_void_p(out.ctypes.data + row0 * self.d * 8), C.c_int64(out.shape[1])))
+
+    def trace_download_wait(self):
+        self._chk(self.L.dz_trace_download_wait(self.h))
 
     def host_register(self, arr):
         """page-lock a result array ahead of the download; returns False if the runtime refuses (the copy still works)."""

@@ -140,6 +140,25 @@ def _sample_dream_batched(eng, step, niterations, verbose, nverbose):
         pinned = []
         pin = threading.Thread(target=lambda: pinned.append(eng.host_register(S)))
         pin.start()
+    nseg = int(os.environ.get("DREAMZS_DOWNLOAD_SEGMENTS", "8"))       # 0: one download after the run
+    if pin is not None and nseg > 0 and not verbose and chunk >= niterations and S.nbytes >= (256 << 20) and hasattr(eng, "trace_download_begin"):
+        # large quiet runs whose trace fits the device: the run goes in a few segments, and each segment's samples leave for the host
+        # (one strided DMA on a stream of its own) while the next segment's generations run
+        eng.trace_reset()
+        seg = -(-niterations // nseg)
+        ok = None
+        while done < niterations:
+            n = min(seg, niterations - done)
+            eng.step(n)
+            if ok is None:
+                pin.join()                                   # the destination has to be page-locked before the first copy is queued
+                ok = bool(pinned and pinned[0])
+            if ok:
+                eng.trace_download_begin(done, n, S, row0=done)
+            done += n
+        if ok:
+            eng.trace_download_wait()
+        eng.get_trace_chains(0, niterations, None if ok else S, logp_out=LP)
     while done < niterations:
         n = min(chunk, niterations - done)
         eng.trace_reset()
@@ -148,13 +167,14 @@ def _sample_dream_batched(eng, step, niterations, verbose, nverbose):
             if pin is not None and pin.is_alive():
                 pin.join()
             eng.get_trace_chains(0, n, S, row0=done, logp_out=LP)
-            tr = eng.get_trace(0, n, with_X=False, with_logp=False)
+            tr = eng.get_trace(0, n, with_X=False, with_logp=False) if verbose else None     # (the decision flags only feed the progress line)
         else:
             tr = eng.get_trace(0, n)
             for c in range(nchains):
                 sampled[c][done:done + n] = tr["X"][:, c, :]
                 log_ps[c][done:done + n, 0] = tr["logp"][:, c]
-        naccepts += int(tr["moved"].sum())
+        if tr is not None:
+            naccepts += int(tr["moved"].sum())
         done += n
         if verbose:
             print('Iteration: ', done, ' acceptance rate: ', naccepts / float(done * nchains),

@@ -11,6 +11,7 @@
 
 #include <hip/hip_ext.h>
 #include <dlfcn.h>
+#include <sys/mman.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -18,6 +19,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -146,6 +148,7 @@ struct dz_engine {
     // Dream.py:281-289: a proposal set whose tries are all impossible is drawn again (redo_possible / one_generation)
     uint8_t* d_redo = nullptr; int32_t* d_redo_list = nullptr; uint8_t* h_redo = nullptr; int32_t* h_redo_list = nullptr;     // (host side: page-locked)
     std::vector<int32_t> h_pkind; std::vector<double> h_pa, h_pb, h_mins, h_maxs;     // host copies: is the uniform priors' support covered by the hard boundaries?
+    hipStream_t copy_stream = nullptr; hipEvent_t copy_ev[8] = {nullptr};   // dz_trace_download_begin / _wait: trace rows leave while later generations run
     int64_t redraw_rounds = 0;      // redraw launches so far (dz_redraw_rounds)
     bool pending_accept = false;    // generation gen-1's Metropolis step has been deferred into the next proposal kernel
     int64_t pending_slot = -1;
@@ -844,6 +847,8 @@ int dz_destroy(dz_engine* e)
     if (e->h_pin) (void)hipHostFree(e->h_pin);
     if (e->h_redo) (void)hipHostFree(e->h_redo);
     if (e->h_redo_list) (void)hipHostFree(e->h_redo_list);
+    if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
+    for (hipEvent_t ev : e->copy_ev) if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return 0;
@@ -1217,9 +1222,63 @@ int dz_get_trace_chains(dz_engine* e, int64_t g0, int64_t ng, double* X, int64_t
     return 0;
 }
 
+// Samples [g0, g0+ng) of every local chain into X (as dz_get_trace_chains) WITHOUT stopping the engine: the copy is queued on a
+// stream of its own behind everything queued so far on the engine's streams and the call returns; generations stepped afterwards
+// run while the DMA engines move the rows.  X must be page-locked (dz_host_register) -- a copy into pageable memory would block --
+// and stay untouched until dz_trace_download_wait.  One 3-D copy (row = d of ld doubles, rows = generations, slices = chains).
+int dz_trace_download_begin(dz_engine* e, int64_t g0, int64_t ng, double* X, int64_t chain_stride_rows)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    if (g0 < 0 || ng < 0 || g0 + ng > e->ntrace) return fail("trace range");
+    if (chain_stride_rows < ng || !X) return fail("bad destination");
+    if (ng == 0) return 0;
+    if (!e->copy_stream) {
+        HIPCK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        for (int s = 0; s < e->nlanes; ++s) HIPCK(hipEventCreateWithFlags(&e->copy_ev[s], hipEventDisableTiming));
+    }
+    for (int s = 0; s < e->nlanes; ++s) {
+        HIPCK(hipEventRecord(e->copy_ev[s], e->lane_stream[s]));
+        HIPCK(hipStreamWaitEvent(e->copy_stream, e->copy_ev[s], 0));
+    }
+    const size_t nl = e->p.nl, d = e->p.d, ld = e->p.ld, tcap = (size_t)e->p.tcap;
+    hipMemcpy3DParms c;
+    memset(&c, 0, sizeof(c));
+    c.srcPtr = make_hipPitchedPtr((void*)(e->p.tX + (size_t)g0 * ld), sizeof(double) * ld, sizeof(double) * ld, tcap);
+    c.dstPtr = make_hipPitchedPtr((void*)X, sizeof(double) * d, sizeof(double) * d, (size_t)chain_stride_rows);
+    c.extent = make_hipExtent(sizeof(double) * d, (size_t)ng, nl);
+    c.kind = hipMemcpyDeviceToHost;
+    HIPCK(hipMemcpy3DAsync(&c, e->copy_stream));
+    return 0;
+}
+int dz_trace_download_wait(dz_engine* e)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    if (e->copy_stream) HIPCK(hipStreamSynchronize(e->copy_stream));
+    return 0;
+}
+
 // page-lock a host array ahead of a download (first-touch faults and pinning then overlap the run instead of the copy)
 int dz_host_register(void* ptr, int64_t bytes)
 {
+    // Page-locking a freshly allocated array is mostly the kernel faulting its pages in, one at a time, on the calling thread (6.5 GB:
+    // 0.27 s).  Large ranges are first touched by several threads -- a byte per page rewritten with its own value, so the contents are
+    // kept -- after asking for huge pages; hipHostRegister then finds the pages present.  DZ_PIN_THREADS (default 8, 1 = off).
+    int nt = 8;
+    if (const char* s = getenv("DZ_PIN_THREADS")) nt = std::max(1, std::min(64, atoi(s)));
+    if (bytes >= ((int64_t)64 << 20) && nt > 1) {
+        const uintptr_t page = 4096, lo = ((uintptr_t)ptr + page - 1) & ~(page - 1), hi = ((uintptr_t)ptr + (uintptr_t)bytes) & ~(page - 1);
+        if (hi > lo) {
+            (void)madvise((void*)lo, hi - lo, MADV_HUGEPAGE);
+            const uintptr_t npages = (hi - lo) / page;
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t)
+                th.emplace_back([=] {
+                    volatile unsigned char* q = (volatile unsigned char*)lo;
+                    for (uintptr_t i = npages * t / nt; i < npages * (t + 1) / nt; ++i) q[i * page] = q[i * page];
+                });
+            for (auto& x : th) x.join();
+        }
+    }
     if (hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return fail("hipHostRegister failed"); }
     return 0;
 }

@@ -151,6 +151,28 @@ def test_converges_on_the_reference_example_target(tmp_path):
     assert np.all(np.abs(S.mean(axis=0)) < 0.6)
 
 
+def test_samples_leaving_while_the_run_continues_equal_one_download_at_the_end(monkeypatch):
+    """Large quiet runs hand their samples to the host segment by segment, on a copy stream, while the next segment's generations
+    run (dz_trace_download_begin / _wait): the same arrays as one download after the run, for segment counts that do and do not
+    divide the run."""
+    N, d, n = 4096, 100, 90                          # 295 MB of samples: above the threshold of the segmented path
+    P = H.mvn_precision(d)
+    hist = "/tmp/_dz_seed_dl%d.npy" % os.getpid()
+    Z0 = H.seed_history(2 * N, d, 8)
+    np.save(hist, Z0)
+    kw = dict(nchains=N, niterations=n, verbose=False, save_history=False, history_file=hist, multitry=5, seed=31,
+              start=[Z0[i] for i in range(N)], adapt_crossover=False)
+    out = {}
+    for segs in ("0", "4", "7"):
+        monkeypatch.setenv("DREAMZS_DOWNLOAD_SEGMENTS", segs)
+        out[segs] = run_dream([FlatParam(np.zeros(d))], MVNormalLogLike(P), **kw)
+    os.remove(hist)
+    for segs in ("4", "7"):
+        np.testing.assert_array_equal(np.array(out["0"][0]), np.array(out[segs][0]))
+        np.testing.assert_array_equal(np.array(out["0"][1]), np.array(out[segs][1]))
+    assert len(np.unique(np.array(out["0"][0])[:, -1, 0])) > N // 2
+
+
 def test_trace_by_chain_equals_trace_by_generation():
     """dz_get_trace_chains (the layout run_dream returns, core.py:98/:127) against dz_get_trace: whole buffer (single
     strided copy) and a window written into the middle of a larger destination (per-chain copies)."""

@@ -1,0 +1,20 @@
+import os, sys, time, cProfile, pstats
+import numpy as np
+sys.path.insert(0, "/root/repo")
+from pydream_amd.core import run_dream
+from pydream_amd.parameters import FlatParam
+from pydream_amd.likelihoods import MVNormalLogLike
+N, d, G, K = 4096, 100, 2000, 5
+i = np.arange(1, d + 1.0)
+P = np.linalg.inv((.5 * np.eye(d) + .5) * np.sqrt(np.outer(i, i)))
+seed = np.random.default_rng(1).uniform(-5, 15, (max(10 * d, 2 * N), d))
+np.save("/tmp/_seed.npy", seed)
+kw = dict(nchains=N, start=[seed[c] for c in range(N)], start_random=False, history_file="/tmp/_seed.npy", multitry=K, save_history=False, verbose=False)
+run_dream([FlatParam(np.zeros(d))], MVNormalLogLike(P), niterations=200, **kw)
+pr = cProfile.Profile(); pr.enable()
+t0 = time.perf_counter()
+sampled, log_ps = run_dream([FlatParam(np.zeros(d))], MVNormalLogLike(P), niterations=G, **kw)
+dt = time.perf_counter() - t0
+pr.disable()
+print("total", dt)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(28)

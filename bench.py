@@ -282,6 +282,7 @@ def main():
         conv = {"chunk": chunk, "criterion": "max R-hat < 1.2 (reference rule: second half of the run so far, all %d chains)" % n_global,
                 "generations_to_rhat_below_1p2": None, "history": []}
         done = 0
+        t_load = time.perf_counter()
         e.trace_reset()
         while done < conv_cap:
             n = min(chunk, conv_cap - done)
@@ -297,7 +298,11 @@ def main():
                     conv["rhat_at_that_point"] = r
             else:
                 e.sync()
-            if done >= args.rhat_min_generations and (not with_rhat or conv["generations_to_rhat_below_1p2"] is not None):
+            # (an engine without the diagnostic -- the dense leg -- has no R-hat window after this loop, and with few chains its 2000
+            #  generations are over before an idle GPU has raised its clocks (1024 chains: 40 ms; seen as 67 M/s instead of 272): it
+            #  keeps the GPU loaded for at least 0.3 s, bounded by the convergence cap)
+            if done >= args.rhat_min_generations and (conv["generations_to_rhat_below_1p2"] is not None if with_rhat
+                                                      else time.perf_counter() - t_load >= 0.3):
                 break
         conv["generations_run"] = done
         if with_rhat:

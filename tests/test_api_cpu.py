@@ -149,3 +149,30 @@ def test_host_evaluator_pool_equals_in_process_evaluation(monkeypatch):
     ev = HostEvaluator(model, True, nchains=8, force=True)
     ev(rng.normal(size=(4, 5)))
     assert ev.pool is None                                   # disabled: in-process
+
+
+def test_open_uniform_prior_run_on_the_oracle_stays_inside_its_support(tmp_path):
+    """run_dream's own sequence (core._setup_mp_dream_pool -> _sample_dream_batched) with the oracle as the engine: uniform prior,
+    hardboundaries=False, multitry -- proposal sets that lie wholly outside the support are drawn again (Dream.py:281-289) and no
+    sample leaves it.  (The GPU engine runs the same call in tests/test_api_gpu.py.)"""
+    import os
+    from oracle import oracle as O
+    from pydream_amd.core import _sample_dream_batched, _setup_mp_dream_pool
+    os.chdir(tmp_path)
+    params, like = multidmodel_uniform()
+    lower = np.array([-5, -9, 5, 3]); upper = np.array([10, 2, 7, 8])
+    rng = np.random.default_rng(4)
+    np.save("seed.npy", lower + (3 * rng.uniform(0, 1, (40, 4)) - 1) * (upper - lower))        # an archive wider than the support
+    starts = [lower + rng.uniform(0, 1, 4) * (upper - lower) for _ in range(5)]
+    step = Dream(model=Model(like, params), variables=params, verbose=False, multitry=3, hardboundaries=False, history_file="seed.npy",
+                 save_history=False)
+    pool = _setup_mp_dream_pool(5, 300, step, start_pt=starts, seed=8, engine_cls=O.Engine)
+    try:
+        pool._initializer(*pool._initargs)
+        sampled, log_ps = _sample_dream_batched(pool.engine, step, 300, False, 10)
+    finally:
+        pool.close(); pool.join()
+    S = np.concatenate(sampled)
+    assert np.all(S >= lower) and np.all(S <= upper) and np.all(np.isfinite(np.concatenate(log_ps)))
+    assert len(np.unique(S[:, 0])) > 50
+

@@ -126,6 +126,11 @@ int64_t dz_generation(dz_engine* e);
 #define DZ_REDRAW_KEY_STEP 0x9E3779B97F4A7C15ull
 #define DZ_MAX_REDRAWS 64
 int64_t dz_redraw_rounds(dz_engine* e);
+/* What the most recent generation(s) ran as: the template instantiation of the persistent kernel, e.g.
+ * "k_generations<7,tri,xlds,16,1,lean>" (row tiles, matrix form, chain states in LDS or HBM, chains per block, waves per chain,
+ * lean / full proposal code [, k1 = multitry off]), "k_generations_mix", or "multi-kernel path".  Lets a parity test assert that the
+ * instantiation a benchmark times is the one it compared with the oracle.  The string lives until the next dz_step on the handle. */
+const char* dz_last_kernel_variant(dz_engine* e);
 
 int dz_get_state(dz_engine* e, double* X, double* prior, double* like);             /* [nl,d],[nl],[nl] */
 /* trace of generations [g0,g0+ng) since the last reset: sampled_params / log_ps of

@@ -37,7 +37,7 @@ SYMBOLS = [
     "dz_version", "dz_last_error", "dz_device_count", "dz_create", "dz_destroy", "dz_set_bounds", "dz_set_gamma_table",
     "dz_set_history", "dz_set_state", "dz_set_cr_probs", "dz_set_gamma_probs", "dz_set_prior", "dz_set_likelihood_mvn",
     "dz_set_likelihood_mixture", "dz_set_likelihood_host", "dz_hip_library", "dz_comm_library", "dz_comm_unique_id", "dz_comm_init_rccl", "dz_comm_barrier", "dz_set_exchange", "dz_set_temperatures", "dz_get_swaps",
-    "dz_step", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_sync", "dz_trace_reset", "dz_generation", "dz_redraw_rounds", "dz_get_state", "dz_get_trace", "dz_get_trace_chains", "dz_trace_download_begin", "dz_trace_download_wait", "dz_host_register", "dz_host_unregister", "dz_get_history",
+    "dz_step", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_sync", "dz_trace_reset", "dz_generation", "dz_redraw_rounds", "dz_last_kernel_variant", "dz_get_state", "dz_get_trace", "dz_get_trace_chains", "dz_trace_download_begin", "dz_trace_download_wait", "dz_host_register", "dz_host_unregister", "dz_get_history",
     "dz_get_cr_state", "dz_get_gamma_state", "dz_get_rhat", "dz_get_chain_moments", "dz_eval_logp", "dz_debug_propose",
     "dz_profile_enable", "dz_profile_get", "dz_profile_reset",
 ]
@@ -63,6 +63,8 @@ def load_library():
     L.dz_generation.argtypes = [V]
     L.dz_redraw_rounds.restype = C.c_int64
     L.dz_redraw_rounds.argtypes = [V]
+    L.dz_last_kernel_variant.restype = C.c_char_p
+    L.dz_last_kernel_variant.argtypes = [V]
     L.dz_create.argtypes = [C.POINTER(Config), C.POINTER(V)]
     L.dz_destroy.argtypes = [V]
     L.dz_set_bounds.argtypes = [V, V, V]
@@ -301,6 +303,10 @@ class Engine:
     def redraw_rounds(self):
         """Redraw launches so far (Dream.py:281-289: proposal sets whose tries were all impossible, drawn again)."""
         return int(self.L.dz_redraw_rounds(self.h))
+
+    def last_kernel_variant(self):
+        """what the most recent generations ran as (template instantiation of the persistent kernel, or "multi-kernel path")"""
+        return self.L.dz_last_kernel_variant(self.h).decode()
 
     # ---- getters ----
     def get_state(self):

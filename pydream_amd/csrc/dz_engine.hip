@@ -8,6 +8,7 @@
 #include "../../include/dreamzs.h"
 #include "dz_kernels.h"
 #include "dz_megakernel.h"
+#include "dz_mega_launch.h"
 
 #include <hip/hip_ext.h>
 #include <dlfcn.h>
@@ -150,6 +151,7 @@ struct dz_engine {
     std::vector<int32_t> h_pkind; std::vector<double> h_pa, h_pb, h_mins, h_maxs;     // host copies: is the uniform priors' support covered by the hard boundaries?
     hipStream_t copy_stream = nullptr; hipEvent_t copy_ev[8] = {nullptr};   // dz_trace_download_begin / _wait: trace rows leave while later generations run
     int64_t redraw_rounds = 0;      // redraw launches so far (dz_redraw_rounds)
+    std::string last_variant;       // what the last dz_step launched for its generations (dz_last_kernel_variant)
     bool pending_accept = false;    // generation gen-1's Metropolis step has been deferred into the next proposal kernel
     int64_t pending_slot = -1;
     int propose_split = 0;          // waves per chain in k_propose (DZ_PROPOSE_SPLIT); 0 = by problem shape
@@ -565,6 +567,7 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
         NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_pt_swap<NCH>, dim3(1), dim3(64), 0, e->stream, p, g, slot, publish ? 1 : 0));
         DZCK(launch_check("k_pt_swap"));
     }
+    e->last_variant = "multi-kernel path";
     for (int c = c0; c < c0 + nc; ++c) e->gen_c[c] = (int64_t)g + 1;
     if (full) e->gen = (int64_t)g + 1;
     if (slot >= 0) e->ntrace++;
@@ -642,6 +645,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
         const size_t ldsm = sizeof(double) * (size_t)dz::MIXW * dz::mega_mix_wave_doubles(p.d, p.k, p.J);
         DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, dz::k_generations_mix, gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0);
         DZCK(launch_check("k_generations_mix"));
+        e->last_variant = "k_generations_mix";
         if (append_last) { DZCK(allgather_rows(e, p.Z + (size_t)e->M * p.ld)); e->M += p.N; }
         e->need_join = true;
         e->draws_gen = -1;
@@ -667,22 +671,22 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
         e->params_uploaded = true;
     }
     {
-#define DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, CH_, WPC_, PB_, K1_) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations<NRT_, TRI_, X_, CH_, WPC_, PB_, K1_>), grid, block, lds, (const dz::Params*)e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0)
-#define DZ_MEGA_LAUNCH(NRT_, TRI_, X_, PB_) do { \
-        if (k1) { if (ch == 16) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 16, 1, PB_, true); else if (ch == 8) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 8, 1, PB_, true); else DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 4, 1, PB_, true); } \
-        else if (ch == 16) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 16, 1, PB_, false); \
-        else if (ch == 8) DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 8, 1, PB_, false); else DZ_MEGA_LAUNCH_CH(NRT_, TRI_, X_, 4, 4, PB_, false); } while (0)
-    // (priors / boundaries: only with the chain states in LDS -- mega_eligible -- which keeps the number of kernels down)
-#define DZ_MEGA_CASE(NRT_)                                                              \
-    case NRT_:                                                                          \
-        if (pb) { if (p.tri) DZ_MEGA_LAUNCH(NRT_, true, true, true); else DZ_MEGA_LAUNCH(NRT_, false, true, true); }     \
-        else if (p.tri) { if (xlds) DZ_MEGA_LAUNCH(NRT_, true, true, false); else DZ_MEGA_LAUNCH(NRT_, true, false, false); }    \
-        else { if (xlds) DZ_MEGA_LAUNCH(NRT_, false, true, false); else DZ_MEGA_LAUNCH(NRT_, false, false, false); }        \
-        break;
-        switch (nrt) { DZ_MEGA_CASE(1) DZ_MEGA_CASE(2) DZ_MEGA_CASE(3) DZ_MEGA_CASE(4) DZ_MEGA_CASE(5) DZ_MEGA_CASE(6) DZ_MEGA_CASE(7) DZ_MEGA_CASE(8) }
-#undef DZ_MEGA_CASE
-#undef DZ_MEGA_LAUNCH
-#undef DZ_MEGA_LAUNCH_CH
+        // the instantiations live in one translation unit per row-tile count (dz_mega_tu.hip)
+        dz::MegaLaunch ml;
+        ml.tri = p.tri != 0; ml.xlds = pb ? true : xlds; ml.pb = pb; ml.k1 = k1; ml.ch = ch; ml.wpc = wpc;
+        ml.grid = grid; ml.block = block; ml.lds = lds; ml.st = e->stream; ml.ka = nullptr; ml.kb = nullptr;
+        ml.pp = (const dz::Params*)e->d_params; ml.g = g; ml.n = n; ml.M = (uint32_t)e->M; ml.slot0 = slot0; ml.append_last = append_last ? 1 : 0;
+        if (e->prof) { ml.ka = prof_event(e); ml.kb = prof_event(e); e->ev[PR_GENERATIONS].emplace_back(ml.ka, ml.kb); }
+        const char* name = nullptr;
+        switch (nrt) {
+            case 1: name = dz::mega_launch_nrt1(ml); break; case 2: name = dz::mega_launch_nrt2(ml); break;
+            case 3: name = dz::mega_launch_nrt3(ml); break; case 4: name = dz::mega_launch_nrt4(ml); break;
+            case 5: name = dz::mega_launch_nrt5(ml); break; case 6: name = dz::mega_launch_nrt6(ml); break;
+            case 7: name = dz::mega_launch_nrt7(ml); break; case 8: name = dz::mega_launch_nrt8(ml); break;
+            default: return fail("persistent kernel: ld > 128");
+        }
+        char buf[96]; snprintf(buf, sizeof buf, name, ch, wpc);
+        e->last_variant = buf;
     }
     DZCK(launch_check("k_generations"));
     if (append_last) { DZCK(allgather_rows(e, p.Z + (size_t)e->M * p.ld)); e->M += p.N; }
@@ -1141,6 +1145,7 @@ int dz_sync(dz_engine* e)
 int dz_trace_reset(dz_engine* e) { e->ntrace = 0; return 0; }
 int64_t dz_generation(dz_engine* e) { return e->gen; }
 int64_t dz_redraw_rounds(dz_engine* e) { return e->redraw_rounds; }
+const char* dz_last_kernel_variant(dz_engine* e) { return e->last_variant.c_str(); }
 
 int dz_get_state(dz_engine* e, double* X, double* prior, double* like)
 {

@@ -733,6 +733,7 @@ __global__ __launch_bounds__(NCH >= 4 ? 256 : 1024) void k_propose(Params p, int
     DZ_STAMP(p, phase, c, 15);
 }
 
+#ifndef DZ_TEMPLATES_ONLY   // plain (non-template) kernels: defined once, in dz_engine.hip's translation unit
 // Large d (ld > 256): one wave per (chain, try) STREAMS over the 128-dimension chunks instead of holding all of them in registers
 // (k_propose<8> needs 344 registers: one wave per SIMD, every latency exposed).  Two passes, each a chunk at a time with the next
 // chunk's base and archive rows in flight: DE -- pass 1 counts the crossed-over dimensions d' (the crossover uniforms are the
@@ -843,6 +844,7 @@ __global__ __launch_bounds__(256) void k_propose_stream(Params p, int phase, uin
         snooker_logps(p, wave_bfly(accN), 1, lane, sl + i);                         // :823-824
     }
 }
+#endif  // DZ_TEMPLATES_ONLY
 
 // debug entry: flags supplied by the host (function-level parity tests); one wave, all tries
 template <int NCH>
@@ -1362,6 +1364,7 @@ __global__ __launch_bounds__(256) void k_logp_mvn_gemm(Params p, const double* _
     }
 }
 
+#ifndef DZ_TEMPLATES_ONLY   // plain (non-template) kernels: defined once, in dz_engine.hip's translation unit
 // tlogp [generation][chain] -> [chain][generation] for the chain-by-chain download (dz_get_trace_chains)
 __global__ void k_transpose_logp(const double* __restrict__ src, int nl, int64_t g0, int ng, double* __restrict__ dst)
 {
@@ -1397,6 +1400,7 @@ __global__ void k_prior_consts(const double* __restrict__ pb, int n, double* __r
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) plogb[j] = dlog(pb[j]);
 }
+#endif  // DZ_TEMPLATES_ONLY
 template <int NCH>
 __global__ __launch_bounds__(256) void k_prior_only(Params p, const double* __restrict__ pts, int npts, double* prior_out)
 {
@@ -1547,6 +1551,7 @@ __global__ __launch_bounds__(64) void k_pt_swap(Params p, uint32_t g, int64_t tr
     if (lane == 0 && trace_slot >= 0) { int32_t* q = p.tswap + 3 * trace_slot; q[0] = (int32_t)a; q[1] = (int32_t)b; q[2] = acc ? 1 : 0; }
 }
 
+#ifndef DZ_TEMPLATES_ONLY   // plain (non-template) kernels: defined once, in dz_engine.hip's translation unit
 // Dream.py:281-282: `while np.all(np.isfinite(np.array(log_ps))==False)` -- marks the chains whose k tries are all impossible
 // (log_ps = T log_likes + log_priors, :279); the host draws their proposal sets again (redraw_impossible_sets).
 __global__ void k_redo_flags(Params p, int c0, int nc, uint8_t* __restrict__ redo)
@@ -1625,6 +1630,7 @@ __global__ void k_strip_finish(const double* __restrict__ partial, int nstrips, 
     if (pass == 0) mean[j] = tot / (double)N;
     else { const double v = sqrt(tot / (double)N); sd[j] = v; sdc[j] = v == 0.0 ? 1e-12 : v; }
 }
+#endif  // DZ_TEMPLATES_ONLY
 
 // one wave per GLOBAL chain: bins and normalised squared jumps (:481, :527)
 template <int NCH>
@@ -1673,6 +1679,7 @@ __global__ __launch_bounds__(256) void k_jump(Params p, uint32_t g, int gc0, int
     }
 }
 
+#ifndef DZ_TEMPLATES_ONLY   // plain (non-template) kernels: defined once, in dz_engine.hip's translation unit
 // single block: thread m < ncr updates crossover bin m, thread ncr+m updates gamma bin m; then renormalise
 __global__ void k_adapt_update(Params p, const double* __restrict__ dl, const double* __restrict__ dlg, const int* __restrict__ binc, const int* __restrict__ bing)
 {
@@ -1740,5 +1747,6 @@ __global__ void k_rhat(const double* __restrict__ mean, const double* __restrict
     const double var_est = W * (1.0 - 1.0 / (double)nsamples) + B;
     rhat[j] = sqrt(var_est / W);
 }
+#endif  // DZ_TEMPLATES_ONLY
 
 }  // namespace dz

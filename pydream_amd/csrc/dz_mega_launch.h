@@ -1,0 +1,25 @@
+// dz_mega_launch.h -- the launch interface between dz_engine.hip and the translation units that hold the instantiations of the
+// persistent generation kernel (dz_mega_tu.hip, compiled once per row-tile count NRT = ld / 16 so that the ~300 instantiations
+// build in parallel: pydream_amd/build.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dz {
+
+struct Params;
+
+struct MegaLaunch {
+    bool tri, xlds, pb, k1;     // triangular factor / chain states in LDS / full proposal code (priors, bounds, DEpairs > 1) / multitry off
+    int ch, wpc;                // chains per block (16, 8, 4), waves per chain (1; 4 at 4 chains per block with multitry on)
+    dim3 grid, block; size_t lds; hipStream_t st;
+    hipEvent_t ka, kb;          // the launch's own start / stop events (profiling pass) or null
+    const Params* pp; uint32_t g; int n; uint32_t M; int64_t slot0; int append_last;
+};
+
+// returns a static string naming the instantiation that was launched ("k_generations<7,tri,xlds,16,1,lean>")
+#define DZ_MEGA_DECL(N_) const char* mega_launch_nrt##N_(const MegaLaunch& a);
+DZ_MEGA_DECL(1) DZ_MEGA_DECL(2) DZ_MEGA_DECL(3) DZ_MEGA_DECL(4) DZ_MEGA_DECL(5) DZ_MEGA_DECL(6) DZ_MEGA_DECL(7) DZ_MEGA_DECL(8)
+#undef DZ_MEGA_DECL
+
+}  // namespace dz

@@ -1,0 +1,53 @@
+// dz_mega_tu.hip -- the instantiations of k_generations (dz_megakernel.h) for ONE row-tile count, -DDZ_TU_NRT=1..8.
+#define DZ_TEMPLATES_ONLY
+#include "dz_megakernel.h"
+#include "dz_mega_launch.h"
+#include <hip/hip_ext.h>
+
+#ifndef DZ_TU_NRT
+#error "compile with -DDZ_TU_NRT=<1..8>"
+#endif
+
+namespace dz {
+
+#define DZ_CAT_(a, b) a##b
+#define DZ_CAT(a, b) DZ_CAT_(a, b)
+#define DZ_STR_(x) #x
+#define DZ_STR(x) DZ_STR_(x)
+
+template <bool TRI, bool X, int CH, int WPC, bool PB, bool K1>
+static const char* launch_one(const MegaLaunch& a)
+{
+    hipExtLaunchKernelGGL((k_generations<DZ_TU_NRT, TRI, X, CH, WPC, PB, K1>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0,
+                          a.pp, a.g, a.n, a.M, a.slot0, a.append_last);
+    // (NRT, matrix, chain states, chains per block, waves per chain, proposal code)
+    return TRI ? (X ? (PB ? (K1 ? "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,full,k1>" : "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,full>")
+                          : (K1 ? "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,lean,k1>" : "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,lean>"))
+                      : (K1 ? "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,lean,k1>" : "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,lean>"))
+               : (X ? (PB ? (K1 ? "k_generations<" DZ_STR(DZ_TU_NRT) ",dense,xlds,%d,%d,full,k1>" : "k_generations<" DZ_STR(DZ_TU_NRT) ",dense,xlds,%d,%d,full>")
+                          : (K1 ? "k_generations<" DZ_STR(DZ_TU_NRT) ",dense,xlds,%d,%d,lean,k1>" : "k_generations<" DZ_STR(DZ_TU_NRT) ",dense,xlds,%d,%d,lean>"))
+                      : (K1 ? "k_generations<" DZ_STR(DZ_TU_NRT) ",dense,xhbm,%d,%d,lean,k1>" : "k_generations<" DZ_STR(DZ_TU_NRT) ",dense,xhbm,%d,%d,lean>"));
+}
+
+template <bool TRI, bool X, bool PB>
+static const char* launch_ch(const MegaLaunch& a)
+{
+    if (a.k1) {
+        if (a.ch == 16) return launch_one<TRI, X, 16, 1, PB, true>(a);
+        if (a.ch == 8) return launch_one<TRI, X, 8, 1, PB, true>(a);
+        return launch_one<TRI, X, 4, 1, PB, true>(a);
+    }
+    if (a.ch == 16) return launch_one<TRI, X, 16, 1, PB, false>(a);
+    if (a.ch == 8) return launch_one<TRI, X, 8, 1, PB, false>(a);
+    return launch_one<TRI, X, 4, 4, PB, false>(a);
+}
+
+// (priors / boundaries / several pairs: only with the chain states in LDS -- mega_eligible -- which keeps the number of kernels down)
+const char* DZ_CAT(mega_launch_nrt, DZ_TU_NRT)(const MegaLaunch& a)
+{
+    if (a.pb) return a.tri ? launch_ch<true, true, true>(a) : launch_ch<false, true, true>(a);
+    if (a.tri) return a.xlds ? launch_ch<true, true, false>(a) : launch_ch<true, false, false>(a);
+    return a.xlds ? launch_ch<false, true, false>(a) : launch_ch<false, false, false>(a);
+}
+
+}  // namespace dz

@@ -445,6 +445,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     }
 }
 
+#ifndef DZ_TEMPLATES_ONLY
 // ---------------------------------------------------------------------------------------------------------------------
 // The same persistent scheme for a likelihood a single wave evaluates on its own (Gaussian mixture): nothing is shared
 // between the chains of a block, so there are no tiles and no barriers at all -- every wave carries its chain through the
@@ -597,5 +598,6 @@ __global__ __launch_bounds__(64 * MIXW) void k_generations_mix(const Params* __r
         }
     }
 }
+#endif  // DZ_TEMPLATES_ONLY
 
 }  // namespace dz

@@ -42,7 +42,12 @@ typedef struct dz_config {
     int32_t hardboundaries;   /* Dream.py:80                                                   */
     int32_t schedule;         /* must be 2 (lockstep generations, DESIGN.md "Schedule")        */
     int32_t device;           /* HIP device ordinal                                            */
-    int32_t reserved0;
+    int32_t history_lag;      /* 0: the rows a generation appends are sampleable from the next generation on (the schedule the
+                               * reference has when driven in lockstep).  L >= 1: they become sampleable L appends later, i.e. the
+                               * generations between two appends sample from the archive as it was L appends ago -- which lets the
+                               * exchange of appended rows between GPUs run behind the next thin-cycle's generations instead of
+                               * between two launches (the reference's own chains see each other's appends with
+                               * an arbitrary, scheduler-dependent delay, Dream.py:646-668 under core.py:80) */
     int64_t history_capacity; /* rows the Z archive can hold (core.py:260-268)                 */
     int64_t trace_capacity;   /* generations the device trace buffer holds (0 = no trace)      */
     uint64_t seed;            /* key of the counter-based random contract                      */
@@ -97,6 +102,18 @@ const char* dz_comm_library(void);     /* path of the librccl in use: the one ne
 int dz_comm_unique_id(void* id128);                                                 /* rank 0: 128-byte RCCL unique id */
 int dz_comm_init_rccl(dz_engine* e, int32_t rank, int32_t world, const void* id128);
 int dz_set_exchange(dz_engine* e, dz_exchange_cb cb, void* user);
+/* Third transport, "peer": every rank maps the other ranks' archive (and published-position buffers) through HIP IPC and its COPY
+ * ENGINES push the rank's rows into them on streams of their own, each push followed by the rank's flag word -- no compute unit is
+ * involved, so the transfer runs while the next persistent launch (which owns every CU's LDS) computes.  A one-wave gate kernel in front
+ * of the first launch that samples the new rows waits for the flags.  With dz_config.history_lag = 0 that is right behind the append
+ * (replaces the shared arrays of core.py:281-297 / Dream.py:919-945 like the all-gather does); with history_lag = 1 a whole thin-cycle
+ * later, i.e. the exchange is hidden.  Bootstrap: dz_peer_export fills this rank's blob, the control plane all-gathers the blobs (rank
+ * order), dz_peer_attach maps them.  dz_exchange_stats (after dz_sync): exchanges queued, gates passed and the time the gates spent
+ * waiting -- the exposed part of the exchange. */
+#define DZ_PEER_BLOB_BYTES 512
+int dz_peer_export(dz_engine* e, void* blob /* DZ_PEER_BLOB_BYTES */);
+int dz_peer_attach(dz_engine* e, int32_t rank, int32_t world, const void* blobs /* world x DZ_PEER_BLOB_BYTES */);
+int dz_exchange_stats(dz_engine* e, int64_t* exchanges, int64_t* gates, double* gate_wait_us);
 int dz_comm_barrier(dz_engine* e);     /* device-side rendezvous of the ranks (one-element RCCL all-gather + stream sync; replaces the mp.Barrier-like role of a host barrier in front of a timed region); without a communicator: a sync */
 
 /* Parallel tempering (core.py:131-236).  T[nchains]: the temperature of every (global) chain -- Dream.astep's T argument
@@ -116,6 +133,10 @@ int     dz_step(dz_engine* e, int64_t generations);
 int     dz_step_range(dz_engine* e, int32_t chain0, int32_t nchains);
 int     dz_set_chain_state(dz_engine* e, int32_t chain, const double* x, const double* prior, const double* like); /* NULL logps => evaluate */
 int     dz_get_chain_state(dz_engine* e, int32_t chain, double* x, double* prior, double* like);
+/* The crossover / gamma-level probabilities the Dream instance driving `chain` decides with (Dream.CR_probabilities, Dream.py:134, :375;
+ * Dream.gamma_probabilities, :143, :383): under dz_step_range every chain keeps its own copy, refreshed by its own adaptation updates and
+ * at the end of the burn-in (:409-415); before any single-chain step, and under dz_step, the shared vectors.  [ncr], [ngamma]; NULL skips. */
+int     dz_get_chain_probs(dz_engine* e, int32_t chain, double* cr_probs, double* gamma_probs);
 int     dz_sync(dz_engine* e);
 int     dz_trace_reset(dz_engine* e);
 int64_t dz_generation(dz_engine* e);
@@ -171,6 +192,7 @@ int dz_debug_propose(dz_engine* e, int32_t chain_local, int64_t gen, int32_t pha
 int dz_profile_enable(dz_engine* e, int32_t on);
 int dz_profile_get(dz_engine* e, int32_t which, double* total_ms, int64_t* launches);
 int dz_profile_reset(dz_engine* e);
+int dz_profile_get_list(dz_engine* e, int32_t which, double* ms /* [cap] */, int64_t cap, int64_t* launches);   /* every launch of the class, in order */
 
 #ifdef __cplusplus
 }

@@ -304,7 +304,7 @@ struct orc_engine {
     int d, nl, N, k;
     double *mins, *maxs;
     double* gtab;
-    double* Z; int64_t M;
+    double* Z; int64_t M; int64_t napp;     /* rows written; appends made by this run (history_lag: the last `lag` of them are not sampleable yet) */
     double *X, *lprior, *llike; int have_logp;
     double *cp_prev, *cp_new;   /* [N,d] published positions (Dream.py:424-449) */
     double *cr_probs, *cr_delta, *cr_n;         /* shared (core.py:287-289) */
@@ -333,6 +333,7 @@ int orc_create(const orc_config* cfg, orc_engine** out)
     if (cfg->depairs < 1 || cfg->depairs > 8) return fail("DEpairs must be 1..8");
     if (cfg->ncr < 1 || cfg->ngamma < 1) return fail("bad nCR/gamma_levels");
     if (cfg->schedule != 1 && cfg->schedule != 2) return fail("schedule must be 1 or 2");
+    if (cfg->history_lag < 0 || (cfg->history_lag && cfg->schedule != 2)) return fail("history_lag needs schedule 2 and must be >= 0");
     if (cfg->chain_offset < 0 || cfg->chain_offset + cfg->nchains_local > cfg->nchains) return fail("bad shard");
     orc_engine* e = zalloc(sizeof *e);
     e->c = *cfg; e->d = cfg->ndim; e->nl = cfg->nchains_local; e->N = cfg->nchains; e->k = cfg->multitry;
@@ -385,7 +386,7 @@ int orc_set_gamma_table(orc_engine* e, const double* t)
 int orc_set_history(orc_engine* e, const double* Z, int64_t rows)
 {   /* core.py:255-263, 281-283: seed rows first */
     if (rows > e->c.history_capacity) return fail("history exceeds capacity");
-    memcpy(e->Z, Z, sizeof(double) * (size_t)rows * e->d); e->M = rows; return 0;
+    memcpy(e->Z, Z, sizeof(double) * (size_t)rows * e->d); e->M = rows; e->napp = 0; return 0;
 }
 int orc_set_state(orc_engine* e, const double* X, const double* prior, const double* like)
 {
@@ -857,6 +858,9 @@ static int generation_s2(orc_engine* e)
     double* Xn = zalloc(sizeof(double) * nl * d); step_res* R = zalloc(sizeof(step_res) * nl);
     int rc = 0;
     if (g == 0 && (e->c.adapt_crossover || e->c.adapt_gamma)) rc = exchange(e, e->X, e->cp_new, d);
+    /* history_lag: the rows of the last `lag` appends exist (their place in Z is fixed by the append order) but are not sampled yet */
+    const int64_t lagged = e->napp < (int64_t)e->c.history_lag ? e->napp : (int64_t)e->c.history_lag;
+    const int64_t Mvis = e->M - (int64_t)N * lagged;
     /* The chains of a generation are independent (schedule S2), so the CPU baseline may spread them over the host's
      * cores the way the reference spreads them over processes: each thread works on a shallow copy of the engine with
      * private scratch.  Results do not depend on the thread count.  The Python likelihood callback stays serial. */
@@ -870,7 +874,7 @@ static int generation_s2(orc_engine* e)
             te.pts = zalloc(sizeof(double) * e->k * d); te.refs = zalloc(sizeof(double) * e->k * d); te.work = zalloc(sizeof(double) * 8 * d);
             int trc = 0;
             #pragma omp for schedule(static)
-            for (int c = 0; c < nl; ++c) if (!trc) trc = chain_step(&te, c, g, e->M, e->cr_probs, e->g_probs, Xn + (size_t)c * d, &R[c]);
+            for (int c = 0; c < nl; ++c) if (!trc) trc = chain_step(&te, c, g, Mvis, e->cr_probs, e->g_probs, Xn + (size_t)c * d, &R[c]);
             if (trc) {
                 #pragma omp critical
                 rc = trc;
@@ -879,7 +883,7 @@ static int generation_s2(orc_engine* e)
         }
     } else
 #endif
-    for (int c = 0; c < nl && !rc; ++c) rc = chain_step(e, c, g, e->M, e->cr_probs, e->g_probs, Xn + (size_t)c * d, &R[c]);
+    for (int c = 0; c < nl && !rc; ++c) rc = chain_step(e, c, g, Mvis, e->cr_probs, e->g_probs, Xn + (size_t)c * d, &R[c]);
     if (rc) { free(Xn); free(R); return rc; }
     for (int c = 0; c < nl; ++c) {
         record_trace(e, c, Xn + (size_t)c * d, &R[c]);
@@ -924,7 +928,7 @@ static int generation_s2(orc_engine* e)
     if (g % (uint32_t)e->c.history_thin == 0) {
         if (e->M + N > e->c.history_capacity) { free(Xn); free(R); return fail("history capacity exceeded"); }
         rc = exchange(e, e->X, e->Z + (size_t)e->M * d, d);
-        e->M += N;
+        e->M += N; e->napp += 1;
     }
     /* temperature swap (core.py:185-221): one random pair per generation, after every chain's step */
     if (e->tempering && !rc) {

@@ -45,7 +45,7 @@ typedef struct orc_config {
     int32_t hardboundaries;   /* Dream.py:80                                    */
     int32_t schedule;         /* 1 = S1 sequential round-robin, 2 = S2 lockstep */
     int32_t device;           /* unused by the oracle                           */
-    int32_t reserved0;
+    int32_t history_lag;      /* schedule S2 only: appended rows become sampleable `history_lag` appends late (0 = at once) */
     int64_t history_capacity; /* rows Z can hold                                */
     int64_t trace_capacity;   /* generations the trace buffer can hold          */
     uint64_t seed;

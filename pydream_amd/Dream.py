@@ -95,7 +95,7 @@ class Dream():
         self.parallel = parallel
         # multitry: False -> 1 try, True -> 5 tries, a number -> that many (Dream.py:155-161)
         # (compared by value like the reference does, so 0 counts as False and 1 as True)
-        self.multitry = {False: 1, True: 5}.get(multitry, multitry) if isinstance(multitry, (bool, int, np.integer)) else multitry
+        self.multitry = 1 if multitry == False else (5 if multitry == True else multitry)      # noqa: E712  (1.0 / 0.0 too, as in the reference)
         if self.multitry == 2:
             raise Exception('multitry=2 fails inside the reference (Dream.py:867-868); use 1 or >= 3.')
 
@@ -160,5 +160,12 @@ class Dream():
         Dream_shared_vars.host_state[c] = q_new.copy()
         self.last_prior, self.last_like = float(pr), float(lk)
         self.last_logp = T * self.last_like + self.last_prior       # Dream.py:243
+        if (self.adapt_crossover or self.adapt_gamma) and self.crossover_burnin is not None and self.iter <= self.crossover_burnin and hasattr(eng, "get_chain_probs"):
+            # this instance's own copies, refreshed by its own updates (Dream.py:375, :383, :409-415)
+            cr, gp = eng.get_chain_probs(c)
+            if self.adapt_crossover:
+                self.CR_probabilities = list(cr)
+            if self.adapt_gamma:
+                self.gamma_probabilities = list(gp)
         self.iter += 1
         return q_new, self.last_prior, self.last_like

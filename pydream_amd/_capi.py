@@ -23,7 +23,7 @@ class Config(C.Structure):
         ("multitry", C.c_int32), ("depairs", C.c_int32), ("ncr", C.c_int32), ("ngamma", C.c_int32),
         ("history_thin", C.c_int32), ("crossover_burnin", C.c_int32), ("adapt_crossover", C.c_int32),
         ("adapt_gamma", C.c_int32), ("hardboundaries", C.c_int32), ("schedule", C.c_int32), ("device", C.c_int32),
-        ("reserved0", C.c_int32), ("history_capacity", C.c_int64), ("trace_capacity", C.c_int64),
+        ("history_lag", C.c_int32), ("history_capacity", C.c_int64), ("trace_capacity", C.c_int64),
         ("seed", C.c_uint64), ("lamb", C.c_double), ("zeta", C.c_double), ("snooker", C.c_double),
         ("p_gamma_unity", C.c_double), ("temperature", C.c_double),
     ]
@@ -36,10 +36,10 @@ XCHG_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 SYMBOLS = [
     "dz_version", "dz_last_error", "dz_device_count", "dz_create", "dz_destroy", "dz_set_bounds", "dz_set_gamma_table",
     "dz_set_history", "dz_set_state", "dz_set_cr_probs", "dz_set_gamma_probs", "dz_set_prior", "dz_set_likelihood_mvn",
-    "dz_set_likelihood_mixture", "dz_set_likelihood_host", "dz_hip_library", "dz_comm_library", "dz_comm_unique_id", "dz_comm_init_rccl", "dz_comm_barrier", "dz_set_exchange", "dz_set_temperatures", "dz_get_swaps",
-    "dz_step", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_sync", "dz_trace_reset", "dz_generation", "dz_redraw_rounds", "dz_last_kernel_variant", "dz_get_state", "dz_get_trace", "dz_get_trace_chains", "dz_trace_download_begin", "dz_trace_download_wait", "dz_host_register", "dz_host_unregister", "dz_get_history",
+    "dz_set_likelihood_mixture", "dz_set_likelihood_host", "dz_hip_library", "dz_comm_library", "dz_comm_unique_id", "dz_comm_init_rccl", "dz_comm_barrier", "dz_set_exchange", "dz_peer_export", "dz_peer_attach", "dz_exchange_stats", "dz_set_temperatures", "dz_get_swaps",
+    "dz_step", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_get_chain_probs", "dz_sync", "dz_trace_reset", "dz_generation", "dz_redraw_rounds", "dz_last_kernel_variant", "dz_get_state", "dz_get_trace", "dz_get_trace_chains", "dz_trace_download_begin", "dz_trace_download_wait", "dz_host_register", "dz_host_unregister", "dz_get_history",
     "dz_get_cr_state", "dz_get_gamma_state", "dz_get_rhat", "dz_get_chain_moments", "dz_eval_logp", "dz_debug_propose",
-    "dz_profile_enable", "dz_profile_get", "dz_profile_reset",
+    "dz_profile_enable", "dz_profile_get", "dz_profile_reset", "dz_profile_get_list",
 ]
 
 _lib = None
@@ -83,11 +83,15 @@ def load_library():
     L.dz_comm_init_rccl.argtypes = [V, C.c_int32, C.c_int32, V]
     L.dz_comm_barrier.argtypes = [V]
     L.dz_set_exchange.argtypes = [V, XCHG_CB, V]
+    L.dz_peer_export.argtypes = [V, V]
+    L.dz_peer_attach.argtypes = [V, C.c_int32, C.c_int32, V]
+    L.dz_exchange_stats.argtypes = [V, V, V, V]
     L.dz_step.argtypes = [V, C.c_int64]
     L.dz_sync.argtypes = [V]
     L.dz_step_range.argtypes = [V, C.c_int32, C.c_int32]
     L.dz_set_chain_state.argtypes = [V, C.c_int32, V, V, V]
     L.dz_get_chain_state.argtypes = [V, C.c_int32, V, V, V]
+    L.dz_get_chain_probs.argtypes = [V, C.c_int32, V, V]
     L.dz_trace_reset.argtypes = [V]
     L.dz_get_state.argtypes = [V, V, V, V]
     L.dz_get_trace.argtypes = [V, C.c_int64, C.c_int64] + [V] * 6
@@ -101,6 +105,7 @@ def load_library():
     L.dz_profile_enable.argtypes = [V, C.c_int32]
     L.dz_profile_get.argtypes = [V, C.c_int32, V, V]
     L.dz_profile_reset.argtypes = [V]
+    L.dz_profile_get_list.argtypes = [V, C.c_int32, V, C.c_int64, V]
     L.dz_device_count.argtypes = [V]
     _lib = L
     return L
@@ -153,7 +158,7 @@ class Engine:
         cfg = Config()
         defaults = dict(nchains_local=kw.get("nchains"), chain_offset=0, multitry=1, depairs=1, ncr=3, ngamma=1,
                         history_thin=10, crossover_burnin=0, adapt_crossover=0, adapt_gamma=0, hardboundaries=1,
-                        schedule=2, device=0, reserved0=0, trace_capacity=0, seed=0, lamb=0.05, zeta=1e-12,
+                        schedule=2, device=0, history_lag=0, trace_capacity=0, seed=0, lamb=0.05, zeta=1e-12,
                         snooker=0.1, p_gamma_unity=0.2, temperature=1.0)
         defaults.update(kw)
         for k, v in defaults.items():
@@ -259,6 +264,25 @@ class Engine:
     def comm_init_rccl(self, rank, world, unique_id):
         self._chk(self.L.dz_comm_init_rccl(self.h, rank, world, C.c_char_p(unique_id)))
 
+    PEER_BLOB_BYTES = 512
+
+    def peer_export(self):
+        """this rank's blob for the peer transport (IPC handles of its archive, position buffers and flag words)"""
+        buf = C.create_string_buffer(self.PEER_BLOB_BYTES)
+        self._chk(self.L.dz_peer_export(self.h, buf))
+        return buf.raw
+
+    def peer_attach(self, rank, world, blobs):
+        """blobs: the ranks' exports in rank order (bytes, world x PEER_BLOB_BYTES)"""
+        assert len(blobs) == world * self.PEER_BLOB_BYTES
+        self._chk(self.L.dz_peer_attach(self.h, rank, world, C.c_char_p(blobs)))
+
+    def exchange_stats(self):
+        """(exchanges queued, gates passed, microseconds the gates spent waiting) -- the exposed part of the peer exchange"""
+        n, g, us = C.c_int64(), C.c_int64(), C.c_double()
+        self._chk(self.L.dz_exchange_stats(self.h, C.byref(n), C.byref(g), C.byref(us)))
+        return n.value, g.value, us.value
+
     def comm_barrier(self):
         self._chk(self.L.dz_comm_barrier(self.h))
 
@@ -289,6 +313,12 @@ class Engine:
         x = np.zeros(self.d); pr = np.zeros(1); lk = np.zeros(1)
         self._chk(self.L.dz_get_chain_state(self.h, int(chain), _p(x), _p(pr), _p(lk)))
         return x, float(pr[0]), float(lk[0])
+
+    def get_chain_probs(self, chain):
+        """(CR_probabilities, gamma_probabilities) of the Dream instance that drives `chain` (its own copies under step_range)"""
+        cr, gp = np.zeros(self.cfg.ncr), np.zeros(self.cfg.ngamma)
+        self._chk(self.L.dz_get_chain_probs(self.h, int(chain), _p(cr), _p(gp)))
+        return cr, gp
 
     def sync(self):
         self._chk(self.L.dz_sync(self.h))
@@ -409,6 +439,12 @@ class Engine:
 
     def profile_reset(self):
         self._chk(self.L.dz_profile_reset(self.h))
+
+    def profile_get_list(self, which, cap=65536):
+        """milliseconds of every launch of the class since the last reset, in launch order"""
+        ms, n = np.zeros(cap), C.c_int64()
+        self._chk(self.L.dz_profile_get_list(self.h, PROFILE_CLASSES[which], _p(ms), cap, C.byref(n)))
+        return ms[:min(cap, n.value)]
 
     def profile_get(self, which):
         ms, n = C.c_double(), C.c_int64()

@@ -27,7 +27,9 @@ def run_dream(parameters, likelihood, nchains=5, niterations=50000, start=None, 
         (nchains, 2*niterations, 1) with the samples before and after each swap attempt interleaved
     mp_context: accepted for compatibility, ignored (there are no worker processes)
     kwargs: passed to Dream (see Dream).  Extra keys understood here: ``seed`` (int, key of the random
-        contract; default drawn from the OS), ``device`` (HIP device ordinal).
+        contract; default drawn from the OS), ``device`` (HIP device ordinal), ``history_lag`` (int, default 0: the rows a
+        generation appends to the history are sampled from the next generation on; L >= 1: L appends later -- see
+        include/dreamzs.h dz_config.history_lag).
 
     Returns
     -------
@@ -54,7 +56,7 @@ def run_dream(parameters, likelihood, nchains=5, niterations=50000, start=None, 
         step_instance = Dream(model=model, variables=parameters, verbose=verbose, mp_context=mp_context, **kwargs)
 
     pool = _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=start, mp_context=mp_context,
-                                seed=kwargs.get('seed'), device=kwargs.get('device', 0))
+                                seed=kwargs.get('seed'), device=kwargs.get('device', 0), history_lag=kwargs.get('history_lag', 0))
     try:
         pool._initializer(*pool._initargs)
         if tempering:
@@ -241,7 +243,7 @@ def _mp_dream_init(engine, nchains):
 
 
 def _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=None, mp_context=None, seed=None, device=0,
-                         chain_offset=0, nchains_local=None, engine_cls=None):
+                         chain_offset=0, nchains_local=None, engine_cls=None, history_lag=0):
     """Validate, size and allocate the shared sampler state (core.py:250-314) -- in HBM."""
     min_njobs = (2 * len(step_instance.DEpairs)) + 1
     if nchains < min_njobs:
@@ -279,7 +281,7 @@ def _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=None, mp_
                        depairs=len(step_instance.DEpairs), ncr=int(step_instance.nCR), ngamma=int(step_instance.ngamma),
                        history_thin=int(thin), crossover_burnin=int(min(step_instance.crossover_burnin, 2 ** 31 - 1)),
                        adapt_crossover=int(bool(step_instance.adapt_crossover)), adapt_gamma=int(bool(step_instance.adapt_gamma)),
-                       hardboundaries=int(bool(step_instance.boundaries)), schedule=2, device=int(device),
+                       hardboundaries=int(bool(step_instance.boundaries)), schedule=2, device=int(device), history_lag=int(history_lag),
                        history_capacity=len(seed_rows) + nchains * n_appends, trace_capacity=trace_cap, seed=int(seed),
                        lamb=float(step_instance.lamb), zeta=float(step_instance.zeta), snooker=float(step_instance.snooker),
                        p_gamma_unity=float(step_instance.p_gamma_unity))

@@ -62,13 +62,14 @@ struct Rccl {
         if (const char* ov = getenv("DZ_RCCL_LIB")) cand.push_back(ov);
         cand.push_back(dir + "/librccl.so.1");
         cand.push_back(dir + "/librccl.so");
+        cand.push_back("librccl.so.1");        // installs that keep RCCL apart from HIP (split packages, LD_LIBRARY_PATH): the runtime check below still applies
         std::string tried;
         for (const std::string& c : cand) {
             lib = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (lib) { path = c; break; }
             tried += c + " (" + dlerror() + "); ";
         }
-        if (!lib) return fail("cannot load librccl next to " + hip_path + ": " + tried);
+        if (!lib) return fail("cannot load librccl (next to " + hip_path + " or by soname): " + tried);
         GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
         CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
         AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
@@ -119,6 +120,7 @@ struct dz_engine {
     int ra_stride = 32; hipEvent_t ra_ev[4] = {nullptr}; bool ra_used[4] = {false, false, false, false}; int64_t ra_n = 0;
     int nch = 1;
     int64_t M = 0, gen = 0, ntrace = 0, draws_gen = -1;
+    int64_t napp = 0;               // appends made since the archive was set (dz_config.history_lag: the last `lag` of them are not sampleable yet)
     std::vector<int64_t> gen_c;     // per-chain generation counters (differ only under single-chain stepping)
     uint4* d_draws[2] = {nullptr, nullptr};
     dz::ChainCtl* d_ctl[2] = {nullptr, nullptr};
@@ -127,6 +129,16 @@ struct dz_engine {
     dz_logp_cb cb = nullptr; void* cb_user = nullptr;
     dz_exchange_cb xcb = nullptr; void* xcb_user = nullptr;
     ncclComm_t comm = nullptr; int rank = 0, world = 1;
+    // peer transport (dz_peer_export / dz_peer_attach): the other ranks' archives, position buffers and flag words mapped into this
+    // process; rows travel on copy streams (one per peer: xGMI is point to point), never through a kernel
+    struct Peer { double* Z = nullptr; double* cp[3] = {nullptr, nullptr, nullptr}; unsigned long long* flags = nullptr; hipStream_t st = nullptr; };
+    std::vector<Peer> peers; bool peer_on = false;
+    unsigned long long* d_flags = nullptr;      // [2][world]: exchange number received from every rank -- [0] history appends, [1] published positions
+    unsigned long long* d_seq = nullptr; int64_t seq_cap = 0;     // seq[i] = i: the source of the flag pushes
+    unsigned long long* h_gate = nullptr;       // host-mapped: ticks waited, gates passed, error (k_peer_gate)
+    hipEvent_t push_ev[8] = {nullptr}; int push_n = 0;
+    int64_t z_pushed = 0, z_gated = 0, pos_pushed = 0;
+    double* d_cp[3] = {nullptr, nullptr, nullptr}; int cp_idx = 1;      // published positions rotate through three buffers (a peer may run one generation ahead)
     // owned device buffers (also referenced from p)
     double *d_mins = nullptr, *d_maxs = nullptr, *d_gtab = nullptr, *d_mu = nullptr, *d_Mt = nullptr, *d_Mtp = nullptr, *d_mixF = nullptr;
     double *d_pa = nullptr, *d_pb = nullptr, *d_plogb = nullptr; int32_t* d_pkind = nullptr;
@@ -143,6 +155,7 @@ struct dz_engine {
     bool fuse = true;               // DZ_FUSE=0 disables the accept+propose fusion
     bool stream_propose = true;     // ld > 256: the streaming proposal kernel (k_propose_stream); DZ_STREAM=0 keeps k_propose<4|8>
     bool mega = true;               // the persistent generation kernel serves every eligible configuration (mega_eligible); DZ_MEGA=0 forces the multi-kernel path
+    bool mega_burnin = true;        // ... the generations of the crossover burn-in too, one per launch (positions published by the kernel); DZ_MEGA_BURNIN=0: multi-kernel path there
     int mega_max_gen = 1 << 20;     // DZ_MEGA_MAXGEN: generations per launch cap (measurement)
     int mega_ch = 0;                // DZ_MEGA_CHAINS: force 16 / 8 / 4 chains per block (0: by chain count)
     bool tempering = false; double* d_Tc = nullptr; int32_t* d_tswap = nullptr;    // parallel tempering (dz_set_temperatures)
@@ -151,6 +164,7 @@ struct dz_engine {
     std::vector<int32_t> h_pkind; std::vector<double> h_pa, h_pb, h_mins, h_maxs;     // host copies: is the uniform priors' support covered by the hard boundaries?
     hipStream_t copy_stream = nullptr; hipEvent_t copy_ev[8] = {nullptr};   // dz_trace_download_begin / _wait: trace rows leave while later generations run
     int64_t redraw_rounds = 0;      // redraw launches so far (dz_redraw_rounds)
+    double *d_own_cr = nullptr, *d_own_g = nullptr; std::vector<char> own_init;      // per-instance probabilities of single-chain stepping (Params::own_cr)
     std::string last_variant;       // what the last dz_step launched for its generations (dz_last_kernel_variant)
     bool pending_accept = false;    // generation gen-1's Metropolis step has been deferred into the next proposal kernel
     int64_t pending_slot = -1;
@@ -197,6 +211,13 @@ hipEvent_t prof_event(dz_engine* e)
             (E)->ev[CLS].emplace_back(ka_, kb_);                                                           \
         } else hipLaunchKernelGGL(KERN, GRID, BLOCK, LDS, ST, __VA_ARGS__);                                \
     } while (0)
+
+// archive rows the next generation samples from: everything written, less the rows of the last `history_lag` appends
+int64_t visible_rows(const dz_engine* e)
+{
+    const int64_t lag = std::min<int64_t>(e->napp, (int64_t)e->c.history_lag);
+    return e->M - (int64_t)e->p.N * lag;
+}
 
 int sync_all(dz_engine* e)
 {
@@ -363,26 +384,83 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
     return launch_check("logp kernel");
 }
 
-// in-place all-gather of `rows_local` rows per rank inside buf (global layout [N,ld])
-int allgather_rows(dz_engine* e, double* buf)
+enum { XK_Z = 0, XK_POS = 1 };
+double gate_timeout_s()
 {
-    if (!e->comm && e->p.nl == e->p.N) return 0;     // single GPU, no communicator: the kernels wrote the rows in place
+    if (const char* s = getenv("DZ_PEER_TIMEOUT_S")) return std::max(0.01, atof(s));
+    return 20.0;
+}
+// peer transport: this rank's rows of `buf` (global layout [N,ld], rows [off, off+nl) at `row0`) go to every peer's copy of the
+// buffer, each followed by this rank's flag word for exchange number `seq` of that kind
+int peer_push(dz_engine* e, int kind, double* buf, int which_cp, size_t row0, unsigned long long seq)
+{
+    if ((int64_t)seq >= e->seq_cap) return fail("peer exchange: sequence capacity exceeded");
+    hipEvent_t ev = e->push_ev[e->push_n++ & 7];
+    HIPCK(hipEventRecord(ev, e->stream));
+    const size_t first = (row0 + (size_t)e->p.off) * e->p.ld, cnt = (size_t)e->p.nl * e->p.ld;
+    for (int r = 0; r < e->world; ++r) {
+        if (r == e->rank) continue;
+        dz_engine::Peer& pr = e->peers[r];
+        double* dst = kind == XK_Z ? pr.Z : pr.cp[which_cp];
+        HIPCK(hipStreamWaitEvent(pr.st, ev, 0));
+        HIPCK(hipMemcpyAsync(dst + first, buf + first, sizeof(double) * cnt, hipMemcpyDeviceToDevice, pr.st));
+        HIPCK(hipMemcpyAsync(pr.flags + (size_t)kind * e->world + e->rank, e->d_seq + seq, sizeof(unsigned long long), hipMemcpyDeviceToDevice, pr.st));
+    }
+    return 0;
+}
+// ... and the wait for everybody else's rows of exchange `need`: a one-wave kernel on the engine's stream (k_peer_gate)
+int peer_gate(dz_engine* e, int kind, unsigned long long need)
+{
+    const unsigned long long ticks = (unsigned long long)(gate_timeout_s() * 1e8);
+    hipLaunchKernelGGL(dz::k_peer_gate, dim3(1), dim3(64), 0, e->stream, (const unsigned long long*)(e->d_flags + (size_t)kind * e->world), e->world, e->rank, need, ticks, e->h_gate);
+    return launch_check("k_peer_gate");
+}
+int peer_check(dz_engine* e)
+{   // after a device sync: did a gate give up?
+    if (e->peer_on && e->h_gate && e->h_gate[2]) {
+        const int r = (int)e->h_gate[2] - 1;
+        return fail("peer exchange: no rows from rank " + std::to_string(r) + " within " + std::to_string(gate_timeout_s()) + " s (DZ_PEER_TIMEOUT_S)");
+    }
+    return 0;
+}
+// before generations that sample the archive: the rows of every append that is visible now have arrived from every rank
+int ensure_visible(dz_engine* e)
+{
+    if (!e->peer_on) return 0;
+    const int64_t need = e->napp - std::min<int64_t>(e->napp, (int64_t)e->c.history_lag);
+    if (need > e->z_gated) { DZCK(peer_gate(e, XK_Z, (unsigned long long)need)); e->z_gated = need; }
+    return 0;
+}
+
+// Replicates this rank's rows of `buf` (global layout [N,ld]; the rank's nl rows sit at row0 + off) on every rank.
+//   RCCL: in-place ncclAllGather on the engine's stream;  host: staged through the exchange callback (tests, gloo);
+//   peer: pushed by the copy engines into the peers' mapped buffers -- history appends are waited for only when their rows become
+//   sampleable (ensure_visible: with history_lag >= 1 a whole thin-cycle later), published positions at once.
+int exchange_rows(dz_engine* e, int kind, double* buf, size_t row0)
+{
+    if (!e->comm && !e->peer_on && e->p.nl == e->p.N) return 0;     // single GPU, no communicator: the kernels wrote the rows in place
     ProfScope ps(e, PR_EXCHANGE);
     const size_t cnt = (size_t)e->p.nl * e->p.ld;
-    double* mine = buf + (size_t)e->p.off * e->p.ld;
+    double* base = buf + row0 * e->p.ld;
+    double* mine = base + (size_t)e->p.off * e->p.ld;
+    if (e->peer_on) {
+        if (kind == XK_Z) { DZCK(peer_push(e, XK_Z, buf, 0, row0, (unsigned long long)(e->z_pushed + 1))); e->z_pushed++; return 0; }
+        DZCK(peer_push(e, XK_POS, buf, e->cp_idx, row0, (unsigned long long)(e->pos_pushed + 1))); e->pos_pushed++;
+        return peer_gate(e, XK_POS, (unsigned long long)e->pos_pushed);
+    }
     if (e->comm) {
-        ncclResult_t r = g_rccl.AllGather(mine, buf, cnt, ncclDouble, e->comm, e->stream);
+        ncclResult_t r = g_rccl.AllGather(mine, base, cnt, ncclDouble, e->comm, e->stream);
         if (r != ncclSuccess) return fail(std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
         return 0;
     }
-    if (!e->xcb) return fail("sharded run needs dz_comm_init_rccl or dz_set_exchange");
+    if (!e->xcb) return fail("sharded run needs dz_comm_init_rccl, dz_peer_attach or dz_set_exchange");
     const size_t nranks = (size_t)e->p.N / e->p.nl;
     e->h_stage.resize(cnt * (nranks + 1));
     double* hs = e->h_stage.data(); double* hr = hs + cnt;
     HIPCK(hipMemcpyAsync(hs, mine, sizeof(double) * cnt, hipMemcpyDeviceToHost, e->stream));
     DZCK(sync_all(e));
     if (e->xcb(hs, hr, (int64_t)(sizeof(double) * cnt), e->xcb_user)) return fail("exchange callback failed");
-    HIPCK(hipMemcpyAsync(buf, hr, sizeof(double) * cnt * nranks, hipMemcpyHostToDevice, e->stream));
+    HIPCK(hipMemcpyAsync(base, hr, sizeof(double) * cnt * nranks, hipMemcpyHostToDevice, e->stream));
     DZCK(sync_all(e));
     return 0;
 }
@@ -391,18 +469,28 @@ int adapt_generation(dz_engine* e, uint32_t g, int gc0, int ngc)
 {
     ProfScope ps(e, PR_ADAPT);
     const dz::Params& p = e->p;
-    const int nstrips = (p.N + 63) / 64;
+    // lockstep generations: strips of 64 chains, then the strips in order (the reduction contract); a single chain's update (Dream.astep,
+    // schedule S1): all rows in row order, numpy's own
+    const bool single = ngc != p.N;
+    const int strip = single ? p.N : 64, nstrips = (p.N + strip - 1) / strip;
     const dim3 b(128), gcol((p.d + 127) / 128, nstrips), gfin((p.d + 127) / 128);
-    hipLaunchKernelGGL(dz::k_strip_partial, gcol, b, 0, e->stream, p.cp_new, p.N, p.d, p.ld, e->d_mean, 0, e->d_partial);
-    hipLaunchKernelGGL(dz::k_strip_finish, gfin, b, 0, e->stream, e->d_partial, nstrips, p.N, p.d, p.ld, 0, e->d_mean, e->d_sd, e->d_sdc);
-    hipLaunchKernelGGL(dz::k_strip_partial, gcol, b, 0, e->stream, p.cp_new, p.N, p.d, p.ld, e->d_mean, 1, e->d_partial);
-    hipLaunchKernelGGL(dz::k_strip_finish, gfin, b, 0, e->stream, e->d_partial, nstrips, p.N, p.d, p.ld, 1, e->d_mean, e->d_sd, e->d_sdc);
+    // four launches: strip sums -> (column means, made by every block for itself) strip sums of squared deviations -> (standard
+    // deviations, likewise) normalised jumps per chain -> accumulators and probabilities.  The same additions in the same order as the
+    // six-launch form with its two one-block finishing kernels (k_strip_finish); a kernel boundary is the cheapest grid-wide
+    // synchronisation on this chip (an agent-scope fence costs more), so what is left is one per true dependency.
+    (void)gfin;
+    double* partial1 = e->d_partial + (size_t)((p.N + 63) / 64) * p.ld;
+    hipLaunchKernelGGL(dz::k_strip_partial, gcol, b, 0, e->stream, p.cp_new, p.N, p.d, p.ld, e->d_mean, 0, e->d_partial, strip, single ? 1 : 0);
+    hipLaunchKernelGGL(dz::k_strip_dev, gcol, b, 0, e->stream, p.cp_new, p.N, p.d, p.ld, (const double*)e->d_partial, nstrips, partial1, e->d_mean, strip, single ? 1 : 0);
     if (ngc != p.N) {   // single-chain stepping: every other chain contributes nothing this time
         HIPCK(hipMemsetAsync(e->d_binc, 0xFF, sizeof(int) * p.N, e->stream));
         HIPCK(hipMemsetAsync(e->d_bing, 0xFF, sizeof(int) * p.N, e->stream));
     }
-    NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_jump<NCH>, dim3((ngc + 3) / 4), dim3(256), 0, e->stream, p, g, gc0, ngc, e->d_sdc, e->d_sd, e->d_dl, e->d_dlg, e->d_binc, e->d_bing));
+    NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_jump<NCH>, dim3((ngc + dz::JUMP_CHAINS - 1) / dz::JUMP_CHAINS), dim3(256), 0, e->stream, p, g, gc0, ngc, (const double*)partial1, nstrips,
+                                       e->d_sd, e->d_sdc, e->d_dl, e->d_dlg, e->d_binc, e->d_bing));
     hipLaunchKernelGGL(dz::k_adapt_update, dim3(1), dim3(64), 0, e->stream, p, e->d_dl, e->d_dlg, e->d_binc, e->d_bing);
+    if (single && e->d_own_cr)      // the chains that updated the shared probabilities adopt them (Dream.py:375, :383, :409-415)
+        hipLaunchKernelGGL(dz::k_own_probs, dim3((ngc + 63) / 64), dim3(64), 0, e->stream, p, gc0 - p.off, ngc, (const int*)e->d_binc, (const int*)e->d_bing, 0, e->d_own_cr, e->d_own_g);
     return launch_check("adaptation kernels");
 }
 
@@ -442,11 +530,10 @@ int redraw_impossible_sets(dz_engine* e, uint32_t g, int lc0, int lnc, int sp0, 
 {
     dz::Params& p = e->p;
     const int k = p.k;
-    if (!e->d_redo) {
-        DZCK(ealloc(e, &e->d_redo, (size_t)p.nl)); DZCK(ealloc(e, &e->d_redo_list, (size_t)p.nl));
-        HIPCK(hipHostMalloc((void**)&e->h_redo, (size_t)p.nl, hipHostMallocDefault));
-        HIPCK(hipHostMalloc((void**)&e->h_redo_list, sizeof(int32_t) * (size_t)p.nl, hipHostMallocDefault));
-    }
+    if (!e->d_redo) DZCK(ealloc(e, &e->d_redo, (size_t)p.nl));
+    if (!e->d_redo_list) DZCK(ealloc(e, &e->d_redo_list, (size_t)p.nl));
+    if (!e->h_redo && hipHostMalloc((void**)&e->h_redo, (size_t)p.nl, hipHostMallocDefault) != hipSuccess) { e->h_redo = nullptr; return fail("hipHostMalloc (redraw flags) failed"); }
+    if (!e->h_redo_list && hipHostMalloc((void**)&e->h_redo_list, sizeof(int32_t) * (size_t)p.nl, hipHostMallocDefault) != hipSuccess) { e->h_redo_list = nullptr; return fail("hipHostMalloc (redraw list) failed"); }
     for (int round = 1; round <= DZ_MAX_REDRAWS;) {
         hipLaunchKernelGGL(dz::k_redo_flags, dim3((lnc + 255) / 256), dim3(256), 0, st, p, lc0, lnc, e->d_redo);
         DZCK(launch_check("k_redo_flags"));
@@ -464,7 +551,7 @@ int redraw_impossible_sets(dz_engine* e, uint32_t g, int lc0, int lnc, int sp0, 
             const uint64_t key = e->c.seed + (uint64_t)round * DZ_REDRAW_KEY_STEP;
             pr.k0 = (uint32_t)key; pr.k1 = (uint32_t)(key >> 32);
             pr.draws = nullptr; pr.redo_list = e->d_redo_list; pr.redo = e->d_redo;
-            NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((n * sp0 + wpb - 1) / wpb), dim3(64 * wpb), 0, pr, 0, g, (uint32_t)e->M, 0, n, sp0, 0, (int64_t)-1));
+            NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((n * sp0 + wpb - 1) / wpb), dim3(64 * wpb), 0, pr, 0, g, (uint32_t)visible_rows(e), 0, n, sp0, 0, (int64_t)-1));
             DZCK(launch_check("propose(redraw)"));
             const size_t nd2 = (size_t)n * k * p.ld / 2;
             hipLaunchKernelGGL(dz::k_gather_sets, dim3((unsigned)((nd2 + 255) / 256)), dim3(256), 0, st, p, (const int32_t*)e->d_redo_list, n, p.R);
@@ -487,12 +574,29 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
     const int k = p.k;
     const bool full = (c0 == 0 && nc == p.nl);
     if (!full && e->world > 1) return fail("single-chain stepping is not available on a sharded engine");
+    if (!full && e->c.history_lag) return fail("single-chain stepping (Dream.astep) appends with immediate effect: history_lag must be 0");
+    DZCK(ensure_visible(e));
+    const uint32_t Mv = (uint32_t)visible_rows(e);
     const int L = (full && e->lk != LK_HOST && !redo_possible(e)) ? e->nlanes : 1;     // the host-callback likelihood is synchronous anyway; redraw rounds use shared buffers
     if (e->need_join || !full) { DZCK(join_all(e)); e->need_join = false; }
+    p.own_cr = nullptr; p.own_g = nullptr;
+    if (!full && e->adapt) {
+        // Dream.astep chain by chain: every Dream instance decides with its OWN copy of the crossover / gamma-level probabilities
+        // (Dream.py:134, :143; refreshed at :375, :383, :409-415) -- the shared vectors may have moved on through other chains' updates
+        if (!e->d_own_cr) {
+            DZCK(ealloc(e, &e->d_own_cr, (size_t)p.nl * p.ncr)); DZCK(ealloc(e, &e->d_own_g, (size_t)p.nl * p.ngamma));
+            e->own_init.assign((size_t)p.nl, 0);
+        }
+        for (int c = c0; c < c0 + nc; ++c) if (!e->own_init[c]) {
+            hipLaunchKernelGGL(dz::k_own_probs, dim3(1), dim3(64), 0, e->stream, p, c, 1, (const int*)nullptr, (const int*)nullptr, 1, e->d_own_cr, e->d_own_g);
+            e->own_init[c] = 1;
+        }
+        p.own_cr = e->d_own_cr; p.own_g = e->d_own_g;
+    }
     if (full && g == 0 && e->adapt) {   // publish the start positions (Dream_shared_vars.current_positions)
         const size_t n = (size_t)p.nl * p.ld;
         hipLaunchKernelGGL(dz::k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, p.X, p.cp_new + (size_t)p.off * p.ld, n);
-        DZCK(allgather_rows(e, p.cp_new));
+        DZCK(exchange_rows(e, XK_POS, p.cp_new, 0));
         DZCK(join_all(e));
     }
     p.draws = e->d_draws[g & 1]; p.draws_next = e->d_draws[(g + 1) & 1];
@@ -504,7 +608,7 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
     const int nrows = full ? p.N : nc;
     if (append && e->M + nrows > e->c.history_capacity) return fail("history capacity exceeded");
     if (publish) {
-        if (full) std::swap(p.cp_prev, p.cp_new);
+        if (full) { e->cp_idx = (e->cp_idx + 1) % 3; p.cp_prev = p.cp_new; p.cp_new = e->d_cp[e->cp_idx]; }      // (three buffers: a peer may be one generation ahead)
         else {   // the jump of a single chain is measured from its state at the start of the step
             const size_t n = (size_t)nc * p.ld;
             hipLaunchKernelGGL(dz::k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, p.X + (size_t)c0 * p.ld, p.cp_prev + (size_t)(p.off + c0) * p.ld, n);
@@ -530,18 +634,18 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
         hipStream_t st = e->lane_stream[s];
         if (need_draws)
             hipLaunchKernelGGL(dz::k_draws, dim3((lnc * p.nslots + 255) / 256), dim3(256), 0, st, p, g, lc0, lnc, e->d_draws[g & 1], e->d_ctl[g & 1]);
-        if (streamed && !fused_in) DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose_stream, dim3((lnc * k + 3) / 4), dim3(256), 0, p, 0, g, (uint32_t)e->M, lc0, lnc);
+        if (streamed && !fused_in) DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose_stream, dim3((lnc * k + 3) / 4), dim3(256), 0, p, 0, g, Mv, lc0, lnc);
         else {
-            if (fused_in) { NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc + wpb - 1) / wpb), dim3(64 * wpb), 0, p, 0, g, (uint32_t)e->M, lc0, lnc, 1, 1, e->pending_slot)); }
-            else { NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc * sp0 + wpb - 1) / wpb), dim3(64 * wpb), 0, p, 0, g, (uint32_t)e->M, lc0, lnc, sp0, 0, (int64_t)-1)); }
+            if (fused_in) { NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc + wpb - 1) / wpb), dim3(64 * wpb), 0, p, 0, g, Mv, lc0, lnc, 1, 1, e->pending_slot)); }
+            else { NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc * sp0 + wpb - 1) / wpb), dim3(64 * wpb), 0, p, 0, g, Mv, lc0, lnc, sp0, 0, (int64_t)-1)); }
         }
         DZCK(launch_check("propose"));
         DZCK(eval_logp(e, p.P + (size_t)lc0 * k * p.ld, lnc * k, p.p_prior + (size_t)lc0 * k, p.p_like + (size_t)lc0 * k, st));
         if (redo) DZCK(redraw_impossible_sets(e, g, lc0, lnc, sp0, wpb, st));
         if (k > 1) {
-            if (streamed) DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose_stream, dim3((lnc * (k - 1) + 3) / 4), dim3(256), 0, p, 1, g, (uint32_t)e->M, lc0, lnc);
+            if (streamed) DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose_stream, dim3((lnc * (k - 1) + 3) / 4), dim3(256), 0, p, 1, g, Mv, lc0, lnc);
             else {
-                NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc * sp1 + wpb - 1) / wpb), dim3(64 * wpb), 0, p, 1, g, (uint32_t)e->M, lc0, lnc, sp1, 0, (int64_t)-1));
+                NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc * sp1 + wpb - 1) / wpb), dim3(64 * wpb), 0, p, 1, g, Mv, lc0, lnc, sp1, 0, (int64_t)-1));
             }
             DZCK(launch_check("propose(ref)"));
             DZCK(eval_logp(e, p.R + (size_t)lc0 * (k - 1) * p.ld, lnc * (k - 1), p.r_prior + (size_t)lc0 * (k - 1), p.r_like + (size_t)lc0 * (k - 1), st));
@@ -556,10 +660,10 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
     if (publish || append) {         // shared state changed: the lanes meet before anything reads it
         if (L > 1) DZCK(join_all(e));
         if (publish) {
-            if (full) DZCK(allgather_rows(e, p.cp_new));
+            if (full) DZCK(exchange_rows(e, XK_POS, p.cp_new, 0));
             DZCK(adapt_generation(e, g, full ? 0 : p.off + c0, full ? p.N : nc));
         }
-        if (append) { if (full) DZCK(allgather_rows(e, p.Z + (size_t)e->M * p.ld)); e->M += nrows; }
+        if (append) { if (full) DZCK(exchange_rows(e, XK_Z, p.Z, (size_t)e->M)); e->M += nrows; e->napp += 1; }
         e->need_join = true;
     }
     if (e->tempering && full) {      // temperature swap (core.py:185-221): after every chain's step and the updates above
@@ -618,11 +722,28 @@ bool mega_eligible(const dz_engine* e)
 }
 // number of generations, starting at g, that one launch may cover: none of them publishes positions
 // (crossover burn-in), and only the last one may append to the history
+// The persistent kernels read Params through a pointer: the device copy is refreshed when a field THEY read has changed (the buffers
+// that rotate from generation to generation -- published positions, the draw tables of the multi-kernel path -- are not among them).
+int upload_params(dz_engine* e)
+{
+    dz::Params q = e->p;
+    q.cp_prev = nullptr; q.cp_new = nullptr; q.draws = nullptr; q.draws_next = nullptr; q.ctl = nullptr; q.ctl_next = nullptr;
+    q.own_cr = nullptr; q.own_g = nullptr; q.redo = nullptr; q.redo_list = nullptr;
+    if (e->params_uploaded && memcmp(&e->p_shadow, &q, sizeof(dz::Params)) == 0) return 0;
+    // (through a staging copy that outlives the call: the source of an asynchronous copy from pageable memory must not be a local)
+    memcpy(&e->p_shadow, &q, sizeof(dz::Params));
+    HIPCK(hipMemcpyAsync(e->d_params, &e->p_shadow, sizeof(dz::Params), hipMemcpyHostToDevice, e->stream));
+    e->params_uploaded = true;
+    return 0;
+}
+bool publishing(const dz_engine* e, uint32_t g) { return e->adapt && (int64_t)g < (int64_t)e->p.burnin + 1; }      // Dream.py:364
 int mega_segment(const dz_engine* e, uint32_t g, int64_t remaining)
 {
+    // crossover burn-in: the positions are published and the probabilities adapted after every generation -- one generation per launch
+    if (publishing(e, g)) return (e->mega_burnin && remaining > 0) ? 1 : 0;
     int n = 0;
     for (uint32_t gg = g; n < remaining && n < e->mega_max_gen; ++gg) {
-        if (e->adapt && (int64_t)gg < (int64_t)e->p.burnin + 1) break;
+        if (publishing(e, gg)) break;
         ++n;
         if (gg % (uint32_t)e->p.thin == 0) break;
     }
@@ -634,23 +755,33 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
     const bool append_last = ((g + (uint32_t)n - 1) % (uint32_t)p.thin) == 0;
     if (append_last && e->M + p.N > e->c.history_capacity) return fail("history capacity exceeded");
     DZCK(join_all(e));
-    const int64_t slot0 = e->c.trace_capacity ? e->ntrace : -1;
-    if (e->lk == LK_MIX) {
-        if (!e->params_uploaded || memcmp(&e->p_shadow, &p, sizeof(dz::Params)) != 0) {
-            HIPCK(hipMemcpyAsync(e->d_params, &p, sizeof(dz::Params), hipMemcpyHostToDevice, e->stream));
-            memcpy(&e->p_shadow, &p, sizeof(dz::Params));
-            e->params_uploaded = true;
-        }
-        const dim3 gridm((p.nl + dz::MIXW - 1) / dz::MIXW), blockm(64 * dz::MIXW);
-        const size_t ldsm = sizeof(double) * (size_t)dz::MIXW * dz::mega_mix_wave_doubles(p.d, p.k, p.J);
-        DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, dz::k_generations_mix, gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)e->M, slot0, append_last ? 1 : 0);
-        DZCK(launch_check("k_generations_mix"));
-        e->last_variant = "k_generations_mix";
-        if (append_last) { DZCK(allgather_rows(e, p.Z + (size_t)e->M * p.ld)); e->M += p.N; }
+    DZCK(ensure_visible(e));
+    const bool publish = publishing(e, g);            // (then n == 1: mega_segment)
+    if (g == 0 && e->adapt) {   // publish the start positions (Dream_shared_vars.current_positions)
+        const size_t nn = (size_t)p.nl * p.ld;
+        hipLaunchKernelGGL(dz::k_copy_rows, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, e->stream, p.X, p.cp_new + (size_t)p.off * p.ld, nn);
+        DZCK(exchange_rows(e, XK_POS, p.cp_new, 0));
+    }
+    if (publish) { e->cp_idx = (e->cp_idx + 1) % 3; p.cp_prev = p.cp_new; p.cp_new = e->d_cp[e->cp_idx]; }
+    double* pubto = publish ? p.cp_new : nullptr;
+    auto after_launch = [&]() -> int {      // end of the generation(s): positions -> adaptation -> history append (schedule S2)
+        if (publish) { DZCK(exchange_rows(e, XK_POS, p.cp_new, 0)); DZCK(adapt_generation(e, g, 0, p.N)); }
+        if (append_last) { DZCK(exchange_rows(e, XK_Z, p.Z, (size_t)e->M)); e->M += p.N; e->napp += 1; }
         e->need_join = true;
         e->draws_gen = -1;
         e->gen = (int64_t)g + n;
         for (auto& gcv : e->gen_c) gcv = e->gen;
+        return 0;
+    };
+    const int64_t slot0 = e->c.trace_capacity ? e->ntrace : -1;
+    if (e->lk == LK_MIX) {
+        DZCK(upload_params(e));
+        const dim3 gridm((p.nl + dz::MIXW - 1) / dz::MIXW), blockm(64 * dz::MIXW);
+        const size_t ldsm = sizeof(double) * (size_t)dz::MIXW * dz::mega_mix_wave_doubles(p.d, p.k, p.J);
+        DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, dz::k_generations_mix, gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, pubto);
+        DZCK(launch_check("k_generations_mix"));
+        e->last_variant = "k_generations_mix";
+        DZCK(after_launch());
         if (slot0 >= 0) e->ntrace += n;
         return 0;
     }
@@ -665,17 +796,13 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
     const bool xlds = mega_xlds(e);
     const bool pb = p.hard || p.have_prior || p.depairs > 1;      // the instantiations with the full proposal code
     const size_t lds = mega_lds_bytes(e, xlds);
-    if (!e->params_uploaded || memcmp(&e->p_shadow, &p, sizeof(dz::Params)) != 0) {   // the kernel reads Params through a pointer
-        HIPCK(hipMemcpyAsync(e->d_params, &p, sizeof(dz::Params), hipMemcpyHostToDevice, e->stream));
-        memcpy(&e->p_shadow, &p, sizeof(dz::Params));
-        e->params_uploaded = true;
-    }
+    DZCK(upload_params(e));
     {
         // the instantiations live in one translation unit per row-tile count (dz_mega_tu.hip)
         dz::MegaLaunch ml;
         ml.tri = p.tri != 0; ml.xlds = pb ? true : xlds; ml.pb = pb; ml.k1 = k1; ml.ch = ch; ml.wpc = wpc;
         ml.grid = grid; ml.block = block; ml.lds = lds; ml.st = e->stream; ml.ka = nullptr; ml.kb = nullptr;
-        ml.pp = (const dz::Params*)e->d_params; ml.g = g; ml.n = n; ml.M = (uint32_t)e->M; ml.slot0 = slot0; ml.append_last = append_last ? 1 : 0;
+        ml.pp = (const dz::Params*)e->d_params; ml.g = g; ml.n = n; ml.M = (uint32_t)visible_rows(e); ml.slot0 = slot0; ml.zappend = append_last ? e->M : (int64_t)-1; ml.publish = pubto;
         if (e->prof) { ml.ka = prof_event(e); ml.kb = prof_event(e); e->ev[PR_GENERATIONS].emplace_back(ml.ka, ml.kb); }
         const char* name = nullptr;
         switch (nrt) {
@@ -689,11 +816,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
         e->last_variant = buf;
     }
     DZCK(launch_check("k_generations"));
-    if (append_last) { DZCK(allgather_rows(e, p.Z + (size_t)e->M * p.ld)); e->M += p.N; }
-    e->need_join = true;
-    e->draws_gen = -1;
-    e->gen = (int64_t)g + n;
-    for (auto& gcv : e->gen_c) gcv = e->gen;
+    DZCK(after_launch());
     if (slot0 >= 0) e->ntrace += n;
     return 0;
 }
@@ -725,6 +848,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     if (cfg->chain_offset < 0 || cfg->chain_offset + cfg->nchains_local > cfg->nchains) return fail("bad shard");
     if (cfg->nchains % cfg->nchains_local) return fail("nchains must be a multiple of nchains_local");
     if (cfg->history_thin < 1) return fail("history_thin must be >= 1");
+    if (cfg->history_lag < 0 || cfg->history_lag > 64) return fail("history_lag must be 0..64");
     int ndev = 0;
     hipError_t derr = hipGetDeviceCount(&ndev);
     if (derr != hipSuccess || ndev < 1) return fail("no HIP device available: libdreamzs has no CPU fallback");
@@ -736,6 +860,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     if (const char* kv = getenv("DZ_STREAM")) e->stream_propose = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA")) e->mega = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_MAXGEN")) e->mega_max_gen = std::max(1, atoi(kv));
+    if (const char* kv = getenv("DZ_MEGA_BURNIN")) e->mega_burnin = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_LOGP_BM")) e->logp_bm = atoi(kv);          // 64 / 128: points per block of k_logp_mvn_gemm (default: by size)
     if (const char* kv = getenv("DZ_MEGA_CHAINS")) { const int v = atoi(kv); e->mega_ch = (v == 16 || v == 8 || v == 4) ? v : 0; }
     if (const char* kv = getenv("DZ_WPB")) e->waves_per_block = atoi(kv);
@@ -798,8 +923,9 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     rc |= ealloc(e, &e->d_shared, (size_t)3 * (cfg->ncr + cfg->ngamma));
     rc |= ealloc(e, &e->d_pkind, ld); rc |= ealloc(e, &e->d_pa, ld); rc |= ealloc(e, &e->d_pb, ld); rc |= ealloc(e, &e->d_plogb, ld);
     if (e->adapt) {
-        rc |= ealloc(e, &p.cp_prev, N * ld); rc |= ealloc(e, &p.cp_new, N * ld);
-        rc |= ealloc(e, &e->d_partial, (size_t)((N + 63) / 64) * ld);
+        for (int i = 0; i < 3; ++i) rc |= ealloc(e, &e->d_cp[i], N * ld);
+        p.cp_prev = e->d_cp[0]; p.cp_new = e->d_cp[1]; e->cp_idx = 1;
+        rc |= ealloc(e, &e->d_partial, (size_t)2 * ((N + 63) / 64) * ld);      // strip sums of pass 0 | of pass 1
         rc |= ealloc(e, &e->d_mean, ld); rc |= ealloc(e, &e->d_sd, ld); rc |= ealloc(e, &e->d_sdc, ld);
         rc |= ealloc(e, &e->d_dl, N); rc |= ealloc(e, &e->d_dlg, N); rc |= ealloc(e, &e->d_binc, N); rc |= ealloc(e, &e->d_bing, N);
     }
@@ -845,6 +971,14 @@ int dz_destroy(dz_engine* e)
     for (auto& v : e->ev) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t x : e->ev_pool) (void)hipEventDestroy(x);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
+    for (auto& pr : e->peers) {
+        if (pr.st) { (void)hipStreamSynchronize(pr.st); (void)hipStreamDestroy(pr.st); }
+        if (pr.Z) (void)hipIpcCloseMemHandle(pr.Z);
+        if (pr.flags) (void)hipIpcCloseMemHandle(pr.flags);
+        for (double* q : pr.cp) if (q) (void)hipIpcCloseMemHandle(q);
+    }
+    for (hipEvent_t x : e->push_ev) if (x) (void)hipEventDestroy(x);
+    if (e->h_gate) (void)hipHostFree(e->h_gate);
     for (void* q : e->to_free) (void)hipFree(q);
     if (e->d_scratch) (void)hipFree(e->d_scratch);
     if (e->d_qpart) (void)hipFree(e->d_qpart);
@@ -894,7 +1028,7 @@ int dz_set_history(dz_engine* e, const double* Z, int64_t rows)
     if (rows > e->c.history_capacity) return fail("history exceeds capacity");
     if (rows > 0xffffffffll) return fail("history too long");
     DZCK(upload_padded(e, e->p.Z, Z, (int)rows, 0.0));
-    e->M = rows;
+    e->M = rows; e->napp = 0;
     return 0;
 }
 
@@ -916,6 +1050,7 @@ int dz_set_cr_probs(dz_engine* e, const double* pr, int32_t n)
     HIPCK(hipSetDevice(e->c.device));
     DZCK(sync_all(e));
     HIPCK(hipMemcpy(e->p.cr_probs, pr, sizeof(double) * n, hipMemcpyHostToDevice));
+    std::fill(e->own_init.begin(), e->own_init.end(), 0);
     e->draws_gen = -1;
     return 0;
 }
@@ -925,6 +1060,7 @@ int dz_set_gamma_probs(dz_engine* e, const double* pr, int32_t n)
     HIPCK(hipSetDevice(e->c.device));
     DZCK(sync_all(e));
     HIPCK(hipMemcpy(e->p.g_probs, pr, sizeof(double) * n, hipMemcpyHostToDevice));
+    std::fill(e->own_init.begin(), e->own_init.end(), 0);
     e->draws_gen = -1;
     return 0;
 }
@@ -1033,6 +1169,74 @@ int dz_comm_init_rccl(dz_engine* e, int32_t rank, int32_t world, const void* id1
 
 int dz_set_exchange(dz_engine* e, dz_exchange_cb cb, void* user) { e->xcb = cb; e->xcb_user = user; return 0; }
 
+// ---- peer transport: rows pushed by the copy engines into the other ranks' buffers, mapped through HIP IPC ----
+namespace {
+struct PeerBlob {          // what a rank publishes about itself (DZ_PEER_BLOB_BYTES)
+    uint32_t magic, nchains, nchains_local, ld; int64_t capacity; int32_t has_cp, rank;
+    hipIpcMemHandle_t z, flags, cp[3];
+};
+static_assert(sizeof(PeerBlob) <= DZ_PEER_BLOB_BYTES, "PeerBlob does not fit DZ_PEER_BLOB_BYTES");
+}  // namespace
+
+int dz_peer_export(dz_engine* e, void* blob)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    if (e->world < 2) return fail("dz_peer_export: the engine is not sharded");
+    if (!e->d_flags) {
+        DZCK(ealloc(e, &e->d_flags, (size_t)2 * e->world));
+        // one flag push per history append and per published generation: bounded by the archive's capacity and the burn-in
+        e->seq_cap = (e->c.history_capacity / std::max(1, e->p.N)) + (int64_t)e->c.crossover_burnin + 16;
+        if (e->seq_cap > ((int64_t)1 << 24)) e->seq_cap = (int64_t)1 << 24;
+        DZCK(ealloc(e, &e->d_seq, (size_t)e->seq_cap));
+        std::vector<unsigned long long> h((size_t)e->seq_cap);
+        for (size_t i = 0; i < h.size(); ++i) h[i] = i;
+        HIPCK(hipMemcpy(e->d_seq, h.data(), sizeof(unsigned long long) * h.size(), hipMemcpyHostToDevice));
+        HIPCK(hipHostMalloc((void**)&e->h_gate, 4 * sizeof(unsigned long long), hipHostMallocMapped));
+        memset(e->h_gate, 0, 4 * sizeof(unsigned long long));
+    }
+    PeerBlob b; memset(&b, 0, sizeof b);
+    b.magic = 0x445a5058u; b.nchains = (uint32_t)e->p.N; b.nchains_local = (uint32_t)e->p.nl; b.ld = (uint32_t)e->p.ld; b.capacity = e->c.history_capacity;
+    b.has_cp = e->adapt ? 1 : 0; b.rank = e->rank;
+    HIPCK(hipIpcGetMemHandle(&b.z, e->p.Z));
+    HIPCK(hipIpcGetMemHandle(&b.flags, e->d_flags));
+    if (e->adapt) for (int i = 0; i < 3; ++i) HIPCK(hipIpcGetMemHandle(&b.cp[i], e->d_cp[i]));
+    memset(blob, 0, DZ_PEER_BLOB_BYTES);
+    memcpy(blob, &b, sizeof b);
+    return 0;
+}
+
+int dz_peer_attach(dz_engine* e, int32_t rank, int32_t world, const void* blobs)
+{
+    HIPCK(hipSetDevice(e->c.device));
+    if (world != e->world || rank != e->rank) return fail("rank/world do not match the chain shard in dz_config");
+    if (!e->d_flags) return fail("dz_peer_attach: call dz_peer_export first");
+    if (e->peer_on) return fail("dz_peer_attach: already attached");
+    e->peers.assign((size_t)world, dz_engine::Peer());
+    for (int r = 0; r < world; ++r) {
+        if (r == rank) continue;
+        PeerBlob b; memcpy(&b, (const char*)blobs + (size_t)r * DZ_PEER_BLOB_BYTES, sizeof b);
+        if (b.magic != 0x445a5058u || b.rank != r) return fail("dz_peer_attach: blob " + std::to_string(r) + " is not rank " + std::to_string(r) + "'s export");
+        if ((int)b.nchains != e->p.N || (int)b.nchains_local != e->p.nl || (int)b.ld != e->p.ld || b.capacity != e->c.history_capacity || b.has_cp != (e->adapt ? 1 : 0))
+            return fail("dz_peer_attach: rank " + std::to_string(r) + " was created with a different configuration");
+        dz_engine::Peer& pr = e->peers[r];
+        HIPCK(hipIpcOpenMemHandle((void**)&pr.Z, b.z, hipIpcMemLazyEnablePeerAccess));
+        HIPCK(hipIpcOpenMemHandle((void**)&pr.flags, b.flags, hipIpcMemLazyEnablePeerAccess));
+        if (e->adapt) for (int i = 0; i < 3; ++i) HIPCK(hipIpcOpenMemHandle((void**)&pr.cp[i], b.cp[i], hipIpcMemLazyEnablePeerAccess));
+        HIPCK(hipStreamCreateWithFlags(&pr.st, hipStreamNonBlocking));
+    }
+    for (int i = 0; i < 8; ++i) HIPCK(hipEventCreateWithFlags(&e->push_ev[i], hipEventDisableTiming));
+    e->peer_on = true;
+    return 0;
+}
+
+int dz_exchange_stats(dz_engine* e, int64_t* exchanges, int64_t* gates, double* gate_wait_us)
+{   // (k_peer_gate's counters; call after dz_sync)
+    if (exchanges) *exchanges = e->z_pushed + e->pos_pushed;
+    if (gates) *gates = e->h_gate ? (int64_t)e->h_gate[1] : 0;
+    if (gate_wait_us) *gate_wait_us = e->h_gate ? (double)e->h_gate[0] * 0.01 : 0.0;      // 100 MHz ticks
+    return 0;
+}
+
 // A rendezvous of the ranks on the device: a one-element all-gather on the engine's stream, then a stream synchronise.  Ranks leave
 // an RCCL collective within microseconds of each other (a host barrier's exits are spread by tens of microseconds), which is what a
 // timed region over a few hundred microseconds wants in front of it.  No communicator (one GPU, or the host transport): just the sync.
@@ -1083,6 +1287,8 @@ int dz_step(dz_engine* e, int64_t generations)
     }
     for (int c = 1; c < e->p.nl; ++c) if (e->gen_c[c] != e->gen_c[0]) return fail("chains are out of lockstep (single-chain stepping in progress)");
     e->gen = e->gen_c[0];
+    e->p.own_cr = nullptr; e->p.own_g = nullptr;                   // lockstep generations read the shared probabilities;
+    std::fill(e->own_init.begin(), e->own_init.end(), 0);          // a later single-chain step starts from them again
     const bool mega = mega_eligible(e);
     for (int64_t i = 0; i < generations;) {
         const int n = mega ? mega_segment(e, (uint32_t)e->gen, generations - i) : 0;
@@ -1136,11 +1342,22 @@ int dz_get_chain_state(dz_engine* e, int32_t c, double* x, double* prior, double
     return 0;
 }
 
+int dz_get_chain_probs(dz_engine* e, int32_t c, double* cr_probs, double* gamma_probs)
+{   // Dream.CR_probabilities / Dream.gamma_probabilities of the instance that drives chain c (Dream.py:375, :383)
+    HIPCK(hipSetDevice(e->c.device));
+    if (c < 0 || c >= e->p.nl) return fail("bad chain index");
+    DZCK(sync_all(e));
+    const bool own = e->d_own_cr && c < (int)e->own_init.size() && e->own_init[c];
+    if (cr_probs) HIPCK(hipMemcpy(cr_probs, own ? e->d_own_cr + (size_t)c * e->p.ncr : e->p.cr_probs, sizeof(double) * e->p.ncr, hipMemcpyDeviceToHost));
+    if (gamma_probs) HIPCK(hipMemcpy(gamma_probs, own ? e->d_own_g + (size_t)c * e->p.ngamma : e->p.g_probs, sizeof(double) * e->p.ngamma, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int dz_sync(dz_engine* e)
 {
     HIPCK(hipSetDevice(e->c.device));
     DZCK(sync_all(e));
-    return 0;
+    return peer_check(e);
 }
 int dz_trace_reset(dz_engine* e) { e->ntrace = 0; return 0; }
 int64_t dz_generation(dz_engine* e) { return e->gen; }
@@ -1266,8 +1483,9 @@ int dz_trace_download_wait(dz_engine* e)
 int dz_host_register(void* ptr, int64_t bytes)
 {
     // Page-locking a freshly allocated array is mostly the kernel faulting its pages in, one at a time, on the calling thread (6.5 GB:
-    // 0.27 s).  Large ranges are first touched by several threads -- a byte per page rewritten with its own value, so the contents are
-    // kept -- after asking for huge pages; hipHostRegister then finds the pages present.  DZ_PIN_THREADS (default 8, 1 = off).
+    // 0.27 s).  Large ranges are first populated by several threads after asking for huge pages -- madvise(MADV_POPULATE_WRITE) where the
+    // kernel has it (5.14+), else an atomic add of zero to a byte of every page: either way nothing another thread writes meanwhile is
+    // lost --; hipHostRegister then finds the pages present.  DZ_PIN_THREADS (default 8, 1 = off).
     int nt = 8;
     if (const char* s = getenv("DZ_PIN_THREADS")) nt = std::max(1, std::min(64, atoi(s)));
     if (bytes >= ((int64_t)64 << 20) && nt > 1) {
@@ -1278,8 +1496,13 @@ int dz_host_register(void* ptr, int64_t bytes)
             std::vector<std::thread> th;
             for (int t = 0; t < nt; ++t)
                 th.emplace_back([=] {
-                    volatile unsigned char* q = (volatile unsigned char*)lo;
-                    for (uintptr_t i = npages * t / nt; i < npages * (t + 1) / nt; ++i) q[i * page] = q[i * page];
+                    const uintptr_t i0 = npages * t / nt, i1 = npages * (t + 1) / nt;
+                    if (i1 <= i0) return;
+#ifdef MADV_POPULATE_WRITE
+                    if (madvise((void*)(lo + i0 * page), (i1 - i0) * page, MADV_POPULATE_WRITE) == 0) return;
+#endif
+                    unsigned char* q = (unsigned char*)lo;
+                    for (uintptr_t i = i0; i < i1; ++i) __atomic_fetch_add(q + i * page, (unsigned char)0, __ATOMIC_RELAXED);
                 });
             for (auto& x : th) x.join();
         }
@@ -1297,7 +1520,13 @@ int dz_get_history(dz_engine* e, double* Z, int64_t cap_rows, int64_t* rows)
 {
     HIPCK(hipSetDevice(e->c.device));
     if (rows) *rows = e->M;
-    if (Z) { if (cap_rows < e->M) return fail("buffer too small"); DZCK(download_rows(e, Z, e->p.Z, (size_t)e->M)); }
+    if (Z) {
+        if (cap_rows < e->M) return fail("buffer too small");
+        // peer transport with history_lag: the rows of the last appends may still be on their way
+        if (e->peer_on && e->z_gated < e->napp) { DZCK(peer_gate(e, XK_Z, (unsigned long long)e->napp)); e->z_gated = e->napp; }
+        DZCK(download_rows(e, Z, e->p.Z, (size_t)e->M));
+        DZCK(peer_check(e));
+    }
     return 0;
 }
 
@@ -1417,6 +1646,17 @@ int dz_profile_get(dz_engine* e, int32_t which, double* total_ms, int64_t* launc
     double tot = 0.0;
     for (auto& pr : e->ev[which]) { float ms = 0.f; HIPCK(hipEventElapsedTime(&ms, pr.first, pr.second)); tot += ms; }
     if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int64_t)e->ev[which].size();
+    return 0;
+}
+
+int dz_profile_get_list(dz_engine* e, int32_t which, double* ms, int64_t cap, int64_t* launches)
+{   // the individual launches of a class, in launch order (dz_profile_get gives their sum)
+    if (which < 0 || which >= PR_COUNT) return fail("bad profile class");
+    HIPCK(hipSetDevice(e->c.device));
+    DZCK(sync_all(e));
+    int64_t i = 0;
+    for (auto& pr : e->ev[which]) { if (i >= cap) break; float t = 0.f; HIPCK(hipEventElapsedTime(&t, pr.first, pr.second)); ms[i++] = t; }
     if (launches) *launches = (int64_t)e->ev[which].size();
     return 0;
 }

@@ -51,6 +51,10 @@ struct Params {
     unsigned long long snk_thr;   // ceil(snooker 2^53): the same for set_snooker's draw (0 when snooker == 0)
     const uint8_t* redo;      // redraw round only: [nl] 1 = every try of the chain's current set is impossible (k_redo_flags); a listed chain whose flag has cleared is left alone
     const int32_t* redo_list; // redraw round only (Dream.py:281-289; redraw_impossible_sets): the local chains whose proposal set is drawn again -- wave w works on chain redo_list[w / split]; null otherwise
+    // Dream.astep driven chain by chain (dz_step_range, schedule S1): every Dream instance keeps its OWN copy of the crossover / gamma-level
+    // probabilities (Dream.py:375, :383, :497, :538, :409-415), refreshed only by its own adaptation updates; [nl][ncr] / [nl][ngamma], or
+    // null in lockstep mode (every chain reads the shared vectors)
+    const double *own_cr, *own_g;
     unsigned long long* dbg;  // cycle-stamp buffer of instrumented builds (-DDZ_EXPERIMENTS, dz_experiments.h); null otherwise
 };
 // per-phase cycle stamps: defined by dz_experiments.h in instrumented builds only (tools/variants.sh), no-ops in the product
@@ -80,6 +84,11 @@ DZ_DEV StepFlags step_flags_from(const Params& p, const Ctrl& u, const double* c
     return f;
 }
 DZ_DEV StepFlags step_flags(const Params& p, const Ctrl& u) { return step_flags_from(p, u, p.cr_probs, p.g_probs); }
+// ... of LOCAL chain c: its own copy of the probabilities under single-chain stepping (Params::own_cr), else the shared ones
+DZ_DEV StepFlags step_flags_chain(const Params& p, const Ctrl& u, int c)
+{
+    return step_flags_from(p, u, p.own_cr ? p.own_cr + (size_t)c * p.ncr : p.cr_probs, p.own_g ? p.own_g + (size_t)c * p.ngamma : p.g_probs);
+}
 
 // mt_choose_proposal_pt :883-917.  Lane i < k evaluates try i's weight (one dexp per wave instead of
 // k); the sums run over the tries in order, so every lane ends with the same scalars.
@@ -1590,9 +1599,34 @@ __global__ void k_draws(Params p, uint32_t g, int c0, int nc, uint4* __restrict_
     out[(size_t)c * p.nslots + slot] = make_uint4(w.x, w.y, w.z, w.w);
     if (slot == 0) {
         const Ctrl u = draw_ctrl(p.k0, p.k1, gc, g);
-        const StepFlags f = step_flags(p, u);
+        const StepFlags f = step_flags_chain(p, u, c);
         ChainCtl o; o.snk = f.snk ? 1 : 0; o.cr_idx = f.cr_idx; o.delta = f.delta; o.glev = f.glev; o.u_sel = u.u_sel; o.u_acc = u.u_acc;
         ctl[c] = o;
+    }
+}
+
+// Peer exchange (dz_peer_attach): waits until every other rank's copy engine has delivered its rows of exchange number `need` -- the
+// rank's flag word, written behind the rows on the same copy stream, has reached `need`.  One wave, lane r polls rank r's flag with
+// system-scope loads (the words are written by another GPU's DMA engine).  Runs as a kernel of its own IN FRONT of the kernels that read
+// the rows, so that those start behind a kernel boundary (their caches hold nothing of the freshly written lines).  stats (host-mapped):
+// [0] ticks of the 100 MHz clock spent waiting, [1] gates passed, [2] set to 1 + the missing rank when `timeout_ticks` run out.
+__global__ __launch_bounds__(64) void k_peer_gate(const unsigned long long* __restrict__ flags, int world, int rank, unsigned long long need,
+                                                   unsigned long long timeout_ticks, unsigned long long* __restrict__ stats)
+{
+    const int r = threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    bool ok = (r >= world) || (r == rank);
+    unsigned long long t1 = t0;
+    while (!__all(ok)) {
+        if (!ok) ok = __hip_atomic_load(flags + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need;
+        t1 = wall_clock64();
+        if (t1 - t0 > timeout_ticks) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    const unsigned long long bad = __ballot(!ok);
+    if (r == 0) {
+        stats[0] += t1 - t0; stats[1] += 1ull;
+        if (bad) stats[2] = 1ull + (unsigned long long)__ffsll((long long)bad) - 1ull;
     }
 }
 
@@ -1609,16 +1643,30 @@ __global__ void k_copy_rows(const double* __restrict__ src, double* __restrict__
 // np.std(axis=0) :476 in two-level order: strips of 64 rows, then strips in order.
 // ------------------------------------------------------------------------------------------
 // pass 0: partial[s][j] = sum rows of strip s; pass 1: sum of squared deviations from mean[j]
-__global__ void k_strip_partial(const double* __restrict__ pos, int N, int d, int ld, const double* __restrict__ mean, int pass, double* __restrict__ partial)
+// strip = 64 (lockstep generations); single-chain stepping (schedule S1) sums all N rows in row order, squares by multiply-then-add --
+// numpy's own order for np.std(axis=0): strip = N, plain = 1
+__global__ void k_strip_partial(const double* __restrict__ pos, int N, int d, int ld, const double* __restrict__ mean, int pass, double* __restrict__ partial, int strip, int plain)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int s = blockIdx.y;
     if (j >= d) return;
-    const int r0 = s * 64, r1 = min(N, r0 + 64);
+    const int r0 = s * strip, r1 = min(N, r0 + strip);
     double ps = 0.0;
     if (pass == 0) for (int c = r0; c < r1; ++c) ps = ps + pos[(size_t)c * ld + j];
+    else if (plain) { const double m = mean[j]; for (int c = r0; c < r1; ++c) { const double t = pos[(size_t)c * ld + j] - m; ps = ps + t * t; } }
     else { const double m = mean[j]; for (int c = r0; c < r1; ++c) { const double t = pos[(size_t)c * ld + j] - m; ps = fma(t, t, ps); } }
     partial[(size_t)s * ld + j] = ps;
+}
+// single-chain stepping: the chains of [c0, c0 + nc) that have just updated the shared probabilities adopt them as their own copy
+// (Dream.py:375 / :383 through :497 / :538; at the end of the burn-in :409-415 -- there binc / bing are set as well); init != 0: all of
+// the range's chains take the shared vectors (a chain's first step, Dream.py:134 / :143)
+__global__ void k_own_probs(Params p, int c0, int nc, const int* __restrict__ binc, const int* __restrict__ bing, int init, double* __restrict__ own_cr, double* __restrict__ own_g)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nc) return;
+    const int c = c0 + t, gcn = p.off + c;
+    if (init || binc[gcn] >= 0) for (int m = 0; m < p.ncr; ++m) own_cr[(size_t)c * p.ncr + m] = p.cr_probs[m];
+    if (init || bing[gcn] >= 0) for (int m = 0; m < p.ngamma; ++m) own_g[(size_t)c * p.ngamma + m] = p.g_probs[m];
 }
 // pass 0: mean[j] = (sum_s partial)/N ; pass 1: sd[j] = sqrt((sum_s partial)/N), sdc = sd with 0 -> 1e-12 (:479)
 __global__ void k_strip_finish(const double* __restrict__ partial, int nstrips, int N, int d, int ld, int pass, double* __restrict__ mean, double* __restrict__ sd, double* __restrict__ sdc)
@@ -1630,52 +1678,85 @@ __global__ void k_strip_finish(const double* __restrict__ partial, int nstrips, 
     if (pass == 0) mean[j] = tot / (double)N;
     else { const double v = sqrt(tot / (double)N); sd[j] = v; sdc[j] = v == 0.0 ? 1e-12 : v; }
 }
+// k_strip_finish(pass 0) and k_strip_partial(pass 1) in one launch: every block makes the column means it needs itself, from the strip sums
+// of pass 0 in strip order (the same additions k_strip_finish makes), then its strip's sum of squared deviations
+__global__ void k_strip_dev(const double* __restrict__ pos, int N, int d, int ld, const double* __restrict__ partial0, int nstrips, double* __restrict__ partial1,
+                            double* __restrict__ mean_out, int strip, int plain)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.y;
+    if (j >= d) return;
+    double tot = 0.0;
+    for (int s2 = 0; s2 < nstrips; ++s2) tot = tot + partial0[(size_t)s2 * ld + j];
+    const double m = tot / (double)N;
+    if (s == 0) mean_out[j] = m;
+    const int r0 = s * strip, r1 = min(N, r0 + strip);
+    double ps = 0.0;
+    if (plain) for (int c = r0; c < r1; ++c) { const double t = pos[(size_t)c * ld + j] - m; ps = ps + t * t; }
+    else for (int c = r0; c < r1; ++c) { const double t = pos[(size_t)c * ld + j] - m; ps = fma(t, t, ps); }
+    partial1[(size_t)s * ld + j] = ps;
+}
 #endif  // DZ_TEMPLATES_ONLY
 
-// one wave per GLOBAL chain: bins and normalised squared jumps (:481, :527)
+// one wave per GLOBAL chain (16 chains per block of four waves): bins and normalised squared jumps (:481, :527).  The standard deviations
+// come from the strip sums of pass 1, added in strip order by every block for itself (k_strip_finish's additions; block 0 also stores
+// them): sd[j] = sqrt((sum_s partial1[s][j]) / N), for the crossover statistic with 0 -> 1e-12 (:479).
+constexpr int JUMP_CHAINS = 16;
 template <int NCH>
-__global__ __launch_bounds__(256) void k_jump(Params p, uint32_t g, int gc0, int ngc, const double* __restrict__ sdc, const double* __restrict__ sdg,
+__global__ __launch_bounds__(256) void k_jump(Params p, uint32_t g, int gc0, int ngc, const double* __restrict__ partial1, int nstrips,
+                                              double* __restrict__ sd_out, double* __restrict__ sdc_out,
                                               double* __restrict__ dl, double* __restrict__ dlg, int* __restrict__ binc, int* __restrict__ bing)
 {
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= ngc) return;
-    const int gcn = gc0 + w;
-    const int lane = threadIdx.x & 63;
-    const Ctrl u = draw_ctrl(p.k0, p.k1, (uint32_t)gcn, g);
-    const StepFlags f = step_flags(p, u);
-    // np.any(self.gamma == 1.0) of the LAST generate_proposal_points call (:371, :705/:730)
-    bool gu = false;
-    if (!f.snk) {
-        const int phase = p.k > 1 ? 1 : 0, n = p.k > 1 ? p.k - 1 : 1;
-        for (int i = 0; i < n; ++i) {
-            const u32x4 w = philox(p.k0, p.k1, 0, stream_id(K_PT, (uint32_t)i, (uint32_t)phase), (uint32_t)gcn, g);
-            gu = gu || (u53(w.x, w.y) < p.pgu);
-        }
+    __shared__ double s_sdc[128 * NCH], s_sdg[128 * NCH];
+    for (int j = threadIdx.x; j < p.d; j += 256) {
+        double tot = 0.0;
+        for (int s = 0; s < nstrips; ++s) tot = tot + partial1[(size_t)s * p.ld + j];
+        const double v = sqrt(tot / (double)p.N);
+        s_sdg[j] = v; s_sdc[j] = v == 0.0 ? 1e-12 : v;
+        if (blockIdx.x == 0) { sd_out[j] = v; sdc_out[j] = v == 0.0 ? 1e-12 : v; }
     }
-    const bool at_end = (int)g == p.burnin;
-    const bool window = g > 10 && (int)g < p.burnin;
-    const bool do_c = p.adapt_cr && (at_end || (window && !gu));               // :371, :395
-    const bool do_g = p.adapt_g && (at_end || (window && !gu && !f.snk));      // :381, :391
-    double accC = 0.0, accG = 0.0;
-#pragma unroll
-    for (int it = 0; it < NCH; ++it) {
-        const int jj = 128 * it + 2 * lane;
-        if (jj < p.ld) {
-            const double2 a = *reinterpret_cast<const double2*>(p.cp_new + (size_t)gcn * p.ld + jj);
-            const double2 b = *reinterpret_cast<const double2*>(p.cp_prev + (size_t)gcn * p.ld + jj);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) if (jj + s < p.d) {
-                const double df = (s ? a.y : a.x) - (s ? b.y : b.x);
-                const double t = df / sdc[jj + s]; accC = fma(t, t, accC);
-                const double t2 = df / sdg[jj + s]; accG = fma(t2, t2, accG);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int q = 0; q < JUMP_CHAINS / 4; ++q) {
+        const int w = blockIdx.x * JUMP_CHAINS + 4 * q + (threadIdx.x >> 6);
+        if (w >= ngc) break;
+        const int gcn = gc0 + w;
+        const Ctrl u = draw_ctrl(p.k0, p.k1, (uint32_t)gcn, g);
+        const StepFlags f = step_flags_chain(p, u, gcn - p.off);          // (own copies exist only on an unsharded engine: local == global)
+        // np.any(self.gamma == 1.0) of the LAST generate_proposal_points call (:371, :705/:730)
+        bool gu = false;
+        if (!f.snk) {
+            const int phase = p.k > 1 ? 1 : 0, n = p.k > 1 ? p.k - 1 : 1;
+            for (int i = 0; i < n; ++i) {
+                const u32x4 w4 = philox(p.k0, p.k1, 0, stream_id(K_PT, (uint32_t)i, (uint32_t)phase), (uint32_t)gcn, g);
+                gu = gu || (u53(w4.x, w4.y) < p.pgu);
             }
         }
-    }
-    const double dC = nan_to_num(wave_bfly(accC)), dG = nan_to_num(wave_bfly(accG));
-    if (lane == 0) {
-        binc[gcn] = do_c ? (f.snk ? p.ncr - 1 : f.cr_idx) : -1;               // :374-378
-        bing[gcn] = do_g ? f.glev - 1 : -1;
-        dl[gcn] = dC; dlg[gcn] = dG;
+        const bool at_end = (int)g == p.burnin;
+        const bool window = g > 10 && (int)g < p.burnin;
+        const bool do_c = p.adapt_cr && (at_end || (window && !gu));               // :371, :395
+        const bool do_g = p.adapt_g && (at_end || (window && !gu && !f.snk));      // :381, :391
+        double accC = 0.0, accG = 0.0;
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) {
+            const int jj = 128 * it + 2 * lane;
+            if (jj < p.ld) {
+                const double2 a = *reinterpret_cast<const double2*>(p.cp_new + (size_t)gcn * p.ld + jj);
+                const double2 b = *reinterpret_cast<const double2*>(p.cp_prev + (size_t)gcn * p.ld + jj);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) if (jj + s < p.d) {
+                    const double df = (s ? a.y : a.x) - (s ? b.y : b.x);
+                    const double t = df / s_sdc[jj + s]; accC = fma(t, t, accC);
+                    const double t2 = df / s_sdg[jj + s]; accG = fma(t2, t2, accG);
+                }
+            }
+        }
+        const double dC = nan_to_num(wave_bfly(accC)), dG = nan_to_num(wave_bfly(accG));
+        if (lane == 0) {
+            binc[gcn] = do_c ? (f.snk ? p.ncr - 1 : f.cr_idx) : -1;               // :374-378
+            bing[gcn] = do_g ? f.glev - 1 : -1;
+            dl[gcn] = dC; dlg[gcn] = dG;
+        }
     }
 }
 

@@ -19,7 +19,7 @@ template <bool TRI, bool X, int CH, int WPC, bool PB, bool K1>
 static const char* launch_one(const MegaLaunch& a)
 {
     hipExtLaunchKernelGGL((k_generations<DZ_TU_NRT, TRI, X, CH, WPC, PB, K1>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0,
-                          a.pp, a.g, a.n, a.M, a.slot0, a.append_last);
+                          a.pp, a.g, a.n, a.M, a.slot0, a.zappend, a.publish);
     // (NRT, matrix, chain states, chains per block, waves per chain, proposal code)
     return TRI ? (X ? (PB ? (K1 ? "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,full,k1>" : "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,full>")
                           : (K1 ? "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,lean,k1>" : "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,lean>"))

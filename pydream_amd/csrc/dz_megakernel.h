@@ -178,8 +178,12 @@ DZ_DEV void propose_de_pf(const Params& p, int phase, uint32_t g, uint32_t M, in
 // propose_point with its prior evaluation; the flat, unbounded case keeps the lean code (2.4 % faster at the headline size).
 // K1: multitry off (the reference's default, Dream.py:271-275 and :326-334) -- one proposal per generation, no reference set, the
 // snooker move's current-point term; a template flag so that the multi-try kernels carry none of it (it cost them a register spill).
+// M: archive rows the generations of this launch sample from; zappend: first row of the append its last generation makes (the rows go
+// to zappend + global chain), or -1 -- with dz_config.history_lag the two differ (rows written earlier are not sampleable yet).
+// publish: during the crossover burn-in (one generation per launch) the new states also go to the published positions
+// (set_current_position_arr, Dream.py:364-366, :447-449: [N][ld], row = global chain); null otherwise.
 template <int NRT, bool TRI, bool XLDS, int CH, int WPC, bool PB, bool K1 = false>
-__global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int append_last)
+__global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int64_t zappend, double* __restrict__ publish)
 {
     const Params& p = *pp;       // read through the scalar cache on demand: keeps the ~70 fields out of the SGPR file
     constexpr int NCH = 1;
@@ -425,7 +429,8 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 if (jj < ld) {
                     if (XLDS ? last : accept) gstore2(p.X + (size_t)c * ld + jj, xn);
                     if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn);
-                    if (last && append_last) gstore2(p.Z + ((size_t)M + gc) * ld + jj, xn);      // record_history :933-936
+                    if (last && zappend >= 0) gstore2(p.Z + ((size_t)zappend + gc) * ld + jj, xn);      // record_history :933-936
+                    if (publish) gstore2(publish + (size_t)gc * ld + jj, xn);                          // set_current_position_arr :447-449
                 }
                 if (lane == 0) {
                     if (trace_slot0 >= 0) {
@@ -456,7 +461,7 @@ constexpr int MIXW = 4;       // waves (= chains) per block
 
 __host__ __device__ inline int mega_mix_wave_doubles(int d, int k, int J) { return k * (4 * ((d + 3) / 4) + 1) + 5 * k + k * J + 8 + (k & 1); }
 
-__global__ __launch_bounds__(64 * MIXW) void k_generations_mix(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int append_last)
+__global__ __launch_bounds__(64 * MIXW) void k_generations_mix(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int64_t zappend, double* __restrict__ publish)
 {
     const Params& p = *pp;
     constexpr int NCH = 1;
@@ -583,7 +588,8 @@ __global__ __launch_bounds__(64 * MIXW) void k_generations_mix(const Params* __r
                 if (jj < ld) {
                     if (last) *reinterpret_cast<double2*>(p.X + (size_t)c * ld + jj) = xn;
                     if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn);
-                    if (last && append_last) gstore2(p.Z + ((size_t)M + gc) * ld + jj, xn);      // record_history :933-936
+                    if (last && zappend >= 0) gstore2(p.Z + ((size_t)zappend + gc) * ld + jj, xn);      // record_history :933-936
+                    if (publish) gstore2(publish + (size_t)gc * ld + jj, xn);                          // set_current_position_arr :447-449
                 }
                 if (lane == 0) {
                     if (trace_slot0 >= 0) {

@@ -44,6 +44,12 @@ from pydream.model import Model  # noqa: E402
 from pydream.parameters import FlatParam, SampledParam  # noqa: E402
 from pydream.convergence import Gelman_Rubin  # noqa: E402
 
+# the repository has a `pydream` alias package of its own (pydream/__init__.py -> pydream_amd): the vectors must come from the
+# reference, never from the implementation under test
+for _m in (RD, SV, RC):
+    assert os.path.realpath(_m.__file__).startswith(os.path.realpath("/root/reference") + os.sep), \
+        "%s was imported from %s, not from /root/reference" % (_m.__name__, _m.__file__)
+
 
 # --------------------------------------------------------------------------
 # the random contract, as seen through numpy.random / random (App. B order)
@@ -278,8 +284,14 @@ BASE = {"hist": RD.Dream.record_history, "pos": RD.Dream.set_current_position_ar
         "cr": RD.Dream.estimate_crossover_probabilities, "gam": RD.Dream.estimate_gamma_level_probs}
 
 
-def run_reference(params, likelihood, Z0, starts, N, G, seed, schedule, dream_kwargs, workdir):
-    """Drive the reference's astep for G generations; return everything it produced."""
+def run_reference(params, likelihood, Z0, starts, N, G, seed, schedule, dream_kwargs, workdir, history_lag=0):
+    """Drive the reference's astep for G generations; return everything it produced.
+
+    history_lag (schedule S2 only): the deferred record_history calls of an appending generation are replayed `history_lag` appends
+    late -- the reference's own record_history / sample_from_history then see the archive grow with that delay (its `count` lags),
+    which is the schedule the engine runs when the exchange of appended rows between GPUs is hidden behind the next thin-cycle
+    (include/dreamzs.h dz_config.history_lag).  Row positions do not change: record_history appends at `count`, and the held-back
+    appends are replayed oldest first; whatever is still held at the end of the run is flushed before the archive is read out."""
     d = Z0.shape[1]
     hist_file = os.path.join(workdir, "seed_hist.npy")
     np.save(hist_file, Z0)
@@ -306,6 +318,7 @@ def run_reference(params, likelihood, Z0, starts, N, G, seed, schedule, dream_kw
                    redraws=np.zeros((G, N), np.int32),
                    cross_probs=np.zeros((G, step.nCR)), gamma_probs=np.zeros((G, step.ngamma)),
                    hist_rows=np.zeros(G, np.int64))
+        held = []                                         # appends not replayed yet (history_lag), oldest first
         for g in range(G):
             for ci, c in enumerate(chains):
                 rnd.begin_step(ci, g, step.p_gamma_unity)
@@ -323,13 +336,19 @@ def run_reference(params, likelihood, Z0, starts, N, G, seed, schedule, dream_kw
                 out["redraws"][g, ci] = rnd.log.get("redraws", 0)
                 x[ci] = xn
             if schedule == 2:
-                for kind in ("pos", "cr", "gam", "hist"):
+                for kind in ("pos", "cr", "gam"):
                     for c in chains:
                         for (kk, a, kw) in c.queue:
                             if kk == kind:
                                 c.iter -= 1           # astep already advanced iter (Dream.py:417); the
                                 BASE[kind](c, *a, **kw)   # base methods must see this generation's value (:446)
                                 c.iter += 1
+                this_append = [(c, a, kw) for c in chains for (kk, a, kw) in c.queue if kk == "hist"]       # chain order
+                if this_append:
+                    held.append(this_append)
+                while len(held) > history_lag or (g == G - 1 and held):
+                    for (c, a, kw) in held.pop(0):
+                        BASE["hist"](c, *a, **kw)
                 for c in chains:
                     c.queue = []
                     if g <= burnin:
@@ -538,7 +557,7 @@ def save(name, **arrs):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
-def trace_case(name, *, d, N, G, k, schedule, seed, target, dream_kwargs=None, prior="flat", rng_seed=0, nseed=None, restart_from=None):
+def trace_case(name, *, d, N, G, k, schedule, seed, target, dream_kwargs=None, prior="flat", rng_seed=0, nseed=None, restart_from=None, history_lag=0):
     """restart_from: name of an earlier trace fixture -- this run then restarts it the way run_dream(restart=True) does
     (core.py:46-62, 255-263; Dream.py:128-141): seed history = everything that run left in its history file (seed rows + appended
     rows), crossover probabilities loaded from its crossover file through Dream's `crossover_file`, starts = its last states."""
@@ -547,6 +566,8 @@ def trace_case(name, *, d, N, G, k, schedule, seed, target, dream_kwargs=None, p
     rng = np.random.default_rng(rng_seed)
     cfg = dict(d=d, N=N, G=G, k=k, schedule=schedule, seed=seed)
     extra = {}
+    if history_lag:
+        cfg["history_lag"] = history_lag
     nseed = nseed or max(10 * d, 2 * N * dream_kwargs.get("DEpairs", 1))
     if prior == "flat":
         params = [FlatParam(test_value=np.zeros(d))]
@@ -593,7 +614,7 @@ def trace_case(name, *, d, N, G, k, schedule, seed, target, dream_kwargs=None, p
                 np.save(os.path.join(wd, "prev_crossoverprob.npy"), prev["cross_probs"][-1])      # Dream.py:961-964
                 dream_kwargs["crossover_file"] = os.path.join(wd, "prev_crossoverprob.npy")
                 extra.update(restart_cr_probs=prev["cross_probs"][-1])
-            out = run_reference(params, like, Z0, starts, N, G, seed, schedule, dict(multitry=mt, **dream_kwargs), wd)
+            out = run_reference(params, like, Z0, starts, N, G, seed, schedule, dict(multitry=mt, **dream_kwargs), wd, history_lag=history_lag)
             dream_kwargs.pop("crossover_file", None)
         finally:
             os.chdir(cwd)
@@ -707,6 +728,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "pt":
         pt_case("trace_pt_mvn10", d=10, N=6, G=150, k=5, seed=23)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "lag":
+        lag_cases()
+        return
     function_cases()
     density_cases()
     # T1: the C1 plumbing config (3 chains, 10-D MVN, multitry 5), unmodified reference, schedule S1
@@ -750,6 +774,17 @@ def main():
     # crossover probabilities, adaptation on again
     trace_case("trace_s2_restart", d=10, N=4, G=60, k=5, schedule=2, seed=12, target=("mvn",), restart_from="trace_s2_adapt",
                dream_kwargs=dict(adapt_crossover=True, crossover_burnin=30))
+    lag_cases()
+
+
+def lag_cases():
+    # T9: history_lag = 1 (and 2): lockstep S2 whose appended rows become sampleable one (two) appends late -- the schedule under which
+    # the exchange of appended rows between GPUs hides behind the next thin-cycle.  Appends every 5 generations (24 of them), the
+    # crossover burn-in ends inside the run; the snooker share is raised so that the lagged archive length shows in many row draws.
+    trace_case("trace_s2_lag1", d=10, N=4, G=120, k=5, schedule=2, seed=41, target=("mvn",), history_lag=1,
+               dream_kwargs=dict(adapt_crossover=True, crossover_burnin=40, history_thin=5, snooker=.2))
+    trace_case("trace_s2_lag2_k1", d=6, N=5, G=90, k=1, schedule=2, seed=43, target=("mvn",), history_lag=2,
+               dream_kwargs=dict(adapt_crossover=False, crossover_burnin=10 ** 9, history_thin=3))
 
 
 if __name__ == "__main__":

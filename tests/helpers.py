@@ -27,6 +27,8 @@ def engine_from_trace_fixture(EngineCls, fx, schedule=None, trace=True, **over):
               history_capacity=len(Z0) + N * (G // thin + 2), trace_capacity=G if trace else 0, seed=int(fx["cfg_seed"]),
               lamb=float(fx["cfg_lamb"]), zeta=float(fx["cfg_zeta"]), snooker=float(fx["cfg_snooker"]),
               p_gamma_unity=float(fx["cfg_p_gamma_unity"]))
+    if "cfg_history_lag" in fx:
+        kw["history_lag"] = int(fx["cfg_history_lag"])
     kw.update(over)
     e = EngineCls(**kw)
     if "mins" in fx:

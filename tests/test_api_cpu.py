@@ -151,14 +151,13 @@ def test_host_evaluator_pool_equals_in_process_evaluation(monkeypatch):
     assert ev.pool is None                                   # disabled: in-process
 
 
-def test_open_uniform_prior_run_on_the_oracle_stays_inside_its_support(tmp_path):
+def test_open_uniform_prior_run_on_the_oracle_stays_inside_its_support(tmp_path, monkeypatch):
     """run_dream's own sequence (core._setup_mp_dream_pool -> _sample_dream_batched) with the oracle as the engine: uniform prior,
     hardboundaries=False, multitry -- proposal sets that lie wholly outside the support are drawn again (Dream.py:281-289) and no
     sample leaves it.  (The GPU engine runs the same call in tests/test_api_gpu.py.)"""
-    import os
     from oracle import oracle as O
     from pydream_amd.core import _sample_dream_batched, _setup_mp_dream_pool
-    os.chdir(tmp_path)
+    monkeypatch.chdir(tmp_path)
     params, like = multidmodel_uniform()
     lower = np.array([-5, -9, 5, 3]); upper = np.array([10, 2, 7, 8])
     rng = np.random.default_rng(4)

@@ -19,19 +19,23 @@ from tests.test_api_cpu import multidmodel, multidmodel_uniform, onedmodel
 pytestmark = pytest.mark.gpu
 
 
-def test_astep_round_robin_equals_reference_s1(tmp_path):
+@pytest.mark.parametrize("name", ["trace_s1_c1", "trace_s1_adapt"])
+def test_astep_round_robin_equals_reference_s1(tmp_path, name):
     """Dream.astep driven round-robin in one process, the reference's own idiom (test_dream.py:507-518):
-    identical to the UNMODIFIED reference's trace (golden trace_s1_c1: 3 chains, 10-D MVN, multitry 5)
-    and bit-identical to the oracle's schedule S1."""
+    identical to the UNMODIFIED reference's trace and bit-identical to the oracle's schedule S1.
+    trace_s1_c1: 3 chains, 10-D MVN, multitry 5, adaptation off.  trace_s1_adapt: crossover adaptation on -- the reference's
+    default -- with the burn-in ending inside the run: every Dream instance decides with its OWN copy of the crossover probabilities
+    (Dream.py:375, :497, :409-415), the standard deviations are summed in numpy's row order."""
     import copy
     from oracle import oracle as O
-    fx = H.load("trace_s1_c1")
+    fx = H.load(name)
     d, N, G = int(fx["cfg_d"]), int(fx["cfg_N"]), int(fx["cfg_G"])
+    adapt = bool(int(fx["cfg_adapt_crossover"]))
     hist = tmp_path / "seed.npy"
     np.save(hist, fx["Z0"])
     like = MVNormalLogLike(fx["invC"], log_F=float(fx["log_F"]), factorize=False)
     step = Dream(model=Model(like, [FlatParam(np.zeros(d))]), history_file=str(hist), start_random=False, save_history=False,
-                 multitry=5, adapt_crossover=False, crossover_burnin=10 ** 9)
+                 multitry=5, adapt_crossover=adapt, crossover_burnin=int(min(fx["burnin"], 10 ** 9)))
     pool = _setup_mp_dream_pool(N, G, step, start_pt=[fx["starts"][i] for i in range(N)], seed=int(fx["cfg_seed"]))
     pool._initializer(*pool._initargs)
     try:
@@ -55,12 +59,41 @@ def test_astep_round_robin_equals_reference_s1(tmp_path):
                 x[c] = q; X[g, c] = q; lp[g, c] = pr + lk
         np.testing.assert_allclose(X, fx["X"], rtol=1e-9, atol=1e-11)
         np.testing.assert_allclose(lp, fx["logp"], rtol=0, atol=1e-10)
+        np.testing.assert_array_equal(np.any(np.diff(np.concatenate([fx["starts"][None, :N], X]), axis=0) != 0, axis=2), fx["moved"].astype(bool))
         o = H.engine_from_trace_fixture(O.Engine, fx)      # schedule S1
         o.step(G)
         np.testing.assert_array_equal(X, o.get_trace(0, G)["X"])
         np.testing.assert_array_equal(pool.engine.get_history(), o.get_history())
+        if adapt:
+            cr, dm, nu = pool.engine.get_cr_state()
+            np.testing.assert_allclose(cr, fx["cross_probs"][-1], rtol=1e-11)
+            np.testing.assert_allclose(dm, fx["delta_m"], rtol=1e-11)
+            np.testing.assert_array_equal(nu, fx["ncr_updates"])
+            for a, b in zip(pool.engine.get_cr_state(), o.get_cr_state()):
+                np.testing.assert_array_equal(a, b)
+            assert len(np.unique(fx["cr_idx"])) == 3 and not np.allclose(cr, 1 / 3.)      # the probabilities did move
+            # every instance keeps the vector as it stood after ITS OWN last update (Dream.py:409-415 in one process): the chain driven
+            # last holds the final shared one, the one driven first an earlier one
+            np.testing.assert_array_equal(np.asarray(claimed[N - 1].CR_probabilities), cr)
+            assert not np.array_equal(np.asarray(claimed[0].CR_probabilities), cr)
     finally:
         pool.close(); pool.join()
+
+
+def test_the_pydream_alias_package_runs_a_reference_script_unchanged():
+    """`import pydream` resolves to this repository's alias package (pydream/__init__.py): a PyDREAM script's own imports
+    (examples/ndim_gaussian/dream_ex_ndim_gaussian.py:8-12) and calls run on the GPU engine."""
+    from pydream.core import run_dream as rd
+    from pydream.parameters import SampledParam as SP
+    from pydream.convergence import Gelman_Rubin as GR
+    import pydream.Dream as PD
+    import pydream_amd.core
+    assert rd is pydream_amd.core.run_dream and PD.Dream is Dream
+    from scipy.stats import norm
+    sampled, log_ps = rd([SP(norm, loc=np.zeros(3), scale=np.ones(3))], lambda x: -0.5 * float(np.sum(x * x)), nchains=5, niterations=60,
+                         verbose=False, save_history=False, seed=3, multitry=3)
+    assert len(sampled) == 5 and sampled[0].shape == (60, 3) and log_ps[0].shape == (60, 1)
+    assert GR(sampled).shape == (3,)
 
 
 def test_run_dream_shapes_and_types():

@@ -8,7 +8,7 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 S2_TRACES = ["trace_s2_adapt", "trace_s2_k1_bounds", "trace_s2_k3_bounds", "trace_s2_k3_redraw", "trace_s2_k5_redraw_mvn", "trace_s2_depairs_gamma",
-             "trace_s2_mvn100", "trace_s2_mix3", "trace_s2_restart"]
+             "trace_s2_mvn100", "trace_s2_mix3", "trace_s2_restart", "trace_s2_lag1", "trace_s2_lag2_k1"]
 
 
 @pytest.fixture(scope="module")
@@ -210,6 +210,32 @@ def test_persistent_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, k, tr
         assert_traces_identical(a[0], other[0])
         np.testing.assert_array_equal(a[1], other[1])
         np.testing.assert_array_equal(a[2], other[2])
+
+
+@pytest.mark.parametrize("N,tri,target,variant", [(4096, 1, "mvn", "k_generations<7,tri,xlds,16,1,lean>"),       # bench.py's headline `value`
+                                                  (4096, 0, "mvn", "k_generations<7,dense,xhbm,16,1,lean>"),    # ... `dense_value`
+                                                  (1024, 1, "mvn", "k_generations<7,tri,xlds,4,4,lean>"),       # BASELINE configs[1]
+                                                  (2048, 1, "mvn", "k_generations<7,tri,xlds,8,1,lean>"),
+                                                  (4096, 1, "mix3", "k_generations_mix")])                      # BASELINE configs[2] after the burn-in
+def test_the_instantiations_the_bench_times_equal_the_oracle(G, O, N, tri, target, variant):
+    """Exactly what bench.py times -- 100-D, multitry 5, flat prior, bench.py's own engine set-up -- against the oracle, bit for bit,
+    over 35 generations (three history appends), with the engine reporting which instantiation ran (dz_last_kernel_variant):
+    16 chains per block with one wave per chain needs >= ~2100 chains, which no other oracle comparison reaches."""
+    import argparse
+    import bench
+    n = 35
+    args = argparse.Namespace(dim=100, multitry=5, seed=20260929, thin=10, snooker=0.1, target=target, mvn_kind="tri" if tri else "dense",
+                              steps=n, warmup=0)
+    out = []
+    for Cls in (G.Engine, O.Engine):
+        e = bench.setup_engine(Cls, args, N, N, 0, n, trace_capacity=n, **({"schedule": 2} if Cls is O.Engine else {}))
+        e.step(n)
+        if Cls is G.Engine:
+            assert e.last_kernel_variant() == variant
+        out.append((e.get_trace(0, n), e.get_history()))
+    assert_traces_identical(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    assert 0.05 < out[0][0]["moved"].mean() < 0.9
 
 
 @pytest.mark.parametrize("N,d,k,depairs,ngamma,prior", [(1000, 100, 5, 3, 2, None), (96, 10, 3, 2, 1, "uniform"), (256, 100, 1, 2, 3, None),

@@ -1,0 +1,19 @@
+#!/bin/bash
+# round 3, first pass: the GPU suite (timed), the driver's bench line, configs[2] with adaptation on, kernel stats of the burn-in
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+( time python -m pytest tests -m gpu -q --durations=15 ) > gpurun_out/r03b_gputests.log 2>&1
+python bench.py --steps 20 --warmup 5 > gpurun_out/r03b_bench_k20.json 2> gpurun_out/r03b_bench_k20.err
+python bench.py --steps 20 --warmup 5 --target mix3 --adapt --no-cpu-baseline > gpurun_out/r03b_bench_mix3_adapt.json 2> gpurun_out/r03b_bench_mix3_adapt.err
+DZ_MEGA_BURNIN=0 python bench.py --steps 20 --warmup 5 --target mix3 --adapt --no-cpu-baseline --rhat-max-generations 2000 --rhat-window 500 > gpurun_out/r03b_bench_mix3_adapt_oldpath.json 2> gpurun_out/r03b_bench_mix3_adapt_oldpath.err
+python bench.py --steps 20 --warmup 5 --adapt --no-cpu-baseline --no-dense --rhat-max-generations 2000 --rhat-window 500 > gpurun_out/r03b_bench_mvn_adapt.json 2> gpurun_out/r03b_bench_mvn_adapt.err
+rocprofv3 --kernel-trace --stats -d gpurun_out/r03b_stats_mix3_adapt -o stats -- python bench.py --steps 20 --warmup 5 --target mix3 --adapt --no-cpu-baseline --no-events --rhat-max-generations 1000 --rhat-min-generations 500 --rhat-window 200 --min-timed-ms 10 > gpurun_out/r03b_stats_mix3_adapt.log 2>&1
+tail -5 gpurun_out/r03b_gputests.log
+for f in gpurun_out/r03b_bench_*.json; do echo $f; python - "$f" <<'PY'
+import json,sys
+try:
+    d=json.load(open(sys.argv[1]))
+    print({k:d.get(k) for k in ("value","burnin_value","dense_value","ms_per_step","kernel_variant","rhat_max")}, d.get("roofline",{}).get("frac"), d.get("burnin"))
+except Exception as ex: print("ERR",ex)
+PY
+done

@@ -357,7 +357,7 @@ def main():
         # needs ~0.1 s of load), because the burn-in is by definition the START of the measured engine's run.
         import copy
         aw = copy.copy(args); aw.adapt = False
-        ew = setup_engine(_capi.Engine, aw, n_local, n_local, 0, 20000, device=device, trace_capacity=2)
+        ew = setup_engine(_capi.Engine, aw, n_local, n_local, 0, 20000, device=device, trace_capacity=0)
         t_w = time.perf_counter()
         while time.perf_counter() - t_w < 0.4:
             ew.trace_reset(); ew.step(500); ew.sync()

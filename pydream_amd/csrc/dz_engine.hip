@@ -145,6 +145,7 @@ struct dz_engine {
     double *d_shared = nullptr;      // cr_probs|cr_delta|cr_n|g_probs|g_delta|g_n
     double *d_partial = nullptr, *d_mean = nullptr, *d_sd = nullptr, *d_sdc = nullptr, *d_dl = nullptr, *d_dlg = nullptr;
     int *d_binc = nullptr, *d_bing = nullptr;
+    double* d_binsum = nullptr; int* d_bincnt = nullptr;      // [strips of 64 chains][ncr + ngamma]: the strips' contributions to the adaptation bins (k_jump)
     dz::Params* d_params = nullptr;  // device copy of `p` for kernels that take it by pointer
     double *d_scratch = nullptr; size_t scratch_rows = 0;   // debug / eval staging [rows, ld]
     double *d_cmean = nullptr, *d_cvar = nullptr, *d_rhat = nullptr;
@@ -482,13 +483,10 @@ int adapt_generation(dz_engine* e, uint32_t g, int gc0, int ngc)
     double* partial1 = e->d_partial + (size_t)((p.N + 63) / 64) * p.ld;
     hipLaunchKernelGGL(dz::k_strip_partial, gcol, b, 0, e->stream, p.cp_new, p.N, p.d, p.ld, e->d_mean, 0, e->d_partial, strip, single ? 1 : 0);
     hipLaunchKernelGGL(dz::k_strip_dev, gcol, b, 0, e->stream, p.cp_new, p.N, p.d, p.ld, (const double*)e->d_partial, nstrips, partial1, e->d_mean, strip, single ? 1 : 0);
-    if (ngc != p.N) {   // single-chain stepping: every other chain contributes nothing this time
-        HIPCK(hipMemsetAsync(e->d_binc, 0xFF, sizeof(int) * p.N, e->stream));
-        HIPCK(hipMemsetAsync(e->d_bing, 0xFF, sizeof(int) * p.N, e->stream));
-    }
-    NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_jump<NCH>, dim3((ngc + dz::JUMP_CHAINS - 1) / dz::JUMP_CHAINS), dim3(256), 0, e->stream, p, g, gc0, ngc, (const double*)partial1, nstrips,
-                                       e->d_sd, e->d_sdc, e->d_dl, e->d_dlg, e->d_binc, e->d_bing));
-    hipLaunchKernelGGL(dz::k_adapt_update, dim3(1), dim3(64), 0, e->stream, p, e->d_dl, e->d_dlg, e->d_binc, e->d_bing);
+    const int nstrips64 = (p.N + 63) / 64;          // (the bins are always summed by strips of 64 chains, then the strips in order)
+    NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_jump<NCH>, dim3(nstrips64), dim3(1024), 0, e->stream, p, g, gc0, ngc, (const double*)partial1, nstrips,
+                                       e->d_sd, e->d_sdc, e->d_dl, e->d_dlg, e->d_binc, e->d_bing, e->d_binsum, e->d_bincnt));
+    hipLaunchKernelGGL(dz::k_adapt_update, dim3(1), dim3(64), 0, e->stream, p, (const double*)e->d_binsum, (const int*)e->d_bincnt, nstrips64);
     if (single && e->d_own_cr)      // the chains that updated the shared probabilities adopt them (Dream.py:375, :383, :409-415)
         hipLaunchKernelGGL(dz::k_own_probs, dim3((ngc + 63) / 64), dim3(64), 0, e->stream, p, gc0 - p.off, ngc, (const int*)e->d_binc, (const int*)e->d_bing, 0, e->d_own_cr, e->d_own_g);
     return launch_check("adaptation kernels");
@@ -928,6 +926,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
         rc |= ealloc(e, &e->d_partial, (size_t)2 * ((N + 63) / 64) * ld);      // strip sums of pass 0 | of pass 1
         rc |= ealloc(e, &e->d_mean, ld); rc |= ealloc(e, &e->d_sd, ld); rc |= ealloc(e, &e->d_sdc, ld);
         rc |= ealloc(e, &e->d_dl, N); rc |= ealloc(e, &e->d_dlg, N); rc |= ealloc(e, &e->d_binc, N); rc |= ealloc(e, &e->d_bing, N);
+        rc |= ealloc(e, &e->d_binsum, (size_t)((N + 63) / 64) * (cfg->ncr + cfg->ngamma)); rc |= ealloc(e, &e->d_bincnt, (size_t)((N + 63) / 64) * (cfg->ncr + cfg->ngamma));
     }
     if (tc) {
         p.tcap = (long long)tc;

@@ -156,7 +156,11 @@ DZ_DEV u32x4 slot_counter_draw(const Params& p, int slot, uint32_t gc, uint32_t 
 }
 // Where a wave gets its uniform draws from: lane s of the wave holds slot s of the chain's precomputed table
 // (ONE coalesced 16-byte load per lane at wave start, then v_readlane), or nothing (evaluate Philox in place).
-struct DrawSrc { uint4 mine; bool have; };
+// xf: the point-stream slots have been turned, lane-parallel and once per generation, into what the tries read from them (persistent
+// kernel, lean instantiations; dz_megakernel.h finish_draws): idx 0 -- .x = 1 if the gamma-unity draw says gamma = 1 (:615), .z/.w the raw
+// words of the snooker gamma; idx 1 -- the archive ROW numbers themselves: DE .x/.y = random.sample(range(M), 2) (:662), snooker
+// .x/.y/.z = z and the projected pair (:808-810).
+struct DrawSrc { uint4 mine; bool have; bool xf = false; };
 DZ_DEV DrawSrc load_draws(const Params& p, const uint4* dr, int lane)
 {
     DrawSrc d; d.have = (dr != nullptr) && p.nslots <= 64; d.mine = make_uint4(0, 0, 0, 0);
@@ -347,12 +351,15 @@ DZ_DEV double propose_point(const Params& p, int phase, uint32_t g, uint32_t M, 
                 keep[it][1] = j0 + 1 < d && (w.x >> 16) < thr;
                 e1[it][1] = uniform16(w.y >> 16, ec1, ec0) + 1.0;
                 zt[it][1] = zeta * (double)z1;
+                // d' :704 / :709 -- ballots of the two plain comparisons, masked by the (loop-invariant) ballots of the lanes that own a
+                // dimension: a ballot of the conjunction is materialised as 0 / 1 and compared again (two extra vector instructions each)
+                dprime += __popcll(__builtin_amdgcn_ballot_w64((w.x & 0xffffu) < thr) & __builtin_amdgcn_ballot_w64(j0 < d))
+                        + __popcll(__builtin_amdgcn_ballot_w64((w.x >> 16) < thr) & __builtin_amdgcn_ballot_w64(j0 + 1 < d));
             }
-            dprime += __popcll(__builtin_amdgcn_ballot_w64(keep[it][0])) + __popcll(__builtin_amdgcn_ballot_w64(keep[it][1]));   // d' :704 / :709
         }
         const u32x4 wg = uniform_draw(p, dr, sc ? sc->slot0 + i * sc->npt : pt_slot(p, phase, i, 0), gc, g);  // set_gamma :615
         double gamma = 1.0;
-        if (!u53_below(wg.x, wg.y, sc ? sc->pgu_thr : p.pgu_thr))              // u53(wg.x, wg.y) < p_gamma_unity
+        if (dr.xf ? (wg.x == 0u) : !u53_below(wg.x, wg.y, sc ? sc->pgu_thr : p.pgu_thr))      // u53(wg.x, wg.y) < p_gamma_unity
             gamma = grow[(dprime == 0 ? d : dprime) - 1];                      // gamma_arr[level-1][delta-1][d'-1], :624 (one address for the whole wave)
 #pragma unroll
         for (int it = 0; it < NCH; ++it)
@@ -433,7 +440,9 @@ DZ_DEV double propose_point(const Params& p, int phase, uint32_t g, uint32_t M, 
             }
             double2 o; o.x = (jj < d) ? pr[it][0] : 0.0; o.y = (jj + 1 < d) ? pr[it][1] : 0.0;
             if (AL16) *reinterpret_cast<double2*>(out + jj) = o;
-            else { if (jj < d) out[jj] = o.x; if (jj + 1 < d) out[jj + 1] = o.y; }     // unpadded, 8-byte aligned row (LDS tile)
+            // 8-byte aligned row of an LDS tile, zero padded to the k-steps (4 ceil(d / 4) + 1 columns: with d odd the lane that owns the
+            // last dimension also rewrites the first pad column with its zero): ONE predicated region, two adjacent stores
+            else if (jj < d) { out[jj] = o.x; out[jj + 1] = o.y; }
         }
     }
     return sqdist;
@@ -650,7 +659,7 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
         double2 rz[NCH], r1[NCH], r2[NCH];
         auto request = [&](int i) {
             const u32x4 w = uniform_draw(p, dsrc, pt_slot(p, phase, i, 1), gc, g);
-            const uint32_t iz = mulhi_idx(w.x, M), i1x = mulhi_idx(w.y, M), i2x = mulhi_idx(w.z, M);
+            const uint32_t iz = dsrc.xf ? w.x : mulhi_idx(w.x, M), i1x = dsrc.xf ? w.y : mulhi_idx(w.y, M), i2x = dsrc.xf ? w.z : mulhi_idx(w.z, M);
 #pragma unroll
             for (int it = 0; it < NCH; ++it) {
                 const int jc = min(128 * it + 2 * lane, p.ld - 2);            // (no lane predicate: see the DE path)
@@ -1560,6 +1569,31 @@ __global__ __launch_bounds__(64) void k_pt_swap(Params p, uint32_t g, int64_t tr
     if (lane == 0 && trace_slot >= 0) { int32_t* q = p.tswap + 3 * trace_slot; q[0] = (int32_t)a; q[1] = (int32_t)b; q[2] = acc ? 1 : 0; }
 }
 
+// Sequential sums with the loads of a batch in flight together: a plain `for` over dependent adds of freshly loaded values waits for
+// one memory round trip per element (64 rows: 18 us, measured); the order of the additions is untouched.
+constexpr int SUM_BATCH = 32;
+template <int SQ>      // 0: sum of v; 1: sum of (v - m)^2 by fma; 2: by multiply-then-add (numpy's own order, single-chain stepping)
+DZ_DEV double strided_sum(const double* __restrict__ q, size_t stride, int n, double m)
+{
+    double ps = 0.0;
+    int c = 0;
+    for (; c + SUM_BATCH <= n; c += SUM_BATCH) {
+        double v[SUM_BATCH];
+#pragma unroll
+        for (int u = 0; u < SUM_BATCH; ++u) v[u] = q[(size_t)(c + u) * stride];
+#pragma unroll
+        for (int u = 0; u < SUM_BATCH; ++u) {
+            if (SQ == 0) ps = ps + v[u];
+            else { const double t = v[u] - m; ps = SQ == 1 ? fma(t, t, ps) : ps + t * t; }
+        }
+    }
+    for (; c < n; ++c) {
+        const double x = q[(size_t)c * stride];
+        if (SQ == 0) ps = ps + x;
+        else { const double t = x - m; ps = SQ == 1 ? fma(t, t, ps) : ps + t * t; }
+    }
+    return ps;
+}
 #ifndef DZ_TEMPLATES_ONLY   // plain (non-template) kernels: defined once, in dz_engine.hip's translation unit
 // Dream.py:281-282: `while np.all(np.isfinite(np.array(log_ps))==False)` -- marks the chains whose k tries are all impossible
 // (log_ps = T log_likes + log_priors, :279); the host draws their proposal sets again (redraw_impossible_sets).
@@ -1651,10 +1685,11 @@ __global__ void k_strip_partial(const double* __restrict__ pos, int N, int d, in
     const int s = blockIdx.y;
     if (j >= d) return;
     const int r0 = s * strip, r1 = min(N, r0 + strip);
-    double ps = 0.0;
-    if (pass == 0) for (int c = r0; c < r1; ++c) ps = ps + pos[(size_t)c * ld + j];
-    else if (plain) { const double m = mean[j]; for (int c = r0; c < r1; ++c) { const double t = pos[(size_t)c * ld + j] - m; ps = ps + t * t; } }
-    else { const double m = mean[j]; for (int c = r0; c < r1; ++c) { const double t = pos[(size_t)c * ld + j] - m; ps = fma(t, t, ps); } }
+    const double* q = pos + (size_t)r0 * ld + j;
+    double ps;
+    if (pass == 0) ps = strided_sum<0>(q, (size_t)ld, r1 - r0, 0.0);
+    else if (plain) ps = strided_sum<2>(q, (size_t)ld, r1 - r0, mean[j]);
+    else ps = strided_sum<1>(q, (size_t)ld, r1 - r0, mean[j]);
     partial[(size_t)s * ld + j] = ps;
 }
 // single-chain stepping: the chains of [c0, c0 + nc) that have just updated the shared probabilities adopt them as their own copy
@@ -1686,41 +1721,47 @@ __global__ void k_strip_dev(const double* __restrict__ pos, int N, int d, int ld
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int s = blockIdx.y;
     if (j >= d) return;
-    double tot = 0.0;
-    for (int s2 = 0; s2 < nstrips; ++s2) tot = tot + partial0[(size_t)s2 * ld + j];
+    const double tot = strided_sum<0>(partial0 + j, (size_t)ld, nstrips, 0.0);
     const double m = tot / (double)N;
     if (s == 0) mean_out[j] = m;
     const int r0 = s * strip, r1 = min(N, r0 + strip);
-    double ps = 0.0;
-    if (plain) for (int c = r0; c < r1; ++c) { const double t = pos[(size_t)c * ld + j] - m; ps = ps + t * t; }
-    else for (int c = r0; c < r1; ++c) { const double t = pos[(size_t)c * ld + j] - m; ps = fma(t, t, ps); }
-    partial1[(size_t)s * ld + j] = ps;
+    const double* q = pos + (size_t)r0 * ld + j;
+    partial1[(size_t)s * ld + j] = plain ? strided_sum<2>(q, (size_t)ld, r1 - r0, m) : strided_sum<1>(q, (size_t)ld, r1 - r0, m);
 }
 #endif  // DZ_TEMPLATES_ONLY
 
-// one wave per GLOBAL chain (16 chains per block of four waves): bins and normalised squared jumps (:481, :527).  The standard deviations
-// come from the strip sums of pass 1, added in strip order by every block for itself (k_strip_finish's additions; block 0 also stores
-// them): sd[j] = sqrt((sum_s partial1[s][j]) / N), for the crossover statistic with 0 -> 1e-12 (:479).
-constexpr int JUMP_CHAINS = 16;
+// Bins and normalised squared jumps (:481, :527): one block of 16 waves per strip of 64 GLOBAL chains (a wave takes four of them), of
+// which [gc0, gc0 + ngc) take part (everything in a lockstep generation; one chain under Dream.astep).  The standard deviations come
+// from the strip sums of pass 1, added in strip order by every block for itself (k_strip_finish's additions; block 0 also stores them):
+// sd[j] = sqrt((sum_s partial1[s][j]) / N), for the crossover statistic with 0 -> 1e-12 (:479).  The block ends with its strip's
+// contribution to every bin -- the chains of the strip in order, the contract's inner sum --: binsum[s][m], bincnt[s][m], crossover
+// bins first, then the gamma-level bins; k_adapt_update adds the strips.
 template <int NCH>
-__global__ __launch_bounds__(256) void k_jump(Params p, uint32_t g, int gc0, int ngc, const double* __restrict__ partial1, int nstrips,
-                                              double* __restrict__ sd_out, double* __restrict__ sdc_out,
-                                              double* __restrict__ dl, double* __restrict__ dlg, int* __restrict__ binc, int* __restrict__ bing)
+__global__ __launch_bounds__(1024) void k_jump(Params p, uint32_t g, int gc0, int ngc, const double* __restrict__ partial1, int nstrips,
+                                               double* __restrict__ sd_out, double* __restrict__ sdc_out,
+                                               double* __restrict__ dl, double* __restrict__ dlg, int* __restrict__ binc, int* __restrict__ bing,
+                                               double* __restrict__ binsum, int* __restrict__ bincnt)
 {
     __shared__ double s_sdc[128 * NCH], s_sdg[128 * NCH];
-    for (int j = threadIdx.x; j < p.d; j += 256) {
-        double tot = 0.0;
-        for (int s = 0; s < nstrips; ++s) tot = tot + partial1[(size_t)s * p.ld + j];
+    __shared__ double s_dl[64], s_dlg[64];
+    __shared__ int s_bc[64], s_bg[64];
+    for (int j = threadIdx.x; j < p.d; j += 1024) {
+        const double tot = strided_sum<0>(partial1 + j, (size_t)p.ld, nstrips, 0.0);
         const double v = sqrt(tot / (double)p.N);
         s_sdg[j] = v; s_sdc[j] = v == 0.0 ? 1e-12 : v;
         if (blockIdx.x == 0) { sd_out[j] = v; sdc_out[j] = v == 0.0 ? 1e-12 : v; }
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    for (int q = 0; q < JUMP_CHAINS / 4; ++q) {
-        const int w = blockIdx.x * JUMP_CHAINS + 4 * q + (threadIdx.x >> 6);
-        if (w >= ngc) break;
-        const int gcn = gc0 + w;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int q = 0; q < 4; ++q) {
+        const int ls = 4 * wv + q;                                         // chain inside the strip
+        const int gcn = blockIdx.x * 64 + ls;
+        if (gcn >= p.N) { if (lane == 0) { s_bc[ls] = -1; s_bg[ls] = -1; s_dl[ls] = 0.0; s_dlg[ls] = 0.0; } continue; }
+        const bool in_range = gcn >= gc0 && gcn < gc0 + ngc;
+        if (!in_range) {                                                   // (Dream.astep: every other chain contributes nothing this time)
+            if (lane == 0) { s_bc[ls] = -1; s_bg[ls] = -1; s_dl[ls] = 0.0; s_dlg[ls] = 0.0; binc[gcn] = -1; bing[gcn] = -1; }
+            continue;
+        }
         const Ctrl u = draw_ctrl(p.k0, p.k1, (uint32_t)gcn, g);
         const StepFlags f = step_flags_chain(p, u, gcn - p.off);          // (own copies exist only on an unsharded engine: local == global)
         // np.any(self.gamma == 1.0) of the LAST generate_proposal_points call (:371, :705/:730)
@@ -1753,31 +1794,35 @@ __global__ __launch_bounds__(256) void k_jump(Params p, uint32_t g, int gc0, int
         }
         const double dC = nan_to_num(wave_bfly(accC)), dG = nan_to_num(wave_bfly(accG));
         if (lane == 0) {
-            binc[gcn] = do_c ? (f.snk ? p.ncr - 1 : f.cr_idx) : -1;               // :374-378
-            bing[gcn] = do_g ? f.glev - 1 : -1;
-            dl[gcn] = dC; dlg[gcn] = dG;
+            const int bc = do_c ? (f.snk ? p.ncr - 1 : f.cr_idx) : -1, bg = do_g ? f.glev - 1 : -1;      // :374-378
+            binc[gcn] = bc; bing[gcn] = bg; dl[gcn] = dC; dlg[gcn] = dG;
+            s_bc[ls] = bc; s_bg[ls] = bg; s_dl[ls] = dC; s_dlg[ls] = dG;
         }
+    }
+    __syncthreads();
+    const int t = threadIdx.x, nb = p.ncr + p.ngamma;
+    if (t < nb) {
+        const bool isg = t >= p.ncr; const int m = isg ? t - p.ncr : t;
+        double ps = 0.0; int cnt = 0;
+        for (int c = 0; c < 64; ++c) if ((isg ? s_bg[c] : s_bc[c]) == m) { ps = ps + (isg ? s_dlg[c] : s_dl[c]); cnt++; }
+        binsum[(size_t)blockIdx.x * nb + t] = ps; bincnt[(size_t)blockIdx.x * nb + t] = cnt;
     }
 }
 
 #ifndef DZ_TEMPLATES_ONLY   // plain (non-template) kernels: defined once, in dz_engine.hip's translation unit
-// single block: thread m < ncr updates crossover bin m, thread ncr+m updates gamma bin m; then renormalise
-__global__ void k_adapt_update(Params p, const double* __restrict__ dl, const double* __restrict__ dlg, const int* __restrict__ binc, const int* __restrict__ bing)
+// single block: thread m < ncr updates crossover bin m, thread ncr+m updates gamma bin m -- the strips' contributions (k_jump) added in
+// strip order --; then the probabilities are renormalised
+__global__ void k_adapt_update(Params p, const double* __restrict__ binsum, const int* __restrict__ bincnt, int nstrips)
 {
     __shared__ int any[2];
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, nb = p.ncr + p.ngamma;
     if (t < 2) any[t] = 0;
     __syncthreads();
-    if (t < p.ncr + p.ngamma) {
+    if (t < nb) {
         const bool isg = t >= p.ncr; const int m = isg ? t - p.ncr : t;
-        const double* dd = isg ? dlg : dl; const int* bb = isg ? bing : binc;
-        double tot = 0.0; int cnt = 0;
-        for (int s = 0; s < p.N; s += 64) {
-            double ps = 0.0;
-            const int e = min(p.N, s + 64);
-            for (int c = s; c < e; ++c) if (bb[c] == m) { ps = ps + dd[c]; cnt++; }
-            tot = tot + ps;
-        }
+        const double tot = strided_sum<0>(binsum + t, (size_t)nb, nstrips, 0.0);
+        int cnt = 0;
+        for (int s = 0; s < nstrips; ++s) cnt += bincnt[(size_t)s * nb + t];
         if (cnt) {
             double* delta = isg ? p.g_delta : p.cr_delta; double* n = isg ? p.g_n : p.cr_n;
             delta[m] = delta[m] + tot; n[m] += (double)cnt; atomicOr(&any[isg ? 1 : 0], 1);
@@ -1785,14 +1830,14 @@ __global__ void k_adapt_update(Params p, const double* __restrict__ dl, const do
     }
     __syncthreads();
     if (t < 2 && any[t]) {     // :487-493 / :531-536
-        const int nb = t ? p.ngamma : p.ncr;
+        const int nbb = t ? p.ngamma : p.ncr;
         double* probs = t ? p.g_probs : p.cr_probs; const double* delta = t ? p.g_delta : p.cr_delta; const double* n = t ? p.g_n : p.cr_n;
         bool all = true;
-        for (int m = 0; m < nb; ++m) if (delta[m] == 0.0) all = false;
+        for (int m = 0; m < nbb; ++m) if (delta[m] == 0.0) all = false;
         if (all) {
             double S = 0.0;
-            for (int m = 0; m < nb; ++m) { probs[m] = (delta[m] / n[m]) * (double)p.N; S = S + probs[m]; }
-            for (int m = 0; m < nb; ++m) probs[m] = probs[m] / S;
+            for (int m = 0; m < nbb; ++m) { probs[m] = (delta[m] / n[m]) * (double)p.N; S = S + probs[m]; }
+            for (int m = 0; m < nbb; ++m) probs[m] = probs[m] / S;
         }
     }
 }
@@ -1800,6 +1845,7 @@ __global__ void k_adapt_update(Params p, const double* __restrict__ dl, const do
 // ------------------------------------------------------------------------------------------
 // Gelman_Rubin (convergence.py:3-20) from the device-resident trace
 // ------------------------------------------------------------------------------------------
+// (sample order and chain order of the sums are those of the oracle's restatement -- the loads of a batch travel together)
 __global__ void k_chain_moments(const double* __restrict__ tX, int nl, int d, int ld, long long tcap, int nsamples, double* __restrict__ mean, double* __restrict__ var)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1807,23 +1853,17 @@ __global__ void k_chain_moments(const double* __restrict__ tX, int nl, int d, in
     if (j >= d) return;
     const int nb = nsamples / 2, n2 = nsamples - nb;
     const double* x = tX + ((size_t)c * tcap + nb) * ld + j;
-    const size_t st = (size_t)ld;
-    double s = 0.0;
-    for (int t = 0; t < n2; ++t) s = s + x[(size_t)t * st];
-    const double m = s / (double)n2;
-    double v = 0.0;
-    for (int t = 0; t < n2; ++t) { const double q = x[(size_t)t * st] - m; v = v + q * q; }
+    const double m = strided_sum<0>(x, (size_t)ld, n2, 0.0) / (double)n2;
+    const double v = strided_sum<2>(x, (size_t)ld, n2, m);
     mean[(size_t)c * d + j] = m; var[(size_t)c * d + j] = v / (double)n2;
 }
 __global__ void k_rhat(const double* __restrict__ mean, const double* __restrict__ var, int nch, int d, int nsamples, double* __restrict__ rhat)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= d) return;
-    double W = 0.0, mm = 0.0;
-    for (int c = 0; c < nch; ++c) { W = W + var[(size_t)c * d + j]; mm = mm + mean[(size_t)c * d + j]; }
+    double W = strided_sum<0>(var + j, (size_t)d, nch, 0.0), mm = strided_sum<0>(mean + j, (size_t)d, nch, 0.0);
     W = W / (double)nch; mm = mm / (double)nch;
-    double B = 0.0;
-    for (int c = 0; c < nch; ++c) { const double q = mean[(size_t)c * d + j] - mm; B = B + q * q; }
+    double B = strided_sum<2>(mean + j, (size_t)d, nch, mm);
     B = B / (double)nch;
     const double var_est = W * (1.0 - 1.0 / (double)nsamples) + B;
     rhat[j] = sqrt(var_est / W);

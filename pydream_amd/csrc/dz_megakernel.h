@@ -135,20 +135,50 @@ DZ_DEV void mfma_units(const Params& p, const double* __restrict__ Ms, const dou
 // (chain, generation, phase, try) only, never on the selected point.
 struct RowPair { double2 a, b; };
 
-DZ_DEV void request_pair(const Params& p, const DrawSrc& ds, int slot, uint32_t gc, uint32_t g, uint32_t M, int lane, RowPair& R)
-{   // slot = pt_slot(p, phase, i, 1)
+// The two row numbers of a DE try, random.sample(range(M), 2) (:662), from the words of its idx-1 slot
+DZ_DEV void sample_pair(uint32_t wx, uint32_t wy, uint32_t M, uint32_t& r0, uint32_t& r1)
+{
+    r0 = mulhi_idx(wx, M);
+    r1 = mulhi_idx(wy, M - 1u);
+    r1 += (r1 >= r0) ? 1u : 0u;
+}
+// What the tries read from the generation's slot draws, made lane-parallel once per generation instead of on the scalar unit once per
+// try (DrawSrc::xf): lane s holds slot s.  snk: the chain's move of this generation (wave-uniform).
+DZ_DEV void finish_draws(const Params& p, DrawSrc& q, bool snk, uint32_t M, int lane)
+{
+    const int sl = lane - 3;
+    const bool pt = lane >= 3 && lane < p.nslots;
+    const bool rows = pt && (sl % p.npt) == 1;            // (DEpairs = 1: npt = 2 -- idx 0 the gamma draws, idx 1 the rows)
+    const bool gam = pt && (sl % p.npt) == 0;
+    uint32_t r0, r1;
+    sample_pair(q.mine.x, q.mine.y, M, r0, r1);
+    const uint32_t s0 = mulhi_idx(q.mine.x, M), s1 = mulhi_idx(q.mine.y, M), s2 = mulhi_idx(q.mine.z, M);      // :808-810
+    const uint32_t gu = u53_below(q.mine.x, q.mine.y, p.pgu_thr) ? 1u : 0u;                                  // :615
+    q.mine.x = rows ? (snk ? s0 : r0) : (gam ? gu : q.mine.x);
+    q.mine.y = rows ? (snk ? s1 : r1) : q.mine.y;
+    q.mine.z = (rows && snk) ? s2 : q.mine.z;
+    q.xf = true;
+}
+
+template <bool XF>
+DZ_DEV void request_pair(const Params& p, const DrawSrc& ds, int slot, uint32_t gc, uint32_t g, uint32_t M, int lane, RowPair& R, const double* Zb, uint32_t ldb)
+{   // slot = pt_slot(p, phase, i, 1); Zb / ldb: the archive and its row pitch in BYTES (fetched once per set, SetConsts)
     const u32x4 w = uniform_draw(p, ds, slot, gc, g);
-    const uint32_t r0 = __builtin_amdgcn_readfirstlane(mulhi_idx(w.x, M));
-    uint32_t r1 = __builtin_amdgcn_readfirstlane(mulhi_idx(w.y, M - 1u));
-    if (r1 >= r0) r1++;                                   // random.sample(range(M), 2) :662  (wave-uniform: kept on the scalar unit)
-    const uint32_t uld = (uint32_t)p.ld;
-    const int jc = min(2 * lane, p.ld - 2);               // (no lane predicate: lanes past ld re-read the row's last pair, masked where used)
-    R.a = gload2(p.Z + (uint64_t)r0 * uld + jc);
-    R.b = gload2(p.Z + (uint64_t)r1 * uld + jc);
+    uint32_t r0, r1;
+    if (XF) { r0 = w.x; r1 = w.y; }                        // (finish_draws)
+    else {
+        r0 = __builtin_amdgcn_readfirstlane(mulhi_idx(w.x, M));
+        r1 = __builtin_amdgcn_readfirstlane(mulhi_idx(w.y, M - 1u));
+        if (r1 >= r0) r1++;                                // random.sample(range(M), 2) :662  (wave-uniform: kept on the scalar unit)
+    }
+    // (no lane predicate: lanes past ld re-read the row's last pair, masked where used)  scalar row base + 32-bit lane offset in bytes
+    const uint32_t jb = (uint32_t)min(16 * lane, (int)ldb - 16);
+    R.a = gload2(reinterpret_cast<const double*>(reinterpret_cast<const char*>(Zb) + (uint64_t)r0 * ldb + jb));
+    R.b = gload2(reinterpret_cast<const double*>(reinterpret_cast<const char*>(Zb) + (uint64_t)r1 * ldb + jb));
 }
 
 // DE tries i0..i1-1 of one chain's set (one pair, the common case); A and B already hold the rows of tries i0 and i0 + 1.
-template <int LEAN>
+template <int LEAN, bool XF>
 DZ_DEV void propose_de_pf(const Params& p, int phase, uint32_t g, uint32_t M, int c, uint32_t gc, int i0, int i1, int n, int lane,
                           const double (&xb)[1][2], const double* __restrict__ grow, int cr_idx, int glev, const DrawSrc& ds,
                           double* out, int out_stride, double* sl, double* prior_out, RowPair& A, RowPair& B, RowPair& C)
@@ -161,14 +191,15 @@ DZ_DEV void propose_de_pf(const Params& p, int phase, uint32_t g, uint32_t M, in
         if (!LEAN && prior_out) point_prior<1>(p, out + (size_t)i * out_stride, lane, prior_out + i);
     };
     const int rs = sc.slot0 + 1;                          // pt_slot(phase, i, 1) = rs + i npt
+    const double* Zb = p.Z; const uint32_t ldb = 8u * (uint32_t)p.ld;
     for (int i = i0; i < i1; i += 3) {
-        if (i + 2 < i1) request_pair(p, ds, rs + (i + 2) * sc.npt, gc, g, M, lane, C);
+        if (i + 2 < i1) request_pair<XF>(p, ds, rs + (i + 2) * sc.npt, gc, g, M, lane, C, Zb, ldb);
         body(i, A);
         if (i + 1 >= i1) break;
-        if (i + 3 < i1) request_pair(p, ds, rs + (i + 3) * sc.npt, gc, g, M, lane, A);
+        if (i + 3 < i1) request_pair<XF>(p, ds, rs + (i + 3) * sc.npt, gc, g, M, lane, A, Zb, ldb);
         body(i + 1, B);
         if (i + 2 >= i1) break;
-        if (i + 4 < i1) request_pair(p, ds, rs + (i + 4) * sc.npt, gc, g, M, lane, B);
+        if (i + 4 < i1) request_pair<XF>(p, ds, rs + (i + 4) * sc.npt, gc, g, M, lane, B, Zb, ldb);
         body(i + 2, C);
     }
     if (lane >= i0 && lane < i1) { sl[lane] = 0.0; if (LEAN && prior_out) prior_out[lane] = 0.0; }            // snooker_logp = 0 (flat priors: 0)
@@ -246,9 +277,14 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     // A generation's wave-uniform draws: lane s holds slot s (both phases read them; four registers across the likelihood pass are
     // cheaper than a second Philox call).  They are made at the end of the PREVIOUS generation's second proposal phase, together
     // with the requests for the first archive rows the generation will need.
+    constexpr bool XF = !PB;                                                         // (the full-code instantiations read the raw draws: several pairs per try)
     auto generation_draws = [&](uint32_t g_) {
         DrawSrc q; q.have = true; q.mine = make_uint4(0, 0, 0, 0);
         if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g_); q.mine = make_uint4(w.x, w.y, w.z, w.w); }
+        if (XF) {
+            const uint32_t hx = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.mine.x), hy = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.mine.y);
+            finish_draws(p, q, u53_below(hx, hy, p.snk_thr), M, lane);               // (slot 0 = lane 0: set_snooker's draw)
+        }
         return q;
     };
     RowPair RA, RB, RC;
@@ -256,8 +292,8 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     auto prefetch_first = [&](const DrawSrc& q, int phase_, uint32_t g_) {          // rows of this wave's first two tries of (g_, phase_)
         const int n_ = k - phase_;
         const int a0 = WPC == 1 ? 0 : (sub * n_) / WPC, a1 = WPC == 1 ? n_ : ((sub + 1) * n_) / WPC;
-        if (a0 < a1) request_pair(p, q, pt_slot(p, phase_, a0, 1), gc, g_, M, lane, RA);
-        if (a0 + 1 < a1) request_pair(p, q, pt_slot(p, phase_, a0 + 1, 1), gc, g_, M, lane, RB);
+        if (a0 < a1) request_pair<XF>(p, q, pt_slot(p, phase_, a0, 1), gc, g_, M, lane, RA, p.Z, 8u * (uint32_t)p.ld);
+        if (a0 + 1 < a1) request_pair<XF>(p, q, pt_slot(p, phase_, a0 + 1, 1), gc, g_, M, lane, RB, p.Z, 8u * (uint32_t)p.ld);
     };
     auto draws_say_snooker = [&](const DrawSrc& q, uint32_t g_) {                   // set_snooker :542-554 on the integer form of the draw
         const u32x4 w0 = uniform_draw(p, q, 0, gc, g_);
@@ -340,7 +376,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                     propose_set<NCH, false, true, 0>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, false, f.cr_idx, f.delta, f.glev, ds,
                                                       region + (size_t)phase * tstride, tstride, slp, nullptr, prp);
             } else if (!snk_s) {
-                propose_de_pf<LEANV>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, f.cr_idx, f.glev, ds,
+                propose_de_pf<LEANV, XF>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, f.cr_idx, f.glev, ds,
                                    region + (size_t)phase * tstride, tstride, slp, prp, RA, RB, RC);
                 if (phase == 0) prefetch_first(ds, 1, g);                            // the reference set's first rows, ahead of the likelihood pass
             } else if (i0 < i1) {

@@ -145,7 +145,7 @@ struct dz_engine {
     double *d_shared = nullptr;      // cr_probs|cr_delta|cr_n|g_probs|g_delta|g_n
     double *d_partial = nullptr, *d_mean = nullptr, *d_sd = nullptr, *d_sdc = nullptr, *d_dl = nullptr, *d_dlg = nullptr;
     int *d_binc = nullptr, *d_bing = nullptr;
-    double* d_binsum = nullptr; int* d_bincnt = nullptr;      // [strips of 64 chains][ncr + ngamma]: the strips' contributions to the adaptation bins (k_jump)
+    double* d_binsum = nullptr;     // k_adapt_update's scratch: [strips of 64 chains][ncr + ngamma] sums, then the same shape of counts
     dz::Params* d_params = nullptr;  // device copy of `p` for kernels that take it by pointer
     double *d_scratch = nullptr; size_t scratch_rows = 0;   // debug / eval staging [rows, ld]
     double *d_cmean = nullptr, *d_cvar = nullptr, *d_rhat = nullptr;
@@ -156,6 +156,8 @@ struct dz_engine {
     bool fuse = true;               // DZ_FUSE=0 disables the accept+propose fusion
     bool stream_propose = true;     // ld > 256: the streaming proposal kernel (k_propose_stream); DZ_STREAM=0 keeps k_propose<4|8>
     bool mega = true;               // the persistent generation kernel serves every eligible configuration (mega_eligible); DZ_MEGA=0 forces the multi-kernel path
+    bool mega_redo_on = true;       // redraw rounds (Dream.py:281-289) inside the persistent kernel; DZ_MEGA_REDO=0: such configurations take the multi-kernel path
+    unsigned long long* d_redraw_count = nullptr;
     bool mega_burnin = true;        // ... the generations of the crossover burn-in too, one per launch (positions published by the kernel); DZ_MEGA_BURNIN=0: multi-kernel path there
     int mega_max_gen = 1 << 20;     // DZ_MEGA_MAXGEN: generations per launch cap (measurement)
     int mega_ch = 0;                // DZ_MEGA_CHAINS: force 16 / 8 / 4 chains per block (0: by chain count)
@@ -484,9 +486,11 @@ int adapt_generation(dz_engine* e, uint32_t g, int gc0, int ngc)
     hipLaunchKernelGGL(dz::k_strip_partial, gcol, b, 0, e->stream, p.cp_new, p.N, p.d, p.ld, e->d_mean, 0, e->d_partial, strip, single ? 1 : 0);
     hipLaunchKernelGGL(dz::k_strip_dev, gcol, b, 0, e->stream, p.cp_new, p.N, p.d, p.ld, (const double*)e->d_partial, nstrips, partial1, e->d_mean, strip, single ? 1 : 0);
     const int nstrips64 = (p.N + 63) / 64;          // (the bins are always summed by strips of 64 chains, then the strips in order)
-    NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_jump<NCH>, dim3(nstrips64), dim3(1024), 0, e->stream, p, g, gc0, ngc, (const double*)partial1, nstrips,
-                                       e->d_sd, e->d_sdc, e->d_dl, e->d_dlg, e->d_binc, e->d_bing, e->d_binsum, e->d_bincnt));
-    hipLaunchKernelGGL(dz::k_adapt_update, dim3(1), dim3(64), 0, e->stream, p, (const double*)e->d_binsum, (const int*)e->d_bincnt, nstrips64);
+    NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_jump<NCH>, dim3((p.N + dz::JUMP_CHAINS - 1) / dz::JUMP_CHAINS), dim3(64 * dz::JUMP_CHAINS), 0, e->stream, p, g, gc0, ngc,
+                                       (const double*)partial1, nstrips, e->d_sd, e->d_sdc, e->d_dl, e->d_dlg, e->d_binc, e->d_bing));
+    (void)nstrips64;
+    hipLaunchKernelGGL(dz::k_adapt_update, dim3(1), dim3(1024), (size_t)(dz::ADAPT_CHUNK + dz::ADAPT_CHUNK / 64) * 24, e->stream, p,
+                       (const double*)e->d_dl, (const double*)e->d_dlg, (const int*)e->d_binc, (const int*)e->d_bing, e->d_binsum);
     if (single && e->d_own_cr)      // the chains that updated the shared probabilities adopt them (Dream.py:375, :383, :409-415)
         hipLaunchKernelGGL(dz::k_own_probs, dim3((ngc + 63) / 64), dim3(64), 0, e->stream, p, gc0 - p.off, ngc, (const int*)e->d_binc, (const int*)e->d_bing, 0, e->d_own_cr, e->d_own_g);
     return launch_check("adaptation kernels");
@@ -706,15 +710,17 @@ bool mega_xlds(const dz_engine* e) { return mega_lds_bytes(e, true) <= (size_t)1
 bool mega_mix_eligible(const dz_engine* e)
 {
     const dz::Params& p = e->p;
-    return e->mega && !p.Tc && e->lk == LK_MIX && !p.hard && !p.have_prior && p.ld <= 128 && (p.k == 1 || p.k >= 3) && p.k <= dz::MAXK && p.depairs == 1 &&
+    return e->mega && !p.Tc && e->lk == LK_MIX && !redo_possible(e) && !p.hard && !p.have_prior && p.ld <= 128 && (p.k == 1 || p.k >= 3) && p.k <= dz::MAXK && p.depairs == 1 &&
            p.nslots <= 64 && p.J <= 32;
 }
+// redraw rounds inside the persistent kernel: the instantiations with the full proposal code, multi-try, device MVN likelihood
+bool mega_redo(const dz_engine* e) { return redo_possible(e) && e->lk == LK_MVN && e->p.k > 1 && e->mega_redo_on; }
 bool mega_eligible(const dz_engine* e)
 {
     const dz::Params& p = e->p;
-    if (redo_possible(e)) return false;
+    if (redo_possible(e) && !mega_redo(e)) return false;
     if (mega_mix_eligible(e)) return true;
-    if ((p.hard || p.have_prior || p.depairs > 1) && !mega_xlds(e)) return false;      // (the full-code instantiations keep the states in LDS)
+    if ((p.hard || p.have_prior || p.depairs > 1 || mega_redo(e)) && !mega_xlds(e)) return false;      // (the full-code instantiations keep the states in LDS)
     return e->mega && !p.Tc && e->lk == LK_MVN && p.ld <= 128 && (p.k == 1 || p.k >= 3) && p.k <= dz::MAXK &&
            p.nslots <= 64 && (!p.tri || p.Mtp) && mega_lds_bytes(e, false) <= (size_t)160 * 1024;
 }
@@ -792,13 +798,13 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
     const int wpc = (ch == 4 && !k1) ? 4 : 1;
     const dim3 grid((p.nl + ch - 1) / ch), block(64 * ch * wpc);
     const bool xlds = mega_xlds(e);
-    const bool pb = p.hard || p.have_prior || p.depairs > 1;      // the instantiations with the full proposal code
+    const bool pb = p.hard || p.have_prior || p.depairs > 1 || mega_redo(e);      // the instantiations with the full proposal code
     const size_t lds = mega_lds_bytes(e, xlds);
     DZCK(upload_params(e));
     {
         // the instantiations live in one translation unit per row-tile count (dz_mega_tu.hip)
         dz::MegaLaunch ml;
-        ml.tri = p.tri != 0; ml.xlds = pb ? true : xlds; ml.pb = pb; ml.k1 = k1; ml.ch = ch; ml.wpc = wpc;
+        ml.tri = p.tri != 0; ml.xlds = pb ? true : xlds; ml.pb = pb; ml.k1 = k1; ml.ch = ch; ml.wpc = wpc; ml.redo = mega_redo(e);
         ml.grid = grid; ml.block = block; ml.lds = lds; ml.st = e->stream; ml.ka = nullptr; ml.kb = nullptr;
         ml.pp = (const dz::Params*)e->d_params; ml.g = g; ml.n = n; ml.M = (uint32_t)visible_rows(e); ml.slot0 = slot0; ml.zappend = append_last ? e->M : (int64_t)-1; ml.publish = pubto;
         if (e->prof) { ml.ka = prof_event(e); ml.kb = prof_event(e); e->ev[PR_GENERATIONS].emplace_back(ml.ka, ml.kb); }
@@ -859,6 +865,8 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     if (const char* kv = getenv("DZ_MEGA")) e->mega = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_MAXGEN")) e->mega_max_gen = std::max(1, atoi(kv));
     if (const char* kv = getenv("DZ_MEGA_BURNIN")) e->mega_burnin = atoi(kv) != 0;
+    if (const char* kv = getenv("DZ_MEGA_REDO")) e->mega_redo_on = atoi(kv) != 0;
+    static_assert(dz::DZ_MAX_REDRAWS_DEV == DZ_MAX_REDRAWS && dz::DZ_REDRAW_KEY_STEP_DEV == DZ_REDRAW_KEY_STEP, "redraw constants");
     if (const char* kv = getenv("DZ_LOGP_BM")) e->logp_bm = atoi(kv);          // 64 / 128: points per block of k_logp_mvn_gemm (default: by size)
     if (const char* kv = getenv("DZ_MEGA_CHAINS")) { const int v = atoi(kv); e->mega_ch = (v == 16 || v == 8 || v == 4) ? v : 0; }
     if (const char* kv = getenv("DZ_WPB")) e->waves_per_block = atoi(kv);
@@ -916,6 +924,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     { void* hp = nullptr; if (hipHostMalloc(&hp, (size_t)4 * nl * 16 * 8, hipHostMallocDefault) == hipSuccess) { memset(hp, 0, (size_t)4 * nl * 16 * 8); p.dbg = (unsigned long long*)hp; } }
 #endif
     rc |= ealloc(e, &e->d_params, 1);
+    rc |= ealloc(e, &e->d_redraw_count, 1); p.redraw_count = e->d_redraw_count;
     rc |= ealloc(e, &e->d_mins, ld); rc |= ealloc(e, &e->d_maxs, ld);
     rc |= ealloc(e, &e->d_gtab, (size_t)cfg->ngamma * cfg->depairs * p.d);
     rc |= ealloc(e, &e->d_shared, (size_t)3 * (cfg->ncr + cfg->ngamma));
@@ -926,7 +935,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
         rc |= ealloc(e, &e->d_partial, (size_t)2 * ((N + 63) / 64) * ld);      // strip sums of pass 0 | of pass 1
         rc |= ealloc(e, &e->d_mean, ld); rc |= ealloc(e, &e->d_sd, ld); rc |= ealloc(e, &e->d_sdc, ld);
         rc |= ealloc(e, &e->d_dl, N); rc |= ealloc(e, &e->d_dlg, N); rc |= ealloc(e, &e->d_binc, N); rc |= ealloc(e, &e->d_bing, N);
-        rc |= ealloc(e, &e->d_binsum, (size_t)((N + 63) / 64) * (cfg->ncr + cfg->ngamma)); rc |= ealloc(e, &e->d_bincnt, (size_t)((N + 63) / 64) * (cfg->ncr + cfg->ngamma));
+        rc |= ealloc(e, &e->d_binsum, (size_t)2 * ((N + 63) / 64) * (cfg->ncr + cfg->ngamma));
     }
     if (tc) {
         p.tcap = (long long)tc;
@@ -1360,7 +1369,13 @@ int dz_sync(dz_engine* e)
 }
 int dz_trace_reset(dz_engine* e) { e->ntrace = 0; return 0; }
 int64_t dz_generation(dz_engine* e) { return e->gen; }
-int64_t dz_redraw_rounds(dz_engine* e) { return e->redraw_rounds; }
+int64_t dz_redraw_rounds(dz_engine* e)
+{   // launches of the multi-kernel path's redraw rounds + (block, round) pairs of the persistent kernel's
+    unsigned long long dev = 0;
+    if (e->d_redraw_count && hipSetDevice(e->c.device) == hipSuccess && sync_all(e) == 0)
+        (void)hipMemcpy(&dev, e->d_redraw_count, sizeof dev, hipMemcpyDeviceToHost);
+    return e->redraw_rounds + (int64_t)dev;
+}
 const char* dz_last_kernel_variant(dz_engine* e) { return e->last_variant.c_str(); }
 
 int dz_get_state(dz_engine* e, double* X, double* prior, double* like)

@@ -55,6 +55,7 @@ struct Params {
     // probabilities (Dream.py:375, :383, :497, :538, :409-415), refreshed only by its own adaptation updates; [nl][ncr] / [nl][ngamma], or
     // null in lockstep mode (every chain reads the shared vectors)
     const double *own_cr, *own_g;
+    unsigned long long* redraw_count;    // redraw rounds made inside the persistent kernel (one count per block and round), or null
     unsigned long long* dbg;  // cycle-stamp buffer of instrumented builds (-DDZ_EXPERIMENTS, dz_experiments.h); null otherwise
 };
 // per-phase cycle stamps: defined by dz_experiments.h in instrumented builds only (tools/variants.sh), no-ops in the product
@@ -147,20 +148,23 @@ DZ_DEV uint32_t mulhi_idx(uint32_t w, uint32_t M) { return (uint32_t)(((uint64_t
 
 // slot layout of the precomputed uniform draws
 DZ_DEV int pt_slot(const Params& p, int phase, int tr, int idx) { return 3 + ((phase ? p.k + tr : tr) * p.npt + idx); }
-DZ_DEV u32x4 slot_counter_draw(const Params& p, int slot, uint32_t gc, uint32_t g)
+DZ_DEV u32x4 slot_counter_draw_key(const Params& p, int slot, uint32_t gc, uint32_t g, uint32_t k0, uint32_t k1)
 {   // the Philox call a slot stands for
-    if (slot < 3) return philox(p.k0, p.k1, (uint32_t)slot, stream_id(K_CTRL, 0, 0), gc, g);
+    if (slot < 3) return philox(k0, k1, (uint32_t)slot, stream_id(K_CTRL, 0, 0), gc, g);
     const int q = (slot - 3) / p.npt, idx = (slot - 3) % p.npt;
     const int phase = q >= p.k ? 1 : 0, tr = phase ? q - p.k : q;
-    return philox(p.k0, p.k1, (uint32_t)idx, stream_id(K_PT, (uint32_t)tr, (uint32_t)phase), gc, g);
+    return philox(k0, k1, (uint32_t)idx, stream_id(K_PT, (uint32_t)tr, (uint32_t)phase), gc, g);
 }
+DZ_DEV u32x4 slot_counter_draw(const Params& p, int slot, uint32_t gc, uint32_t g) { return slot_counter_draw_key(p, slot, gc, g, p.k0, p.k1); }
 // Where a wave gets its uniform draws from: lane s of the wave holds slot s of the chain's precomputed table
 // (ONE coalesced 16-byte load per lane at wave start, then v_readlane), or nothing (evaluate Philox in place).
 // xf: the point-stream slots have been turned, lane-parallel and once per generation, into what the tries read from them (persistent
 // kernel, lean instantiations; dz_megakernel.h finish_draws): idx 0 -- .x = 1 if the gamma-unity draw says gamma = 1 (:615), .z/.w the raw
 // words of the snooker gamma; idx 1 -- the archive ROW numbers themselves: DE .x/.y = random.sample(range(M), 2) (:662), snooker
 // .x/.y/.z = z and the projected pair (:808-810).
-struct DrawSrc { uint4 mine; bool have; bool xf = false; };
+// rekey: a redraw round of the persistent kernel (Dream.py:281-289) -- the point, dimension and boundary streams of the proposal set come
+// from the Philox key (k0, k1) = seed + round * DZ_REDRAW_KEY_STEP instead of the run's (DESIGN.md section 4 "Redraw rounds").
+struct DrawSrc { uint4 mine; bool have; bool xf = false; bool rekey = false; uint32_t k0 = 0, k1 = 0; };
 DZ_DEV DrawSrc load_draws(const Params& p, const uint4* dr, int lane)
 {
     DrawSrc d; d.have = (dr != nullptr) && p.nslots <= 64; d.mine = make_uint4(0, 0, 0, 0);
@@ -331,6 +335,7 @@ DZ_DEV double propose_point(const Params& p, int phase, uint32_t g, uint32_t M, 
     const uint32_t thr = sc ? sc->thr : p.crthr[__builtin_amdgcn_readfirstlane(cr_idx)];   // CR = CR_values[m], :146 (the decision is wave-uniform)
     const uint32_t s_dim = stream_id(K_DIM, (uint32_t)i, (uint32_t)phase),
                    s_bnd = stream_id(K_BND, (uint32_t)i, (uint32_t)phase);
+    const uint32_t K0 = dr.rekey ? dr.k0 : p.k0, K1 = dr.rekey ? dr.k1 : p.k1;      // (a redraw round's key)
     double pr[NCH][2];
     double sqdist = 0.0;
     if (!snk) {
@@ -342,7 +347,7 @@ DZ_DEV double propose_point(const Params& p, int phase, uint32_t g, uint32_t M, 
             const int j0 = 128 * it + 2 * lane;    // the lane's two dimensions j0, j0+1 = pair j0/2
             {   // no lane predicate around the arithmetic (the lanes past d compute on their own, unused draws; `keep` masks them):
                 // a predicated region costs the zero defaults of every value it defines plus the exec-mask round trip
-                const u32x4 w = (NCH == 1 && wpre) ? *wpre : philox(p.k0, p.k1, (uint32_t)(j0 >> 1), s_dim, gc, g);
+                const u32x4 w = (NCH == 1 && wpre) ? *wpre : philox(K0, K1, (uint32_t)(j0 >> 1), s_dim, gc, g);
                 float z0, z1;
                 normal32_pair(w.z, w.w, z0, z1);
                 keep[it][0] = j0 < d && (w.x & 0xffffu) < thr;               // U_j < CR
@@ -432,7 +437,7 @@ DZ_DEV double propose_point(const Params& p, int phase, uint32_t g, uint32_t M, 
                     if (bl) x = 2 * lo - x;
                     if (bh) x = 2 * hi - x;
                     if (x < lo || x > hi) {
-                        const u32x4 w = philox(p.k0, p.k1, (uint32_t)(jj + s), s_bnd, gc, g);
+                        const u32x4 w = philox(K0, K1, (uint32_t)(jj + s), s_bnd, gc, g);
                         x = lo + u32d(w.x) * (hi - lo);
                     }
                     pr[it][s] = x;
@@ -1730,21 +1735,18 @@ __global__ void k_strip_dev(const double* __restrict__ pos, int N, int d, int ld
 }
 #endif  // DZ_TEMPLATES_ONLY
 
-// Bins and normalised squared jumps (:481, :527): one block of 16 waves per strip of 64 GLOBAL chains (a wave takes four of them), of
-// which [gc0, gc0 + ngc) take part (everything in a lockstep generation; one chain under Dream.astep).  The standard deviations come
-// from the strip sums of pass 1, added in strip order by every block for itself (k_strip_finish's additions; block 0 also stores them):
-// sd[j] = sqrt((sum_s partial1[s][j]) / N), for the crossover statistic with 0 -> 1e-12 (:479).  The block ends with its strip's
-// contribution to every bin -- the chains of the strip in order, the contract's inner sum --: binsum[s][m], bincnt[s][m], crossover
-// bins first, then the gamma-level bins; k_adapt_update adds the strips.
+// Bins and normalised squared jumps (:481, :527): one wave per GLOBAL chain, 16 chains per block, of which [gc0, gc0 + ngc) take part
+// (everything in a lockstep generation; one chain under Dream.astep).  The standard deviations come from the strip sums of pass 1, added
+// in strip order by every block for itself (k_strip_finish's additions; block 0 also stores them): sd[j] = sqrt((sum_s partial1[s][j]) / N),
+// for the crossover statistic with 0 -> 1e-12 (:479).  The chain's control draws and the gamma-unity draws of its last proposal call are
+// made lane-parallel (lane s = slot s: ONE Philox call per wave instead of 2 + k).
+constexpr int JUMP_CHAINS = 16;
 template <int NCH>
 __global__ __launch_bounds__(1024) void k_jump(Params p, uint32_t g, int gc0, int ngc, const double* __restrict__ partial1, int nstrips,
                                                double* __restrict__ sd_out, double* __restrict__ sdc_out,
-                                               double* __restrict__ dl, double* __restrict__ dlg, int* __restrict__ binc, int* __restrict__ bing,
-                                               double* __restrict__ binsum, int* __restrict__ bincnt)
+                                               double* __restrict__ dl, double* __restrict__ dlg, int* __restrict__ binc, int* __restrict__ bing)
 {
     __shared__ double s_sdc[128 * NCH], s_sdg[128 * NCH];
-    __shared__ double s_dl[64], s_dlg[64];
-    __shared__ int s_bc[64], s_bg[64];
     for (int j = threadIdx.x; j < p.d; j += 1024) {
         const double tot = strided_sum<0>(partial1 + j, (size_t)p.ld, nstrips, 0.0);
         const double v = sqrt(tot / (double)p.N);
@@ -1752,80 +1754,98 @@ __global__ __launch_bounds__(1024) void k_jump(Params p, uint32_t g, int gc0, in
         if (blockIdx.x == 0) { sd_out[j] = v; sdc_out[j] = v == 0.0 ? 1e-12 : v; }
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int q = 0; q < 4; ++q) {
-        const int ls = 4 * wv + q;                                         // chain inside the strip
-        const int gcn = blockIdx.x * 64 + ls;
-        if (gcn >= p.N) { if (lane == 0) { s_bc[ls] = -1; s_bg[ls] = -1; s_dl[ls] = 0.0; s_dlg[ls] = 0.0; } continue; }
-        const bool in_range = gcn >= gc0 && gcn < gc0 + ngc;
-        if (!in_range) {                                                   // (Dream.astep: every other chain contributes nothing this time)
-            if (lane == 0) { s_bc[ls] = -1; s_bg[ls] = -1; s_dl[ls] = 0.0; s_dlg[ls] = 0.0; binc[gcn] = -1; bing[gcn] = -1; }
-            continue;
-        }
-        const Ctrl u = draw_ctrl(p.k0, p.k1, (uint32_t)gcn, g);
-        const StepFlags f = step_flags_chain(p, u, gcn - p.off);          // (own copies exist only on an unsharded engine: local == global)
-        // np.any(self.gamma == 1.0) of the LAST generate_proposal_points call (:371, :705/:730)
-        bool gu = false;
-        if (!f.snk) {
-            const int phase = p.k > 1 ? 1 : 0, n = p.k > 1 ? p.k - 1 : 1;
-            for (int i = 0; i < n; ++i) {
-                const u32x4 w4 = philox(p.k0, p.k1, 0, stream_id(K_PT, (uint32_t)i, (uint32_t)phase), (uint32_t)gcn, g);
-                gu = gu || (u53(w4.x, w4.y) < p.pgu);
-            }
-        }
-        const bool at_end = (int)g == p.burnin;
-        const bool window = g > 10 && (int)g < p.burnin;
-        const bool do_c = p.adapt_cr && (at_end || (window && !gu));               // :371, :395
-        const bool do_g = p.adapt_g && (at_end || (window && !gu && !f.snk));      // :381, :391
-        double accC = 0.0, accG = 0.0;
+    const int lane = threadIdx.x & 63;
+    const int gcn = blockIdx.x * JUMP_CHAINS + (threadIdx.x >> 6);
+    if (gcn >= p.N) return;
+    if (gcn < gc0 || gcn >= gc0 + ngc) {                                   // (Dream.astep: every other chain contributes nothing this time)
+        if (lane == 0) { binc[gcn] = -1; bing[gcn] = -1; }
+        return;
+    }
+    // lanes 0, 1: control stream idx 0, 1 (set_snooker / set_CR, set_DEpair / set_gamma_level); lanes 2 .. 2 + n - 1: the gamma-unity draws
+    // of the tries of the LAST generate_proposal_points call (:371, :705 / :730: the reference set's, or the single try's)
+    const int phase = p.k > 1 ? 1 : 0, n = p.k > 1 ? p.k - 1 : 1;
+    u32x4 w = u32x4{0, 0, 0, 0};
+    if (lane < 2 + n) w = lane < 2 ? philox(p.k0, p.k1, (uint32_t)lane, stream_id(K_CTRL, 0, 0), (uint32_t)gcn, g)
+                                   : philox(p.k0, p.k1, 0u, stream_id(K_PT, (uint32_t)(lane - 2), (uint32_t)phase), (uint32_t)gcn, g);
+    Ctrl u;
+    u.u_snk = u53(__shfl(w.x, 0, 64), __shfl(w.y, 0, 64)); u.u_cr = u53(__shfl(w.z, 0, 64), __shfl(w.w, 0, 64));
+    u.u_de = u53(__shfl(w.x, 1, 64), __shfl(w.y, 1, 64)); u.u_glev = u53(__shfl(w.z, 1, 64), __shfl(w.w, 1, 64));
+    u.u_sel = 0.0; u.u_acc = 0.0;
+    const StepFlags f = step_flags_chain(p, u, gcn - p.off);              // (own copies exist only on an unsharded engine: local == global)
+    const bool gu = !f.snk && __any(lane >= 2 && lane < 2 + n && u53(w.x, w.y) < p.pgu);
+    const bool at_end = (int)g == p.burnin;
+    const bool window = g > 10 && (int)g < p.burnin;
+    const bool do_c = p.adapt_cr && (at_end || (window && !gu));               // :371, :395
+    const bool do_g = p.adapt_g && (at_end || (window && !gu && !f.snk));      // :381, :391
+    double accC = 0.0, accG = 0.0;
 #pragma unroll
-        for (int it = 0; it < NCH; ++it) {
-            const int jj = 128 * it + 2 * lane;
-            if (jj < p.ld) {
-                const double2 a = *reinterpret_cast<const double2*>(p.cp_new + (size_t)gcn * p.ld + jj);
-                const double2 b = *reinterpret_cast<const double2*>(p.cp_prev + (size_t)gcn * p.ld + jj);
+    for (int it = 0; it < NCH; ++it) {
+        const int jj = 128 * it + 2 * lane;
+        if (jj < p.ld) {
+            const double2 a = *reinterpret_cast<const double2*>(p.cp_new + (size_t)gcn * p.ld + jj);
+            const double2 b = *reinterpret_cast<const double2*>(p.cp_prev + (size_t)gcn * p.ld + jj);
 #pragma unroll
-                for (int s = 0; s < 2; ++s) if (jj + s < p.d) {
-                    const double df = (s ? a.y : a.x) - (s ? b.y : b.x);
-                    const double t = df / s_sdc[jj + s]; accC = fma(t, t, accC);
-                    const double t2 = df / s_sdg[jj + s]; accG = fma(t2, t2, accG);
-                }
+            for (int s = 0; s < 2; ++s) if (jj + s < p.d) {
+                const double df = (s ? a.y : a.x) - (s ? b.y : b.x);
+                const double t = df / s_sdc[jj + s]; accC = fma(t, t, accC);
+                const double t2 = df / s_sdg[jj + s]; accG = fma(t2, t2, accG);
             }
-        }
-        const double dC = nan_to_num(wave_bfly(accC)), dG = nan_to_num(wave_bfly(accG));
-        if (lane == 0) {
-            const int bc = do_c ? (f.snk ? p.ncr - 1 : f.cr_idx) : -1, bg = do_g ? f.glev - 1 : -1;      // :374-378
-            binc[gcn] = bc; bing[gcn] = bg; dl[gcn] = dC; dlg[gcn] = dG;
-            s_bc[ls] = bc; s_bg[ls] = bg; s_dl[ls] = dC; s_dlg[ls] = dG;
         }
     }
-    __syncthreads();
-    const int t = threadIdx.x, nb = p.ncr + p.ngamma;
-    if (t < nb) {
-        const bool isg = t >= p.ncr; const int m = isg ? t - p.ncr : t;
-        double ps = 0.0; int cnt = 0;
-        for (int c = 0; c < 64; ++c) if ((isg ? s_bg[c] : s_bc[c]) == m) { ps = ps + (isg ? s_dlg[c] : s_dl[c]); cnt++; }
-        binsum[(size_t)blockIdx.x * nb + t] = ps; bincnt[(size_t)blockIdx.x * nb + t] = cnt;
+    const double dC = nan_to_num(wave_bfly(accC)), dG = nan_to_num(wave_bfly(accG));
+    if (lane == 0) {
+        binc[gcn] = do_c ? (f.snk ? p.ncr - 1 : f.cr_idx) : -1;               // :374-378
+        bing[gcn] = do_g ? f.glev - 1 : -1;
+        dl[gcn] = dC; dlg[gcn] = dG;
     }
 }
 
 #ifndef DZ_TEMPLATES_ONLY   // plain (non-template) kernels: defined once, in dz_engine.hip's translation unit
-// single block: thread m < ncr updates crossover bin m, thread ncr+m updates gamma bin m -- the strips' contributions (k_jump) added in
-// strip order --; then the probabilities are renormalised
-__global__ void k_adapt_update(Params p, const double* __restrict__ binsum, const int* __restrict__ bincnt, int nstrips)
+// Single block of 1024 threads.  Step 1: the chains' jumps and bins are staged in LDS with coalesced loads, 4096 chains at a time (a
+// thread reading its strip straight from memory makes 128 line requests of its own: 34 us for 4096 chains, measured), and thread
+// (strip s, bin b) adds the jumps of the strip's 64 chains that fell into the bin, in chain order (crossover bins first, then the
+// gamma-level bins) -- the contract's inner sum; step 2: thread b adds the strips in order, updates delta / n of its bin; step 3: the
+// probabilities are renormalised (:487-493 / :531-536).
+constexpr int ADAPT_CHUNK = 4096;       // chains staged per round: 4096 (8 + 8 + 4 + 4) bytes = 96 KB of LDS
+__global__ __launch_bounds__(1024) void k_adapt_update(Params p, const double* __restrict__ dl, const double* __restrict__ dlg, const int* __restrict__ binc, const int* __restrict__ bing,
+                                                       double* __restrict__ sm)      // scratch: [nstrips][nb] sums, then [nstrips][nb] counts (as doubles: exact)
 {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int PADDED = ADAPT_CHUNK + ADAPT_CHUNK / 64;          // a strip's 64 values, then one pad: the strips start in different banks
+    double* s_dl = lds; double* s_dlg = lds + PADDED;
+    int* s_bc = reinterpret_cast<int*>(lds + 2 * PADDED); int* s_bg = s_bc + PADDED;
     __shared__ int any[2];
-    const int t = threadIdx.x, nb = p.ncr + p.ngamma;
+    const int t = threadIdx.x, nb = p.ncr + p.ngamma, nstrips = (p.N + 63) / 64;
     if (t < 2) any[t] = 0;
+    for (int c0 = 0; c0 < p.N; c0 += ADAPT_CHUNK) {
+        const int cn = min(ADAPT_CHUNK, p.N - c0);
+        __syncthreads();
+        for (int i = t; i < cn; i += 1024) { const int q = i + (i >> 6); s_dl[q] = dl[c0 + i]; s_dlg[q] = dlg[c0 + i]; s_bc[q] = binc[c0 + i]; s_bg[q] = bing[c0 + i]; }
+        __syncthreads();
+        const int ns = (cn + 63) / 64;
+        for (int w = t; w < ns * nb; w += 1024) {
+            const int s = w / nb, b = w - s * nb;
+            const bool isg = b >= p.ncr; const int m = isg ? b - p.ncr : b;
+            const double* dd = (isg ? s_dlg : s_dl) + s * 65; const int* bb = (isg ? s_bg : s_bc) + s * 65;
+            const int n64 = min(64, cn - s * 64);
+            double ps = 0.0; int cnt = 0;
+            if (n64 == 64) {
+#pragma unroll 16
+                for (int c = 0; c < 64; ++c) { const bool in = bb[c] == m; ps = in ? ps + dd[c] : ps; cnt += in ? 1 : 0; }
+            } else for (int c = 0; c < n64; ++c) if (bb[c] == m) { ps = ps + dd[c]; cnt++; }
+            const int gs = c0 / 64 + s;
+            sm[(size_t)gs * nb + b] = ps; sm[(size_t)nstrips * nb + (size_t)gs * nb + b] = (double)cnt;
+        }
+    }
+    __threadfence_block();
     __syncthreads();
     if (t < nb) {
         const bool isg = t >= p.ncr; const int m = isg ? t - p.ncr : t;
-        const double tot = strided_sum<0>(binsum + t, (size_t)nb, nstrips, 0.0);
-        int cnt = 0;
-        for (int s = 0; s < nstrips; ++s) cnt += bincnt[(size_t)s * nb + t];
-        if (cnt) {
+        const double tot = strided_sum<0>(sm + t, (size_t)nb, nstrips, 0.0);                               // (the strips in order; loads in batches)
+        const double cnt = strided_sum<0>(sm + (size_t)nstrips * nb + t, (size_t)nb, nstrips, 0.0);       // (small integers: exact)
+        if (cnt > 0.0) {
             double* delta = isg ? p.g_delta : p.cr_delta; double* n = isg ? p.g_n : p.cr_n;
-            delta[m] = delta[m] + tot; n[m] += (double)cnt; atomicOr(&any[isg ? 1 : 0], 1);
+            delta[m] = delta[m] + tot; n[m] += cnt; atomicOr(&any[isg ? 1 : 0], 1);
         }
     }
     __syncthreads();

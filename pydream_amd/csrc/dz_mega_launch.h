@@ -10,7 +10,8 @@ namespace dz {
 struct Params;
 
 struct MegaLaunch {
-    bool tri, xlds, pb, k1;     // triangular factor / chain states in LDS / full proposal code (priors, bounds, DEpairs > 1) / multitry off
+    bool tri, xlds, pb, k1, redo;     // (redo: redraw rounds inside the kernel, with pb and multitry on)
+    // triangular factor / chain states in LDS / full proposal code (priors, bounds, DEpairs > 1) / multitry off
     int ch, wpc;                // chains per block (16, 8, 4), waves per chain (1; 4 at 4 chains per block with multitry on)
     dim3 grid, block; size_t lds; hipStream_t st;
     hipEvent_t ka, kb;          // the launch's own start / stop events (profiling pass) or null

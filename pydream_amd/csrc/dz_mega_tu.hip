@@ -18,6 +18,13 @@ namespace dz {
 template <bool TRI, bool X, int CH, int WPC, bool PB, bool K1>
 static const char* launch_one(const MegaLaunch& a)
 {
+    if constexpr (PB && !K1) {
+        if (a.redo) {
+            hipExtLaunchKernelGGL((k_generations<DZ_TU_NRT, TRI, X, CH, WPC, PB, K1, true>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0,
+                                  a.pp, a.g, a.n, a.M, a.slot0, a.zappend, a.publish);
+            return TRI ? "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,full,redo>" : "k_generations<" DZ_STR(DZ_TU_NRT) ",dense,xlds,%d,%d,full,redo>";
+        }
+    }
     hipExtLaunchKernelGGL((k_generations<DZ_TU_NRT, TRI, X, CH, WPC, PB, K1>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0,
                           a.pp, a.g, a.n, a.M, a.slot0, a.zappend, a.publish);
     // (NRT, matrix, chain states, chains per block, waves per chain, proposal code)

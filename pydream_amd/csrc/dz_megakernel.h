@@ -26,6 +26,8 @@
 
 namespace dz {
 
+constexpr int DZ_MAX_REDRAWS_DEV = 64;                                  // == DZ_MAX_REDRAWS (include/dreamzs.h; checked in dz_engine.hip)
+constexpr unsigned long long DZ_REDRAW_KEY_STEP_DEV = 0x9E3779B97F4A7C15ull;   // == DZ_REDRAW_KEY_STEP
 constexpr int MEGA_CHAINS = 16;      // chains (= waves) per block at full size; 8 or 4 when there are too few chains to give every CU a block
 
 struct MegaLayout { int LDM, LDP, rows, off_P, off_q, off_sP, off_sS, off_sL, off_rP, off_rS, off_mu, off_pr, off_st, off_dec, off_gt, off_X, total; };
@@ -213,7 +215,11 @@ DZ_DEV void propose_de_pf(const Params& p, int phase, uint32_t g, uint32_t M, in
 // to zappend + global chain), or -1 -- with dz_config.history_lag the two differ (rows written earlier are not sampleable yet).
 // publish: during the crossover burn-in (one generation per launch) the new states also go to the published positions
 // (set_current_position_arr, Dream.py:364-366, :447-449: [N][ld], row = global chain); null otherwise.
-template <int NRT, bool TRI, bool XLDS, int CH, int WPC, bool PB, bool K1 = false>
+// REDO (with PB, multi-try): a proposal set whose tries are ALL impossible is generated again, with the same decisions, from the key of the
+// next redraw round, and evaluated again (Dream.py:281-289) -- a block-level loop around the proposal and likelihood steps of phase 0: only
+// the chains that need it propose again, every wave takes part in the barriers and the likelihood units (the other chains' points have not
+// changed: their sums come out the same), and the block leaves the loop when none of its chains needs another round (DZ_MAX_REDRAWS caps it).
+template <int NRT, bool TRI, bool XLDS, int CH, int WPC, bool PB, bool K1 = false, bool REDO = false>
 __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int64_t zappend, double* __restrict__ publish)
 {
     const Params& p = *pp;       // read through the scalar cache on demand: keeps the ~70 fields out of the SGPR file
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     // A generation's wave-uniform draws: lane s holds slot s (both phases read them; four registers across the likelihood pass are
     // cheaper than a second Philox call).  They are made at the end of the PREVIOUS generation's second proposal phase, together
     // with the requests for the first archive rows the generation will need.
-    constexpr bool XF = !PB;                                                         // (the full-code instantiations read the raw draws: several pairs per try)
+    constexpr bool XF = !PB && !K1;      // (the full-code instantiations read the raw draws: several pairs per try; with one try per generation the pass costs more than it saves)
     auto generation_draws = [&](uint32_t g_) {
         DrawSrc q; q.have = true; q.mine = make_uint4(0, 0, 0, 0);
         if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g_); q.mine = make_uint4(w.x, w.y, w.z, w.w); }
@@ -334,9 +340,9 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 } else load_row<NCH>(p.X + (size_t)c * ld, ld, lane, base);
             } else {
                 const double* dc = dec + 8 * cl;
-                const double u_sel = dc[0];
                 f.snk = dc[2] != 0.0; f.cr_idx = (int)dc[3]; f.delta = PB ? (int)dc[5] : 1; f.glev = (int)dc[4];
                 // likelihoods of the chain's k points, mt_choose_proposal_pt (:291)
+                const double u_sel = dc[0];
                 double lp = -__builtin_huge_val();
                 if (lane < k) {
                     const int pt = lane * CH + cl;
@@ -371,37 +377,64 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
             const int i0 = WPC == 1 ? 0 : (sub * n) / WPC, i1 = WPC == 1 ? n : ((sub + 1) * n) / WPC;     // this wave's tries
             double* slp = phase ? rS + cl * (k - 1) : sS + cl * k;
             double* prp = phase ? rP + cl * (k - 1) : sP + cl * k;
-            if (!snk_s && multipair) {
-                if (i0 < i1)
-                    propose_set<NCH, false, true, 0>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, false, f.cr_idx, f.delta, f.glev, ds,
-                                                      region + (size_t)phase * tstride, tstride, slp, nullptr, prp);
-            } else if (!snk_s) {
-                propose_de_pf<LEANV, XF>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, f.cr_idx, f.glev, ds,
-                                   region + (size_t)phase * tstride, tstride, slp, prp, RA, RB, RC);
-                if (phase == 0) prefetch_first(ds, 1, g);                            // the reference set's first rows, ahead of the likelihood pass
-            } else if (i0 < i1) {
-                // a snooker set is the longest path to the block's barrier (three rows and three reductions per try, one chain in
-                // ten): its wave gets issue priority over the three DE waves it shares a SIMD with
-                __builtin_amdgcn_s_setprio(3);
-                propose_set<NCH, false, false, LEANV>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, true, f.cr_idx, 1, f.glev, ds,
-                                                     region + (size_t)phase * tstride, tstride, slp, K1 ? st + 4 * cl + 3 : nullptr, prp);   // (k = 1: log |x - z|^(d-1) of the current point, :328-329)
-                __builtin_amdgcn_s_setprio(0);
+            DrawSrc dcur = ds;                                                       // (REDO: a redraw round's draws)
+            int round = 0; bool mine = true, redrew = false;
+            for (;;) {
+                if (!mine) { }
+                else if (!snk_s && multipair) {
+                    if (i0 < i1)
+                        propose_set<NCH, false, true, 0>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, false, f.cr_idx, f.delta, f.glev, dcur,
+                                                          region + (size_t)phase * tstride, tstride, slp, nullptr, prp);
+                } else if (!snk_s) {
+                    if (REDO && round > 0) prefetch_first(dcur, 0, g);               // (round 0's first rows were requested a phase ahead)
+                    propose_de_pf<LEANV, XF>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, f.cr_idx, f.glev, dcur,
+                                       region + (size_t)phase * tstride, tstride, slp, prp, RA, RB, RC);
+                    if (phase == 0 && round == 0) prefetch_first(ds, 1, g);          // the reference set's first rows, ahead of the likelihood pass
+                } else if (i0 < i1) {
+                    // a snooker set is the longest path to the block's barrier (three rows and three reductions per try, one chain in
+                    // ten): its wave gets issue priority over the three DE waves it shares a SIMD with
+                    __builtin_amdgcn_s_setprio(3);
+                    propose_set<NCH, false, false, LEANV>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, true, f.cr_idx, 1, f.glev, dcur,
+                                                         region + (size_t)phase * tstride, tstride, slp, K1 ? st + 4 * cl + 3 : nullptr, prp);   // (k = 1: log |x - z|^(d-1) of the current point, :328-329)
+                    __builtin_amdgcn_s_setprio(0);
+                }
+                if (round == 0 && phase == nph - 1 && !last) {                       // the next generation's draws and first rows
+                    dsn = generation_draws(g + 1u);
+                    if (!multipair && !draws_say_snooker(dsn, g + 1u)) prefetch_first(dsn, 0, g + 1u);
+                }
+                DZ_MSTAMP(1 + 4 * phase);
+                __syncthreads();                                                     // points visible
+                DZ_MSTAMP(2 + 4 * phase);
+                // mt_evaluate_logps :278, :302 (x - 0.0 == x bit for bit, so a zero mean skips the subtraction and its LDS read)
+                {
+                    const int row0 = phase ? CH : 0, ntl = ((k - phase) * CH + 15) / 16;
+                    if (p.mu_zero) mfma_units<NRT, TRI, true>(p, Ms, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, L.LDM, L.LDP);
+                    else mfma_units<NRT, TRI, false>(p, Ms, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, L.LDM, L.LDP);
+                }
+                DZ_MSTAMP(3 + 4 * phase);
+                __syncthreads();                                                     // q visible
+                if (!(REDO && phase == 0)) break;
+                // `while np.all(np.isfinite(np.array(log_ps))==False)` (:281-282): log_ps = log_priors + T * log_likes of the chain's k tries
+                double lpv = -__builtin_huge_val();
+                if (lane < k) {
+                    const int pt = lane * CH + cl;
+                    double Q = 0.0;
+#pragma unroll
+                    for (int t = 0; t < NRT; ++t) Q = Q + qb[pt * NRT + t];
+                    lpv = sP[cl * k + lane] + p.T * nan_to_ninf(p.logF - 0.5 * Q);
+                }
+                const bool need = __any(lane < k && is_finite(lpv)) == 0 && round < DZ_MAX_REDRAWS_DEV;
+                if (!__syncthreads_or(need ? 1 : 0)) break;
+                ++round; mine = need; redrew = redrew || need;
+                if (threadIdx.x == 0 && p.redraw_count) atomicAdd(p.redraw_count, 1ull);
+                if (mine) {   // round r of the set: point / dimension / boundary streams from the key seed + r * step (:284-289 with the same decisions)
+                    const unsigned long long key = (((unsigned long long)p.k1 << 32) | (unsigned long long)p.k0) + (unsigned long long)round * DZ_REDRAW_KEY_STEP_DEV;
+                    dcur.rekey = true; dcur.k0 = (uint32_t)key; dcur.k1 = (uint32_t)(key >> 32);
+                    dcur.mine = make_uint4(0, 0, 0, 0);
+                    if (lane < p.nslots) { const u32x4 w = slot_counter_draw_key(p, lane, gc, g, dcur.k0, dcur.k1); dcur.mine = make_uint4(w.x, w.y, w.z, w.w); }
+                }
             }
-            if (phase == nph - 1 && !last) {                                         // the next generation's draws and first rows
-                dsn = generation_draws(g + 1u);
-                if (!multipair && !draws_say_snooker(dsn, g + 1u)) prefetch_first(dsn, 0, g + 1u);
-            }
-            DZ_MSTAMP(1 + 4 * phase);
-            __syncthreads();                                                         // points visible
-            DZ_MSTAMP(2 + 4 * phase);
-            // mt_evaluate_logps :278, :302 (x - 0.0 == x bit for bit, so a zero mean skips the subtraction and its LDS read)
-            {
-                const int row0 = phase ? CH : 0, ntl = ((k - phase) * CH + 15) / 16;
-                if (p.mu_zero) mfma_units<NRT, TRI, true>(p, Ms, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, L.LDM, L.LDP);
-                else mfma_units<NRT, TRI, false>(p, Ms, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, L.LDM, L.LDP);
-            }
-            DZ_MSTAMP(3 + 4 * phase);
-            __syncthreads();                                                         // q visible
+            if (REDO && phase == 0 && redrew && !snk_s && !multipair) prefetch_first(ds, 1, g);      // (the redraw rounds used the row buffers)
             DZ_MSTAMP(4 + 4 * phase);
         }
         // ---- Metropolis step (:305-347), trace (core.py:114-116), record_history (:919-938)
@@ -413,7 +446,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
             const double lpri = st[4 * cl], llik = st[4 * cl + 1];
             const int sf = (int)st[4 * cl + 2]; const int sel = sf & 255; const bool fin = (sf & 256) != 0;
             double val = -__builtin_huge_val();
-            if (K1) {                                                                // single try: the proposal's density straight from the q sums (:271-275)
+            if (K1) {                                                           // single try: the proposal's density straight from the q sums (:271-275)
                 double qt[NRT];
 #pragma unroll
                 for (int t = 0; t < NRT; ++t) qt[t] = qb[cl * NRT + t];

@@ -274,13 +274,17 @@ def test_persistent_kernel_with_several_pairs_and_gamma_levels(G, O, N, d, k, de
         np.testing.assert_array_equal(a[1], other[1])
 
 
-@pytest.mark.parametrize("N,d,k,snooker,split", [(256, 10, 3, 0.1, None), (200, 6, 5, 0.3, "5"), (32, 140, 4, 0.1, None)])
+@pytest.mark.parametrize("N,d,k,snooker,split", [(256, 10, 3, 0.1, None), (200, 6, 5, 0.3, "5"), (32, 140, 4, 0.1, None), (4096, 100, 5, 0.1, None)])
 def test_impossible_proposal_sets_are_drawn_again(G, O, N, d, k, snooker, split, monkeypatch):
     """Dream.py:281-289 at sizes the fixtures do not reach: a uniform prior without hard boundaries and an archive wider than its
-    support, so that whole proposal sets are impossible and are generated again (round r from the key seed + r*step).  Such a
-    configuration takes the multi-kernel path with its host-side check (never the persistent kernel); states, decisions and the
-    archive equal the oracle's bit for bit, one wave per chain or per (chain, try), one or two 128-dimension chunks per lane."""
+    support, so that whole proposal sets are impossible and are generated again (round r from the key seed + r*step).  With the device
+    MVN likelihood and d <= 128 the redraw rounds run INSIDE the persistent kernel (its `redo` instantiations: a block-level loop around
+    the proposal and likelihood steps); DZ_MEGA_REDO=0 and d > 128 take the multi-kernel path with its host-side check.  States,
+    decisions and the archive equal the oracle's bit for bit on both paths, one wave per chain or per (chain, try), one or two
+    128-dimension chunks per lane, through a crossover burn-in and beyond it."""
     n, seed = (25 if d < 100 else 12), 41
+    if N >= 4096:
+        n = 24
     rng = np.random.default_rng(seed)
     P = H.mvn_precision(d)
     lo, width = np.full(d, -2.0), np.full(d, 6.0)
@@ -289,24 +293,38 @@ def test_impossible_proposal_sets_are_drawn_again(G, O, N, d, k, snooker, split,
     if split:
         monkeypatch.setenv("DZ_PROPOSE_SPLIT", split)
 
-    def run(Cls):
+    def run(Cls, in_kernel=True):
+        monkeypatch.setenv("DZ_MEGA_REDO", "1" if in_kernel else "0")
         e = Cls(nchains=N, ndim=d, multitry=k, hardboundaries=0, snooker=snooker, crossover_burnin=12, adapt_crossover=1,
                 history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed)
         e.set_prior(np.full(d, 2, np.int32), lo, width)
-        e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), P, 0, 0.0)
+        e.set_history(Z0); e.set_state(Z0[:N])
+        if N >= 4096:      # (at 16 chains per block only the packed triangle leaves room for the chain states the full-code kernels keep in LDS)
+            e.set_likelihood_mvn(np.zeros(d), np.linalg.cholesky((P + P.T) / 2).T, 1, 0.0)
+        else:
+            e.set_likelihood_mvn(np.zeros(d), P, 0, 0.0)
         if Cls is G.Engine:
             e.profile_enable(True); e.profile_reset()
         e.step(n)
-        extra = (e.profile_get("generations")[1], e.redraw_rounds()) if Cls is G.Engine else None
+        extra = (e.profile_get("generations")[1], e.redraw_rounds(), e.last_kernel_variant()) if Cls is G.Engine else None
         return e.get_trace(0, n), e.get_history(), e.get_cr_state(), extra
 
     a, o = run(G.Engine), run(O.Engine)
-    assert a[3][0] == 0 and a[3][1] > n          # no persistent launch; more redraw rounds than generations
+    b = run(G.Engine, in_kernel=False) if N < 4096 else None
+    if d <= 128:
+        assert a[3][0] > 0 and a[3][1] > 0 and a[3][2].endswith(",full,redo>"), a[3]      # persistent launches, with redraw rounds inside
+    else:
+        assert a[3][0] == 0 and a[3][1] > n                                              # no persistent launch; more redraw rounds than generations
+    if b is not None:
+        assert b[3][0] == 0 and b[3][1] > n
     assert np.isfinite(a[0]["logp"]).all()
-    assert_traces_identical(a[0], o[0])
-    np.testing.assert_array_equal(a[1], o[1])
-    for x, y in zip(a[2], o[2]):
-        np.testing.assert_array_equal(x, y)
+    for other in (o, b):
+        if other is None:
+            continue
+        assert_traces_identical(a[0], other[0])
+        np.testing.assert_array_equal(a[1], other[1])
+        for x, y in zip(a[2], other[2]):
+            np.testing.assert_array_equal(x, y)
 
 
 def test_a_host_likelihood_sees_only_the_redrawn_sets(G, monkeypatch):

@@ -1191,7 +1191,19 @@ int dz_peer_export(dz_engine* e, void* blob)
     HIPCK(hipSetDevice(e->c.device));
     if (e->world < 2) return fail("dz_peer_export: the engine is not sharded");
     if (!e->d_flags) {
-        DZCK(ealloc(e, &e->d_flags, (size_t)2 * e->world));
+        // The flag words are written by OTHER GPUs' copy engines while a kernel of this GPU polls them: ordinary (coarse-grained) device
+        // memory may sit in this GPU's L2, which a write arriving over the fabric does not update -- the poll would spin on its own cached
+        // copy.  Uncached device memory (what RCCL uses for its peer-to-peer flags) is read from memory by every system-scope load.
+        {
+            void* q = nullptr;
+            if (hipExtMallocWithFlags(&q, sizeof(unsigned long long) * 2 * (size_t)e->world, hipDeviceMallocUncached) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail("hipExtMallocWithFlags(hipDeviceMallocUncached) for the peer flags failed");
+            }
+            HIPCK(hipMemset(q, 0, sizeof(unsigned long long) * 2 * (size_t)e->world));
+            HIPCK(hipStreamSynchronize(nullptr));
+            e->d_flags = (unsigned long long*)q; e->to_free.push_back(q);
+        }
         // one flag push per history append and per published generation: bounded by the archive's capacity and the burn-in
         e->seq_cap = (e->c.history_capacity / std::max(1, e->p.N)) + (int64_t)e->c.crossover_burnin + 16;
         if (e->seq_cap > ((int64_t)1 << 24)) e->seq_cap = (int64_t)1 << 24;

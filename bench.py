@@ -286,6 +286,11 @@ def main():
             if not any(errs):
                 return transport, "; ".join(notes) or None
             notes.append("%s unavailable: %s" % (transport, next(x for x in errs if x)))
+            if transport == "peer":
+                try:
+                    e.peer_detach()               # (ranks on which it did attach must not keep using it)
+                except Exception:
+                    pass
         raise SystemExit("no transport could be attached: " + "; ".join(notes))
 
     def rhat_now(e, nsamples):

@@ -108,11 +108,13 @@ int dz_set_exchange(dz_engine* e, dz_exchange_cb cb, void* user);
  * of the first launch that samples the new rows waits for the flags.  With dz_config.history_lag = 0 that is right behind the append
  * (replaces the shared arrays of core.py:281-297 / Dream.py:919-945 like the all-gather does); with history_lag = 1 a whole thin-cycle
  * later, i.e. the exchange is hidden.  Bootstrap: dz_peer_export fills this rank's blob, the control plane all-gathers the blobs (rank
- * order), dz_peer_attach maps them.  dz_exchange_stats (after dz_sync): exchanges queued, gates passed and the time the gates spent
+ * order), dz_peer_attach maps them and runs a self-test (every rank pushes one flag word to every peer and waits for theirs: a refusal at
+ * attach time instead of a timeout in the middle of a run).  dz_exchange_stats (after dz_sync): exchanges queued, gates passed and the time the gates spent
  * waiting -- the exposed part of the exchange. */
 #define DZ_PEER_BLOB_BYTES 512
 int dz_peer_export(dz_engine* e, void* blob /* DZ_PEER_BLOB_BYTES */);
 int dz_peer_attach(dz_engine* e, int32_t rank, int32_t world, const void* blobs /* world x DZ_PEER_BLOB_BYTES */);
+int dz_peer_detach(dz_engine* e);      /* stop using it (e.g. another rank could not attach and all ranks fall back to the same other transport) */
 int dz_exchange_stats(dz_engine* e, int64_t* exchanges, int64_t* gates, double* gate_wait_us);
 int dz_comm_barrier(dz_engine* e);     /* device-side rendezvous of the ranks (one-element RCCL all-gather + stream sync; replaces the mp.Barrier-like role of a host barrier in front of a timed region); without a communicator: a sync */
 

@@ -36,7 +36,7 @@ XCHG_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 SYMBOLS = [
     "dz_version", "dz_last_error", "dz_device_count", "dz_create", "dz_destroy", "dz_set_bounds", "dz_set_gamma_table",
     "dz_set_history", "dz_set_state", "dz_set_cr_probs", "dz_set_gamma_probs", "dz_set_prior", "dz_set_likelihood_mvn",
-    "dz_set_likelihood_mixture", "dz_set_likelihood_host", "dz_hip_library", "dz_comm_library", "dz_comm_unique_id", "dz_comm_init_rccl", "dz_comm_barrier", "dz_set_exchange", "dz_peer_export", "dz_peer_attach", "dz_exchange_stats", "dz_set_temperatures", "dz_get_swaps",
+    "dz_set_likelihood_mixture", "dz_set_likelihood_host", "dz_hip_library", "dz_comm_library", "dz_comm_unique_id", "dz_comm_init_rccl", "dz_comm_barrier", "dz_set_exchange", "dz_peer_export", "dz_peer_attach", "dz_peer_detach", "dz_exchange_stats", "dz_set_temperatures", "dz_get_swaps",
     "dz_step", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_get_chain_probs", "dz_sync", "dz_trace_reset", "dz_generation", "dz_redraw_rounds", "dz_last_kernel_variant", "dz_get_state", "dz_get_trace", "dz_get_trace_chains", "dz_trace_download_begin", "dz_trace_download_wait", "dz_host_register", "dz_host_unregister", "dz_get_history",
     "dz_get_cr_state", "dz_get_gamma_state", "dz_get_rhat", "dz_get_chain_moments", "dz_eval_logp", "dz_debug_propose",
     "dz_profile_enable", "dz_profile_get", "dz_profile_reset", "dz_profile_get_list",
@@ -86,6 +86,7 @@ def load_library():
     L.dz_peer_export.argtypes = [V, V]
     L.dz_peer_attach.argtypes = [V, C.c_int32, C.c_int32, V]
     L.dz_exchange_stats.argtypes = [V, V, V, V]
+    L.dz_peer_detach.argtypes = [V]
     L.dz_step.argtypes = [V, C.c_int64]
     L.dz_sync.argtypes = [V]
     L.dz_step_range.argtypes = [V, C.c_int32, C.c_int32]
@@ -276,6 +277,9 @@ class Engine:
         """blobs: the ranks' exports in rank order (bytes, world x PEER_BLOB_BYTES)"""
         assert len(blobs) == world * self.PEER_BLOB_BYTES
         self._chk(self.L.dz_peer_attach(self.h, rank, world, C.c_char_p(blobs)))
+
+    def peer_detach(self):
+        self._chk(self.L.dz_peer_detach(self.h))
 
     def exchange_stats(self):
         """(exchanges queued, gates passed, microseconds the gates spent waiting) -- the exposed part of the peer exchange"""

@@ -133,7 +133,7 @@ struct dz_engine {
     // process; rows travel on copy streams (one per peer: xGMI is point to point), never through a kernel
     struct Peer { double* Z = nullptr; double* cp[3] = {nullptr, nullptr, nullptr}; unsigned long long* flags = nullptr; hipStream_t st = nullptr; };
     std::vector<Peer> peers; bool peer_on = false;
-    unsigned long long* d_flags = nullptr;      // [2][world]: exchange number received from every rank -- [0] history appends, [1] published positions
+    unsigned long long* d_flags = nullptr;      // [3][world]: exchange number received from every rank -- [0] history appends, [1] published positions, [2] the attach-time self-test
     unsigned long long* d_seq = nullptr; int64_t seq_cap = 0;     // seq[i] = i: the source of the flag pushes
     unsigned long long* h_gate = nullptr;       // host-mapped: ticks waited, gates passed, error (k_peer_gate)
     hipEvent_t push_ev[8] = {nullptr}; int push_n = 0;
@@ -387,7 +387,7 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
     return launch_check("logp kernel");
 }
 
-enum { XK_Z = 0, XK_POS = 1 };
+enum { XK_Z = 0, XK_POS = 1, XK_HELLO = 2, XK_KINDS = 3 };
 double gate_timeout_s()
 {
     if (const char* s = getenv("DZ_PEER_TIMEOUT_S")) return std::max(0.01, atof(s));
@@ -406,15 +406,15 @@ int peer_push(dz_engine* e, int kind, double* buf, int which_cp, size_t row0, un
         dz_engine::Peer& pr = e->peers[r];
         double* dst = kind == XK_Z ? pr.Z : pr.cp[which_cp];
         HIPCK(hipStreamWaitEvent(pr.st, ev, 0));
-        HIPCK(hipMemcpyAsync(dst + first, buf + first, sizeof(double) * cnt, hipMemcpyDeviceToDevice, pr.st));
+        if (kind != XK_HELLO) HIPCK(hipMemcpyAsync(dst + first, buf + first, sizeof(double) * cnt, hipMemcpyDeviceToDevice, pr.st));
         HIPCK(hipMemcpyAsync(pr.flags + (size_t)kind * e->world + e->rank, e->d_seq + seq, sizeof(unsigned long long), hipMemcpyDeviceToDevice, pr.st));
     }
     return 0;
 }
 // ... and the wait for everybody else's rows of exchange `need`: a one-wave kernel on the engine's stream (k_peer_gate)
-int peer_gate(dz_engine* e, int kind, unsigned long long need)
+int peer_gate(dz_engine* e, int kind, unsigned long long need, double timeout_s = 0.0)
 {
-    const unsigned long long ticks = (unsigned long long)(gate_timeout_s() * 1e8);
+    const unsigned long long ticks = (unsigned long long)((timeout_s > 0.0 ? timeout_s : gate_timeout_s()) * 1e8);
     hipLaunchKernelGGL(dz::k_peer_gate, dim3(1), dim3(64), 0, e->stream, (const unsigned long long*)(e->d_flags + (size_t)kind * e->world), e->world, e->rank, need, ticks, e->h_gate);
     return launch_check("k_peer_gate");
 }
@@ -1196,11 +1196,11 @@ int dz_peer_export(dz_engine* e, void* blob)
         // copy.  Uncached device memory (what RCCL uses for its peer-to-peer flags) is read from memory by every system-scope load.
         {
             void* q = nullptr;
-            if (hipExtMallocWithFlags(&q, sizeof(unsigned long long) * 2 * (size_t)e->world, hipDeviceMallocUncached) != hipSuccess) {
+            if (hipExtMallocWithFlags(&q, sizeof(unsigned long long) * XK_KINDS * (size_t)e->world, hipDeviceMallocUncached) != hipSuccess) {
                 (void)hipGetLastError();
                 return fail("hipExtMallocWithFlags(hipDeviceMallocUncached) for the peer flags failed");
             }
-            HIPCK(hipMemset(q, 0, sizeof(unsigned long long) * 2 * (size_t)e->world));
+            HIPCK(hipMemset(q, 0, sizeof(unsigned long long) * XK_KINDS * (size_t)e->world));
             HIPCK(hipStreamSynchronize(nullptr));
             e->d_flags = (unsigned long long*)q; e->to_free.push_back(q);
         }
@@ -1246,6 +1246,32 @@ int dz_peer_attach(dz_engine* e, int32_t rank, int32_t world, const void* blobs)
     }
     for (int i = 0; i < 8; ++i) HIPCK(hipEventCreateWithFlags(&e->push_ev[i], hipEventDisableTiming));
     e->peer_on = true;
+    // Self-test before anything depends on it: every rank pushes one flag word into every peer and waits for theirs (a mapping that
+    // cannot be written, a write this GPU's poll does not see: better a refusal here -- the caller then falls back to another
+    // transport -- than a timeout in the middle of a run).
+    {
+        const double t_self = getenv("DZ_PEER_SELFTEST_S") ? std::max(0.5, atof(getenv("DZ_PEER_SELFTEST_S"))) : 30.0;
+        int rc = peer_push(e, XK_HELLO, nullptr, 0, 0, 1ull);
+        if (!rc) rc = peer_gate(e, XK_HELLO, 1ull, t_self);
+        if (!rc && hipStreamSynchronize(e->stream) != hipSuccess) rc = fail("peer self-test: stream error");
+        if (!rc) for (int r = 0; r < world; ++r) if (r != rank && hipStreamSynchronize(e->peers[r].st) != hipSuccess) rc = fail("peer self-test: copy stream error");
+        if (!rc) rc = peer_check(e);
+        if (rc) {
+            const std::string why = g_err;
+            e->peer_on = false; e->h_gate[2] = 0;
+            return fail("peer transport self-test failed: " + why);
+        }
+        e->h_gate[0] = 0; e->h_gate[1] = 0;          // (the self-test's wait is not an exchange)
+    }
+    return 0;
+}
+
+int dz_peer_detach(dz_engine* e)
+{   // stop using the peer transport (another rank could not attach: every rank moves on to the same fallback); the mappings stay until dz_destroy
+    HIPCK(hipSetDevice(e->c.device));
+    DZCK(sync_all(e));
+    for (auto& pr : e->peers) if (pr.st) HIPCK(hipStreamSynchronize(pr.st));
+    e->peer_on = false;
     return 0;
 }
 

@@ -1576,7 +1576,7 @@ __global__ __launch_bounds__(64) void k_pt_swap(Params p, uint32_t g, int64_t tr
 
 // Sequential sums with the loads of a batch in flight together: a plain `for` over dependent adds of freshly loaded values waits for
 // one memory round trip per element (64 rows: 18 us, measured); the order of the additions is untouched.
-constexpr int SUM_BATCH = 32;
+constexpr int SUM_BATCH = 64;      // (a strip of 64 chains, the 64 strips of 4096 chains: one memory round trip)
 template <int SQ>      // 0: sum of v; 1: sum of (v - m)^2 by fma; 2: by multiply-then-add (numpy's own order, single-chain stepping)
 DZ_DEV double strided_sum(const double* __restrict__ q, size_t stride, int n, double m)
 {
@@ -1806,6 +1806,7 @@ __global__ __launch_bounds__(1024) void k_jump(Params p, uint32_t g, int gc0, in
 // (strip s, bin b) adds the jumps of the strip's 64 chains that fell into the bin, in chain order (crossover bins first, then the
 // gamma-level bins) -- the contract's inner sum; step 2: thread b adds the strips in order, updates delta / n of its bin; step 3: the
 // probabilities are renormalised (:487-493 / :531-536).
+constexpr int ADAPT_SM = 1024;
 constexpr int ADAPT_CHUNK = 4096;       // chains staged per round: 4096 (8 + 8 + 4 + 4) bytes = 96 KB of LDS
 __global__ __launch_bounds__(1024) void k_adapt_update(Params p, const double* __restrict__ dl, const double* __restrict__ dlg, const int* __restrict__ binc, const int* __restrict__ bing,
                                                        double* __restrict__ sm)      // scratch: [nstrips][nb] sums, then [nstrips][nb] counts (as doubles: exact)
@@ -1815,7 +1816,9 @@ __global__ __launch_bounds__(1024) void k_adapt_update(Params p, const double* _
     double* s_dl = lds; double* s_dlg = lds + PADDED;
     int* s_bc = reinterpret_cast<int*>(lds + 2 * PADDED); int* s_bg = s_bc + PADDED;
     __shared__ int any[2];
+    __shared__ double sm_lds[2 * ADAPT_SM];        // the strips' sums and counts stay in LDS when they fit (4096 chains x 4 bins: 512 doubles)
     const int t = threadIdx.x, nb = p.ncr + p.ngamma, nstrips = (p.N + 63) / 64;
+    if (2 * nstrips * nb <= 2 * ADAPT_SM) sm = sm_lds;
     if (t < 2) any[t] = 0;
     for (int c0 = 0; c0 < p.N; c0 += ADAPT_CHUNK) {
         const int cn = min(ADAPT_CHUNK, p.N - c0);
@@ -1841,8 +1844,14 @@ __global__ __launch_bounds__(1024) void k_adapt_update(Params p, const double* _
     __syncthreads();
     if (t < nb) {
         const bool isg = t >= p.ncr; const int m = isg ? t - p.ncr : t;
-        const double tot = strided_sum<0>(sm + t, (size_t)nb, nstrips, 0.0);                               // (the strips in order; loads in batches)
-        const double cnt = strided_sum<0>(sm + (size_t)nstrips * nb + t, (size_t)nb, nstrips, 0.0);       // (small integers: exact)
+        double tot, cnt;
+        if (sm == sm_lds) {
+            tot = 0.0; cnt = 0.0;
+            for (int s2 = 0; s2 < nstrips; ++s2) { tot = tot + sm[s2 * nb + t]; cnt += sm[nstrips * nb + s2 * nb + t]; }
+        } else {
+            tot = strided_sum<0>(sm + t, (size_t)nb, nstrips, 0.0);                               // (the strips in order; loads in batches)
+            cnt = strided_sum<0>(sm + (size_t)nstrips * nb + t, (size_t)nb, nstrips, 0.0);       // (small integers: exact)
+        }
         if (cnt > 0.0) {
             double* delta = isg ? p.g_delta : p.cr_delta; double* n = isg ? p.g_n : p.cr_n;
             delta[m] = delta[m] + tot; n[m] += cnt; atomicOr(&any[isg ? 1 : 0], 1);

@@ -731,6 +731,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "lag":
         lag_cases()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "s1gamma":
+        s1_gamma_case()
+        return
     function_cases()
     density_cases()
     # T1: the C1 plumbing config (3 chains, 10-D MVN, multitry 5), unmodified reference, schedule S1
@@ -775,6 +778,14 @@ def main():
     trace_case("trace_s2_restart", d=10, N=4, G=60, k=5, schedule=2, seed=12, target=("mvn",), restart_from="trace_s2_adapt",
                dream_kwargs=dict(adapt_crossover=True, crossover_burnin=30))
     lag_cases()
+    s1_gamma_case()
+
+
+def s1_gamma_case():
+    # T1c: S1 with crossover AND gamma-level adaptation (3 levels, DEpairs = 2): every Dream instance keeps its own copy of both
+    # probability vectors between its own updates (Dream.py:375, :383, :409-415)
+    trace_case("trace_s1_adapt_gamma", d=6, N=5, G=90, k=5, schedule=1, seed=19, target=("mvn",),
+               dream_kwargs=dict(adapt_crossover=True, adapt_gamma=True, gamma_levels=3, DEpairs=2, crossover_burnin=45))
 
 
 def lag_cases():

@@ -19,23 +19,26 @@ from tests.test_api_cpu import multidmodel, multidmodel_uniform, onedmodel
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["trace_s1_c1", "trace_s1_adapt"])
+@pytest.mark.parametrize("name", ["trace_s1_c1", "trace_s1_adapt", "trace_s1_adapt_gamma"])
 def test_astep_round_robin_equals_reference_s1(tmp_path, name):
     """Dream.astep driven round-robin in one process, the reference's own idiom (test_dream.py:507-518):
     identical to the UNMODIFIED reference's trace and bit-identical to the oracle's schedule S1.
     trace_s1_c1: 3 chains, 10-D MVN, multitry 5, adaptation off.  trace_s1_adapt: crossover adaptation on -- the reference's
     default -- with the burn-in ending inside the run: every Dream instance decides with its OWN copy of the crossover probabilities
-    (Dream.py:375, :497, :409-415), the standard deviations are summed in numpy's row order."""
+    (Dream.py:375, :497, :409-415), the standard deviations are summed in numpy's row order.  trace_s1_adapt_gamma: gamma-level
+    adaptation as well (three levels, two DE pairs): the instances' own gamma-level probabilities (Dream.py:383, :538)."""
     import copy
     from oracle import oracle as O
     fx = H.load(name)
     d, N, G = int(fx["cfg_d"]), int(fx["cfg_N"]), int(fx["cfg_G"])
     adapt = bool(int(fx["cfg_adapt_crossover"]))
+    adapt_g = bool(int(fx["cfg_adapt_gamma"]))
     hist = tmp_path / "seed.npy"
     np.save(hist, fx["Z0"])
     like = MVNormalLogLike(fx["invC"], log_F=float(fx["log_F"]), factorize=False)
     step = Dream(model=Model(like, [FlatParam(np.zeros(d))]), history_file=str(hist), start_random=False, save_history=False,
-                 multitry=5, adapt_crossover=adapt, crossover_burnin=int(min(fx["burnin"], 10 ** 9)))
+                 multitry=5, adapt_crossover=adapt, crossover_burnin=int(min(fx["burnin"], 10 ** 9)), adapt_gamma=adapt_g,
+                 gamma_levels=int(fx["cfg_gamma_levels"]), DEpairs=int(fx["cfg_DEpairs"]))
     pool = _setup_mp_dream_pool(N, G, step, start_pt=[fx["starts"][i] for i in range(N)], seed=int(fx["cfg_seed"]))
     pool._initializer(*pool._initargs)
     try:
@@ -76,6 +79,14 @@ def test_astep_round_robin_equals_reference_s1(tmp_path, name):
             # last holds the final shared one, the one driven first an earlier one
             np.testing.assert_array_equal(np.asarray(claimed[N - 1].CR_probabilities), cr)
             assert not np.array_equal(np.asarray(claimed[0].CR_probabilities), cr)
+        if adapt_g:
+            gp, gdm, gnu = pool.engine.get_gamma_state()
+            np.testing.assert_allclose(gp, fx["gamma_probs"][-1], rtol=1e-11)
+            np.testing.assert_allclose(gdm, fx["delta_m_gamma"], rtol=1e-11)
+            np.testing.assert_array_equal(gnu, fx["ngamma_updates"])
+            for a, b in zip(pool.engine.get_gamma_state(), o.get_gamma_state()):
+                np.testing.assert_array_equal(a, b)
+            np.testing.assert_array_equal(np.asarray(claimed[N - 1].gamma_probabilities), gp)
     finally:
         pool.close(); pool.join()
 

@@ -277,6 +277,23 @@ def test_bench_eight_rank_control_flow_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_with_crossover_adaptation_reports_the_burnin_rate(tmp_path):
+    """BASELINE configs[2] as written (crossover adaptation ON): `bench.py --target mix3 --adapt` times blocks inside the burn-in
+    (`burnin_value`, persistent kernel with one generation per launch + the adaptation launches) and after it (`value`)."""
+    import json
+    import subprocess
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--target", "mix3", "--adapt",
+                          "--burnin-generations", "160", "--chains-per-gpu", "512", "--rhat-max-generations", "400", "--rhat-min-generations", "200",
+                          "--rhat-chunk", "100", "--rhat-window", "200", "--min-timed-ms", "5", "--no-cpu-baseline"],
+                         cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith('{"metric"')][0])
+    assert d["burnin"]["kernel_variant"] == "k_generations_mix" and d["kernel_variant"] == "k_generations_mix"
+    assert d["burnin_value"] > 0 and d["value"] > d["burnin_value"]
+    assert not np.allclose(d["burnin"]["cr_probs_after_burnin"], 1 / 3.)          # the probabilities were adapted
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_over_the_peer_transport_on_one_gpu(tmp_path):
     """bench.py --gpus 2, the two ranks sharing device 0, rows exchanged by the PEER transport (IPC-mapped archives, copy-stream
     pushes, gate kernels) with history_lag = 1: the line names the transport and reports how long the gates

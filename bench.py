@@ -328,8 +328,10 @@ def main():
             # (an engine without the diagnostic -- the dense leg -- has no R-hat window after this loop, and with few chains its 2000
             #  generations are over before an idle GPU has raised its clocks (1024 chains: 40 ms; seen as 67 M/s instead of 272): it
             #  keeps the GPU loaded for at least 0.3 s, bounded by the convergence cap)
-            if done >= args.rhat_min_generations and (conv["generations_to_rhat_below_1p2"] is not None if with_rhat
-                                                      else time.perf_counter() - t_load >= 0.3):
+            # (small populations finish the minimum before an idle GPU has raised its clocks -- 1024 chains x 2000 generations are
+            #  35 ms, seen as 64 M/s instead of 297 --: the run also lasts at least 0.3 s, bounded by the convergence cap)
+            if done >= args.rhat_min_generations and time.perf_counter() - t_load >= 0.3 and \
+                    (conv["generations_to_rhat_below_1p2"] is not None if with_rhat else True):
                 break
         conv["generations_run"] = done
         if with_rhat:
@@ -361,7 +363,7 @@ def main():
         # at generation 11, Dream.py:371).  The GPU is taken out of its idle clock state first by a throw-away engine (an idle MI355X
         # needs ~0.1 s of load), because the burn-in is by definition the START of the measured engine's run.
         import copy
-        aw = copy.copy(args); aw.adapt = False
+        aw = copy.copy(args); aw.adapt = False; aw.thin = 10 ** 6          # (appends once: the archive stays at its seed size however long it runs)
         ew = setup_engine(_capi.Engine, aw, n_local, n_local, 0, 20000, device=device, trace_capacity=0)
         t_w = time.perf_counter()
         while time.perf_counter() - t_w < 0.4:

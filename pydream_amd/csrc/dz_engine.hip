@@ -1190,6 +1190,7 @@ int dz_peer_export(dz_engine* e, void* blob)
 {
     HIPCK(hipSetDevice(e->c.device));
     if (e->world < 2) return fail("dz_peer_export: the engine is not sharded");
+    if (e->world > 64) return fail("dz_peer_export: more than 64 ranks (the gate kernel polls one flag word per lane)");
     if (!e->d_flags) {
         // The flag words are written by OTHER GPUs' copy engines while a kernel of this GPU polls them: ordinary (coarse-grained) device
         // memory may sit in this GPU's L2, which a write arriving over the fabric does not update -- the poll would spin on its own cached

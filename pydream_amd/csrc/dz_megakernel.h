@@ -283,7 +283,10 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     // A generation's wave-uniform draws: lane s holds slot s (both phases read them; four registers across the likelihood pass are
     // cheaper than a second Philox call).  They are made at the end of the PREVIOUS generation's second proposal phase, together
     // with the requests for the first archive rows the generation will need.
-    constexpr bool XF = !PB && !K1;      // (the full-code instantiations read the raw draws: several pairs per try; with one try per generation the pass costs more than it saves)
+    // (the full-code instantiations read the raw draws: several pairs per try; with one try per generation -- multitry off -- or one or
+    //  two tries per wave -- four waves per chain, every one of which would make the pass -- it costs more than it saves: 583 -> 557 M/s
+    //  and 320 -> 301 M/s at 1024 chains)
+    constexpr bool XF = !PB && !K1 && WPC == 1;
     auto generation_draws = [&](uint32_t g_) {
         DrawSrc q; q.have = true; q.mine = make_uint4(0, 0, 0, 0);
         if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g_); q.mine = make_uint4(w.x, w.y, w.z, w.w); }

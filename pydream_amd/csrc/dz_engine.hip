@@ -476,12 +476,11 @@ int adapt_generation(dz_engine* e, uint32_t g, int gc0, int ngc)
     // schedule S1): all rows in row order, numpy's own
     const bool single = ngc != p.N;
     const int strip = single ? p.N : 64, nstrips = (p.N + strip - 1) / strip;
-    const dim3 b(128), gcol((p.d + 127) / 128, nstrips), gfin((p.d + 127) / 128);
+    const dim3 b(128), gcol((p.d + 127) / 128, nstrips);
     // four launches: strip sums -> (column means, made by every block for itself) strip sums of squared deviations -> (standard
     // deviations, likewise) normalised jumps per chain -> accumulators and probabilities.  The same additions in the same order as the
-    // six-launch form with its two one-block finishing kernels (k_strip_finish); a kernel boundary is the cheapest grid-wide
+    // six-launch form of round 2 with its two one-block finishing kernels; a kernel boundary is the cheapest grid-wide
     // synchronisation on this chip (an agent-scope fence costs more), so what is left is one per true dependency.
-    (void)gfin;
     double* partial1 = e->d_partial + (size_t)((p.N + 63) / 64) * p.ld;
     hipLaunchKernelGGL(dz::k_strip_partial, gcol, b, 0, e->stream, p.cp_new, p.N, p.d, p.ld, e->d_mean, 0, e->d_partial, strip, single ? 1 : 0);
     hipLaunchKernelGGL(dz::k_strip_dev, gcol, b, 0, e->stream, p.cp_new, p.N, p.d, p.ld, (const double*)e->d_partial, nstrips, partial1, e->d_mean, strip, single ? 1 : 0);

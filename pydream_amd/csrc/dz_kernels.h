@@ -1708,18 +1708,8 @@ __global__ void k_own_probs(Params p, int c0, int nc, const int* __restrict__ bi
     if (init || binc[gcn] >= 0) for (int m = 0; m < p.ncr; ++m) own_cr[(size_t)c * p.ncr + m] = p.cr_probs[m];
     if (init || bing[gcn] >= 0) for (int m = 0; m < p.ngamma; ++m) own_g[(size_t)c * p.ngamma + m] = p.g_probs[m];
 }
-// pass 0: mean[j] = (sum_s partial)/N ; pass 1: sd[j] = sqrt((sum_s partial)/N), sdc = sd with 0 -> 1e-12 (:479)
-__global__ void k_strip_finish(const double* __restrict__ partial, int nstrips, int N, int d, int ld, int pass, double* __restrict__ mean, double* __restrict__ sd, double* __restrict__ sdc)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= d) return;
-    double tot = 0.0;
-    for (int s = 0; s < nstrips; ++s) tot = tot + partial[(size_t)s * ld + j];
-    if (pass == 0) mean[j] = tot / (double)N;
-    else { const double v = sqrt(tot / (double)N); sd[j] = v; sdc[j] = v == 0.0 ? 1e-12 : v; }
-}
-// k_strip_finish(pass 0) and k_strip_partial(pass 1) in one launch: every block makes the column means it needs itself, from the strip sums
-// of pass 0 in strip order (the same additions k_strip_finish makes), then its strip's sum of squared deviations
+// The column means and pass 1 in one launch: every block makes the means it needs itself -- mean[j] = (sum_s partial0[s][j]) / N, the strips
+// in order --, then its strip's sum of squared deviations
 __global__ void k_strip_dev(const double* __restrict__ pos, int N, int d, int ld, const double* __restrict__ partial0, int nstrips, double* __restrict__ partial1,
                             double* __restrict__ mean_out, int strip, int plain)
 {
@@ -1737,7 +1727,7 @@ __global__ void k_strip_dev(const double* __restrict__ pos, int N, int d, int ld
 
 // Bins and normalised squared jumps (:481, :527): one wave per GLOBAL chain, 16 chains per block, of which [gc0, gc0 + ngc) take part
 // (everything in a lockstep generation; one chain under Dream.astep).  The standard deviations come from the strip sums of pass 1, added
-// in strip order by every block for itself (k_strip_finish's additions; block 0 also stores them): sd[j] = sqrt((sum_s partial1[s][j]) / N),
+// in strip order by every block for itself (block 0 also stores them): sd[j] = sqrt((sum_s partial1[s][j]) / N),
 // for the crossover statistic with 0 -> 1e-12 (:479).  The chain's control draws and the gamma-unity draws of its last proposal call are
 // made lane-parallel (lane s = slot s: ONE Philox call per wave instead of 2 + k).
 constexpr int JUMP_CHAINS = 16;

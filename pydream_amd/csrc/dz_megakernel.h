@@ -382,24 +382,29 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
             double* prp = phase ? rP + cl * (k - 1) : sP + cl * k;
             DrawSrc dcur = ds;                                                       // (REDO: a redraw round's draws)
             int round = 0; bool mine = true, redrew = false;
-            for (;;) {
-                if (!mine) { }
-                else if (!snk_s && multipair) {
-                    if (i0 < i1)
-                        propose_set<NCH, false, true, 0>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, false, f.cr_idx, f.delta, f.glev, dcur,
+            // tries [a, b) of this wave's share; A_ / B_ hold the archive rows of tries a and a + 1 of a one-pair DE set
+            auto propose_range = [&](int a, int b, RowPair& A_, RowPair& B_, RowPair& C_) {
+                if (!snk_s && multipair) {
+                    if (a < b)
+                        propose_set<NCH, false, true, 0>(p, phase, g, M, c, gc, a, b, n, lane, base, grow, false, f.cr_idx, f.delta, f.glev, dcur,
                                                           region + (size_t)phase * tstride, tstride, slp, nullptr, prp);
                 } else if (!snk_s) {
-                    if (REDO && round > 0) prefetch_first(dcur, 0, g);               // (round 0's first rows were requested a phase ahead)
-                    propose_de_pf<LEANV, XF>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, f.cr_idx, f.glev, dcur,
-                                       region + (size_t)phase * tstride, tstride, slp, prp, RA, RB, RC);
-                    if (phase == 0 && round == 0) prefetch_first(ds, 1, g);          // the reference set's first rows, ahead of the likelihood pass
-                } else if (i0 < i1) {
+                    propose_de_pf<LEANV, XF>(p, phase, g, M, c, gc, a, b, n, lane, base, grow, f.cr_idx, f.glev, dcur,
+                                       region + (size_t)phase * tstride, tstride, slp, prp, A_, B_, C_);
+                } else if (a < b) {
                     // a snooker set is the longest path to the block's barrier (three rows and three reductions per try, one chain in
                     // ten): its wave gets issue priority over the three DE waves it shares a SIMD with
                     __builtin_amdgcn_s_setprio(3);
-                    propose_set<NCH, false, false, LEANV>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, true, f.cr_idx, 1, f.glev, dcur,
+                    propose_set<NCH, false, false, LEANV>(p, phase, g, M, c, gc, a, b, n, lane, base, grow, true, f.cr_idx, 1, f.glev, dcur,
                                                          region + (size_t)phase * tstride, tstride, slp, K1 ? st + 4 * cl + 3 : nullptr, prp);   // (k = 1: log |x - z|^(d-1) of the current point, :328-329)
                     __builtin_amdgcn_s_setprio(0);
+                }
+            };
+            for (;;) {
+                if (mine) {
+                    if (REDO && round > 0 && !snk_s && !multipair) prefetch_first(dcur, 0, g);      // (round 0's first rows were requested a phase ahead)
+                    propose_range(i0, i1, RA, RB, RC);
+                    if (phase == 0 && round == 0 && !snk_s && !multipair) prefetch_first(ds, 1, g);  // the reference set's first rows, ahead of the likelihood pass
                 }
                 if (round == 0 && phase == nph - 1 && !last) {                       // the next generation's draws and first rows
                     dsn = generation_draws(g + 1u);

@@ -116,7 +116,7 @@ int dz_peer_export(dz_engine* e, void* blob /* DZ_PEER_BLOB_BYTES */);
 int dz_peer_attach(dz_engine* e, int32_t rank, int32_t world, const void* blobs /* world x DZ_PEER_BLOB_BYTES */);
 int dz_peer_detach(dz_engine* e);      /* stop using it (e.g. another rank could not attach and all ranks fall back to the same other transport) */
 int dz_exchange_stats(dz_engine* e, int64_t* exchanges, int64_t* gates, double* gate_wait_us);
-int dz_comm_barrier(dz_engine* e);     /* device-side rendezvous of the ranks (one-element RCCL all-gather + stream sync; replaces the mp.Barrier-like role of a host barrier in front of a timed region); without a communicator: a sync */
+int dz_comm_barrier(dz_engine* e);     /* device-side rendezvous of the ranks (RCCL: a one-element all-gather; peer transport: every rank pushes a flag word to every peer and a gate kernel waits for theirs; then a stream sync) -- the ranks leave it within microseconds of each other, which a timed region of a few hundred microseconds wants in front of it; no transport: a sync */
 
 /* Parallel tempering (core.py:131-236).  T[nchains]: the temperature of every (global) chain -- Dream.astep's T argument
  * (Dream.py:193), the ladder of core.py:133-136 is computed by the caller.  swaps != 0 adds the swap step of

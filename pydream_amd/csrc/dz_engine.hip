@@ -137,7 +137,7 @@ struct dz_engine {
     unsigned long long* d_seq = nullptr; int64_t seq_cap = 0;     // seq[i] = i: the source of the flag pushes
     unsigned long long* h_gate = nullptr;       // host-mapped: ticks waited, gates passed, error (k_peer_gate)
     hipEvent_t push_ev[8] = {nullptr}; int push_n = 0;
-    int64_t z_pushed = 0, z_gated = 0, pos_pushed = 0;
+    int64_t z_pushed = 0, z_gated = 0, pos_pushed = 0, hello_seq = 1;      // (hello 1 = the attach-time self-test)
     double* d_cp[3] = {nullptr, nullptr, nullptr}; int cp_idx = 1;      // published positions rotate through three buffers (a peer may run one generation ahead)
     // owned device buffers (also referenced from p)
     double *d_mins = nullptr, *d_maxs = nullptr, *d_gtab = nullptr, *d_mu = nullptr, *d_Mt = nullptr, *d_Mtp = nullptr, *d_mixF = nullptr;
@@ -415,13 +415,15 @@ int peer_push(dz_engine* e, int kind, double* buf, int which_cp, size_t row0, un
 int peer_gate(dz_engine* e, int kind, unsigned long long need, double timeout_s = 0.0)
 {
     const unsigned long long ticks = (unsigned long long)((timeout_s > 0.0 ? timeout_s : gate_timeout_s()) * 1e8);
-    hipLaunchKernelGGL(dz::k_peer_gate, dim3(1), dim3(64), 0, e->stream, (const unsigned long long*)(e->d_flags + (size_t)kind * e->world), e->world, e->rank, need, ticks, e->h_gate);
+    // (rendezvous gates keep their own counters, [4..6]: what they wait for is the other ranks' lateness, not an exchange)
+    hipLaunchKernelGGL(dz::k_peer_gate, dim3(1), dim3(64), 0, e->stream, (const unsigned long long*)(e->d_flags + (size_t)kind * e->world), e->world, e->rank, need, ticks,
+                       e->h_gate + (kind == XK_HELLO ? 4 : 0));
     return launch_check("k_peer_gate");
 }
 int peer_check(dz_engine* e)
 {   // after a device sync: did a gate give up?
-    if (e->peer_on && e->h_gate && e->h_gate[2]) {
-        const int r = (int)e->h_gate[2] - 1;
+    if (e->peer_on && e->h_gate && (e->h_gate[2] || e->h_gate[6])) {
+        const int r = (int)(e->h_gate[2] ? e->h_gate[2] : e->h_gate[6]) - 1;
         return fail("peer exchange: no rows from rank " + std::to_string(r) + " within " + std::to_string(gate_timeout_s()) + " s (DZ_PEER_TIMEOUT_S)");
     }
     return 0;
@@ -1205,14 +1207,14 @@ int dz_peer_export(dz_engine* e, void* blob)
             e->d_flags = (unsigned long long*)q; e->to_free.push_back(q);
         }
         // one flag push per history append and per published generation: bounded by the archive's capacity and the burn-in
-        e->seq_cap = (e->c.history_capacity / std::max(1, e->p.N)) + (int64_t)e->c.crossover_burnin + 16;
+        e->seq_cap = (e->c.history_capacity / std::max(1, e->p.N)) + (int64_t)e->c.crossover_burnin + 65536;      // (+ rendezvous numbers: dz_comm_barrier)
         if (e->seq_cap > ((int64_t)1 << 24)) e->seq_cap = (int64_t)1 << 24;
         DZCK(ealloc(e, &e->d_seq, (size_t)e->seq_cap));
         std::vector<unsigned long long> h((size_t)e->seq_cap);
         for (size_t i = 0; i < h.size(); ++i) h[i] = i;
         HIPCK(hipMemcpy(e->d_seq, h.data(), sizeof(unsigned long long) * h.size(), hipMemcpyHostToDevice));
-        HIPCK(hipHostMalloc((void**)&e->h_gate, 4 * sizeof(unsigned long long), hipHostMallocMapped));
-        memset(e->h_gate, 0, 4 * sizeof(unsigned long long));
+        HIPCK(hipHostMalloc((void**)&e->h_gate, 8 * sizeof(unsigned long long), hipHostMallocMapped));
+        memset(e->h_gate, 0, 8 * sizeof(unsigned long long));
     }
     PeerBlob b; memset(&b, 0, sizeof b);
     b.magic = 0x445a5058u; b.nchains = (uint32_t)e->p.N; b.nchains_local = (uint32_t)e->p.nl; b.ld = (uint32_t)e->p.ld; b.capacity = e->c.history_capacity;
@@ -1258,10 +1260,9 @@ int dz_peer_attach(dz_engine* e, int32_t rank, int32_t world, const void* blobs)
         if (!rc) rc = peer_check(e);
         if (rc) {
             const std::string why = g_err;
-            e->peer_on = false; e->h_gate[2] = 0;
+            e->peer_on = false; e->h_gate[2] = 0; e->h_gate[6] = 0;
             return fail("peer transport self-test failed: " + why);
         }
-        e->h_gate[0] = 0; e->h_gate[1] = 0;          // (the self-test's wait is not an exchange)
     }
     return 0;
 }
@@ -1290,6 +1291,13 @@ int dz_comm_barrier(dz_engine* e)
 {
     HIPCK(hipSetDevice(e->c.device));
     DZCK(sync_all(e));
+    if (e->peer_on) {   // peer transport: every rank pushes its next "hello" number to every peer and waits for theirs
+        e->hello_seq++;
+        DZCK(peer_push(e, XK_HELLO, nullptr, 0, 0, (unsigned long long)e->hello_seq));
+        DZCK(peer_gate(e, XK_HELLO, (unsigned long long)e->hello_seq));
+        HIPCK(hipStreamSynchronize(e->stream));
+        return peer_check(e);
+    }
     if (!e->comm) return 0;
     if (!e->d_bar) DZCK(ealloc(e, &e->d_bar, (size_t)std::max(1, e->world)));
     ncclResult_t r = g_rccl.AllGather(e->d_bar + e->rank, e->d_bar, 1, ncclDouble, e->comm, e->stream);

@@ -247,6 +247,47 @@ DZ_DEV double wave_bfly(double v)
     v = swap16_sum(v);
     return bfly16(v);       // all four rows now hold the same 16 values
 }
+// FOUR wave sums for little more than the price of one: the two lane-swap steps are where the values merge -- v_permlane32_swap with
+// (a, b) leaves a's two halves in the lower lanes of the two results and b's in the upper lanes, so ONE addition makes a[i] + a[i ^ 32] in
+// lanes 0-31 and b[i] + b[i ^ 32] in lanes 32-63; v_permlane16_swap does the same for rows -- and the four DPP row steps then finish the
+// four values side by side.  Every value is added along the same tree as in wave_bfly (the same pairs at every step; addition commutes):
+// the same bits.  Returns in row 0 (lanes 0-15) the total of a, row 1 of c, row 2 of b, row 3 of d, in every lane of the row.
+DZ_DEV void swap32_pair(double a, double b, double& lo_sum)
+{
+    const long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+    const auto lo = __builtin_amdgcn_permlane32_swap((int)(ba & 0xffffffffll), (int)(bb & 0xffffffffll), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((int)(ba >> 32), (int)(bb >> 32), false, false);
+    const double x = __longlong_as_double(((long long)(int)hi[0] << 32) | (unsigned int)lo[0]);
+    const double y = __longlong_as_double(((long long)(int)hi[1] << 32) | (unsigned int)lo[1]);
+    lo_sum = x + y;
+}
+DZ_DEV void swap16_pair(double a, double b, double& out)
+{
+    const long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+    const auto lo = __builtin_amdgcn_permlane16_swap((int)(ba & 0xffffffffll), (int)(bb & 0xffffffffll), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((int)(ba >> 32), (int)(bb >> 32), false, false);
+    const double x = __longlong_as_double(((long long)(int)hi[0] << 32) | (unsigned int)lo[0]);
+    const double y = __longlong_as_double(((long long)(int)hi[1] << 32) | (unsigned int)lo[1]);
+    out = x + y;
+}
+DZ_DEV double wave_bfly4(double a, double b, double c, double d)
+{
+    double ab, cd, q;
+    swap32_pair(a, b, ab);          // lanes 0-31: a, 32-63: b
+    swap32_pair(c, d, cd);          // lanes 0-31: c, 32-63: d
+    swap16_pair(ab, cd, q);         // rows: a, c, b, d
+    return bfly16(q);
+}
+// the row (0..3) of wave_bfly4's result that holds its u-th argument
+DZ_DEV int bfly4_row(int u) { return u == 1 ? 2 : (u == 2 ? 1 : u); }
+// two sums: the total of a in lanes 0-31, of b in lanes 32-63
+DZ_DEV double wave_bfly2(double a, double b)
+{
+    double ab;
+    swap32_pair(a, b, ab);
+    return bfly16(swap16_sum(ab));
+}
+
 // value of lane ln (wave-uniform index) -- v_readlane, no LDS crossbar round trip
 DZ_DEV double readlane_f64(double v, int ln)
 {

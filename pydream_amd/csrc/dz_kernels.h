@@ -390,9 +390,10 @@ DZ_DEV double propose_point(const Params& p, int phase, uint32_t g, uint32_t M, 
                 if (jj + s < d) { accD = fma(v[it][s], v[it][s], accD); accS = fma(dzz[it][s], v[it][s], accS); }
             }
         }
-        const double D = wave_bfly(accD);                                      // :816 / :827
+        const double DS = wave_bfly2(accD, accS);                              // (both sums for the price of one: D in the lower lanes, S in the upper)
+        const double D = readlane_f64(DS, 0);                                  // :816 / :827
         if (LEAN == 1 || n > 1) {
-            const double cc = wave_bfly(accS) / D;                             // :820
+            const double cc = readlane_f64(DS, 32) / D;                        // :820
 #pragma unroll
             for (int it = 0; it < NCH; ++it)
 #pragma unroll
@@ -851,8 +852,9 @@ __global__ __launch_bounds__(256) void k_propose_stream(Params p, int phase, uin
             if (jj < d) { accD = fma(v0, v0, accD); accS = fma(a.x - b.x, v0, accS); }
             if (jj + 1 < d) { accD = fma(v1, v1, accD); accS = fma(a.y - b.y, v1, accS); }
         }
-        const double D = wave_bfly(accD);                                           // :816
-        const double cc = wave_bfly(accS) / D;                                      // :820
+        const double DS = wave_bfly2(accD, accS);
+        const double D = readlane_f64(DS, 0);                                       // :816
+        const double cc = readlane_f64(DS, 32) / D;                                 // :820
         double accN = 0.0;
         xn = gload2(base + off(0)); zn = gload2(zz + off(0));
         for (int it = 0; it < nchunk; ++it) {                                       // pass 2: the proposal :820-822 and its distance to z :823
@@ -1782,7 +1784,8 @@ __global__ __launch_bounds__(1024) void k_jump(Params p, uint32_t g, int gc0, in
             }
         }
     }
-    const double dC = nan_to_num(wave_bfly(accC)), dG = nan_to_num(wave_bfly(accG));
+    const double CG = wave_bfly2(accC, accG);
+    const double dC = nan_to_num(readlane_f64(CG, 0)), dG = nan_to_num(readlane_f64(CG, 32));
     if (lane == 0) {
         binc[gcn] = do_c ? (f.snk ? p.ncr - 1 : f.cr_idx) : -1;               // :374-378
         bing[gcn] = do_g ? f.glev - 1 : -1;

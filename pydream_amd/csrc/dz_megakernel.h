@@ -613,10 +613,12 @@ __global__ __launch_bounds__(64 * MIXW) void k_generations_mix(const Params* __r
                         if (2 * lane + 1 < d) { const double t = x1[u] - m1; acc = fma(t, t, acc); }
                         S[u] = acc;
                     }
-#pragma unroll
-                    for (int u = 0; u < GP; ++u) S[u] = wave_bfly(S[u]);
-#pragma unroll
-                    for (int u = 0; u < GP; ++u) if (lane == 0 && i0 + u < n) lh[(i0 + u) * p.J + j] = -0.5 * S[u] + p.mixF[j];
+                    static_assert(GP == 4, "wave_bfly4 sums four values");
+                    const double R = wave_bfly4(S[0], S[1], S[2], S[3]);          // (rows hold the totals of S[0], S[2], S[1], S[3]: the bits of four wave_bfly)
+                    {
+                        const int row = lane >> 4, u = (row == 1) ? 2 : (row == 2 ? 1 : row);
+                        if ((lane & 15) == 0 && i0 + u < n) lh[(i0 + u) * p.J + j] = -0.5 * R + p.mixF[j];
+                    }
                 }
             }
             {

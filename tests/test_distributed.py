@@ -259,18 +259,23 @@ def _launch_bench(nranks, extra_args, env, cwd, timeout=600):
 
 
 @pytest.mark.gpu
-def test_bench_eight_rank_control_flow_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("transport", ["host", "peer"])
+def test_bench_eight_rank_control_flow_on_one_gpu(tmp_path, transport):
     """bench.py as the driver launches it for N = 8 (one process per rank, torch.distributed.run's environment), rehearsed on the one
     GPU of the test box: the eight ranks share device 0 and exchange through the host (DZ_BENCH_DEVICE / DZ_BENCH_TRANSPORT).
     Proves the control flow the 8-GPU run takes: rendezvous, sharded engines, the convergence run with the
     sharded R-hat, timed blocks with the rank-maximum, one JSON line from rank 0 with whole-job throughput."""
-    env = dict(os.environ, DZ_BENCH_DEVICE="0", DZ_BENCH_TRANSPORT="host", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, DZ_BENCH_DEVICE="0", DZ_BENCH_TRANSPORT=transport, HSA_ENABLE_IPC_MODE_LEGACY="0", DZ_PEER_TIMEOUT_S="120")
     d = _launch_bench(8, ["--steps", "20", "--warmup", "5", "--chains-per-gpu", "128", "--rhat-max-generations", "400",
                           "--rhat-min-generations", "200", "--rhat-chunk", "100", "--rhat-window", "200", "--min-timed-ms", "20",
                           "--no-cpu-baseline"], env, str(tmp_path))
     assert d["n_gpus"] == 8 and d["steps"] == 20 and d["scaling"] == "weak"
-    assert d["config"]["chains_global"] == 8 * 128 and "host" in d["config"]["parallelism"]
-    assert d["transport"] == "host-fallback" and d["history_lag"] == 1          # (a host-staged number is named as such at the top level)
+    assert d["config"]["chains_global"] == 8 * 128 and transport in d["config"]["parallelism"]
+    assert d["history_lag"] == 1
+    if transport == "host":
+        assert d["transport"] == "host-fallback"          # (a host-staged number is named as such at the top level)
+    else:                                                  # eight ranks, each mapping the seven others' archives: seven copy streams per rank
+        assert d["transport"] == "peer" and d["exchange"]["gates"] > 0, (d["transport"], d.get("transport_note"))
     assert d["value"] > 0 and abs(d["value"] - 8 * 128 * 5 * 20 / (d["timing"]["block_ms_median"] * 1e-3)) < 1e-6 * d["value"]
     assert d["convergence"]["generations_run"] >= 200 and np.isfinite(d["rhat_max"])
     assert d["kernel_times"]["exchange"]["launches"] > 0            # the Z appends were all-gathered

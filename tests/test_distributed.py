@@ -282,6 +282,36 @@ def test_bench_eight_rank_control_flow_on_one_gpu(tmp_path, transport):
 
 
 @pytest.mark.gpu
+def test_bench_line_has_the_contracted_fields(tmp_path):
+    """`python bench.py --steps K --warmup W` on one GPU (a small population so that it takes seconds): ONE JSON line with the driver's
+    contract fields, `roofline` (achieved = algorithmic bytes / launch duration, frac = achieved / peak) and `cpu_baseline` (the oracle
+    on a bounded sample), the kernel instantiation that ran, and a launch duration the timed blocks allow."""
+    import json
+    import subprocess
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--chains-per-gpu", "512",
+                          "--rhat-max-generations", "600", "--rhat-min-generations", "300", "--rhat-chunk", "100", "--rhat-window", "200",
+                          "--min-timed-ms", "5", "--cpu-chains", "128", "--cpu-seconds", "1"],
+                         cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline", "kernel_variant", "rhat_max", "convergence"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["unit"] == "proposals/s" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert abs(d["value"] - 512 * 5 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
+    assert r["launch_us"] * (20 / r["generations_per_launch"]) <= d["timing"]["block_ms_median"] * 1e3 * (1 + 1e-9)      # a kernel cannot outlast the block around it
+    assert r["launches_timed"] >= 20 and r["kernel_variant"] == d["kernel_variant"] and d["kernel_variant"].startswith("k_generations<7,tri,xlds,")
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "proposals/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+@pytest.mark.gpu
 def test_bench_with_crossover_adaptation_reports_the_burnin_rate(tmp_path):
     """BASELINE configs[2] as written (crossover adaptation ON): `bench.py --target mix3 --adapt` times blocks inside the burn-in
     (`burnin_value`, persistent kernel with one generation per launch + the adaptation launches) and after it (`value`)."""

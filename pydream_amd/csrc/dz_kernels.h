@@ -95,9 +95,6 @@ DZ_DEV StepFlags step_flags_chain(const Params& p, const Ctrl& u, int c)
 // k); the sums run over the tries in order, so every lane ends with the same scalars.
 DZ_DEV int mt_select_vals(int k, double lp, double u_sel, int lane, bool* anyfinite)
 {   // lp: lane i < k holds prior_i + T like_i (:900), other lanes -inf
-#ifdef DZ_KO_SELECT
-    *anyfinite = true; return __builtin_amdgcn_readfirstlane((int)(u_sel * k)) % k;
-#endif
     const double mx = readlane_f64(rowmax16(lp), 0);                                   // MAXK = 16 lanes
     *anyfinite = __any(lane < k && is_finite(lp)) != 0;
     const double w = dexp(lp - mx);
@@ -127,9 +124,6 @@ DZ_DEV int mt_select(const Params& p, int c, double u_sel, int lane, bool* anyfi
 // u_acc: the Metropolis uniform (:993); its logarithm is evaluated in lane 1 of the same dlog pass (one pass instead of two).
 DZ_DEV double mt_log_ratio(int k, double val, double u_acc, int lane, double* log_u)
 {
-#ifdef DZ_KO_RATIO
-    *log_u = u_acc - 0.6; return readlane_f64(val, 0) * 1e-300;
-#endif
     const double rm = rowmax16(val);
     const double m2 = fmax(readlane_f64(rm, 0), readlane_f64(rm, 16));                                 // :320
     const double ev = dexp(val - m2);                                                                // :321-322
@@ -353,17 +347,9 @@ DZ_DEV double propose_point(const Params& p, int phase, uint32_t g, uint32_t M, 
             const int j0 = 128 * it + 2 * lane;    // the lane's two dimensions j0, j0+1 = pair j0/2
             {   // no lane predicate around the arithmetic (the lanes past d compute on their own, unused draws; `keep` masks them):
                 // a predicated region costs the zero defaults of every value it defines plus the exec-mask round trip
-#ifdef DZ_KO_PHILOX       // (knock-out builds, tools/r03_knockouts.sh: the results are wrong on purpose)
-                const u32x4 w = u32x4{(uint32_t)j0 * 2654435761u + g, (uint32_t)j0 * 40503u + gc, (uint32_t)j0 + s_dim, (uint32_t)j0 ^ g};
-#else
                 const u32x4 w = (NCH == 1 && wpre) ? *wpre : philox(K0, K1, (uint32_t)(j0 >> 1), s_dim, gc, g);
-#endif
                 float z0, z1;
-#ifdef DZ_KO_NORMAL
-                z0 = __uint_as_float(0x3f000000u | (w.z >> 9)); z1 = __uint_as_float(0x3f000000u | (w.w >> 9));
-#else
                 normal32_pair(w.z, w.w, z0, z1);
-#endif
                 keep[it][0] = j0 < d && (w.x & 0xffffu) < thr;               // U_j < CR
                 e1[it][0] = uniform16(w.y, ec1, ec0) + 1.0;                  // :696-697
                 zt[it][0] = zeta * (double)z0;

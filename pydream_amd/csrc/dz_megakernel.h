@@ -175,15 +175,8 @@ DZ_DEV void request_pair(const Params& p, const DrawSrc& ds, int slot, uint32_t 
     }
     // (no lane predicate: lanes past ld re-read the row's last pair, masked where used)  scalar row base + 32-bit lane offset in bytes
     const uint32_t jb = (uint32_t)min(16 * lane, (int)ldb - 16);
-#ifdef DZ_KO_NOLOADS     // (knock-out build: no archive loads at all)
-    R.a = double2{1.0 + jb, 2.0}; R.b = double2{0.5, 1.5 + r0 + r1};
-#elif defined(DZ_KO_ROWS)        // (knock-out build: every wave reads the same two rows -- L1 / L2 hits instead of archive gathers)
-    R.a = gload2(reinterpret_cast<const double*>(reinterpret_cast<const char*>(Zb) + (uint64_t)(r0 & 63u) * ldb + jb));
-    R.b = gload2(reinterpret_cast<const double*>(reinterpret_cast<const char*>(Zb) + (uint64_t)(r1 & 63u) * ldb + jb));
-#else
     R.a = gload2(reinterpret_cast<const double*>(reinterpret_cast<const char*>(Zb) + (uint64_t)r0 * ldb + jb));
     R.b = gload2(reinterpret_cast<const double*>(reinterpret_cast<const char*>(Zb) + (uint64_t)r1 * ldb + jb));
-#endif
 }
 
 // DE tries i0..i1-1 of one chain's set (one pair, the common case); A and B already hold the rows of tries i0 and i0 + 1.
@@ -194,9 +187,6 @@ DZ_DEV void propose_de_pf(const Params& p, int phase, uint32_t g, uint32_t M, in
 {
     const SetConsts sc = set_consts(p, phase, cr_idx);
     auto body = [&](int i, const RowPair& R) {
-#ifdef DZ_KO_TRYBODY     // (knock-out build: the try writes the base point plus the rows' difference, nothing else)
-        { double* o = out + (size_t)i * out_stride; const int jj = 2 * lane; if (jj < p.d) { o[jj] = xb[0][0] + (R.a.x - R.b.x) * 1e-3; o[jj + 1] = xb[0][1] + (R.a.y - R.b.y) * 1e-3; } return; }
-#endif
         RowTerms<1> rt;
         rt.a[0][0] = R.a.x - R.b.x; rt.a[0][1] = R.a.y - R.b.y; rt.b[0][0] = 0.0; rt.b[0][1] = 0.0;       // chain_differences :692
         propose_point<1, false, LEAN>(p, phase, g, M, c, i, n, lane, xb, grow, rt, out + (size_t)i * out_stride, nullptr, false, cr_idx, 1, glev, ds, nullptr, &sc);
@@ -299,18 +289,10 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     constexpr bool XF = !PB && !K1 && WPC == 1;
     auto generation_draws = [&](uint32_t g_) {
         DrawSrc q; q.have = true; q.mine = make_uint4(0, 0, 0, 0);
-#ifdef DZ_KO_DRAWS       // (knock-out build: no Philox call for the generation's slot draws)
-        q.mine = make_uint4((uint32_t)lane * 2654435761u + g_ * 40503u, gc * 2246822519u + (uint32_t)lane, g_ * 3266489917u ^ (uint32_t)lane, gc ^ g_);
-#else
         if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g_); q.mine = make_uint4(w.x, w.y, w.z, w.w); }
-#endif
         if (XF) {
             const uint32_t hx = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.mine.x), hy = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.mine.y);
-#ifdef DZ_KO_NOSNOOKER
-            finish_draws(p, q, false, M, lane);
-#else
             finish_draws(p, q, u53_below(hx, hy, p.snk_thr), M, lane);               // (slot 0 = lane 0: set_snooker's draw)
-#endif
         }
         return q;
     };
@@ -323,9 +305,6 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
         if (a0 + 1 < a1) request_pair<XF>(p, q, pt_slot(p, phase_, a0 + 1, 1), gc, g_, M, lane, RB, p.Z, 8u * (uint32_t)p.ld);
     };
     auto draws_say_snooker = [&](const DrawSrc& q, uint32_t g_) {                   // set_snooker :542-554 on the integer form of the draw
-#ifdef DZ_KO_NOSNOOKER   // (knock-out build: every move is a DE move)
-        return false;
-#endif
         const u32x4 w0 = uniform_draw(p, q, 0, gc, g_);
         return u53_below(w0.x, w0.y, p.snk_thr);
     };
@@ -351,9 +330,6 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 u.u_snk = u53(w0.x, w0.y); u.u_cr = u53(w0.z, w0.w); u.u_de = u53(w1.x, w1.y); u.u_glev = u53(w1.z, w1.w);
                 u.u_sel = u53(w2.x, w2.y); u.u_acc = u53(w2.z, w2.w);
                 f = step_flags_from(p, u, probs, probs + p.ncr);                     // Dream.py:246-256
-#ifdef DZ_KO_NOSNOOKER
-                f.snk = false;
-#endif
                 if (lane == 0 && sub == 0) {
                     double* dc = dec + 8 * cl;
                     dc[0] = u.u_sel; dc[1] = u.u_acc; dc[2] = f.snk ? 1.0 : 0.0; dc[3] = (double)f.cr_idx; dc[4] = (double)f.glev;
@@ -435,24 +411,16 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                     if (!multipair && !draws_say_snooker(dsn, g + 1u)) prefetch_first(dsn, 0, g + 1u);
                 }
                 DZ_MSTAMP(1 + 4 * phase);
-#ifndef DZ_KO_BARRIER
                 __syncthreads();                                                     // points visible
-#endif
                 DZ_MSTAMP(2 + 4 * phase);
                 // mt_evaluate_logps :278, :302 (x - 0.0 == x bit for bit, so a zero mean skips the subtraction and its LDS read)
                 {
                     const int row0 = phase ? CH : 0, ntl = ((k - phase) * CH + 15) / 16;
-#ifndef DZ_KO_UNITS
                     if (p.mu_zero) mfma_units<NRT, TRI, true>(p, Ms, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, L.LDM, L.LDP);
                     else mfma_units<NRT, TRI, false>(p, Ms, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, L.LDM, L.LDP);
-#else
-                    (void)row0; (void)ntl;
-#endif
                 }
                 DZ_MSTAMP(3 + 4 * phase);
-#ifndef DZ_KO_BARRIER
                 __syncthreads();                                                     // q visible
-#endif
                 if (!(REDO && phase == 0)) break;
                 // `while np.all(np.isfinite(np.array(log_ps))==False)` (:281-282): log_ps = log_priors + T * log_likes of the chain's k tries
                 double lpv = -__builtin_huge_val();
@@ -478,11 +446,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
             DZ_MSTAMP(4 + 4 * phase);
         }
         // ---- Metropolis step (:305-347), trace (core.py:114-116), record_history (:919-938)
-#ifdef DZ_KO_METRO
-        if (false) {
-#else
         if (sub == 0) {
-#endif
             const double* dc = dec + 8 * cl;
             const double u_acc = dc[1];
             const bool snk = dc[2] != 0.0;
@@ -535,26 +499,18 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
             else if (jj < ld) xo = *reinterpret_cast<const double2*>(p.X + (size_t)c * ld + jj);
             double2 xn = xo;
             if (accept) { xn.x = jj < d ? region[jj] : 0.0; xn.y = jj + 1 < d ? region[jj + 1] : 0.0; }   // the selected proposal
-#ifdef DZ_KO_SNOOKER_OFF
-#endif
             const bool moved = __any((xn.x != xo.x) || (xn.y != xo.y));              // core.py:120
             const double npri = accept ? sP[cl * k + sel] : lpri, nlik = accept ? sL[cl * k + sel] : llik;   // :345-347
             if (XLDS && accept) { double* xr = Xs + cl * L.LDP; if (jj < d) xr[jj] = xn.x; if (jj + 1 < d) xr[jj + 1] = xn.y; }
             if (active) {
                 if (jj < ld) {
                     if (XLDS ? last : accept) gstore2(p.X + (size_t)c * ld + jj, xn);
-#ifndef DZ_KO_TRACE
                     if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn);
-#endif
                     if (last && zappend >= 0) gstore2(p.Z + ((size_t)zappend + gc) * ld + jj, xn);      // record_history :933-936
                     if (publish) gstore2(publish + (size_t)gc * ld + jj, xn);                          // set_current_position_arr :447-449
                 }
                 if (lane == 0) {
-#ifdef DZ_KO_TRACE
-                    if (false) {
-#else
                     if (trace_slot0 >= 0) {
-#endif
                         const size_t o = (size_t)(trace_slot0 + gi) * p.nl + c;
                         p.tlogp[o] = nlik + npri;                                    // core.py:115
                         p.tmoved[o] = moved ? 1 : 0; p.ttry[o] = sel; p.tcr[o] = cr_idx; p.tsnk[o] = snk ? 1 : 0;

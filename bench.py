@@ -197,7 +197,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--min-timed-ms", type=float, default=50.0, help="the block of K timed generations is repeated until this much has been timed")
     ap.add_argument("--rhat-chunk", type=int, default=500, help="generations between R-hat evaluations of the convergence run")
-    ap.add_argument("--rhat-max-generations", type=int, default=10000, help="the convergence run stops here if R-hat has not passed 1.2")
+    ap.add_argument("--rhat-max-generations", type=int, default=None,
+                    help="the convergence run stops here if R-hat has not passed 1.2 (default: max(10000, 16 * dim) -- the 1000-D shard needs ~13000)")
     ap.add_argument("--rhat-min-generations", type=int, default=2000,
                     help="the convergence run lasts at least this long (it doubles as the clock spin-up: a cold MI355X needs ~0.1 s of load)")
     ap.add_argument("--rhat-window", type=int, default=4000, help="generations of the fixed R-hat window after the convergence run")
@@ -232,6 +233,8 @@ def main():
     ap.add_argument("--transport", choices=["peer", "rccl", "host"], default=None,
                     help="row exchange of a multi-GPU run (default: DZ_BENCH_TRANSPORT or peer; falls back peer -> rccl -> host, loudly)")
     args = ap.parse_args()
+    if args.rhat_max_generations is None:
+        args.rhat_max_generations = max(10000, 16 * args.dim)
     if args.spinup is not None:
         args.rhat_min_generations = args.spinup
         args.rhat_max_generations = max(args.spinup, min(args.rhat_max_generations, 4 * args.spinup))

@@ -154,6 +154,10 @@ struct dz_engine {
     int num_cu = 256;
     int waves_per_block = 0;        // DZ_WPB
     bool fuse = true;               // DZ_FUSE=0 disables the accept+propose fusion
+    bool fuse_stream = true;        // streamed generations: the Metropolis step rides in front of the next generation's proposal set (k_accept_propose; DZ_FUSE_STREAM=0: off)
+    int64_t stream_prop_gen = -1;   // the generation whose proposal set k_accept_propose has already made
+    bool q_defer = true;            // streamed generations: no k_q_finish launches, the proposal / Metropolis kernels add the row-tile sums (DZ_QFIN=0: off)
+    double* last_qpart = nullptr;   // the scratch slice the last tiled likelihood launch wrote
     bool stream_propose = true;     // ld > 256: the streaming proposal kernel (k_propose_stream); DZ_STREAM=0 keeps k_propose<4|8>
     bool mega = true;               // the persistent generation kernel serves every eligible configuration (mega_eligible); DZ_MEGA=0 forces the multi-kernel path
     bool mega_redo_on = true;       // redraw rounds (Dream.py:281-289) inside the persistent kernel; DZ_MEGA_REDO=0: such configurations take the multi-kernel path
@@ -285,7 +289,9 @@ int launch_check(const char* what)
 }
 
 // Model.total_logp for n points stored [n,ld] on the device
-int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* like, hipStream_t st = nullptr)
+// defer_finish (large-d MVN only): the row-tile sums stay in the scratch array (e->last_qpart) for the consuming kernel to add
+// (Params::qfin_*) instead of a k_q_finish launch
+int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* like, hipStream_t st = nullptr, bool defer_finish = false)
 {
     if (n <= 0) return 0;
     if (!st) st = e->stream;
@@ -365,7 +371,8 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
                         else hipLaunchKernelGGL(dz::k_logp_mvn_gemm<4>, gridg, block, ldsm, st, e->p, pts, n, qpart, e->num_cu);
                     } else
                     hipLaunchKernelGGL((dz::k_logp_mvn_mfma_tiled<PT, RTC>), dim3((npg * nrg + 3) / 4), block, 0, st, e->p, pts, n, qpart);
-                    hipLaunchKernelGGL(dz::k_q_finish, dim3((n + 63) / 64), dim3(64), 0, st, e->p, (const double*)qpart, n, nrtb, prior, like);
+                    e->last_qpart = qpart;
+                    if (!defer_finish) hipLaunchKernelGGL(dz::k_q_finish, dim3((n + 63) / 64), dim3(64), 0, st, e->p, (const double*)qpart, n, nrtb, prior, like);
                 }
             }
             if (e->p.have_prior) NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_prior_only<NCH>, grid, block, 0, st, e->p, pts, n, prior));
@@ -629,35 +636,52 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
     // ld > 256, one DE pair, multi-try: one wave per (chain, try) streaming over the dimension chunks (dz_kernels.h)
     const bool streamed = e->stream_propose && e->nch >= 4 && p.depairs == 1 && k >= 3 && !redo_possible(e);     // (redraw rounds go through k_propose)
     const bool redo = redo_possible(e);         // (then the proposal set's evaluation is followed by a check on the host: nothing is deferred)
+    const bool have_prop = streamed && full && e->stream_prop_gen == (int64_t)g;
+    e->stream_prop_gen = -1;
+    // ... and the streamed form of the same: accept(g) + proposal set(g+1) in one launch (k_accept_propose)
+    const bool fuse_next = streamed && e->fuse_stream && full && more_follow && !append && !publish && !e->tempering && k <= 16;
     const bool defer = full && e->fuse && more_follow && !append && !publish && split == 1 && e->lk != LK_HOST && !e->tempering && !streamed && !redo;
     const int64_t zbase = full ? e->M : e->M - (int64_t)(p.off + c0);
+    // large d: the row-tile sums of the likelihood product are added by the kernels that use them (no k_q_finish launches)
+    const bool qdefer = streamed && e->q_defer && e->lk == LK_MVN && p.ld / 16 > 8 && !e->force_big;
+    p.qfin_p = nullptr; p.qfin_r = nullptr; p.qfin_nrt = (p.d + 15) / 16;
     for (int s = 0; s < L; ++s) {
         const int lc0 = c0 + (int)((int64_t)nc * s / L), lc1 = c0 + (int)((int64_t)nc * (s + 1) / L), lnc = lc1 - lc0;
         if (lnc <= 0) continue;
         hipStream_t st = e->lane_stream[s];
         if (need_draws)
             hipLaunchKernelGGL(dz::k_draws, dim3((lnc * p.nslots + 255) / 256), dim3(256), 0, st, p, g, lc0, lnc, e->d_draws[g & 1], e->d_ctl[g & 1]);
-        if (streamed && !fused_in) DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose_stream, dim3((lnc * k + 3) / 4), dim3(256), 0, p, 0, g, Mv, lc0, lnc);
+        if (streamed && have_prop) { }                      // made by the k_accept_propose launch of the generation before
+        else if (streamed && !fused_in) DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose_stream, dim3((lnc * k + 3) / 4), dim3(256), 0, p, 0, g, Mv, lc0, lnc);
         else {
             if (fused_in) { NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc + wpb - 1) / wpb), dim3(64 * wpb), 0, p, 0, g, Mv, lc0, lnc, 1, 1, e->pending_slot)); }
             else { NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc * sp0 + wpb - 1) / wpb), dim3(64 * wpb), 0, p, 0, g, Mv, lc0, lnc, sp0, 0, (int64_t)-1)); }
         }
         DZCK(launch_check("propose"));
-        DZCK(eval_logp(e, p.P + (size_t)lc0 * k * p.ld, lnc * k, p.p_prior + (size_t)lc0 * k, p.p_like + (size_t)lc0 * k, st));
+        DZCK(eval_logp(e, p.P + (size_t)lc0 * k * p.ld, lnc * k, p.p_prior + (size_t)lc0 * k, p.p_like + (size_t)lc0 * k, st, qdefer));
         if (redo) DZCK(redraw_impossible_sets(e, g, lc0, lnc, sp0, wpb, st));
         if (k > 1) {
+            if (qdefer) { p.qfin_p = e->last_qpart; p.qfin_c0 = lc0; p.qfin_nc = lnc; }
             if (streamed) DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose_stream, dim3((lnc * (k - 1) + 3) / 4), dim3(256), 0, p, 1, g, Mv, lc0, lnc);
             else {
                 NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc * sp1 + wpb - 1) / wpb), dim3(64 * wpb), 0, p, 1, g, Mv, lc0, lnc, sp1, 0, (int64_t)-1));
             }
             DZCK(launch_check("propose(ref)"));
-            DZCK(eval_logp(e, p.R + (size_t)lc0 * (k - 1) * p.ld, lnc * (k - 1), p.r_prior + (size_t)lc0 * (k - 1), p.r_like + (size_t)lc0 * (k - 1), st));
+            p.qfin_p = nullptr;
+            DZCK(eval_logp(e, p.R + (size_t)lc0 * (k - 1) * p.ld, lnc * (k - 1), p.r_prior + (size_t)lc0 * (k - 1), p.r_like + (size_t)lc0 * (k - 1), st, qdefer));
+            if (qdefer) { p.qfin_r = e->last_qpart; p.qfin_c0 = lc0; p.qfin_nc = lnc; }
         }
-        if (!defer) {
+        if (fuse_next) {
+            const size_t lds = sizeof(double) * (size_t)p.ld + 64 * sizeof(uint4) + sizeof(dz::ChainCtl);
+            NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_ACCEPT, st, dz::k_accept_propose<NCH>, dim3(lnc), dim3(64 * k), lds, p, g, zbase, lc0, lnc, slot, Mv));
+            DZCK(launch_check("accept + propose"));
+        } else if (!defer) {
             NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_ACCEPT, st, dz::k_accept<NCH>, dim3((lnc + wpb - 1) / wpb), dim3(64 * wpb), 0, p, g, zbase, lc0, lnc, slot, append ? 1 : 0, publish ? 1 : 0, (full && !publish) ? 1 : 0));
             DZCK(launch_check("accept"));
         }
+        p.qfin_r = nullptr;
     }
+    if (fuse_next) e->stream_prop_gen = (int64_t)g + 1;
     e->pending_accept = defer; e->pending_slot = defer ? slot : -1;
     e->draws_gen = (full && !publish) ? (int64_t)g + 1 : -1;   // while adapting, next generation's decisions must wait for the new probabilities
     if (publish || append) {         // shared state changed: the lanes meet before anything reads it
@@ -868,6 +892,8 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     if (const char* kv = getenv("DZ_MEGA_BURNIN")) e->mega_burnin = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_REDO")) e->mega_redo_on = atoi(kv) != 0;
     static_assert(dz::DZ_MAX_REDRAWS_DEV == DZ_MAX_REDRAWS && dz::DZ_REDRAW_KEY_STEP_DEV == DZ_REDRAW_KEY_STEP, "redraw constants");
+    if (const char* kv = getenv("DZ_QFIN")) e->q_defer = atoi(kv) != 0;
+    if (const char* kv = getenv("DZ_FUSE_STREAM")) e->fuse_stream = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_LOGP_BM")) e->logp_bm = atoi(kv);          // 64 / 128: points per block of k_logp_mvn_gemm (default: by size)
     if (const char* kv = getenv("DZ_MEGA_CHAINS")) { const int v = atoi(kv); e->mega_ch = (v == 16 || v == 8 || v == 4) ? v : 0; }
     if (const char* kv = getenv("DZ_WPB")) e->waves_per_block = atoi(kv);
@@ -1344,6 +1370,7 @@ int dz_step(dz_engine* e, int64_t generations)
     e->p.own_cr = nullptr; e->p.own_g = nullptr;                   // lockstep generations read the shared probabilities;
     std::fill(e->own_init.begin(), e->own_init.end(), 0);          // a later single-chain step starts from them again
     const bool mega = mega_eligible(e);
+    e->stream_prop_gen = -1;
     for (int64_t i = 0; i < generations;) {
         const int n = mega ? mega_segment(e, (uint32_t)e->gen, generations - i) : 0;
         if (n > 0) { DZCK(run_mega_segment(e, (uint32_t)e->gen, n)); i += n; }

@@ -56,6 +56,10 @@ struct Params {
     // null in lockstep mode (every chain reads the shared vectors)
     const double *own_cr, *own_g;
     unsigned long long* redraw_count;    // redraw rounds made inside the persistent kernel (one count per block and round), or null
+    // large-d MVN likelihood (k_logp_mvn_gemm / k_logp_mvn_mfma_tiled) without a k_q_finish launch: the kernels that consume the proposal
+    // set's (qfin_p) / reference set's (qfin_r) log likelihoods add the row-tile sums [row tile][point] themselves (like_from_q); the
+    // points are those of local chains [qfin_c0, qfin_c0 + qfin_nc).  Null: p_like / r_like hold the values already.
+    const double *qfin_p, *qfin_r; int qfin_nrt, qfin_c0, qfin_nc;
     unsigned long long* dbg;  // cycle-stamp buffer of instrumented builds (-DDZ_EXPERIMENTS, dz_experiments.h); null otherwise
 };
 // per-phase cycle stamps: defined by dz_experiments.h in instrumented builds only (tools/variants.sh), no-ops in the product
@@ -486,6 +490,25 @@ DZ_DEV double prior_of_point(const Params& p, const double (&x)[NCH][2], int lan
     return wave_bfly(acc);
 }
 DZ_DEV double nan_to_ninf(double x) { return x != x ? -__builtin_huge_val() : x; }
+// Q = q_0 + q_1 + ... in ascending row tile t (the MVN contract, v2) for point `pt` of the scratch array [row tile][npts] the tiled
+// likelihood kernels leave -- what k_q_finish does, for the kernels that take the sums over themselves (Params::qfin_*).  32 loads in
+// flight per round trip (index clamped, the add skipped beyond nrt).
+DZ_DEV double q_tile_sum(const double* __restrict__ q, size_t npts, int nrt, size_t pt)
+{
+    double Q = 0.0;
+    for (int t0 = 0; t0 < nrt; t0 += 32) {
+        double v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = q[(size_t)min(t0 + j, nrt - 1) * npts + pt];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) if (t0 + j < nrt) Q = Q + v[j];
+    }
+    return Q;
+}
+DZ_DEV double like_from_q(const Params& p, const double* __restrict__ q, size_t npts, size_t pt)
+{
+    return nan_to_ninf(p.logF - 0.5 * q_tile_sum(q, npts, p.qfin_nrt, pt));
+}
 
 // The transition of chain c at generation g (one wave).  Leaves the new state in xn, and -- when prep_next --
 // the wave-uniform draws and control decisions of generation g+1 in registers (dnext: lane s holds slot s;
@@ -535,8 +558,16 @@ DZ_DEV void accept_chain(const Params& p, uint32_t g, int64_t zbase, int c, int 
             if (f.snk) val = val + p.p_slogp[c * k + lane];                                              // :307
         } else if (lane >= 16 && lane < 16 + k) {
             const int i = lane - 16;
-            val = i < k - 1 ? T * p.r_like[c * (k - 1) + i] + p.r_prior[c * (k - 1) + i]                // :303
-                            : T * last_like + last_prior;                                                // :877-879
+            if (i < k - 1) {
+                double rl, rp;
+                if (p.qfin_r) {      // the reference set's row-tile sums are still in the scratch array: finish them here
+                    rl = like_from_q(p, p.qfin_r, (size_t)p.qfin_nc * (k - 1), (size_t)(c - p.qfin_c0) * (k - 1) + i);
+                    rp = p.have_prior ? p.r_prior[c * (k - 1) + i] : 0.0;
+                    p.r_like[c * (k - 1) + i] = rl;
+                    if (!p.have_prior) p.r_prior[c * (k - 1) + i] = 0.0;
+                } else { rl = p.r_like[c * (k - 1) + i]; rp = p.r_prior[c * (k - 1) + i]; }
+                val = T * rl + rp;                                                                       // :303
+            } else val = T * last_like + last_prior;                                                     // :877-879
             if (f.snk) { const double sr = i < k - 1 ? p.r_slogp[c * (k - 1) + i] : 0.0; val = (val + sr) + p.p_slogp[c * k + i]; }   // :312-313
         }
         ratio = mt_log_ratio(k, val);
@@ -757,34 +788,25 @@ __global__ __launch_bounds__(NCH >= 4 ? 256 : 1024) void k_propose(Params p, int
     DZ_STAMP(p, phase, c, 15);
 }
 
-#ifndef DZ_TEMPLATES_ONLY   // plain (non-template) kernels: defined once, in dz_engine.hip's translation unit
 // Large d (ld > 256): one wave per (chain, try) STREAMS over the 128-dimension chunks instead of holding all of them in registers
 // (k_propose<8> needs 344 registers: one wave per SIMD, every latency exposed).  Two passes, each a chunk at a time with the next
 // chunk's base and archive rows in flight: DE -- pass 1 counts the crossed-over dimensions d' (the crossover uniforms are the
 // first word of the pair's Philox call, which pass 2 makes again), then gamma, pass 2 makes the proposal; snooker -- pass 1 the two
 // dot products, pass 2 the proposal and its distance to z.  Same arithmetic and summation order as propose_point (a lane adds its
 // dimensions chunk by chunk in increasing order, then the butterfly): bit-identical to it.  DEpairs = 1, multitry >= 3.
-__global__ __launch_bounds__(256) void k_propose_stream(Params p, int phase, uint32_t g, uint32_t M, int c0, int nc)
+// (BLDS: the base row lies in LDS -- k_accept_propose, where the Metropolis step of the generation before has just produced it.)
+template <bool BLDS>
+DZ_DEV void stream_try(const Params& p, int phase, uint32_t g, uint32_t M, uint32_t gc, int i, int lane, const double* base, const DrawSrc& dsrc,
+                       const ChainCtl& ct, double* out, double* sl)
 {
-    const int k = p.k, n = phase == 0 ? k : k - 1;
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (wave >= nc * n) return;
-    const int lane = threadIdx.x & 63;
-    const int c = c0 + wave / n, i = wave % n;
     const int d = p.d, ld = p.ld, nchunk = (ld + 127) >> 7;
-    const uint32_t gc = (uint32_t)(p.off + c);
-    const DrawSrc dsrc = load_draws(p, p.draws + (size_t)c * p.nslots, lane);
-    const ChainCtl ct = p.ctl[c];
-    const double* base; double* out; double* sl;
-    if (phase == 0) { base = p.X + (size_t)c * ld; out = p.P + ((size_t)c * k + i) * ld; sl = p.p_slogp + (size_t)c * k; }
-    else {
-        bool fin; const int sel = mt_select(p, c, ct.u_sel, lane, &fin);
-        if (lane == 0 && i == 0) p.sel[c] = sel | (fin ? 256 : 0);
-        base = p.P + ((size_t)c * k + sel) * ld; out = p.R + ((size_t)c * (k - 1) + i) * ld; sl = p.r_slogp + (size_t)c * (k - 1);
-    }
-    const bool snk = __builtin_amdgcn_readfirstlane(ct.snk) != 0;
     const uint32_t s_dim = stream_id(K_DIM, (uint32_t)i, (uint32_t)phase), s_bnd = stream_id(K_BND, (uint32_t)i, (uint32_t)phase);
     auto off = [&](int it) { return min(128 * it + 2 * lane, ld - 2); };            // (lanes past ld re-read the row's last pair; masked where used)
+    auto bload = [&](int it) -> double2 {
+        if (BLDS) { const dz_d2v v = *(const __attribute__((address_space(3))) dz_d2v*)(base + off(it)); double2 r; r.x = v.x; r.y = v.y; return r; }
+        return gload2(base + off(it));
+    };
+    const bool snk = __builtin_amdgcn_readfirstlane(ct.snk) != 0;
     auto bounded = [&](double x, int j) {                                           // hard boundaries :733-791
         const double lo = p.mins[j], hi = p.maxs[j];
         const bool bl = x < lo, bh = x > hi;
@@ -807,7 +829,7 @@ __global__ __launch_bounds__(256) void k_propose_stream(Params p, int phase, uin
         uint32_t r1 = __builtin_amdgcn_readfirstlane(mulhi_idx(wr.y, M - 1u));
         if (r1 >= r0) r1++;                                                         // random.sample(range(M), 2) :662
         const double* za = p.Z + (size_t)r0 * ld; const double* zb = p.Z + (size_t)r1 * ld;
-        double2 xn = gload2(base + off(0)), an = gload2(za + off(0)), bn = gload2(zb + off(0));      // chunk 0 travels during pass 1
+        double2 xn = bload(0), an = gload2(za + off(0)), bn = gload2(zb + off(0));      // chunk 0 travels during pass 1
         const uint32_t thr = p.crthr[__builtin_amdgcn_readfirstlane(ct.cr_idx)];
         int dprime = 0;
         for (int it = 0; it < nchunk; ++it) {                                       // pass 1: d' :704 / :709
@@ -820,9 +842,9 @@ __global__ __launch_bounds__(256) void k_propose_stream(Params p, int phase, uin
         double gamma = 1.0;
         if (!u53_below(wg.x, wg.y, p.pgu_thr)) gamma = gamma_row(p, ct.glev, 1)[(dprime == 0 ? d : dprime) - 1];   // :624
         const double ec1 = p.ec1, ec0 = p.ec0;
-        for (int it = 0; it < nchunk; ++it) {                                       // pass 2: the proposal :714-726
-            const double2 x = xn, a = an, b = bn;
-            if (it + 1 < nchunk) { xn = gload2(base + off(it + 1)); an = gload2(za + off(it + 1)); bn = gload2(zb + off(it + 1)); }
+        for (int it = 0; it < nchunk; ++it) {                                       // pass 2: the proposal :714-726 (the Philox calls of pass 1
+            const double2 x = xn, a = an, b = bn;                                   //  again; keeping their outputs in registers changed nothing)
+            if (it + 1 < nchunk) { xn = bload(it + 1); an = gload2(za + off(it + 1)); bn = gload2(zb + off(it + 1)); }
             const int j0 = 128 * it + 2 * lane;
             const u32x4 w = philox(p.k0, p.k1, (uint32_t)(j0 >> 1), s_dim, gc, g);
             float z0, z1;
@@ -843,10 +865,10 @@ __global__ __launch_bounds__(256) void k_propose_stream(Params p, int phase, uin
         const u32x4 wg = uniform_draw(p, dsrc, pt_slot(p, phase, 0, 0), gc, g);
         const double gamma_s = 1.2 + (2.2 - 1.2) * u53(wg.z, wg.w);                 // :618
         double accD = 0.0, accS = 0.0;
-        double2 xn = gload2(base + off(0)), zn = gload2(zz + off(0)), an = gload2(q1r + off(0)), bn = gload2(q2r + off(0));
+        double2 xn = bload(0), zn = gload2(zz + off(0)), an = gload2(q1r + off(0)), bn = gload2(q2r + off(0));
         for (int it = 0; it < nchunk; ++it) {                                       // pass 1: |x - z|^2 and (zR1 - zR2).(x - z) :813-819
             const double2 x = xn, z = zn, a = an, b = bn;
-            if (it + 1 < nchunk) { xn = gload2(base + off(it + 1)); zn = gload2(zz + off(it + 1)); an = gload2(q1r + off(it + 1)); bn = gload2(q2r + off(it + 1)); }
+            if (it + 1 < nchunk) { xn = bload(it + 1); zn = gload2(zz + off(it + 1)); an = gload2(q1r + off(it + 1)); bn = gload2(q2r + off(it + 1)); }
             const int jj = 128 * it + 2 * lane;
             const double v0 = x.x - z.x, v1 = x.y - z.y;
             if (jj < d) { accD = fma(v0, v0, accD); accS = fma(a.x - b.x, v0, accS); }
@@ -856,10 +878,10 @@ __global__ __launch_bounds__(256) void k_propose_stream(Params p, int phase, uin
         const double D = readlane_f64(DS, 0);                                       // :816
         const double cc = readlane_f64(DS, 32) / D;                                 // :820
         double accN = 0.0;
-        xn = gload2(base + off(0)); zn = gload2(zz + off(0));
+        xn = bload(0); zn = gload2(zz + off(0));
         for (int it = 0; it < nchunk; ++it) {                                       // pass 2: the proposal :820-822 and its distance to z :823
             const double2 x = xn, z = zn;
-            if (it + 1 < nchunk) { xn = gload2(base + off(it + 1)); zn = gload2(zz + off(it + 1)); }
+            if (it + 1 < nchunk) { xn = bload(it + 1); zn = gload2(zz + off(it + 1)); }
             const int jj = 128 * it + 2 * lane;
             const double p0 = x.x + gamma_s * nan_to_num(cc * (x.x - z.x)), p1 = x.y + gamma_s * nan_to_num(cc * (x.y - z.y));
             if (jj < d) { const double t = p0 - z.x; accN = fma(t, t, accN); }
@@ -868,6 +890,37 @@ __global__ __launch_bounds__(256) void k_propose_stream(Params p, int phase, uin
         }
         snooker_logps(p, wave_bfly(accN), 1, lane, sl + i);                         // :823-824
     }
+}
+#ifndef DZ_TEMPLATES_ONLY   // plain (non-template) kernels: defined once, in dz_engine.hip's translation unit
+__global__ __launch_bounds__(256) void k_propose_stream(Params p, int phase, uint32_t g, uint32_t M, int c0, int nc)
+{
+    const int k = p.k, n = phase == 0 ? k : k - 1;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (wave >= nc * n) return;
+    const int lane = threadIdx.x & 63;
+    const int c = c0 + wave / n, i = wave % n;
+    const int ld = p.ld;
+    const uint32_t gc = (uint32_t)(p.off + c);
+    const DrawSrc dsrc = load_draws(p, p.draws + (size_t)c * p.nslots, lane);
+    const ChainCtl ct = p.ctl[c];
+    const double* base; double* out; double* sl;
+    if (phase == 0) { base = p.X + (size_t)c * ld; out = p.P + ((size_t)c * k + i) * ld; sl = p.p_slogp + (size_t)c * k; }
+    else {
+        bool fin; int sel;
+        if (p.qfin_p) {      // the proposal set's row-tile sums are still in the scratch array: every wave of the chain finishes them
+            double lp = -__builtin_huge_val();
+            if (lane < k) {
+                const double like = like_from_q(p, p.qfin_p, (size_t)p.qfin_nc * k, (size_t)(c - p.qfin_c0) * k + lane);
+                const double prior = p.have_prior ? p.p_prior[c * k + lane] : 0.0;
+                lp = prior + chain_T(p, c) * like;
+                if (i == 0) { p.p_like[c * k + lane] = like; if (!p.have_prior) p.p_prior[c * k + lane] = 0.0; }
+            }
+            sel = mt_select_vals(k, lp, ct.u_sel, lane, &fin);
+        } else sel = mt_select(p, c, ct.u_sel, lane, &fin);
+        if (lane == 0 && i == 0) p.sel[c] = sel | (fin ? 256 : 0);
+        base = p.P + ((size_t)c * k + sel) * ld; out = p.R + ((size_t)c * (k - 1) + i) * ld; sl = p.r_slogp + (size_t)c * (k - 1);
+    }
+    stream_try<false>(p, phase, g, M, gc, i, lane, base, dsrc, ct, out, sl);
 }
 #endif  // DZ_TEMPLATES_ONLY
 
@@ -1532,6 +1585,40 @@ __global__ __launch_bounds__(1024) void k_accept(Params p, uint32_t g, int64_t z
     if (wave >= nc) return;
     double xn[NCH][2]; DrawSrc dn; ChainCtl cn;
     accept_chain<NCH>(p, g, zbase, c0 + wave, threadIdx.x & 63, trace_slot, append, publish, prep_next, p.ctl, p.ctl_next, p.draws_next, xn, dn, cn);
+}
+
+// Large d (k_propose_stream's domain), a generation that neither appends nor publishes, another one following: the Metropolis step of
+// generation g and the proposal set of generation g+1 in one launch.  One block per chain, one wave per try: wave 0 makes the step
+// (accept_chain: state, trace, the draws and decisions of generation g+1) and leaves the new state, the draws and the decisions in
+// LDS; behind the barrier wave i makes try i around it (stream_try) -- the set's rows in P are free by then, wave 0 has read the
+// selected one.  M: the archive rows generation g+1 may sample (no append in between: the same as generation g's).
+template <int NCH>
+__global__ __launch_bounds__(1024) void k_accept_propose(Params p, uint32_t g, int64_t zbase, int c0, int nc, int64_t trace_slot, uint32_t M)
+{
+    extern __shared__ __attribute__((aligned(16))) double xs[];           // [ld] state | 64 uint4 draws | ChainCtl
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int c = c0 + blockIdx.x;
+    uint4* sdraw = reinterpret_cast<uint4*>(xs + p.ld);
+    ChainCtl* sctl = reinterpret_cast<ChainCtl*>(sdraw + 64);
+    if (wv == 0) {
+        double xn[NCH][2]; DrawSrc dn; ChainCtl cn;
+        accept_chain<NCH>(p, g, zbase, c, lane, trace_slot, 0, 0, 1, p.ctl, p.ctl_next, p.draws_next, xn, dn, cn);
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) {
+            const int jj = 128 * it + 2 * lane;
+            if (jj < p.ld) { xs[jj] = xn[it][0]; xs[jj + 1] = xn[it][1]; }
+        }
+        sdraw[lane] = dn.mine;
+        if (lane == 0) *sctl = cn;
+    }
+    __syncthreads();
+    DrawSrc dsrc; dsrc.have = p.nslots <= 64; dsrc.mine = sdraw[lane];
+    {
+        const unsigned zero = threadIdx.x >> 12;        // (VALU-defined registers for v_readlane, see load_draws)
+        dsrc.mine.x += zero; dsrc.mine.y += zero; dsrc.mine.z += zero; dsrc.mine.w += zero;
+    }
+    const ChainCtl ct = *sctl;
+    stream_try<true>(p, 0, g + 1, M, (uint32_t)(p.off + c), wv, lane, xs, dsrc, ct, p.P + ((size_t)c * p.k + wv) * p.ld, p.p_slogp + (size_t)c * p.k);
 }
 
 // uniform draws of generation g for local chains [c0, c0+nc): one lane per (chain, slot); the lanes of

@@ -1,0 +1,16 @@
+#!/bin/bash
+exec < /dev/null
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+python -m pytest tests -m gpu -q 2>&1 | tail -4
+for v in "1 0" "1 1"; do
+  set -- $v
+  DZ_QFIN=$1 DZ_FUSE_STREAM=$2 python bench.py --chains-per-gpu 512 --dim 1000 --steps 50 --warmup 10 --no-cpu-baseline --no-dense --rhat-max-generations 2000 > gpurun_out/c4c_q$1f$2.json 2> gpurun_out/c4c_q$1f$2.err
+done
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/c4c_q?f?.json")):
+    try:
+        d=json.load(open(f)); kt=d["kernel_times"]
+        print(f, "%.2f M/s  %.1f us/gen" % (d["value"]/1e6, d["ms_per_step"]*1e3), {k:(round(v["avg_us"],1) if v["avg_us"] else None) for k,v in kt.items() if isinstance(v,dict)})
+    except Exception as ex: print(f, "ERR", ex)
+PY

@@ -127,6 +127,21 @@ DZ_DEV double kd(double c)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// a * b + c with such a constant c as the addend, read straight from its scalar register pair (one v_fma_f64; written as fma(a, b,
+// kd(c)) the compiler copies the pair into vector registers first and uses v_fmac: three vector instructions per Horner step)
+DZ_DEV double fma_k(double a, double b, double c)
+{
+#ifdef DZ_NO_FMAK
+    return fma(a, b, kd(c));
+#endif
+    unsigned lo = (unsigned)((unsigned long long)__double_as_longlong(c) & 0xffffffffull), hi = (unsigned)((unsigned long long)__double_as_longlong(c) >> 32);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    const unsigned long long cb = ((unsigned long long)hi << 32) | lo;
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(cb));
+    return r;
+}
+
 DZ_DEV double dexp(double x)
 {
     if (x != x) return x;
@@ -136,16 +151,16 @@ DZ_DEV double dexp(double x)
     double r = fma(-kf, DZ_LN2_HI, x);
     r = fma(-kf, DZ_LN2_LO, r);
     double p = kd(1.0 / 6227020800.0);
-    p = fma(p, r, kd(1.0 / 479001600.0));
-    p = fma(p, r, kd(1.0 / 39916800.0));
-    p = fma(p, r, kd(1.0 / 3628800.0));
-    p = fma(p, r, kd(1.0 / 362880.0));
-    p = fma(p, r, kd(1.0 / 40320.0));
-    p = fma(p, r, kd(1.0 / 5040.0));
-    p = fma(p, r, kd(1.0 / 720.0));
-    p = fma(p, r, kd(1.0 / 120.0));
-    p = fma(p, r, kd(1.0 / 24.0));
-    p = fma(p, r, kd(1.0 / 6.0));
+    p = fma_k(p, r, 1.0 / 479001600.0);
+    p = fma_k(p, r, 1.0 / 39916800.0);
+    p = fma_k(p, r, 1.0 / 3628800.0);
+    p = fma_k(p, r, 1.0 / 362880.0);
+    p = fma_k(p, r, 1.0 / 40320.0);
+    p = fma_k(p, r, 1.0 / 5040.0);
+    p = fma_k(p, r, 1.0 / 720.0);
+    p = fma_k(p, r, 1.0 / 120.0);
+    p = fma_k(p, r, 1.0 / 24.0);
+    p = fma_k(p, r, 1.0 / 6.0);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
@@ -170,16 +185,16 @@ DZ_DEV double dlog(double x)
     const double s = f / (2.0 + f);
     const double z = s * s;
     double p = kd(1.0 / 23.0);
-    p = fma(p, z, kd(1.0 / 21.0));
-    p = fma(p, z, kd(1.0 / 19.0));
-    p = fma(p, z, kd(1.0 / 17.0));
-    p = fma(p, z, kd(1.0 / 15.0));
-    p = fma(p, z, kd(1.0 / 13.0));
-    p = fma(p, z, kd(1.0 / 11.0));
-    p = fma(p, z, kd(1.0 / 9.0));
-    p = fma(p, z, kd(1.0 / 7.0));
-    p = fma(p, z, kd(1.0 / 5.0));
-    p = fma(p, z, kd(1.0 / 3.0));
+    p = fma_k(p, z, 1.0 / 21.0);
+    p = fma_k(p, z, 1.0 / 19.0);
+    p = fma_k(p, z, 1.0 / 17.0);
+    p = fma_k(p, z, 1.0 / 15.0);
+    p = fma_k(p, z, 1.0 / 13.0);
+    p = fma_k(p, z, 1.0 / 11.0);
+    p = fma_k(p, z, 1.0 / 9.0);
+    p = fma_k(p, z, 1.0 / 7.0);
+    p = fma_k(p, z, 1.0 / 5.0);
+    p = fma_k(p, z, 1.0 / 3.0);
     const double t = 2.0 * s;
     const double lm = fma(t * z, p, t);
     const double ef = (double)e;

@@ -423,12 +423,13 @@ def test_parallel_tempering_reference_and_oracle(G, O):
 
 @pytest.mark.parametrize("N,d,tri,gemm,zero_mean,qfin,prior", [(160, 333, 1, 1, 0, 1, 0), (200, 200, 0, 1, 0, 1, 0), (160, 333, 1, 0, 0, 1, 0), (128, 1000, 1, 1, 0, 1, 0),
                                                                (128, 200, 1, 1, 1, 1, 0), (128, 200, 0, 1, 1, 1, 0), (160, 333, 1, 1, 0, 0, 0),
-                                                               (160, 333, 1, 1, 0, 1, 1), (128, 1000, 1, 1, 0, 0, 1)])
+                                                               (160, 333, 1, 1, 0, 1, 1), (128, 1000, 1, 1, 0, 0, 1), (160, 333, 1, 1, 0, 1, 2)])
 def test_large_d_likelihood_kernels_against_oracle(G, O, N, d, tri, gemm, zero_mean, qfin, prior, monkeypatch):
     """ld > 128: the LDS-tiled product (k_logp_mvn_gemm, >= 512 points per launch) and the register-operand tiled
     kernel (DZ_LOGP_GEMM=0) against the oracle -- dimensions that are not multiples of 16 or 64, non-zero mean, dense and
     triangular matrix; everything bit-exact (the row-tile sums are added in the same order whatever kernel made them, and
-    whoever adds them: k_q_finish -- DZ_QFIN=0 -- or the kernels that use the log likelihoods, ld > 256); with and without priors."""
+    whoever adds them: k_q_finish -- DZ_QFIN=0 -- or the kernels that use the log likelihoods, ld > 256); flat, normal and
+    uniform priors, the last with hard boundaries."""
     monkeypatch.setenv("DZ_LOGP_GEMM", str(gemm))
     monkeypatch.setenv("DZ_QFIN", str(qfin))
     n, seed = 3, 9
@@ -438,8 +439,11 @@ def test_large_d_likelihood_kernels_against_oracle(G, O, N, d, tri, gemm, zero_m
     out = []
     for Cls in (G.Engine, O.Engine):
         e = Cls(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * 3, trace_capacity=n, seed=seed)
-        if prior:
+        if prior == 1:
             e.set_prior(np.full(d, 1, np.int32), np.linspace(-1.0, 2.0, d), np.full(d, 30.0))
+        elif prior == 2:                                                      # uniform(-6, 22) with hard boundaries: reflections and redraws (Dream.py:733-791)
+            e.set_prior(np.full(d, 2, np.int32), np.full(d, -6.0), np.full(d, 22.0))
+            e.set_bounds(np.full(d, -6.0), np.full(d, 16.0))
         e.set_likelihood_mvn(np.zeros(d) if zero_mean else np.linspace(-1, 1, d), M, tri, 0.0)      # (a zero mean skips the subtraction)
         e.set_history(Z0); e.set_state(Z0[:N])
         e.step(n)

@@ -728,7 +728,16 @@ int mega_chains(const dz_engine* e)
 }
 size_t mega_lds_bytes(const dz_engine* e, bool xlds)
 {
-    return sizeof(double) * (size_t)dz::mega_layout(e->p.d, e->p.k, e->p.ld / 16, e->p.ncr, e->p.ngamma, e->p.tri != 0, xlds, mega_chains(e)).total;
+    return sizeof(double) * (size_t)dz::mega_layout(e->p.d, e->p.k, e->p.ld / 16, e->p.ncr, e->p.ngamma, e->p.tri != 0, xlds, mega_chains(e), e->p.pb_lds != 0).total;
+}
+// the full-code instantiations stage the per-dimension prior / boundary constants in LDS when that still fits (Params::pb_lds)
+void mega_set_pb_lds(dz_engine* e)
+{
+    const bool pb = e->p.hard || e->p.have_prior || e->p.depairs > 1 || (redo_possible(e) && e->lk == LK_MVN && e->p.k > 1 && e->mega_redo_on);
+    e->p.pb_lds = 0;
+    if (!pb) return;
+    e->p.pb_lds = 1;
+    if (mega_lds_bytes(e, true) > (size_t)160 * 1024) e->p.pb_lds = 0;
 }
 bool mega_xlds(const dz_engine* e) { return mega_lds_bytes(e, true) <= (size_t)160 * 1024; }
 // the barrier-free variant for the mixture likelihood (k_generations_mix)
@@ -740,8 +749,9 @@ bool mega_mix_eligible(const dz_engine* e)
 }
 // redraw rounds inside the persistent kernel: the instantiations with the full proposal code, multi-try, device MVN likelihood
 bool mega_redo(const dz_engine* e) { return redo_possible(e) && e->lk == LK_MVN && e->p.k > 1 && e->mega_redo_on; }
-bool mega_eligible(const dz_engine* e)
+bool mega_eligible(dz_engine* e)
 {
+    mega_set_pb_lds(e);
     const dz::Params& p = e->p;
     if (redo_possible(e) && !mega_redo(e)) return false;
     if (mega_mix_eligible(e)) return true;

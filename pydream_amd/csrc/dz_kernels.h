@@ -60,6 +60,7 @@ struct Params {
     // set's (qfin_p) / reference set's (qfin_r) log likelihoods add the row-tile sums [row tile][point] themselves (like_from_q); the
     // points are those of local chains [qfin_c0, qfin_c0 + qfin_nc).  Null: p_like / r_like hold the values already.
     const double *qfin_p, *qfin_r; int qfin_nrt, qfin_c0, qfin_nc;
+    int pb_lds;      // persistent kernel, full-code instantiations: the prior / boundary constants are staged in LDS (PBConsts; set by the host when they fit)
     unsigned long long* dbg;  // cycle-stamp buffer of instrumented builds (-DDZ_EXPERIMENTS, dz_experiments.h); null otherwise
 };
 // per-phase cycle stamps: defined by dz_experiments.h in instrumented builds only (tools/variants.sh), no-ops in the product
@@ -316,6 +317,9 @@ DZ_DEV void reduce_rows(const ZRows<NCH>& zr, bool snk, RowTerms<NCH>& rt)
 // the try loop is a scalar load plus a wait, and scalar instructions cost nearly as much issue time as vector ones -- measured: 200 extra
 // s_add per generation = -3 %).  slot(i, idx) = slot0 + i npt + idx is pt_slot() of the set's phase.
 struct SetConsts { uint32_t thr; unsigned long long pgu_thr; double zeta, ec1, ec0; int npt, slot0; };
+// Per-dimension constants of the priors (SampledParam: kind, loc, scale, log scale) and the hard boundaries, staged in LDS by the
+// persistent kernel's full-code instantiations ([ld] each): a try then costs LDS reads instead of eight dependent global loads.
+struct PBConsts { const double *a, *b, *logb, *lo, *hi; const int* kind; };
 DZ_DEV SetConsts set_consts(const Params& p, int phase, int cr_idx)
 {
     SetConsts s;
@@ -332,8 +336,9 @@ template <int NCH, bool AL16 = true, int LEAN = 0>      // LEAN: 0 full, 1 lean 
 DZ_DEV double propose_point(const Params& p, int phase, uint32_t g, uint32_t M, int c, int i, int n, int lane,
                           const double (&xb)[NCH][2], const double* __restrict__ grow, const RowTerms<NCH>& zr, double* __restrict__ out,
                           double* cur_snk_out, bool snk, int cr_idx, int delta, int glev, const DrawSrc& dr, const u32x4* wpre = nullptr,
-                          const SetConsts* sc = nullptr)
+                          const SetConsts* sc = nullptr, const PBConsts* pc = nullptr, double (*prv)[2] = nullptr)
 {   // wpre: the DIM draw of chunk 0, computed by the caller one try ahead (software pipelining, NCH == 1)
+    // pc: bounds from LDS; prv: receives the lane's proposal values as stored (for the prior evaluation: no read-back of the row)
     const int d = p.d, ld = p.ld;
     const uint32_t gc = (uint32_t)(p.off + c);
     const uint32_t thr = sc ? sc->thr : p.crthr[__builtin_amdgcn_readfirstlane(cr_idx)];   // CR = CR_values[m], :146 (the decision is wave-uniform)
@@ -432,8 +437,8 @@ DZ_DEV double propose_point(const Params& p, int phase, uint32_t g, uint32_t M, 
         const int jj = 128 * it + 2 * lane;
         if (jj < ld) {
             if (!LEAN && p.hard) {
-                const double2 mn = *reinterpret_cast<const double2*>(p.mins + jj);
-                const double2 mxx = *reinterpret_cast<const double2*>(p.maxs + jj);
+                const double2 mn = *reinterpret_cast<const double2*>((pc ? pc->lo : p.mins) + jj);
+                const double2 mxx = *reinterpret_cast<const double2*>((pc ? pc->hi : p.maxs) + jj);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const double lo = s ? mn.y : mn.x, hi = s ? mxx.y : mxx.x;
@@ -449,6 +454,7 @@ DZ_DEV double propose_point(const Params& p, int phase, uint32_t g, uint32_t M, 
                 }
             }
             double2 o; o.x = (jj < d) ? pr[it][0] : 0.0; o.y = (jj + 1 < d) ? pr[it][1] : 0.0;
+            if (prv) { prv[it][0] = o.x; prv[it][1] = o.y; }
             if (AL16) *reinterpret_cast<double2*>(out + jj) = o;
             // 8-byte aligned row of an LDS tile, zero padded to the k-steps (4 ceil(d / 4) + 1 columns: with d odd the lane that owns the
             // last dimension also rewrites the first pad column with its zero): ONE predicated region, two adjacent stores
@@ -490,6 +496,24 @@ DZ_DEV double prior_of_point(const Params& p, const double (&x)[NCH][2], int lan
     return wave_bfly(acc);
 }
 DZ_DEV double nan_to_ninf(double x) { return x != x ? -__builtin_huge_val() : x; }
+// ... the same with the constants from LDS (PBConsts) and the point in registers (NCH == 1: the persistent kernels)
+DZ_DEV double prior_of_point_lds(const Params& p, const PBConsts& pc, const double (&x)[1][2], int lane)
+{
+    double acc = 0.0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int j = 2 * lane + s;
+        if (j < p.d) {
+            const int kd = pc.kind[j];
+            const double a = pc.a[j], b = pc.b[j], lb = pc.logb[j];
+            double t = 0.0;
+            if (kd == 1) { const double z = (x[0][s] - a) / b; t = (-(z * z) / 2.0 - 0.91893853320467274178) - lb; }
+            else if (kd == 2) t = (x[0][s] >= a && x[0][s] <= a + b) ? -lb : -__builtin_huge_val();
+            acc = acc + t;
+        }
+    }
+    return wave_bfly(acc);
+}
 // Q = q_0 + q_1 + ... in ascending row tile t (the MVN contract, v2) for point `pt` of the scratch array [row tile][npts] the tiled
 // likelihood kernels leave -- what k_q_finish does, for the kernels that take the sums over themselves (Params::qfin_*).  32 loads in
 // flight per round trip (index clamped, the add skipped beyond nrt).

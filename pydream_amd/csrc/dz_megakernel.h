@@ -30,7 +30,7 @@ constexpr int DZ_MAX_REDRAWS_DEV = 64;                                  // == DZ
 constexpr unsigned long long DZ_REDRAW_KEY_STEP_DEV = 0x9E3779B97F4A7C15ull;   // == DZ_REDRAW_KEY_STEP
 constexpr int MEGA_CHAINS = 16;      // chains (= waves) per block at full size; 8 or 4 when there are too few chains to give every CU a block
 
-struct MegaLayout { int LDM, LDP, rows, off_P, off_q, off_sP, off_sS, off_sL, off_rP, off_rS, off_mu, off_pr, off_st, off_dec, off_gt, off_X, total; };
+struct MegaLayout { int LDM, LDP, rows, off_P, off_q, off_sP, off_sS, off_sL, off_rP, off_rS, off_mu, off_pr, off_st, off_dec, off_gt, off_X, off_pc, pcn, total; };
 
 // point rows of a block: try i of chain c at row i*ch + c; tiles are 16 consecutive rows, from row 0 (k tries) or from
 // row ch (the k-1 reference tries); rows past the last point stay zero
@@ -39,7 +39,9 @@ __host__ __device__ inline int mega_rows(int k, int ch)
     const int a = 16 * ((k * ch + 15) / 16), b = ch + 16 * (((k - 1) * ch + 15) / 16);
     return a > b ? a : b;
 }
-__host__ __device__ inline MegaLayout mega_layout(int d, int k, int nrt, int ncr, int ngamma, bool tri, bool xlds, int ch = MEGA_CHAINS)
+// pb: room for the per-dimension prior / boundary constants of the full-code instantiations (PBConsts: five double arrays and one int
+// array of pcn = 16 nrt entries)
+__host__ __device__ inline MegaLayout mega_layout(int d, int k, int nrt, int ncr, int ngamma, bool tri, bool xlds, int ch = MEGA_CHAINS, bool pb = false)
 {
     MegaLayout L;
     const int ks4 = 4 * ((d + 3) / 4);
@@ -61,6 +63,8 @@ __host__ __device__ inline MegaLayout mega_layout(int d, int k, int nrt, int ncr
     L.off_X = L.off_gt + ngamma * d + (d & 1);   // chain states (XLDS)
     L.total = L.off_X + (xlds ? ch * L.LDP : 0);
     L.total += L.total & 1;
+    L.off_pc = L.total; L.pcn = 16 * nrt;
+    if (pb) L.total += 5 * L.pcn + L.pcn / 2;
     return L;
 }
 
@@ -183,12 +187,21 @@ DZ_DEV void request_pair(const Params& p, const DrawSrc& ds, int slot, uint32_t 
 template <int LEAN, bool XF>
 DZ_DEV void propose_de_pf(const Params& p, int phase, uint32_t g, uint32_t M, int c, uint32_t gc, int i0, int i1, int n, int lane,
                           const double (&xb)[1][2], const double* __restrict__ grow, int cr_idx, int glev, const DrawSrc& ds,
-                          double* out, int out_stride, double* sl, double* prior_out, RowPair& A, RowPair& B, RowPair& C)
+                          double* out, int out_stride, double* sl, double* prior_out, RowPair& A, RowPair& B, RowPair& C, const PBConsts* pc = nullptr)
 {
     const SetConsts sc = set_consts(p, phase, cr_idx);
     auto body = [&](int i, const RowPair& R) {
         RowTerms<1> rt;
         rt.a[0][0] = R.a.x - R.b.x; rt.a[0][1] = R.a.y - R.b.y; rt.b[0][0] = 0.0; rt.b[0][1] = 0.0;       // chain_differences :692
+        if (!LEAN && pc) {      // full code, constants in LDS: the prior is evaluated on the values the lane has just stored
+            double pv[1][2];
+            propose_point<1, false, LEAN>(p, phase, g, M, c, i, n, lane, xb, grow, rt, out + (size_t)i * out_stride, nullptr, false, cr_idx, 1, glev, ds, nullptr, &sc, pc, pv);
+            if (prior_out) {
+                const double pr = p.have_prior ? nan_to_ninf(prior_of_point_lds(p, *pc, pv, lane)) : 0.0;
+                if (lane == 0) prior_out[i] = pr;
+            }
+            return;
+        }
         propose_point<1, false, LEAN>(p, phase, g, M, c, i, n, lane, xb, grow, rt, out + (size_t)i * out_stride, nullptr, false, cr_idx, 1, glev, ds, nullptr, &sc);
         if (!LEAN && prior_out) point_prior<1>(p, out + (size_t)i * out_stride, lane, prior_out + i);
     };
@@ -232,7 +245,8 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     constexpr int LEANV = PB ? 0 : (K1 ? 2 : 1);
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int d = p.d, k = K1 ? 1 : p.k, ld = p.ld;
-    const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, XLDS, CH);
+    const bool pbl = PB && p.pb_lds != 0;
+    const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, XLDS, CH, pbl);
     double* Ms = smem;
     double* Pt = smem + L.off_P;
     double* qb = smem + L.off_q;
@@ -244,6 +258,12 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     double* dec = smem + L.off_dec;
     double* gts = smem + L.off_gt;
     double* Xs = smem + L.off_X;
+    PBConsts pcs;       // (PB) per-dimension prior and boundary constants, staged below
+    {
+        double* q = smem + L.off_pc;
+        pcs.a = q; pcs.b = q + L.pcn; pcs.logb = q + 2 * L.pcn; pcs.lo = q + 3 * L.pcn; pcs.hi = q + 4 * L.pcn;
+        pcs.kind = reinterpret_cast<const int*>(q + 5 * L.pcn);
+    }
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;       // (scalar: everything derived from the wave number stays on the scalar unit)
     const int cl = WPC == 1 ? wv : wv % CH;                              // chain inside the block
     const int sub = WPC == 1 ? 0 : wv / CH;                              // this wave's number among the chain's waves
@@ -274,6 +294,14 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     if (threadIdx.x < p.ncr) probs[threadIdx.x] = p.cr_probs[threadIdx.x];
     if (threadIdx.x < p.ngamma) probs[p.ncr + threadIdx.x] = p.g_probs[threadIdx.x];
     for (int i = threadIdx.x; i < p.ngamma * d; i += NT) gts[i] = p.gtab[(size_t)(i / d) * p.depairs * d + (i % d)];
+    if (pbl && (int)threadIdx.x < L.pcn) {
+        const int j = threadIdx.x;
+        double* q = smem + L.off_pc;
+        const bool hp = p.have_prior && j < d, hb = p.hard && j < d;
+        q[j] = hp ? p.pa[j] : 0.0; q[L.pcn + j] = hp ? p.pb[j] : 1.0; q[2 * L.pcn + j] = hp ? p.plogb[j] : 0.0;
+        q[3 * L.pcn + j] = hb ? p.mins[j] : -__builtin_huge_val(); q[4 * L.pcn + j] = hb ? p.maxs[j] : __builtin_huge_val();
+        reinterpret_cast<int*>(q + 5 * L.pcn)[j] = hp ? p.pkind[j] : 0;
+    }
     if (lane == 0 && sub == 0) { st[4 * cl] = p.lprior[c]; st[4 * cl + 1] = p.llike[c]; st[4 * cl + 2] = 0.0; }
     if (XLDS && sub == 0) {
         for (int j = lane; j < L.LDP; j += 64) Xs[cl * L.LDP + j] = j < d ? p.X[(size_t)c * ld + j] : 0.0;
@@ -390,7 +418,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                                                           region + (size_t)phase * tstride, tstride, slp, nullptr, prp);
                 } else if (!snk_s) {
                     propose_de_pf<LEANV, XF>(p, phase, g, M, c, gc, a, b, n, lane, base, grow, f.cr_idx, f.glev, dcur,
-                                       region + (size_t)phase * tstride, tstride, slp, prp, A_, B_, C_);
+                                       region + (size_t)phase * tstride, tstride, slp, prp, A_, B_, C_, pbl ? &pcs : nullptr);
                 } else if (a < b) {
                     // a snooker set is the longest path to the block's barrier (three rows and three reductions per try, one chain in
                     // ten): its wave gets issue priority over the three DE waves it shares a SIMD with

@@ -658,8 +658,24 @@ DZ_DEV void point_prior(const Params& p, const double* row, int lane, double* pr
 template <int NCH, bool AL16, bool GENERIC = true, int LEAN = 0>
 DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int c, uint32_t gc, int i0, int i1, int n, int lane,
                         const double (&xb)[NCH][2], const double* __restrict__ grow, bool snk, int cr_idx, int delta, int glev, const DrawSrc& dsrc,
-                        double* out, int out_stride, double* sl, double* csn, double* prior_out)
+                        double* out, int out_stride, double* sl, double* csn, double* prior_out, const PBConsts* pc = nullptr)
 {
+    // pc (persistent kernel, NCH == 1): boundary / prior constants in LDS, the prior evaluated on the values the lane has just stored
+    auto point_and_prior = [&](int i, const RowTerms<NCH>& rt, bool snk_, int delta_) -> double {
+        if (NCH == 1 && !LEAN && pc) {
+            double pv[NCH][2];
+            const double sq = propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, grow, rt, out + (size_t)i * out_stride, csn, snk_, cr_idx, delta_, glev, dsrc, nullptr, nullptr, pc, pv);
+            if (prior_out) {
+                double pr = 0.0;
+                if (p.have_prior) { const double (&pv1)[1][2] = reinterpret_cast<const double (&)[1][2]>(pv); pr = nan_to_ninf(prior_of_point_lds(p, *pc, pv1, lane)); }
+                if (lane == 0) prior_out[i] = pr;
+            }
+            return sq;
+        }
+        const double sq = propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, grow, rt, out + (size_t)i * out_stride, csn, snk_, cr_idx, delta_, glev, dsrc);
+        if (prior_out) { if (LEAN) { if (lane == 0) prior_out[i] = 0.0; } else point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i); }
+        return sq;
+    };
     // software pipeline over the tries: the Z rows of try i+1 are requested before try i's arithmetic starts,
     // and no scalar memory wait sits in between because the draws are already in registers
     if (!snk && delta == 1) {
@@ -741,9 +757,8 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
                 rt.b[it][0] = r1[it].x - r2[it].x; rt.b[it][1] = r1[it].y - r2[it].y;          // :819
             }
             if (i + 1 < i1) request(i + 1);
-            const double sq = propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, grow, rt, out + (size_t)i * out_stride, csn, true, cr_idx, delta, glev, dsrc);
+            const double sq = point_and_prior(i, rt, true, delta);
             sqv = (lane == i - i0) ? sq : sqv;
-            if (prior_out) { if (LEAN) { if (lane == 0) prior_out[i] = 0.0; } else point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i); }
         }
         snooker_logps(p, sqv, i1 - i0, lane, sl + i0);
         return;
@@ -753,9 +768,8 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
         RowTerms<NCH> rt;
         fetch_rows<NCH>(p, phase, g, M, gc, i, lane, false, delta, dsrc, raw);
         reduce_rows<NCH>(raw, false, rt);
-        propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, grow, rt, out + (size_t)i * out_stride, csn, false, cr_idx, delta, glev, dsrc);
+        point_and_prior(i, rt, false, delta);
         if (lane == 0) sl[i] = 0.0;
-        if (prior_out) point_prior<NCH>(p, out + (size_t)i * out_stride, lane, prior_out + i);
     }
 }
 

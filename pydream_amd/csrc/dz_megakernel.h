@@ -415,7 +415,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 if (!snk_s && multipair) {
                     if (a < b)
                         propose_set<NCH, false, true, 0>(p, phase, g, M, c, gc, a, b, n, lane, base, grow, false, f.cr_idx, f.delta, f.glev, dcur,
-                                                          region + (size_t)phase * tstride, tstride, slp, nullptr, prp);
+                                                          region + (size_t)phase * tstride, tstride, slp, nullptr, prp, pbl ? &pcs : nullptr);
                 } else if (!snk_s) {
                     propose_de_pf<LEANV, XF>(p, phase, g, M, c, gc, a, b, n, lane, base, grow, f.cr_idx, f.glev, dcur,
                                        region + (size_t)phase * tstride, tstride, slp, prp, A_, B_, C_, pbl ? &pcs : nullptr);
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                     // ten): its wave gets issue priority over the three DE waves it shares a SIMD with
                     __builtin_amdgcn_s_setprio(3);
                     propose_set<NCH, false, false, LEANV>(p, phase, g, M, c, gc, a, b, n, lane, base, grow, true, f.cr_idx, 1, f.glev, dcur,
-                                                         region + (size_t)phase * tstride, tstride, slp, K1 ? st + 4 * cl + 3 : nullptr, prp);   // (k = 1: log |x - z|^(d-1) of the current point, :328-329)
+                                                         region + (size_t)phase * tstride, tstride, slp, K1 ? st + 4 * cl + 3 : nullptr, prp, pbl ? &pcs : nullptr);   // (k = 1: log |x - z|^(d-1) of the current point, :328-329)
                     __builtin_amdgcn_s_setprio(0);
                 }
             };

@@ -1,0 +1,138 @@
+"""Differential fuzzing of the HIP engine against the CPU oracle: random configurations (sizes off every tile and strip boundary,
+multitry on / off, several DE pairs, gamma levels, crossover / gamma adaptation, snooker rates, priors with and without hard boundaries,
+redraw rounds, history thinning and lag, dense / triangular MVN and mixture likelihoods), same seeded inputs to both, everything
+compared bit for bit -- decision sequences, states, log densities, archive, adaptation state.
+
+Test infrastructure (it drives the oracle): `tests/test_gpu_fuzz.py` runs a fixed set of seeds; as a script it runs as many as asked,
+    python tests/fuzz_parity.py --n 400 --seed 1          (on the GPU box)
+and prints the configuration of every mismatch.  References: the step is Dream.astep (/root/reference/pydream/Dream.py:193-422) under
+the lockstep schedule S2 of DESIGN.md section 5."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+DIMS = [2, 3, 5, 10, 16, 17, 31, 32, 33, 48, 64, 65, 100, 100, 100, 112, 127, 128, 129, 200, 333]
+CHAINS = [3, 4, 5, 15, 16, 17, 48, 63, 64, 65, 100, 250, 256, 1000, 1024, 1100, 2048]
+
+
+def draw_config(rng):
+    d = int(rng.choice(DIMS))
+    N = int(rng.choice(CHAINS))
+    if d > 128:
+        N = min(N, 256)
+    if rng.random() < 0.04:
+        d, N = 1000, int(rng.choice([16, 130]))
+    k = int(rng.choice([1, 1, 3, 4, 5, 5, 5, 6]))
+    depairs = int(rng.choice([1, 1, 1, 2, 3]))
+    ngamma = int(rng.choice([1, 1, 2, 4]))
+    ncr = int(min(d, rng.choice([1, 2, 3, 3, 5])))
+    adapt_cr = int(rng.random() < 0.35)
+    adapt_g = int(ngamma > 1 and rng.random() < 0.5)
+    n = int(rng.integers(12, 42))
+    burnin = int(rng.choice([6, 15, n + 5])) if (adapt_cr or adapt_g) else 0
+    lk = str(rng.choice(["mvn_dense", "mvn_tri", "mvn_tri", "mix"]))
+    prior = str(rng.choice(["flat", "flat", "normal", "uniform", "uniform_narrow", "uniform_open"]))
+    if prior == "uniform_open" and k == 1:
+        prior = "uniform"
+    cfg = dict(d=d, N=N, k=k, depairs=depairs, ngamma=ngamma, ncr=ncr, adapt_cr=adapt_cr, adapt_g=adapt_g, burnin=burnin, n=n, lk=lk, prior=prior,
+               thin=int(rng.choice([1, 2, 5, 10, 10])), lag=int(rng.choice([0, 0, 0, 1, 2])), snooker=float(rng.choice([0.0, 0.1, 0.1, 0.4])),
+               pgu=float(rng.choice([0.0, 0.2, 0.2, 0.6])), lamb=float(rng.choice([0.05, 0.2])), zeta=float(rng.choice([1e-12, 1e-6])),
+               zero_mean=int(rng.random() < 0.5), J=int(rng.choice([2, 3])), extra_rows=int(rng.integers(0, 40)), seed=int(rng.integers(1, 2 ** 31 - 1)))
+    return cfg
+
+
+def build(Cls, c, device_kw):
+    d, N, k, n = c["d"], c["N"], c["k"], c["n"]
+    rng = np.random.default_rng(c["seed"])
+    M0 = max(10 * d, 2 * c["depairs"] * N) + c["extra_rows"]
+    Z0 = rng.uniform(-5.0, 15.0, (M0, d))
+    kw = dict(nchains=N, ndim=d, multitry=k, depairs=c["depairs"], ncr=c["ncr"], ngamma=c["ngamma"], history_thin=c["thin"],
+              crossover_burnin=c["burnin"], adapt_crossover=c["adapt_cr"], adapt_gamma=c["adapt_g"], hardboundaries=0 if c["prior"] == "uniform_open" else 1,
+              history_lag=c["lag"], history_capacity=M0 + N * (n // c["thin"] + 2), trace_capacity=n, seed=c["seed"] & 0x7fffffff,
+              lamb=c["lamb"], zeta=c["zeta"], snooker=c["snooker"], p_gamma_unity=c["pgu"])
+    kw.update(device_kw)
+    e = Cls(**kw)
+    table = np.array([[2.38 / np.sqrt(2.0 * (dl + 1) * np.arange(1, d + 1)) / 2.0 ** lev for dl in range(c["depairs"])] for lev in range(c["ngamma"])])
+    e.set_gamma_table(table)
+    if c["prior"] == "normal":
+        e.set_prior(np.full(d, 1, np.int32), np.linspace(-1.0, 2.0, d), np.full(d, 30.0))
+    elif c["prior"] in ("uniform", "uniform_open"):
+        e.set_prior(np.full(d, 2, np.int32), np.full(d, -6.0), np.full(d, 22.0))
+        if c["prior"] == "uniform":
+            e.set_bounds(np.full(d, -6.0), np.full(d, 16.0))
+    elif c["prior"] == "uniform_narrow":                      # boundaries inside the support, and mixed kinds: every third dimension flat
+        kind = np.full(d, 2, np.int32); kind[::3] = 0
+        e.set_prior(kind, np.full(d, -8.0), np.full(d, 30.0))
+        e.set_bounds(np.full(d, -6.0), np.full(d, 16.0))
+    if c["lk"].startswith("mvn"):
+        i = np.arange(1, d + 1.0)
+        P = np.linalg.inv((.5 * np.eye(d) + .5) * np.sqrt(np.outer(i, i)))
+        tri = c["lk"] == "mvn_tri"
+        Mx = np.linalg.cholesky((P + P.T) / 2).T if tri else P
+        e.set_likelihood_mvn(np.zeros(d) if c["zero_mean"] else np.linspace(-1, 1, d), Mx, 1 if tri else 0, 0.0)
+    else:
+        J = c["J"]
+        mu = np.array([np.full(d, m) for m in np.linspace(-4.0, 6.0, J)])
+        logF = np.log(np.arange(1, J + 1) / np.arange(1, J + 1).sum()) - (d / 2.) * np.log(2 * np.pi)
+        e.set_likelihood_mixture(mu, logF)
+    e.set_history(Z0)
+    e.set_state(Z0[:N])
+    return e
+
+
+def run_one(G, O, c):
+    """-> None when the two agree on everything, else a description of the first difference."""
+    out = []
+    for Cls in (G.Engine, O.Engine):
+        e = build(Cls, c, {})
+        half = c["n"] // 2                                      # two step calls: launch segmentation restarts in between
+        e.step(half); e.step(c["n"] - half)
+        out.append((e.get_trace(0, c["n"]), e.get_history(), e.get_cr_state(), e.get_gamma_state(), e.get_state()))
+        e.close()
+    a, b = out
+    for key in ("snooker", "cr_idx", "try_idx", "moved", "X", "logp"):
+        if not np.array_equal(a[0][key], b[0][key]):
+            bad = np.argwhere(np.asarray(a[0][key]) != np.asarray(b[0][key]))
+            return "trace[%s] differs first at %s" % (key, bad[0].tolist())
+    if not np.array_equal(a[1], b[1]):
+        return "archive differs"
+    for name, x, y in (("cr_state", a[2], b[2]), ("gamma_state", a[3], b[3]), ("state", a[4], b[4])):
+        for u, v in zip(x, y):
+            if not np.array_equal(u, v):
+                return name + " differs"
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=0.0, help="stop after this long (0: run all --n)")
+    args = ap.parse_args()
+    from pydream_amd import _capi as G
+    from oracle import oracle as O
+    rng = np.random.default_rng(args.seed)
+    t0 = time.time(); bad = 0; done = 0
+    for i in range(args.n):
+        c = draw_config(rng)
+        try:
+            r = run_one(G, O, c)
+        except Exception as ex:                                 # an engine refusing a configuration must refuse it on both sides: report
+            r = "exception: %s" % ex
+        done += 1
+        if r is not None:
+            bad += 1
+            print("MISMATCH #%d: %s\n   %s" % (i, r, c), flush=True)
+        if args.seconds and time.time() - t0 > args.seconds:
+            break
+    print("fuzz: %d configurations, %d mismatches, %.0f s (seed %d)" % (done, bad, time.time() - t0, args.seed))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

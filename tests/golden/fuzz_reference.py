@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the ORACLE against the REFERENCE itself (runs only where /root/reference exists, like make_golden.py whose
+machinery it uses): random small configurations are run through the reference's own Dream.astep with the contract's draws injected
+(make_golden.run_reference), then through the oracle from the same inputs, and compared the way the committed fixtures are
+(tests/helpers.compare_with_reference: decision sequences exact, log densities 1e-10, states 1e-9 relative, archive, adapted
+probabilities).  Nothing is written to tests/golden; the point is that the pinning does not hang on the dozen committed cases.
+
+    PYTHONPATH=/root/reference python tests/golden/fuzz_reference.py --n 200 --seed 1
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+sys.path.insert(0, HERE)
+
+import make_golden as MG                      # noqa: E402  (asserts that pydream is the reference's)
+from oracle import oracle as O                # noqa: E402
+from tests import helpers as H                # noqa: E402
+
+
+def draw_case(rng):
+    prior = str(rng.choice(["flat", "flat", "normal", "uniform", "uniform_wide_history"]))
+    d = int(rng.integers(2, 5)) if prior.startswith("uniform") else int(rng.choice([2, 3, 4, 7, 10, 12]))
+    N = int(rng.integers(3, 8))
+    k = int(rng.choice([1, 3, 4, 5]))
+    if prior == "uniform_wide_history" and k == 1:
+        k = 3
+    schedule = int(rng.choice([1, 2, 2]))
+    thin = int(rng.choice([1, 3, 10]))
+    G = thin * int(np.ceil(rng.integers(12, 32) / thin))          # a multiple of history_thin: the reference sizes its history as floor(N G / thin)
+    depairs = int(rng.choice([1, 1, 2, 3]))                      # rows (core.py:260-268) but appends at iterations 0, thin, 2 thin, ...
+    N = max(N, 2 * depairs + 1)                                  # core.py:253-254
+    tgt = str(rng.choice(["mvn", "mix", "simple"]))
+    if tgt == "mvn":
+        target = ("mvn",)
+    elif tgt == "mix":
+        J = int(rng.choice([2, 3]))
+        w = rng.dirichlet(np.ones(J))
+        target = ("mix", [float(m) for m in np.linspace(-4, 5, J)], [float(x) for x in w])
+    else:
+        target = ("simple",)
+    ngamma = int(rng.choice([1, 1, 2, 3]))
+    adapt_cr = bool(rng.random() < 0.5)
+    adapt_g = bool(ngamma > 1 and rng.random() < 0.5)
+    kw = dict(nCR=int(min(d, rng.choice([1, 2, 3, 3]))), DEpairs=depairs, gamma_levels=ngamma, adapt_crossover=adapt_cr, adapt_gamma=adapt_g,
+              snooker=float(rng.choice([0.0, 0.1, 0.3])), p_gamma_unity=float(rng.choice([0.0, 0.2, 0.5])), history_thin=thin,
+              lamb=float(rng.choice([0.05, 0.2])), zeta=float(rng.choice([1e-12, 1e-6])))
+    if adapt_cr or adapt_g:
+        kw["crossover_burnin"] = int(rng.choice([5, 10, G + 5]))         # (at iter == burnin the reference spins on a barrier in one process: make_golden handles S2, S1 needs it beyond the run)
+        if schedule == 1:
+            kw["crossover_burnin"] = G + 5
+    if prior == "uniform_wide_history":
+        kw["hardboundaries"] = False
+    elif rng.random() < 0.2:
+        kw["hardboundaries"] = False if prior in ("flat", "normal") else True
+    lag = int(rng.choice([0, 0, 1, 2])) if schedule == 2 else 0
+    return dict(d=d, N=N, G=G, k=k, schedule=schedule, seed=int(rng.integers(1, 2 ** 31 - 1)), target=target, dream_kwargs=kw, prior=prior,
+                rng_seed=int(rng.integers(0, 2 ** 31 - 1)), history_lag=lag)
+
+
+def run_case(c):
+    captured = {}
+    MG.save = lambda name, **arrs: captured.update({k: np.asarray(v) for k, v in arrs.items()})       # (trace_case hands its arrays to save)
+    MG.trace_case("fuzz", **c)
+    fx = captured
+    if int(fx["redraws"].max()) >= 64:         # beyond DZ_MAX_REDRAWS the engines give the step up as a rejection (DESIGN.md deviation D1): not comparable
+        return -1
+    e = H.engine_from_trace_fixture(O.Engine, fx)
+    G = int(fx["cfg_G"])
+    e.step(G)
+    tr = e.get_trace(0, G)
+    gp = e.get_gamma_state()[0] if int(fx["cfg_adapt_gamma"]) else None
+    H.compare_with_reference(tr, fx, e.get_history(), e.get_cr_state()[0], gp)
+    if int(fx["cfg_adapt_crossover"]):
+        _, dm, nu = e.get_cr_state()
+        np.testing.assert_allclose(dm, fx["delta_m"], rtol=1e-11)
+        np.testing.assert_array_equal(nu, fx["ncr_updates"])
+    if int(fx["cfg_adapt_gamma"]):
+        _, dm, nu = e.get_gamma_state()
+        np.testing.assert_allclose(dm, fx["delta_m_gamma"], rtol=1e-11)
+        np.testing.assert_array_equal(nu, fx["ngamma_updates"])
+    return int((fx["redraws"] > 0).sum())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    bad = 0; redrawn = 0; skipped = 0; t0 = time.time()
+    devnull = open(os.devnull, "w")
+    for i in range(args.n):
+        c = draw_case(rng)
+        out = sys.stdout
+        try:
+            sys.stdout = devnull
+            r = run_case(c)
+            redrawn += r > 0
+            skipped += r < 0
+        except Exception as ex:
+            sys.stdout = out
+            bad += 1
+            print("MISMATCH #%d: %s\n   %s" % (i, str(ex).strip().split("\n")[0][:300], c), flush=True)
+        finally:
+            sys.stdout = out
+    print("fuzz vs reference: %d cases, %d mismatches, %d with redraw rounds, %d skipped (a step of the reference took 64 or more redraw rounds: deviation D1), %.0f s (seed %d)"
+          % (args.n, bad, redrawn, skipped, time.time() - t0, args.seed))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -43,6 +43,10 @@ def draw_config(rng):
                thin=int(rng.choice([1, 2, 5, 10, 10])), lag=int(rng.choice([0, 0, 0, 1, 2])), snooker=float(rng.choice([0.0, 0.1, 0.1, 0.4])),
                pgu=float(rng.choice([0.0, 0.2, 0.2, 0.6])), lamb=float(rng.choice([0.05, 0.2])), zeta=float(rng.choice([1e-12, 1e-6])),
                zero_mean=int(rng.random() < 0.5), J=int(rng.choice([2, 3])), extra_rows=int(rng.integers(0, 40)), seed=int(rng.integers(1, 2 ** 31 - 1)))
+    # schedule S1 (Dream.astep driven chain by chain, every chain with its own copy of the adapted probabilities): few chains, no lag
+    cfg["s1"] = int(N <= 17 and rng.random() < 0.5)
+    if cfg["s1"]:
+        cfg["lag"] = 0
     return cfg
 
 
@@ -55,6 +59,9 @@ def build(Cls, c, device_kw):
               crossover_burnin=c["burnin"], adapt_crossover=c["adapt_cr"], adapt_gamma=c["adapt_g"], hardboundaries=0 if c["prior"] == "uniform_open" else 1,
               history_lag=c["lag"], history_capacity=M0 + N * (n // c["thin"] + 2), trace_capacity=n, seed=c["seed"] & 0x7fffffff,
               lamb=c["lamb"], zeta=c["zeta"], snooker=c["snooker"], p_gamma_unity=c["pgu"])
+    if c.get("s1"):
+        kw["schedule"] = 1 if Cls.__module__.startswith("oracle") else 2      # (the device engine is driven chain by chain instead: dz_step_range)
+        kw["trace_capacity"] = 0
     kw.update(device_kw)
     e = Cls(**kw)
     table = np.array([[2.38 / np.sqrt(2.0 * (dl + 1) * np.arange(1, d + 1)) / 2.0 ** lev for dl in range(c["depairs"])] for lev in range(c["ngamma"])])
@@ -90,12 +97,22 @@ def run_one(G, O, c):
     out = []
     for Cls in (G.Engine, O.Engine):
         e = build(Cls, c, {})
+        if c.get("s1"):                                         # the HIP engine steps chain by chain (dz_step_range), the oracle runs its schedule S1
+            if Cls is G.Engine:
+                for _ in range(c["n"]):
+                    for ch in range(c["N"]):
+                        e.step_range(ch, 1)
+            else:
+                e.step(c["n"])
+            out.append(({}, e.get_history(), e.get_cr_state(), e.get_gamma_state(), e.get_state()))
+            e.close()
+            continue
         half = c["n"] // 2                                      # two step calls: launch segmentation restarts in between
         e.step(half); e.step(c["n"] - half)
         out.append((e.get_trace(0, c["n"]), e.get_history(), e.get_cr_state(), e.get_gamma_state(), e.get_state()))
         e.close()
     a, b = out
-    for key in ("snooker", "cr_idx", "try_idx", "moved", "X", "logp"):
+    for key in (() if c.get("s1") else ("snooker", "cr_idx", "try_idx", "moved", "X", "logp")):
         if not np.array_equal(a[0][key], b[0][key]):
             bad = np.argwhere(np.asarray(a[0][key]) != np.asarray(b[0][key]))
             return "trace[%s] differs first at %s" % (key, bad[0].tolist())

@@ -20,9 +20,9 @@ DIMS = [2, 3, 5, 10, 16, 17, 31, 32, 33, 48, 64, 65, 100, 100, 100, 112, 127, 12
 CHAINS = [3, 4, 5, 15, 16, 17, 48, 63, 64, 65, 100, 250, 256, 1000, 1024, 1100, 2048]
 
 
-def draw_config(rng):
+def draw_config(rng, long=False):
     d = int(rng.choice(DIMS))
-    N = int(rng.choice(CHAINS))
+    N = int(rng.choice(CHAINS + ([3000, 4096, 4096] if long else [])))
     if d > 128:
         N = min(N, 256)
     if rng.random() < 0.04:
@@ -33,7 +33,7 @@ def draw_config(rng):
     ncr = int(min(d, rng.choice([1, 2, 3, 3, 5])))
     adapt_cr = int(rng.random() < 0.35)
     adapt_g = int(ngamma > 1 and rng.random() < 0.5)
-    n = int(rng.integers(12, 42))
+    n = int(rng.integers(12, 42)) * (3 if long else 1)
     burnin = int(rng.choice([6, 15, n + 5])) if (adapt_cr or adapt_g) else 0
     lk = str(rng.choice(["mvn_dense", "mvn_tri", "mvn_tri", "mix"]))
     prior = str(rng.choice(["flat", "flat", "normal", "uniform", "uniform_narrow", "uniform_open"]))
@@ -130,13 +130,14 @@ def main():
     ap.add_argument("--n", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=0.0, help="stop after this long (0: run all --n)")
+    ap.add_argument("--long", action="store_true", help="three times the generations, populations up to 4096 chains")
     args = ap.parse_args()
     from pydream_amd import _capi as G
     from oracle import oracle as O
     rng = np.random.default_rng(args.seed)
     t0 = time.time(); bad = 0; done = 0
     for i in range(args.n):
-        c = draw_config(rng)
+        c = draw_config(rng, args.long)
         try:
             r = run_one(G, O, c)
         except Exception as ex:                                 # an engine refusing a configuration must refuse it on both sides: report

@@ -43,8 +43,10 @@ def draw_config(rng, long=False):
                thin=int(rng.choice([1, 2, 5, 10, 10])), lag=int(rng.choice([0, 0, 0, 1, 2])), snooker=float(rng.choice([0.0, 0.1, 0.1, 0.4])),
                pgu=float(rng.choice([0.0, 0.2, 0.2, 0.6])), lamb=float(rng.choice([0.05, 0.2])), zeta=float(rng.choice([1e-12, 1e-6])),
                zero_mean=int(rng.random() < 0.5), J=int(rng.choice([2, 3])), extra_rows=int(rng.integers(0, 40)), seed=int(rng.integers(1, 2 ** 31 - 1)))
+    # parallel tempering (core.py:131-248): the reference's ladder T_i = 0.001^(i/N), one swap attempt per generation (S2 only, no lag)
+    cfg["pt"] = int(rng.random() < 0.08 and cfg["lag"] == 0 and prior != "uniform_open")
     # schedule S1 (Dream.astep driven chain by chain, every chain with its own copy of the adapted probabilities): few chains, no lag
-    cfg["s1"] = int(N <= 17 and rng.random() < 0.5)
+    cfg["s1"] = int(N <= 17 and rng.random() < 0.5 and not cfg["pt"])
     if cfg["s1"]:
         cfg["lag"] = 0
     return cfg
@@ -88,6 +90,8 @@ def build(Cls, c, device_kw):
         logF = np.log(np.arange(1, J + 1) / np.arange(1, J + 1).sum()) - (d / 2.) * np.log(2 * np.pi)
         e.set_likelihood_mixture(mu, logF)
     e.set_history(Z0)
+    if c.get("pt"):
+        e.set_temperatures(np.array([np.power(.001, float(i) / N) for i in range(N)]))
     e.set_state(Z0[:N])
     return e
 
@@ -109,9 +113,11 @@ def run_one(G, O, c):
             continue
         half = c["n"] // 2                                      # two step calls: launch segmentation restarts in between
         e.step(half); e.step(c["n"] - half)
-        out.append((e.get_trace(0, c["n"]), e.get_history(), e.get_cr_state(), e.get_gamma_state(), e.get_state()))
+        out.append((e.get_trace(0, c["n"]), e.get_history(), e.get_cr_state(), e.get_gamma_state(), e.get_state()) + ((e.get_swaps(0, c["n"]),) if c.get("pt") else ()))
         e.close()
     a, b = out
+    if c.get("pt") and not np.array_equal(a[5], b[5]):
+        return "temperature swaps differ"
     for key in (() if c.get("s1") else ("snooker", "cr_idx", "try_idx", "moved", "X", "logp")):
         if not np.array_equal(a[0][key], b[0][key]):
             bad = np.argwhere(np.asarray(a[0][key]) != np.asarray(b[0][key]))

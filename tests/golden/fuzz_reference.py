@@ -63,7 +63,30 @@ def draw_case(rng):
                 rng_seed=int(rng.integers(0, 2 ** 31 - 1)), history_lag=lag)
 
 
+def draw_pt_case(rng):
+    """parallel tempering through the reference's own _sample_dream_pt (make_golden.run_reference_pt): MVN target, reference defaults"""
+    G = int(rng.choice([20, 30, 40]))
+    kw = {}
+    if rng.random() < 0.5:
+        kw = dict(adapt_crossover=True, crossover_burnin=int(rng.choice([5, 12, G + 5])))
+    return dict(pt=True, d=int(rng.choice([3, 5, 10])), N=int(rng.integers(3, 8)), G=G, k=int(rng.choice([3, 5])), seed=int(rng.integers(1, 2 ** 31 - 1)),
+                rng_seed=int(rng.integers(0, 2 ** 31 - 1)), dream_kwargs=kw)
+
+
+def run_pt_case(c):
+    captured = {}
+    MG.save = lambda name, **arrs: captured.update({k: np.asarray(v) for k, v in arrs.items()})
+    c = dict(c); c.pop("pt")
+    MG.pt_case("fuzz_pt", **c)
+    e = H.pt_engine_from_fixture(O.Engine, captured)
+    e.step(int(captured["cfg_G"]))
+    H.compare_pt_with_reference(e, captured)
+    return 0
+
+
 def run_case(c):
+    if c.get("pt"):
+        return run_pt_case(c)
     captured = {}
     MG.save = lambda name, **arrs: captured.update({k: np.asarray(v) for k, v in arrs.items()})       # (trace_case hands its arrays to save)
     MG.trace_case("fuzz", **c)
@@ -96,7 +119,7 @@ def main():
     bad = 0; redrawn = 0; skipped = 0; t0 = time.time()
     devnull = open(os.devnull, "w")
     for i in range(args.n):
-        c = draw_case(rng)
+        c = draw_pt_case(rng) if rng.random() < 0.1 else draw_case(rng)
         out = sys.stdout
         try:
             sys.stdout = devnull

@@ -4,7 +4,10 @@
  * pydream/core.py:89-129 `_sample_dream` drives it).
  *
  * TEST INFRASTRUCTURE ONLY -- see dreamzs_oracle.h.  Parity status: PINNED
- * against the reference run in the build container (tests/golden/).
+ * against the reference run in the build container: the committed fixtures
+ * (tests/golden/*.npz, made by tests/golden/make_golden.py) and, beyond them,
+ * 1240 random configurations run through the reference itself
+ * (tests/golden/fuzz_reference.py; profiles/r03_fuzz_parity.txt).
  *
  * Plain scalar C, one chain at a time, written to be read next to the
  * reference.  The only things that are NOT the reference's are the ones the

@@ -45,8 +45,15 @@ def draw_config(rng, long=False):
                zero_mean=int(rng.random() < 0.5), J=int(rng.choice([2, 3])), extra_rows=int(rng.integers(0, 40)), seed=int(rng.integers(1, 2 ** 31 - 1)))
     # parallel tempering (core.py:131-248): the reference's ladder T_i = 0.001^(i/N), one swap attempt per generation (S2 only, no lag)
     cfg["pt"] = int(rng.random() < 0.08 and cfg["lag"] == 0 and prior != "uniform_open")
+    # chains sharded over W engines (one per rank in production; here W threads of one process, rows exchanged through the host
+    # transport): the result must not depend on W
+    cfg["world"] = 1
+    if not cfg["pt"] and rng.random() < 0.12:
+        ws = [w for w in (2, 3, 4) if N % w == 0 and N // w >= 2]
+        if ws:
+            cfg["world"] = int(rng.choice(ws))
     # schedule S1 (Dream.astep driven chain by chain, every chain with its own copy of the adapted probabilities): few chains, no lag
-    cfg["s1"] = int(N <= 17 and rng.random() < 0.5 and not cfg["pt"])
+    cfg["s1"] = int(N <= 17 and rng.random() < 0.5 and not cfg["pt"] and cfg["world"] == 1)
     if cfg["s1"]:
         cfg["lag"] = 0
     return cfg
@@ -92,14 +99,65 @@ def build(Cls, c, device_kw):
     e.set_history(Z0)
     if c.get("pt"):
         e.set_temperatures(np.array([np.power(.001, float(i) / N) for i in range(N)]))
-    e.set_state(Z0[:N])
+    off, nl = device_kw.get("chain_offset", 0), device_kw.get("nchains_local", N)
+    e.set_state(Z0[off:off + nl])
     return e
+
+
+class ThreadExchange:
+    """all-gather of the ranks' byte blocks between W threads of this process (what HostExchange does between processes)"""
+
+    def __init__(self, world):
+        import threading
+        self.bar, self.buf = threading.Barrier(world), [None] * world
+
+    def callback(self, rank):
+        def cb(send, nbytes):
+            self.buf[rank] = bytes(send)
+            self.bar.wait()
+            out = b"".join(self.buf)
+            self.bar.wait()
+            return out
+        return cb
+
+
+def run_sharded(G, c):
+    """-> (trace dict with the ranks' columns side by side, archive, crossover state) of W sharded HIP engines"""
+    import threading
+    W, N, n = c["world"], c["N"], c["n"]
+    nl = N // W
+    xch = ThreadExchange(W)
+    res, err = [None] * W, []
+
+    def work(r):
+        try:
+            e = build(G.Engine, c, dict(nchains_local=nl, chain_offset=r * nl))
+            e.set_exchange(xch.callback(r))
+            half = n // 2
+            e.step(half); e.step(n - half)
+            res[r] = (e.get_trace(0, n), e.get_history(), e.get_cr_state(), e.get_gamma_state(), e.get_state())
+            e.close()
+        except Exception as ex:
+            err.append(ex)
+            xch.bar.abort()
+    th = [threading.Thread(target=work, args=(r,)) for r in range(W)]
+    [t.start() for t in th]; [t.join() for t in th]
+    if err:
+        raise err[0]
+    tr = {key: np.concatenate([res[r][0][key] for r in range(W)], axis=1) for key in ("snooker", "cr_idx", "try_idx", "moved", "X", "logp")}
+    for r in range(1, W):                                       # archive and adaptation state are replicated
+        assert np.array_equal(res[r][1], res[0][1]) and all(np.array_equal(u, v) for u, v in zip(res[r][2], res[0][2]))
+    state = tuple(np.concatenate([res[r][4][i] for r in range(W)]) for i in range(len(res[0][4])))
+    return tr, res[0][1], res[0][2], res[0][3], state
 
 
 def run_one(G, O, c):
     """-> None when the two agree on everything, else a description of the first difference."""
     out = []
     for Cls in (G.Engine, O.Engine):
+        if Cls is G.Engine and c.get("world", 1) > 1:
+            out.append(run_sharded(G, c))
+            continue
         e = build(Cls, c, {})
         if c.get("s1"):                                         # the HIP engine steps chain by chain (dz_step_range), the oracle runs its schedule S1
             if Cls is G.Engine:

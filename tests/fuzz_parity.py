@@ -1,6 +1,7 @@
 """Differential fuzzing of the HIP engine against the CPU oracle: random configurations (sizes off every tile and strip boundary,
 multitry on / off, several DE pairs, gamma levels, crossover / gamma adaptation, snooker rates, priors with and without hard boundaries,
-redraw rounds, history thinning and lag, dense / triangular MVN and mixture likelihoods), same seeded inputs to both, everything
+redraw rounds, history thinning and lag, dense / triangular MVN, mixture and host likelihoods, parallel tempering, chain-by-chain
+stepping, sharded engines), same seeded inputs to both, everything
 compared bit for bit -- decision sequences, states, log densities, archive, adaptation state.
 
 Test infrastructure (it drives the oracle): `tests/test_gpu_fuzz.py` runs a fixed set of seeds; as a script it runs as many as asked,
@@ -36,6 +37,8 @@ def draw_config(rng, long=False):
     n = int(rng.integers(12, 42)) * (3 if long else 1)
     burnin = int(rng.choice([6, 15, n + 5])) if (adapt_cr or adapt_g) else 0
     lk = str(rng.choice(["mvn_dense", "mvn_tri", "mvn_tri", "mix"]))
+    if N <= 256 and d <= 128 and rng.random() < 0.1:          # a host likelihood (the reference's usual case: a Python function), batch callback
+        lk = "host"
     prior = str(rng.choice(["flat", "flat", "normal", "uniform", "uniform_narrow", "uniform_open"]))
     if prior == "uniform_open" and k == 1:
         prior = "uniform"
@@ -91,6 +94,8 @@ def build(Cls, c, device_kw):
         tri = c["lk"] == "mvn_tri"
         Mx = np.linalg.cholesky((P + P.T) / 2).T if tri else P
         e.set_likelihood_mvn(np.zeros(d) if c["zero_mean"] else np.linspace(-1, 1, d), Mx, 1 if tri else 0, 0.0)
+    elif c["lk"] == "host":
+        e.set_likelihood_host(lambda X: (np.zeros(len(X)), -0.5 * np.sum((X - 2.0) ** 2, axis=1) / 9.0))
     else:
         J = c["J"]
         mu = np.array([np.full(d, m) for m in np.linspace(-4.0, 6.0, J)])

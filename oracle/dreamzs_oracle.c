@@ -6,7 +6,7 @@
  * TEST INFRASTRUCTURE ONLY -- see dreamzs_oracle.h.  Parity status: PINNED
  * against the reference run in the build container: the committed fixtures
  * (tests/golden/*.npz, made by tests/golden/make_golden.py) and, beyond them,
- * 1240 random configurations run through the reference itself
+ * 2440 random configurations run through the reference itself
  * (tests/golden/fuzz_reference.py; profiles/r03_fuzz_parity.txt).
  *
  * Plain scalar C, one chain at a time, written to be read next to the

@@ -23,10 +23,16 @@ Sequence (every part but the timed blocks is untimed):
   5. (one GPU) the same timed blocks with the reference example's own formula, the dense precision matrix: `dense_value`;
   6. (rank 0) the CPU restatement on the host cores.
 
-For N>1 the driver launches one rank per GPU with torch.distributed.run; the ranks rendezvous over plain TCP
-(pydream_amd.distributed.SocketGroup: barrier, max-reduce of the block times, exchange of the IPC handles / the RCCL
-unique id) -- no torch in the process (its first import on a fresh box takes minutes); --control torch uses
+For N>1 there is one rank per GPU: either a launcher started them (torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* in the environment), or -- `python bench.py --gpus N` as ONE process, no WORLD_SIZE -- bench.py starts its own N ranks
+(rank i on device i) and fails if the node has fewer than N devices: it never runs fewer GPUs than it was asked for.  The ranks
+rendezvous over loopback TCP (pydream_amd.distributed.SocketGroup: barrier, max-reduce of the block times, exchange of the IPC
+handles / the RCCL unique id) -- no torch in the process (its first import on a fresh box takes minutes); --control torch uses
 torch.distributed/gloo instead.  The engine itself is libdreamzs.so (HIP; copy-engine peer pushes or RCCL), through ctypes.
+After the timed blocks of an N>1 run every rank reduces its replica of the archive to a 64-bit checksum on the device
+(dz_history_checksum); the line carries "replicas_identical" and the exit code is 3 if they are not.
+history_lag (appended rows become sampleable L appends late) is 1 at EVERY N, so that the 1 -> 8 curve is one algorithm; at N = 1
+the lockstep schedule (lag 0) is timed beside it: `value_history_lag0`.
 
 Prints ONE JSON line on rank 0.
 """
@@ -44,7 +50,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6 # v_mfma_f64_16x16x4_f64: 64 cycles per instruction and SIMD (tools/micro/mfma_f64_rate.hip measured 77.4 TFLOP/s);
                              # equal to the FP64 vector rate -- the guide's table has no FP64 row
-PROFILE_TAG = "r03"          # profiles/<tag>_traffic.json, profiles/<tag>_pmc_summary.json (tools/collect_profiles.sh)
+PROFILE_TAG = next((t for t in ("r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", t + "_pmc_summary.json"))), "r04")
+                             # profiles/<tag>_traffic.json, profiles/<tag>_pmc_summary.json (tools/collect_profiles.sh)
+ENGINE_CLOCK_HZ = 2.4e9      # MI355X peak engine clock (MI355X_MICROARCH.md); the headline kernel's cycle stamps give 2.35 GHz under load
 
 
 def mvn_precision(d):
@@ -162,6 +170,8 @@ def measured_pmc(args, n_local):
     # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 SIMDs
     if v.get("SQ_WAVES") and v.get("SQ_INSTS_VALU") is not None:
         out["valu_insts_per_wave_generation"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"] / args.thin
+        if v.get("SQ_INSTS_MFMA") is not None:
+            out["mfma_insts_per_wave_generation"] = v["SQ_INSTS_MFMA"] / v["SQ_WAVES"] / args.thin
     if v.get("SQ_WAVE_CYCLES") and v.get("SQ_WAVES"):
         nsimd = 1024.0
         waves_per_simd = v["SQ_WAVES"] / nsimd
@@ -222,8 +232,10 @@ def main():
     ap.add_argument("--event-generations", type=int, default=200,
                     help="generations of the event-timed pass (at least --steps): 200 generations are 20 launches of the persistent kernel")
     ap.add_argument("--history-lag", type=int, default=None,
-                    help="dz_config.history_lag: appended rows become sampleable this many appends late.  Default: 0 on one GPU (the "
-                         "lockstep schedule pinned against the reference), 1 on several (the row exchange then hides behind a thin-cycle)")
+                    help="dz_config.history_lag: appended rows become sampleable this many appends late.  Default 1 at every N (on several "
+                         "GPUs the row exchange then hides behind a thin-cycle; one GPU runs the same schedule so that the scaling curve is "
+                         "one algorithm, and times lag 0 -- the lockstep schedule -- beside it: value_history_lag0)")
+    ap.add_argument("--no-lag0", action="store_true", help="one GPU: skip the extra lag-0 pass")
     ap.add_argument("--adapt", action="store_true",
                     help="crossover adaptation on (BASELINE configs[2]; the reference's default): the first --burnin-generations generations "
                          "publish positions and adapt the crossover probabilities; timed on their own as `burnin_value`")
@@ -239,12 +251,14 @@ def main():
         args.rhat_min_generations = args.spinup
         args.rhat_max_generations = max(args.spinup, min(args.rhat_max_generations, 4 * args.spinup))
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))        # one process asked for N GPUs: it starts its own N ranks (or fails)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.history_lag is None:
-        args.history_lag = 0 if world == 1 else 1
+        args.history_lag = 1
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     from pydream_amd import _capi            # loads libdreamzs.so (system ROCm runtime) BEFORE torch
@@ -280,20 +294,11 @@ def main():
         order = [first] + [t for t in ("peer", "rccl", "host") if t != first and ("peer", "rccl", "host").index(t) > ("peer", "rccl", "host").index(first)]
         notes = []
         for transport in order:
-            err = ""
-            try:
+            try:        # (attach_transport makes the same collectives on every rank and raises on EVERY rank if any rank failed)
                 attach_transport(e, rank, world, transport=transport, group=dist.group)
-            except Exception as ex:
-                err = "%s" % ex
-            errs = dist.all_gather_object(err)
-            if not any(errs):
                 return transport, "; ".join(notes) or None
-            notes.append("%s unavailable: %s" % (transport, next(x for x in errs if x)))
-            if transport == "peer":
-                try:
-                    e.peer_detach()               # (ranks on which it did attach must not keep using it)
-                except Exception:
-                    pass
+            except Exception as ex:
+                notes.append("%s unavailable: %s" % (transport, ex))
         raise SystemExit("no transport could be attached: " + "; ".join(notes))
 
     def rhat_now(e, nsamples):
@@ -434,7 +439,18 @@ def main():
         prof["event_pass_generations"] = KE
         ms0, n0 = e.profile_get("empty")
         prof["event_bracket_us"] = (1e3 * ms0 / n0) if n0 else None
+    replicas = None
     if dist is not None:
+        # Every rank holds a replica of the archive (and made the adapted crossover probabilities for itself): reduced to a 64-bit
+        # checksum on the device (dz_history_checksum waits for every rank's last rows first) and compared across ranks.  A transport
+        # that lost, misplaced or served a stale row would otherwise produce a plausible number from a wrong chain.
+        h, rows = e.history_checksum()
+        crb = e.get_cr_state()[0].tobytes()
+        got = dist.all_gather_object([h, rows, crb])
+        replicas = {"identical": all(g[0] == got[0][0] and g[1] == got[0][1] and g[2] == got[0][2] for g in got),
+                    "archive_rows": [int(g[1]) for g in got], "archive_checksums": ["%016x" % g[0] for g in got],
+                    "what": "dz_history_checksum of every rank's archive replica (all appended rows of all ranks, sum mod 2^64 of a "
+                            "position-keyed hash of every element) and the bytes of its crossover probabilities, all-gathered after the run"}
         e.sync()
         dist.barrier()           # every rank is past its last exchange: only now may a rank unmap its buffers
     e.close()
@@ -450,6 +466,19 @@ def main():
         m2 = float(np.median(t2))
         dense = {"value": n_global * args.multitry * K / m2, "ms_per_step": 1e3 * m2 / K, "timed_blocks": len(t2),
                  "formula": "log_F - x.(invC.x)/2 with the dense precision matrix (dream_ex_ndim_gaussian.py:49-52)", "acceptance_rate": acc2}
+    lag0 = None
+    if world == 1 and args.history_lag != 0 and not args.no_lag0:
+        import copy
+        a3 = copy.copy(args)
+        a3.history_lag = 0
+        e3 = setup_engine(_capi.Engine, a3, n_global, n_local, 0, total, device=device, trace_capacity=max(K, args.warmup, chunk, 2))
+        t3, _, acc3 = converge_and_time(e3, False)
+        v3 = e3.last_kernel_variant()
+        e3.close()
+        m3 = float(np.median(t3))
+        lag0 = {"value": n_global * args.multitry * K / m3, "ms_per_step": 1e3 * m3 / K, "timed_blocks": len(t3), "acceptance_rate": acc3,
+                "kernel_variant": v3, "what": "the same timed blocks with history_lag = 0: the lockstep schedule (an append is sampled from the "
+                                              "next generation on) that most of the reference-made fixtures pin"}
     if rank != 0:
         if dist is not None:
             dist.close()
@@ -458,7 +487,8 @@ def main():
     value = n_global * args.multitry * K / med
     flops_gen = n_local * (2 * args.multitry - 1) * (1.0 if args.mvn_kind == "tri" else 2.0) * float(args.dim) ** 2 if args.target == "mvn" else None
     out = {
-        "metric": "proposals/sec (all chains), 100D MVN logpdf, MT-DREAM(ZS) multitry=%d" % args.multitry,
+        "metric": "proposals/sec (all chains), %dD %s logpdf, MT-DREAM(ZS) multitry=%d, history_lag=%d"
+                  % (args.dim, "MVN" if args.target == "mvn" else "3-Gaussian mixture", args.multitry, args.history_lag),
         "value": value, "unit": "proposals/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
         "ms_per_step": 1e3 * med / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
@@ -467,6 +497,7 @@ def main():
                                % (n_local, args.dim, "correlated MVN" if args.target == "mvn" else "3-Gaussian mixture",
                                   args.mvn_kind if args.target == "mvn" else "identity cov", args.multitry, args.snooker, args.thin),
                    "chains_global": n_global, "chains_per_gpu": n_local, "ndim": args.dim, "multitry": args.multitry,
+                   "history_lag": args.history_lag,
                    "parallelism": ("chains sharded x%d, history appends replicated on every GPU (transport: %s, history_lag %d)" % (world, transport, args.history_lag))
                                   if world > 1 else "single GPU"},
         "timing": {"timed_blocks": len(times), "block_generations": K, "block_ms_median": 1e3 * med, "block_ms_min": 1e3 * min(times),
@@ -482,12 +513,18 @@ def main():
     if dense is not None:
         out["dense_value"] = dense["value"]
         out["dense"] = dense
+    if lag0 is not None:
+        out["value_history_lag0"] = lag0["value"]
+        out["history_lag0"] = lag0
     if burn is not None:
         out["burnin_value"] = burn["value"]
         out["burnin"] = burn
         out["config"]["workload"] += "; crossover adaptation ON, crossover_burnin %d: `burnin_value` is the rate inside the burn-in, `value` after it" % args.burnin_generations
     out["kernel_variant"] = kernel_variant
     out["history_lag"] = args.history_lag
+    if replicas is not None:
+        out["replicas_identical"] = replicas["identical"]
+        out["replica_check"] = replicas
     if world > 1:
         # top level, not buried in config: what carried the rows, and how much of the exchange the generations had to wait for
         out["transport"] = transport if transport != "host" else "host-fallback"
@@ -543,6 +580,20 @@ def main():
             if pm:
                 out["roofline"].update({k: v for k, v in pm.items() if k != "source"})
                 out["roofline"]["pmc_source"] = pm["source"]
+                if dom == "generations" and "mfma_insts_per_wave_generation" in pm:
+                    # What bounds this kernel is instruction issue, not HBM: the vector ALU and the FP64 matrix pipe of a SIMD do not
+                    # overlap on gfx950 (profiles/r02_mfma_valu_overlap.txt), so a generation cannot take fewer cycles than its four
+                    # waves per SIMD need to issue their VALU instructions (4 cycles each) and their FP64 MFMAs (64 cycles each).
+                    wps = 4.0
+                    floor_cycles = wps * (pm["valu_insts_per_wave_generation"] * 4.0 + pm["mfma_insts_per_wave_generation"] * 64.0)
+                    gen_cycles = launch_s / gens_per_launch * ENGINE_CLOCK_HZ
+                    out["roofline"]["issue_floor_frac"] = floor_cycles / gen_cycles
+                    out["roofline"]["issue_floor"] = {
+                        "floor_cycles_per_generation": floor_cycles, "measured_cycles_per_generation": gen_cycles, "clock_hz": ENGINE_CLOCK_HZ,
+                        "formula": "4 waves/SIMD x (VALU instructions x 4 cycles + FP64 MFMA instructions x 64 cycles) per wave-generation "
+                                   "(instruction counts: committed PMC file) / (measured launch duration / generations per launch x clock)",
+                        "reading": "the HBM `frac` above is what BASELINE asks for; this is the fraction of the kernel's time its SIMDs need "
+                                   "just to issue its instructions -- the rest is dependent-latency stalls at four waves per SIMD"}
             if flops_gen:
                 out["roofline"]["fp64_matrix_tflops"] = flops_gen * K / med / 1e12
         out["roofline"].update(tmeta)
@@ -554,9 +605,59 @@ def main():
                                  "frac_of_8TBps": gen_bytes * K / med / 1e9 / HBM_PEAK_GBS}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if dist is not None:
         dist.close()
+    if replicas is not None and not replicas["identical"]:
+        sys.stderr.write("bench.py: the ranks' archive replicas DIFFER (see replica_check in the line): the number above is not valid\n")
+        sys.exit(3)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` as ONE process with no launcher's environment: start the N ranks here -- rank i on device i, the
+    same command line, torch.distributed.run's environment variables -- and return the exit code (0 only if every rank returned 0).
+    Never fewer ranks than asked for: with fewer than N devices on the node this is an error, not a smaller run (DZ_BENCH_DEVICE=<i>
+    puts every rank on device i: the control-flow rehearsal on a one-GPU box)."""
+    import signal
+    import subprocess
+    n = args.gpus
+    if "DZ_BENCH_DEVICE" not in os.environ:
+        from pydream_amd import _capi
+        have = _capi.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d but this node shows %d HIP device(s); refusing to run fewer ranks than asked for\n" % (n, have))
+            return 2
+    if args.control == "torch":          # gloo's store needs a real port (the socket control plane does not use MASTER_PORT as a port)
+        import socket
+        probe = socket.socket(); probe.bind(("127.0.0.1", 0)); port = probe.getsockname()[1]; probe.close()
+    else:
+        port = 20000 + os.getpid() % 20000
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=dict(base, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            for pr in list(live):
+                code = pr.poll()
+                if code is None:
+                    continue
+                live.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    # (a rank that died leaves the others waiting in a collective: end them -- exactly these processes)
+                    deadline = time.time() + (30.0 if code == 3 else 5.0)       # (3 = rank 0's replica check failed: the others are already leaving)
+                    while time.time() < deadline and any(q.poll() is None for q in live):
+                        time.sleep(0.05)
+                    for q in live:
+                        if q.poll() is None:
+                            q.send_signal(signal.SIGTERM)
+            time.sleep(0.02)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
 
 
 class TorchGroup:

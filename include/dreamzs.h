@@ -173,6 +173,11 @@ int dz_trace_download_wait(dz_engine* e);
 int dz_host_register(void* ptr, int64_t bytes);
 int dz_host_unregister(void* ptr);
 int dz_get_history(dz_engine* e, double* Z, int64_t cap_rows, int64_t* rows);       /* Dream_shared_vars.history / count */
+/* A 64-bit checksum of the archive as dz_get_history would return it ([rows, d], every appended row of every rank waited for), made on the
+ * device: the sum modulo 2^64 over all elements of mix64(bits(Z[r][j]) + (r d + j + 1) 0x9E3779B97F4A7C15), mix64 = the splitmix64 finaliser.
+ * What the ranks of a sharded run compare afterwards: the reference's chains all see ONE history (the shared array of core.py:281-283),
+ * here every GPU holds a replica, and a replica that missed or misplaced a row would still produce a plausible chain. */
+int dz_history_checksum(dz_engine* e, uint64_t* sum, int64_t* rows);
 int dz_get_cr_state(dz_engine* e, double* probs, double* delta_m, double* n_updates);     /* cross_probs, delta_m, ncr_updates */
 int dz_get_gamma_state(dz_engine* e, double* probs, double* delta_m, double* n_updates);  /* gamma_level_probs, ... */
 /* Gelman_Rubin (convergence.py:3-20) over the traced generations of the local chains */

@@ -37,7 +37,7 @@ SYMBOLS = [
     "dz_version", "dz_last_error", "dz_device_count", "dz_create", "dz_destroy", "dz_set_bounds", "dz_set_gamma_table",
     "dz_set_history", "dz_set_state", "dz_set_cr_probs", "dz_set_gamma_probs", "dz_set_prior", "dz_set_likelihood_mvn",
     "dz_set_likelihood_mixture", "dz_set_likelihood_host", "dz_hip_library", "dz_comm_library", "dz_comm_unique_id", "dz_comm_init_rccl", "dz_comm_barrier", "dz_set_exchange", "dz_peer_export", "dz_peer_attach", "dz_peer_detach", "dz_exchange_stats", "dz_set_temperatures", "dz_get_swaps",
-    "dz_step", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_get_chain_probs", "dz_sync", "dz_trace_reset", "dz_generation", "dz_redraw_rounds", "dz_last_kernel_variant", "dz_get_state", "dz_get_trace", "dz_get_trace_chains", "dz_trace_download_begin", "dz_trace_download_wait", "dz_host_register", "dz_host_unregister", "dz_get_history",
+    "dz_step", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_get_chain_probs", "dz_sync", "dz_trace_reset", "dz_generation", "dz_redraw_rounds", "dz_last_kernel_variant", "dz_get_state", "dz_get_trace", "dz_get_trace_chains", "dz_trace_download_begin", "dz_trace_download_wait", "dz_host_register", "dz_host_unregister", "dz_get_history", "dz_history_checksum",
     "dz_get_cr_state", "dz_get_gamma_state", "dz_get_rhat", "dz_get_chain_moments", "dz_eval_logp", "dz_debug_propose",
     "dz_profile_enable", "dz_profile_get", "dz_profile_reset", "dz_profile_get_list",
 ]
@@ -97,6 +97,7 @@ def load_library():
     L.dz_get_state.argtypes = [V, V, V, V]
     L.dz_get_trace.argtypes = [V, C.c_int64, C.c_int64] + [V] * 6
     L.dz_get_history.argtypes = [V, V, C.c_int64, V]
+    L.dz_history_checksum.argtypes = [V, V, V]
     L.dz_get_cr_state.argtypes = [V, V, V, V]
     L.dz_get_gamma_state.argtypes = [V, V, V, V]
     L.dz_get_rhat.argtypes = [V, V]
@@ -146,6 +147,17 @@ def _p(a):
 
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def history_checksum_host(Z):
+    """include/dreamzs.h dz_history_checksum on a host array [rows, d]: sum mod 2^64 of mix64(bits + (index + 1) * golden)"""
+    Z = _f64(Z)
+    with np.errstate(over="ignore"):
+        z = Z.reshape(-1).view(np.uint64) + (np.arange(1, Z.size + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+        return int(np.sum(z, dtype=np.uint64))
 
 
 PROFILE_CLASSES = {"propose": 0, "logp": 1, "accept": 2, "adapt": 3, "exchange": 4, "generations": 5, "empty": 6}
@@ -392,6 +404,13 @@ class Engine:
         Z = np.zeros((rows.value, self.d))
         self._chk(self.L.dz_get_history(self.h, _p(Z), rows.value, C.byref(rows)))
         return Z
+
+    def history_checksum(self):
+        """(64-bit checksum, rows) of the archive as get_history() would return it, made on the device (dz_history_checksum);
+        `history_checksum_host` is the same sum in numpy."""
+        h, rows = C.c_uint64(), C.c_int64()
+        self._chk(self.L.dz_history_checksum(self.h, C.byref(h), C.byref(rows)))
+        return int(h.value), int(rows.value)
 
     def history_rows(self):
         rows = C.c_int64()

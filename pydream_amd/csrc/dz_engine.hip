@@ -226,10 +226,14 @@ int64_t visible_rows(const dz_engine* e)
     return e->M - (int64_t)e->p.N * lag;
 }
 
+int peer_check(dz_engine* e);
+// everything this engine has queued: the lane streams AND the per-peer copy streams -- a row or flag push still in flight when the
+// caller goes on to a control-plane barrier and then frees or unmaps buffers would be a DMA write into memory that is gone
 int sync_all(dz_engine* e)
 {
     for (int s = 0; s < e->nlanes; ++s) HIPCK(hipStreamSynchronize(e->lane_stream[s]));
-    return 0;
+    for (auto& pr : e->peers) if (pr.st) HIPCK(hipStreamSynchronize(pr.st));
+    return peer_check(e);
 }
 
 // Device -> pageable host, 2-D: through a page-locked bounce buffer owned by the engine (stream-ordered copy, wait, then
@@ -397,8 +401,10 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
 enum { XK_Z = 0, XK_POS = 1, XK_HELLO = 2, XK_KINDS = 3 };
 double gate_timeout_s()
 {
+    // (liveness of the other ranks is the control plane's business; the bound only keeps a kernel from spinning for ever -- a rank with
+    //  a host-callback likelihood or a slow start can legitimately be minutes late)
     if (const char* s = getenv("DZ_PEER_TIMEOUT_S")) return std::max(0.01, atof(s));
-    return 20.0;
+    return 600.0;
 }
 // peer transport: this rank's rows of `buf` (global layout [N,ld], rows [off, off+nl) at `row0`) go to every peer's copy of the
 // buffer, each followed by this rank's flag word for exchange number `seq` of that kind
@@ -427,8 +433,11 @@ int peer_gate(dz_engine* e, int kind, unsigned long long need, double timeout_s 
                        e->h_gate + (kind == XK_HELLO ? 4 : 0));
     return launch_check("k_peer_gate");
 }
+// did a gate give up?  h_gate is host-mapped, so this costs nothing: dz_step asks before it queues each launch (a timed-out gate is
+// fatal for the run: whatever was queued behind it sampled rows that never arrived, and no getter hands such results out), every
+// synchronising entry point asks after its wait
 int peer_check(dz_engine* e)
-{   // after a device sync: did a gate give up?
+{
     if (e->peer_on && e->h_gate && (e->h_gate[2] || e->h_gate[6])) {
         const int r = (int)(e->h_gate[2] ? e->h_gate[2] : e->h_gate[6]) - 1;
         return fail("peer exchange: no rows from rank " + std::to_string(r) + " within " + std::to_string(gate_timeout_s()) + " s (DZ_PEER_TIMEOUT_S)");
@@ -1072,6 +1081,9 @@ int dz_set_history(dz_engine* e, const double* Z, int64_t rows)
     HIPCK(hipSetDevice(e->c.device));
     if (rows > e->c.history_capacity) return fail("history exceeds capacity");
     if (rows > 0xffffffffll) return fail("history too long");
+    // (the peers' flag words count this rank's appends from the attach on: an archive reset underneath them would leave the gates
+    //  comparing exchange numbers of two different histories)
+    if (e->peer_on) return fail("dz_set_history: the archive of an engine attached to the peer transport cannot be reset (set it before dz_peer_attach)");
     DZCK(upload_padded(e, e->p.Z, Z, (int)rows, 0.0));
     e->M = rows; e->napp = 0;
     return 0;
@@ -1382,6 +1394,7 @@ int dz_step(dz_engine* e, int64_t generations)
     const bool mega = mega_eligible(e);
     e->stream_prop_gen = -1;
     for (int64_t i = 0; i < generations;) {
+        DZCK(peer_check(e));            // a gate that gave up is fatal: nothing more is queued behind it
         const int n = mega ? mega_segment(e, (uint32_t)e->gen, generations - i) : 0;
         if (n > 0) { DZCK(run_mega_segment(e, (uint32_t)e->gen, n)); i += n; }
         else { DZCK(one_generation(e, 0, e->p.nl, (uint32_t)e->gen, true, i + 1 < generations && !(mega && mega_segment(e, (uint32_t)e->gen + 1, 1) > 0))); i += 1; }
@@ -1624,6 +1637,28 @@ int dz_get_history(dz_engine* e, double* Z, int64_t cap_rows, int64_t* rows)
         DZCK(download_rows(e, Z, e->p.Z, (size_t)e->M));
         DZCK(peer_check(e));
     }
+    return 0;
+}
+
+int dz_history_checksum(dz_engine* e, uint64_t* sum, int64_t* rows)
+{   // every appended row of every rank has arrived (as dz_get_history), then one pass over the archive on the device
+    HIPCK(hipSetDevice(e->c.device));
+    if (!sum) return fail("null argument");
+    if (e->peer_on && e->z_gated < e->napp) { DZCK(peer_gate(e, XK_Z, (unsigned long long)e->napp)); e->z_gated = e->napp; }
+    DZCK(join_all(e));
+    if (!e->d_bar) DZCK(ealloc(e, &e->d_bar, (size_t)std::max(1, e->world)));
+    unsigned long long* acc = (unsigned long long*)e->d_bar;         // (the rendezvous buffer: idle between barriers)
+    HIPCK(hipMemsetAsync(acc, 0, sizeof(unsigned long long), e->stream));
+    if (e->M > 0) {
+        const unsigned blocks = (unsigned)std::min<int64_t>((e->M + 3) / 4, (int64_t)e->num_cu * 16);
+        hipLaunchKernelGGL(dz::k_checksum, dim3(blocks), dim3(256), 0, e->stream, (const double*)e->p.Z, (long long)e->M, e->p.d, e->p.ld, acc);
+        DZCK(launch_check("k_checksum"));
+    }
+    unsigned long long h = 0;
+    HIPCK(hipMemcpyAsync(&h, acc, sizeof h, hipMemcpyDeviceToHost, e->stream));
+    DZCK(sync_all(e));
+    *sum = (uint64_t)h;
+    if (rows) *rows = e->M;
     return 0;
 }
 

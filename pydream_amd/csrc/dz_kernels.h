@@ -1796,6 +1796,30 @@ __global__ __launch_bounds__(64) void k_peer_gate(const unsigned long long* __re
     }
 }
 
+// 64-bit checksum of elements [0, rows) x [0, d) of a row-major [rows, ld] array: the sum modulo 2^64, over all elements, of
+// mix64(bits(x) + (r d + j + 1) 0x9E3779B97F4A7C15), mix64 = the splitmix64 finaliser.  Addition commutes, so lanes, waves and blocks add
+// in whatever order they finish; every position enters the hash, so equal sums of two replicas mean equal rows in equal places
+// (dz_history_checksum: the replicated archives of a sharded run compared after the run, bench.py "replicas_identical").
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void k_checksum(const double* __restrict__ a, long long rows, int d, int ld, unsigned long long* __restrict__ out)
+{
+    unsigned long long acc = 0ull;
+    const long long nrow_stride = (long long)gridDim.x * (blockDim.x / 64);
+    const int lane = threadIdx.x & 63;
+    for (long long r = (long long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); r < rows; r += nrow_stride)
+        for (int j = lane; j < d; j += 64) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(a[(size_t)r * ld + j]);
+            acc += mix64(bits + ((unsigned long long)r * (unsigned long long)d + (unsigned long long)j + 1ull) * 0x9E3779B97F4A7C15ull);
+        }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) atomicAdd(out, acc);
+}
+
 // copy rows [nl,ld] (used for publishing start positions and the sharded exchange staging)
 __global__ void k_copy_rows(const double* __restrict__ src, double* __restrict__ dst, size_t n)
 {

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""One rank of a BASELINE multi-GPU configuration at full size, for tests/test_distributed.py:
+
+    RANK=r WORLD_SIZE=W MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/shard_rank.py <config> <outdir> [transport] [lag] [generations]
+
+config "c3": configs[3], 32768 chains x 100-D MVN (W ranks of 32768 / W);  "c4": configs[4], 4096 chains x 1000-D correlated MVN
+(triangular factor);  "c3s" / "c4s": the same shapes at an eighth of the chains (quick local runs).  Rank r owns chains
+[r N / W, (r + 1) N / W) on device DZ_SHARD_DEVICE (default 0: the ranks share the test box's one GPU), attaches the transport,
+steps the generations and leaves rank<r>.npz: final states, cached log densities, the decision flags of every generation, the archive's
+checksum and row count (the archive itself from rank 0 only).  W = 1 is the unsharded comparand (`build` is imported by the test).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {   # (chains, d, mvn kind)
+    "c3": (32768, 100, "tri"), "c4": (4096, 1000, "tri"),
+    "c3s": (4096, 100, "tri"), "c4s": (512, 1000, "tri"),
+}
+SEED, K, THIN = 20260930, 5, 10
+
+
+def build(config, rank, world, generations, lag, device=0):
+    from pydream_amd import _capi
+    from tests import helpers as H
+    N, d, kind = CONFIGS[config]
+    nl = N // world
+    m0 = max(10 * d, 2 * N)                                  # Dream.py:168-170, core.py:270-273
+    Z0 = np.random.default_rng(SEED).uniform(-5.0, 15.0, (m0, d))
+    e = _capi.Engine(nchains=N, nchains_local=nl, chain_offset=rank * nl, ndim=d, multitry=K, history_thin=THIN,
+                     history_capacity=m0 + N * (generations // THIN + 2), trace_capacity=generations, seed=SEED, device=device,
+                     history_lag=lag)
+    e.set_history(Z0)
+    e.set_state(Z0[rank * nl:(rank + 1) * nl])
+    P = H.mvn_precision(d)
+    if kind == "tri":
+        e.set_likelihood_mvn(np.zeros(d), np.linalg.cholesky((P + P.T) / 2).T, 1, 0.0)
+    else:
+        e.set_likelihood_mvn(np.zeros(d), P, 0, 0.0)
+    return e
+
+
+def results(e, generations, with_history):
+    X, pr, lk = e.get_state()
+    tr = e.get_trace(0, generations, with_X=False)
+    h, rows = e.history_checksum()
+    out = dict(X=X, prior=pr, like=lk, logp=tr["logp"], moved=tr["moved"], try_idx=tr["try_idx"], cr_idx=tr["cr_idx"], snooker=tr["snooker"],
+               checksum=np.array([h], dtype=np.uint64), rows=np.array([rows]), variant=np.array(e.last_kernel_variant()))
+    if with_history:
+        out["Z"] = e.get_history()
+    return out
+
+
+def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(280, exit=True)          # a rank that is stuck says where and leaves
+    config, outdir = sys.argv[1], sys.argv[2]
+    transport = sys.argv[3] if len(sys.argv) > 3 else "peer"
+    lag = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    G = int(sys.argv[5]) if len(sys.argv) > 5 else 25
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    from pydream_amd.distributed import attach_transport, socket_group_from_env
+    group = socket_group_from_env(timeout=240.0)
+    e = build(config, rank, world, G, lag, device=int(os.environ.get("DZ_SHARD_DEVICE", "0")))
+    attach_transport(e, rank, world, transport=transport, group=group)
+    e.step(G)
+    out = results(e, G, with_history=(rank == 0))
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
+    e.sync()
+    group.barrier()                  # a rank's buffers stay mapped until no peer can still be writing into them
+    e.close()
+    group.close()
+
+
+if __name__ == "__main__":
+    main()

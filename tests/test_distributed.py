@@ -1,9 +1,11 @@
-"""The N>1 path: chains sharded over ranks, Z replicated by all-gather.
+"""The N>1 path: chains sharded over ranks, Z replicated on every rank.
 
 CPU (gloo, world_size 2): the host logic (shard arithmetic, seed agreement, exchange hook, per-rank
 assembly) with the ORACLE standing in for the device engine -- sharded == unsharded, bit for bit.
-GPU (marked gpu): the same with the HIP engine, two ranks sharing the one GPU of the test box
-through the host-staged transport.  The RCCL transport itself needs >= 2 GPUs (driver's 8-GPU run).
+GPU (marked gpu): the same with the HIP engine, the ranks sharing the one GPU of the test box, over the
+host-staged transport and over the PEER transport (IPC-mapped archives, copy-stream pushes, gate kernels)
+with history_lag 0 and 1; BASELINE configs[3] and configs[4] at full size (8 ranks) against the unsharded
+engine; bench.py's N > 1 line incl. its replica check; RCCL with one rank (all a 1-GPU box can run).
 """
 import os
 import time
@@ -56,7 +58,7 @@ KW = dict(nchains=8, niterations=45, multitry=5, adapt_crossover=True, crossover
           nseedchains=40, history_thin=5)
 
 
-def _worker(rank, world, port, backend_engine, outdir, variant="flat"):
+def _worker(rank, world, port, backend_engine, outdir, variant="flat", token=None):
     sys.path.insert(0, ROOT)
     import faulthandler
     faulthandler.dump_traceback_later(150, exit=True)           # a rank that is stuck says where and leaves
@@ -66,7 +68,7 @@ def _worker(rank, world, port, backend_engine, outdir, variant="flat"):
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
         group = None
     else:                                                       # GPU box: the built-in socket group (no torch in the process: its first
-        group = SocketGroup(rank, world, "127.0.0.1", port)     # import on a freshly started box takes minutes)
+        group = SocketGroup(rank, world, "127.0.0.1", port, token=token)     # import on a freshly started box takes minutes)
     from tests import helpers as H
     d = 12
     params, like = _model(d, variant)
@@ -120,7 +122,9 @@ def _run_two_ranks(backend_engine, tmp_path, variant="flat"):
     import multiprocessing as mp
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, backend_engine, str(tmp_path), variant)) for r in range(2)]
+    from pydream_amd.distributed import new_token
+    token = new_token()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, backend_engine, str(tmp_path), variant, token)) for r in range(2)]
     for pr in procs:
         pr.start()
     deadline = time.time() + 240                     # (a rank that never returns fails the test instead of hanging the suite)
@@ -166,19 +170,96 @@ def test_two_ranks_one_gpu_hip_engine(tmp_path, variant):
     _run_two_ranks("hip", tmp_path, variant)
 
 
+def _launch_ranks(script_args, nranks, env, cwd, timeout):
+    """N processes of a script the way torch.distributed.run starts them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment), without that launcher; every one must return 0 in time."""
+    import subprocess
+    port = str(_free_port())
+    procs = []
+    for r in range(nranks):
+        renv = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable] + script_args, cwd=cwd, env=renv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    deadline = time.time() + timeout
+    for pr in procs:
+        try:
+            outs.append(pr.communicate(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("the ranks did not finish in time")
+    for pr, (so, se) in zip(procs, outs):
+        assert pr.returncode == 0, se[-3000:]
+    return outs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,transport,lag", [("c3", "peer", 1), ("c4", "peer", 1), ("c3", "peer", 0), ("c4", "host", 0)])
+def test_baseline_multi_gpu_configs_at_full_size_equal_the_unsharded_engine(tmp_path, config, transport, lag):
+    """BASELINE configs[3] (8 ranks x 4096 chains x 100-D MVN = 32768 chains) and configs[4] (8 x 512 chains x 1000-D correlated MVN)
+    AS WRITTEN, the eight ranks time-sharing the test box's one MI355X: every rank's states, cached log densities and decision
+    sequences over 25 generations -- three history appends, the rows of two of them sampled by later generations -- equal the
+    corresponding slice of ONE engine that holds all chains, bit for bit, and every rank's replica of the archive (device checksum)
+    equals the unsharded archive.  (What replaces the shared arrays of core.py:281-297 / Dream.py:919-945.  The per-GPU shards are
+    compared with the oracle in test_gpu_parity.py; at these sizes the oracle would take minutes, so the comparand is the unsharded
+    engine, which runs different block sizes and, at 1000-D, different tile shapes of the likelihood product than the shards do.)"""
+    from pydream_amd import _capi
+    from tests import shard_rank as SR
+    G, W = 25, 8
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DZ_PEER_TIMEOUT_S="200", DZ_SHARD_DEVICE="0")
+    _launch_ranks([os.path.join(ROOT, "tests", "shard_rank.py"), config, str(tmp_path), transport, str(lag), str(G)], W, env, str(tmp_path), timeout=300)
+    e = SR.build(config, 0, 1, G, lag)
+    e.step(G)
+    ref = SR.results(e, G, with_history=True)
+    e.close()
+    N, d, _ = SR.CONFIGS[config]
+    assert ref["Z"].shape == (max(10 * d, 2 * N) + 3 * N, d) and ref["moved"].mean() > 0.02
+    assert int(ref["checksum"][0]) == _capi.history_checksum_host(ref["Z"])          # the device checksum is the documented sum
+    nl = N // W
+    for r in range(W):
+        got = np.load(tmp_path / ("rank%d.npz" % r))
+        sl = slice(r * nl, (r + 1) * nl)
+        for key in ("X", "prior", "like"):
+            np.testing.assert_array_equal(got[key], ref[key][sl], err_msg="%s of rank %d" % (key, r))
+        for key in ("logp", "moved", "try_idx", "cr_idx", "snooker"):
+            np.testing.assert_array_equal(got[key], ref[key][:, sl], err_msg="%s of rank %d" % (key, r))
+        assert int(got["rows"][0]) == len(ref["Z"]) and int(got["checksum"][0]) == int(ref["checksum"][0]), "archive replica of rank %d" % r
+        if r == 0:
+            np.testing.assert_array_equal(got["Z"], ref["Z"])
+
+
+@pytest.mark.gpu
+def test_history_checksum_is_the_documented_sum_and_sees_a_single_changed_element():
+    from pydream_amd import _capi
+    from tests import helpers as H
+    d, N = 37, 24
+    Z0 = H.seed_history(200, d, 9)
+    sums = []
+    for flip in (False, True):
+        Z = Z0.copy()
+        if flip:
+            Z[150, 36] = np.nextafter(Z[150, 36], 1.0)
+        e = _capi.Engine(nchains=N, ndim=d, multitry=3, history_capacity=400, seed=1)
+        e.set_history(Z)
+        h, rows = e.history_checksum()
+        assert rows == 200 and h == _capi.history_checksum_host(Z)
+        sums.append(h)
+        e.close()
+    assert sums[0] != sums[1]
+    Zs = Z0.copy(); Zs[[3, 4]] = Zs[[4, 3]]                   # the same rows in other places: another sum
+    assert _capi.history_checksum_host(Zs) != sums[0]
+
+
 _RCCL_SINGLE_RANK = r"""
 import faulthandler, os, sys
-faulthandler.dump_traceback_later(90, exit=True)       # a bootstrap that never comes up: say where, then leave
+faulthandler.dump_traceback_later(380, exit=True)       # a bootstrap that never comes up: say where, then leave
 import numpy as np
-import torch            # noqa: F401  (brings its own bundled ROCm stack, torch/lib/librccl.so included, into the process first)
 sys.path.insert(0, sys.argv[1])
 from pydream_amd import _capi
 from tests import helpers as H
-# One ROCm stack for the engine AND its RCCL, whatever else the process holds: librccl is opened next to the HIP runtime the
-# engine's calls are bound to (here torch's copy, because torch was imported first; in bench.py, which loads libdreamzs.so
-# first, /opt/rocm's) and is checked to resolve that same runtime.
+# No torch in this process: the engine's HIP runtime is the system ROCm's, and librccl is opened next to it (dz_comm_library).
 lib, hip = _capi.comm_library(), _capi.hip_library()
-assert os.path.dirname(os.path.realpath(lib)) == os.path.dirname(os.path.realpath(hip)), (lib, hip)
+assert os.path.dirname(os.path.realpath(lib)) == os.path.dirname(os.path.realpath(hip)) and "torch" not in lib, (lib, hip)
 d, N, n = 16, 8, 25
 P = H.mvn_precision(d); Z0 = H.seed_history(40, d, 4)
 res = []
@@ -189,37 +270,33 @@ for use_comm in (False, True):
         e.comm_barrier()
     e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), P, 0, 0.0)
     e.step(n)
-    res.append((e.get_trace(0, n)["X"], e.get_history()))
+    res.append((e.get_trace(0, n)["X"], e.get_history(), e.history_checksum()))
 np.testing.assert_array_equal(res[0][0], res[1][0])
 np.testing.assert_array_equal(res[0][1], res[1][1])
+assert res[0][2] == res[1][2]
 print("rccl single rank: equal")
 """
 
 
-# Loading RCCL costs minutes on a freshly started box (the library and, in the torch-first order, torch itself are paged in from cold
-# storage: 200 s and 430 s of a 700 s suite in round 2) and bench.py's default transport no longer uses it, so the RCCL tests run on
-# request: DZ_TEST_RCCL=1 python -m pytest tests -m gpu -k rccl   (a log of such a run is kept under profiles/).
-needs_rccl_optin = pytest.mark.skipif(os.environ.get("DZ_TEST_RCCL", "0") != "1", reason="RCCL tests run with DZ_TEST_RCCL=1 (cold library load takes minutes)")
+# The cold load of librccl.so (570 MB, paged in from cold storage fault by fault) took 200 s on a freshly started box in round 2;
+# tests/conftest.py reads the file sequentially in the background from the start of a GPU session, so that by the time these tests run
+# (last in the suite) it sits in the page cache.  The torch-first load order costs minutes more and stays opt-in.
+needs_rccl_optin = pytest.mark.skipif(os.environ.get("DZ_TEST_RCCL", "0") != "1", reason="torch-first RCCL test runs with DZ_TEST_RCCL=1 (cold import of torch takes minutes)")
 
 
 @pytest.mark.gpu
-@needs_rccl_optin
 def test_rccl_single_rank_comm(tmp_path):
-    """RCCL bootstrap + in-place ncclAllGather with world size 1 (all the 1-GPU box can run).  In a process of its own with a
-    deadline (and one second attempt): RCCL's bootstrap opens sockets and probes the box's topology, and once in some sixty suite
-    runs it did not return on a fresh box -- a stuck bootstrap must cost this test, not hang the whole suite."""
+    """The transport north_star names, in the DEFAULT suite: RCCL bootstrap (ncclGetUniqueId, ncclCommInitRank) + the in-place
+    ncclAllGather of the history appends + the one-element rendezvous all-gather, with world size 1 -- all a 1-GPU box can run -- in a
+    process without torch, against the same run without a communicator: equal bit for bit.  In a process of its own under a hard
+    400 s cap: a bootstrap that does not come up costs this test, not the suite."""
     import subprocess
-    last = None
-    for attempt in range(2):
-        try:
-            last = subprocess.run([sys.executable, "-c", _RCCL_SINGLE_RANK, ROOT], capture_output=True, text=True, timeout=900, cwd=str(tmp_path),
-                                  env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
-        except subprocess.TimeoutExpired as exc:
-            last = exc
-            continue
-        if last.returncode == 0 and "rccl single rank: equal" in last.stdout:
-            return
-    raise AssertionError("RCCL single-rank run failed twice: %r" % (getattr(last, "stderr", last),))
+    try:
+        res = subprocess.run([sys.executable, "-c", _RCCL_SINGLE_RANK, ROOT], capture_output=True, text=True, timeout=400, cwd=str(tmp_path),
+                             env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    except subprocess.TimeoutExpired as exc:
+        raise AssertionError("the RCCL single-rank run did not finish within 400 s: %r" % (exc.stderr,))
+    assert res.returncode == 0 and "rccl single rank: equal" in res.stdout, res.stderr[-3000:]
 
 
 def _launch_bench(nranks, extra_args, env, cwd, timeout=600):
@@ -271,7 +348,7 @@ def test_bench_eight_rank_control_flow_on_one_gpu(tmp_path, transport):
                           "--no-cpu-baseline"], env, str(tmp_path))
     assert d["n_gpus"] == 8 and d["steps"] == 20 and d["scaling"] == "weak"
     assert d["config"]["chains_global"] == 8 * 128 and transport in d["config"]["parallelism"]
-    assert d["history_lag"] == 1
+    assert d["history_lag"] == 1 and d["replicas_identical"] is True and len(d["replica_check"]["archive_rows"]) == 8
     if transport == "host":
         assert d["transport"] == "host-fallback"          # (a host-staged number is named as such at the top level)
     else:                                                  # eight ranks, each mapping the seven others' archives: seven copy streams per rank
@@ -300,6 +377,9 @@ def test_bench_line_has_the_contracted_fields(tmp_path):
                 "roofline", "cpu_baseline", "kernel_variant", "rhat_max", "convergence"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["unit"] == "proposals/s" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    # one GPU runs the schedule the scaling runs use (history_lag 1) and times the lockstep schedule (lag 0) beside it
+    assert d["history_lag"] == 1 and d["config"]["history_lag"] == 1 and d["value_history_lag0"] > 0 and d["history_lag0"]["kernel_variant"] == d["kernel_variant"]
+    assert "replicas_identical" not in d
     assert abs(d["value"] - 512 * 5 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
@@ -329,19 +409,34 @@ def test_bench_with_crossover_adaptation_reports_the_burnin_rate(tmp_path):
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_over_the_peer_transport_on_one_gpu(tmp_path):
-    """bench.py --gpus 2, the two ranks sharing device 0, rows exchanged by the PEER transport (IPC-mapped archives, copy-stream
-    pushes, gate kernels) with history_lag = 1: the line names the transport and reports how long the gates
-    waited per thin-cycle.  (On one device the pushes are executed by blit kernels that queue behind the persistent launch; on a
-    multi-GPU node they run on the copy engines over xGMI.)"""
-    env = dict(os.environ, DZ_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", DZ_PEER_TIMEOUT_S="60")
-    d = _launch_bench(2, ["--steps", "20", "--warmup", "5", "--chains-per-gpu", "512", "--rhat-max-generations", "400",
-                          "--rhat-min-generations", "200", "--rhat-chunk", "100", "--rhat-window", "200", "--min-timed-ms", "20",
-                          "--no-cpu-baseline", "--transport", "peer"], env, str(tmp_path))
+def test_bench_gpus_2_as_one_command_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 --steps 20 --warmup 5` as ONE process without a launcher's environment (how the driver starts
+    `--gpus 1`): bench.py starts its own two ranks (here both on device 0: DZ_BENCH_DEVICE) and prints "n_gpus": 2 -- it can no longer
+    silently run one GPU.  Rows exchanged by the PEER transport (IPC-mapped archives, copy-stream pushes, gate kernels) with
+    history_lag = 1; the line names the transport, reports how long the gates waited per thin-cycle, and carries the replica check:
+    both ranks' archives reduce to the same checksum.  Without DZ_BENCH_DEVICE on a box with fewer devices than ranks it refuses."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DZ_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", DZ_PEER_TIMEOUT_S="120")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--chains-per-gpu", "512",
+                          "--rhat-max-generations", "400", "--rhat-min-generations", "200", "--rhat-chunk", "100", "--rhat-window", "200",
+                          "--min-timed-ms", "20", "--no-cpu-baseline", "--transport", "peer"], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["transport"] == "peer" and d["history_lag"] == 1, (d.get("transport"), d.get("transport_note"))
+    assert d["replicas_identical"] is True and len(set(d["replica_check"]["archive_checksums"])) == 1 and len(d["replica_check"]["archive_rows"]) == 2
     assert d["exchange"]["gates"] > 0 and d["exchange_exposed_us_per_cycle"] is not None and d["exchange_exposed_us_per_cycle"] >= 0.0
     assert d["kernel_variant"].startswith("k_generations<7,tri,xlds")
     assert np.isfinite(d["rhat_max"]) and d["value"] > 0
+    from pydream_amd import _capi
+    if _capi.device_count() < 2:                           # the refusal: never fewer ranks than asked for
+        env.pop("DZ_BENCH_DEVICE")
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"], cwd=str(tmp_path), env=env,
+                             capture_output=True, text=True, timeout=120)
+        assert res.returncode != 0 and '"metric"' not in res.stdout and "refusing" in res.stderr
 
 
 @pytest.mark.gpu

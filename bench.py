@@ -42,6 +42,12 @@ import os
 import sys
 import time
 
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # several ranks on one node: each rank's BLAS would otherwise start a thread per core the box SHOWS (256 on the GPU boxes, of which
+    # the job's cgroup grants 16) -- eight ranks inverting a 1000 x 1000 matrix at set-up then take minutes instead of a second
+    for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(_v, "2")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -12,6 +12,9 @@ checksum and row count (the archive itself from rank 0 only).  W = 1 is the unsh
 import os
 import sys
 
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):       # (eight ranks on one box: no BLAS thread per core each)
+    os.environ.setdefault(_v, "2")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,9 +27,17 @@ CONFIGS = {   # (chains, d, mvn kind)
 SEED, K, THIN = 20260930, 5, 10
 
 
-def build(config, rank, world, generations, lag, device=0):
-    from pydream_amd import _capi
+def matrix(config):
+    """the likelihood's matrix, made ONCE per test (by the parent, handed to the ranks as a file): LAPACK's inverse and Cholesky factor
+    differ in the last bits between thread counts, and ranks that do not hold the same matrix bit for bit are not one run"""
     from tests import helpers as H
+    N, d, kind = CONFIGS[config]
+    P = H.mvn_precision(d)
+    return np.linalg.cholesky((P + P.T) / 2).T if kind == "tri" else P
+
+
+def build(config, rank, world, generations, lag, device=0, M=None):
+    from pydream_amd import _capi
     N, d, kind = CONFIGS[config]
     nl = N // world
     m0 = max(10 * d, 2 * N)                                  # Dream.py:168-170, core.py:270-273
@@ -36,11 +47,7 @@ def build(config, rank, world, generations, lag, device=0):
                      history_lag=lag)
     e.set_history(Z0)
     e.set_state(Z0[rank * nl:(rank + 1) * nl])
-    P = H.mvn_precision(d)
-    if kind == "tri":
-        e.set_likelihood_mvn(np.zeros(d), np.linalg.cholesky((P + P.T) / 2).T, 1, 0.0)
-    else:
-        e.set_likelihood_mvn(np.zeros(d), P, 0, 0.0)
+    e.set_likelihood_mvn(np.zeros(d), matrix(config) if M is None else M, 1 if kind == "tri" else 0, 0.0)
     return e
 
 
@@ -65,7 +72,7 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     from pydream_amd.distributed import attach_transport, socket_group_from_env
     group = socket_group_from_env(timeout=240.0)
-    e = build(config, rank, world, G, lag, device=int(os.environ.get("DZ_SHARD_DEVICE", "0")))
+    e = build(config, rank, world, G, lag, device=int(os.environ.get("DZ_SHARD_DEVICE", "0")), M=np.load(os.path.join(outdir, "matrix.npy")))
     attach_transport(e, rank, world, transport=transport, group=group)
     e.step(G)
     out = results(e, G, with_history=(rank == 0))

@@ -207,8 +207,10 @@ def test_baseline_multi_gpu_configs_at_full_size_equal_the_unsharded_engine(tmp_
     from tests import shard_rank as SR
     G, W = 25, 8
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DZ_PEER_TIMEOUT_S="200", DZ_SHARD_DEVICE="0")
+    M = SR.matrix(config)
+    np.save(tmp_path / "matrix.npy", M)
     _launch_ranks([os.path.join(ROOT, "tests", "shard_rank.py"), config, str(tmp_path), transport, str(lag), str(G)], W, env, str(tmp_path), timeout=300)
-    e = SR.build(config, 0, 1, G, lag)
+    e = SR.build(config, 0, 1, G, lag, M=M)
     e.step(G)
     ref = SR.results(e, G, with_history=True)
     e.close()

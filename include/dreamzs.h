@@ -139,6 +139,13 @@ int     dz_get_chain_state(dz_engine* e, int32_t chain, double* x, double* prior
  * Dream.gamma_probabilities, :143, :383): under dz_step_range every chain keeps its own copy, refreshed by its own adaptation updates and
  * at the end of the burn-in (:409-415); before any single-chain step, and under dz_step, the shared vectors.  [ncr], [ngamma]; NULL skips. */
 int     dz_get_chain_probs(dz_engine* e, int32_t chain, double* cr_probs, double* gamma_probs);
+/* run_dream(restart=True) on the LIVE engine (core.py:46-62, 255-263; Dream.py:128-147 load the history and the adapted probabilities from
+ * the files of the previous run -- here they are still in HBM): the archive as it stands becomes the new run's seed history, the
+ * crossover / gamma-level probabilities stay, their accumulators (delta_m, ncr_updates; core.py:287-293) restart from zero, the generation
+ * counter restarts at 0 (generation 0 appends, the crossover burn-in of `crossover_burnin` generations runs again), the random contract
+ * takes `seed`.  The archive and the trace grow to the given capacities (device-to-device copy, no upload).  Follow with dz_set_state.
+ * Identical, bit for bit, to a new engine given the downloaded archive and probabilities.  Not for sharded or tempering engines. */
+int     dz_continue_run(dz_engine* e, int64_t history_capacity, int64_t trace_capacity, uint64_t seed, int32_t crossover_burnin);
 int     dz_sync(dz_engine* e);
 int     dz_trace_reset(dz_engine* e);
 int64_t dz_generation(dz_engine* e);

@@ -37,7 +37,7 @@ SYMBOLS = [
     "dz_version", "dz_last_error", "dz_device_count", "dz_create", "dz_destroy", "dz_set_bounds", "dz_set_gamma_table",
     "dz_set_history", "dz_set_state", "dz_set_cr_probs", "dz_set_gamma_probs", "dz_set_prior", "dz_set_likelihood_mvn",
     "dz_set_likelihood_mixture", "dz_set_likelihood_host", "dz_hip_library", "dz_comm_library", "dz_comm_unique_id", "dz_comm_init_rccl", "dz_comm_barrier", "dz_set_exchange", "dz_peer_export", "dz_peer_attach", "dz_peer_detach", "dz_exchange_stats", "dz_set_temperatures", "dz_get_swaps",
-    "dz_step", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_get_chain_probs", "dz_sync", "dz_trace_reset", "dz_generation", "dz_redraw_rounds", "dz_last_kernel_variant", "dz_get_state", "dz_get_trace", "dz_get_trace_chains", "dz_trace_download_begin", "dz_trace_download_wait", "dz_host_register", "dz_host_unregister", "dz_get_history", "dz_history_checksum",
+    "dz_step", "dz_continue_run", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_get_chain_probs", "dz_sync", "dz_trace_reset", "dz_generation", "dz_redraw_rounds", "dz_last_kernel_variant", "dz_get_state", "dz_get_trace", "dz_get_trace_chains", "dz_trace_download_begin", "dz_trace_download_wait", "dz_host_register", "dz_host_unregister", "dz_get_history", "dz_history_checksum",
     "dz_get_cr_state", "dz_get_gamma_state", "dz_get_rhat", "dz_get_chain_moments", "dz_eval_logp", "dz_debug_propose",
     "dz_profile_enable", "dz_profile_get", "dz_profile_reset", "dz_profile_get_list",
 ]
@@ -89,6 +89,7 @@ def load_library():
     L.dz_peer_detach.argtypes = [V]
     L.dz_step.argtypes = [V, C.c_int64]
     L.dz_sync.argtypes = [V]
+    L.dz_continue_run.argtypes = [V, C.c_int64, C.c_int64, C.c_uint64, C.c_int32]
     L.dz_step_range.argtypes = [V, C.c_int32, C.c_int32]
     L.dz_set_chain_state.argtypes = [V, C.c_int32, V, V, V]
     L.dz_get_chain_state.argtypes = [V, C.c_int32, V, V, V]
@@ -315,6 +316,12 @@ class Engine:
     # ---- stepping ----
     def step(self, generations=1):
         self._chk(self.L.dz_step(self.h, int(generations)))
+
+    def continue_run(self, history_capacity, trace_capacity, seed, crossover_burnin):
+        """a new run on the live engine, as run_dream(restart=True) starts one (dz_continue_run); follow with set_state"""
+        self._chk(self.L.dz_continue_run(self.h, int(history_capacity), int(trace_capacity), int(seed), int(crossover_burnin)))
+        self.cfg.history_capacity, self.cfg.trace_capacity = max(self.cfg.history_capacity, int(history_capacity)), max(self.cfg.trace_capacity, int(trace_capacity))
+        self.cfg.seed, self.cfg.crossover_burnin = int(seed), int(crossover_burnin)
 
     def step_range(self, chain0, nchains=1):
         self._chk(self.L.dz_step_range(self.h, int(chain0), int(nchains)))

@@ -55,18 +55,97 @@ def run_dream(parameters, likelihood, nchains=5, niterations=50000, start=None, 
     else:
         step_instance = Dream(model=model, variables=parameters, verbose=verbose, mp_context=mp_context, **kwargs)
 
+    # The examples' convergence loop (dream_ex_ndim_gaussian.py:79-102) calls run_dream(restart=True, model_name=...) again and again:
+    # every call would rebuild the engine and upload the whole -- growing -- history from the .npy file the call before has just
+    # written.  The engine of a run that saved its history under a model name stays alive instead ("parked"), and a restart under the same
+    # name with the same sampler and untouched files continues on it (dz_continue_run): history and adapted probabilities are already
+    # in HBM.  The files are still written.  release_engines() frees a parked engine's memory; DREAMZS_KEEP_ENGINE=0 turns this off.
+    if restart:
+        live = _claim_parked(step_instance, kwargs, nchains, niterations, likelihood, tempering)
+    else:
+        live = None
+        stale = _parked.pop(kwargs.get('model_name'), None)       # a fresh run under a parked name: that engine's memory is needed now
+        if stale is not None:
+            stale["engine"].close()
     pool = _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=start, mp_context=mp_context,
-                                seed=kwargs.get('seed'), device=kwargs.get('device', 0), history_lag=kwargs.get('history_lag', 0))
+                                seed=kwargs.get('seed'), device=kwargs.get('device', 0), history_lag=kwargs.get('history_lag', 0), live=live)
+    park = False
     try:
         pool._initializer(*pool._initargs)
         if tempering:
             sampled_params, log_ps = _sample_dream_pt_batched(pool.engine, step_instance, nchains, niterations, verbose)
         else:
             sampled_params, log_ps = _sample_dream_batched(pool.engine, step_instance, niterations, verbose, nverbose)
+        park = (not tempering and step_instance.save_history and bool(step_instance.model_name) and pool.engine.nl == nchains
+                and os.environ.get("DREAMZS_KEEP_ENGINE", "1") != "0" and hasattr(pool.engine, "continue_run"))
     finally:
         pool.close()
-        pool.join()
+        if park:
+            _park(pool, step_instance, kwargs, nchains, likelihood)
+        else:
+            pool.join()
     return sampled_params, log_ps
+
+
+# ---- engines kept alive between run_dream calls (one per model name) ----
+_parked = {}
+
+
+def _signature(step, kwargs, nchains, likelihood, engine):
+    """everything a continued run must have in common with the run whose engine it takes over"""
+    dev_prior = step.model.device_prior()
+    pri = None if dev_prior is None else tuple(np.asarray(a).tobytes() for a in dev_prior)
+    return (nchains, step.total_var_dimension, int(step.multitry), len(step.DEpairs), int(step.nCR), int(step.ngamma), int(step.history_thin),
+            bool(step.adapt_crossover), bool(step.adapt_gamma), bool(step.boundaries), float(step.lamb), float(step.zeta), float(step.snooker),
+            float(step.p_gamma_unity), int(kwargs.get('device', 0)), int(kwargs.get('history_lag', 0)), bool(getattr(step, 'parallel', False)),
+            np.asarray(step.mins).tobytes() if step.boundaries else None, np.asarray(step.maxs).tobytes() if step.boundaries else None,
+            np.asarray(step.gamma_arr).tobytes(), pri, id(likelihood))
+
+
+def _file_stamps(prefix):
+    out = []
+    for tail in ('DREAM_chain_history.npy', 'DREAM_chain_adapted_crossoverprob.npy', 'DREAM_chain_adapted_gammalevelprob.npy'):
+        st = os.stat(prefix + '_' + tail)
+        out.append((st.st_mtime_ns, st.st_size, st.st_ino))
+    return out
+
+
+def _park(pool, step, kwargs, nchains, likelihood):
+    name = step.model_name
+    old = _parked.pop(name, None)
+    if old is not None and old["engine"] is not pool.engine:
+        old["engine"].close()
+    if Dream_shared_vars.engine is pool.engine:
+        Dream_shared_vars.engine = None
+    try:
+        _parked[name] = dict(engine=pool.engine, sig=_signature(step, kwargs, nchains, likelihood, pool.engine), files=_file_stamps(name),
+                             likelihood=likelihood)          # (the reference keeps id(likelihood) meaningful)
+        pool.engine = None
+    except OSError:
+        pool.join()
+
+
+def _claim_parked(step, kwargs, nchains, niterations, likelihood, tempering):
+    """the parked engine of this model name if the restart may continue on it, else None (and the parked engine is released)"""
+    name = kwargs.get('model_name')
+    ent = _parked.pop(name, None)
+    if ent is None:
+        return None
+    try:
+        ok = (not tempering and os.environ.get("DREAMZS_KEEP_ENGINE", "1") != "0" and ent["files"] == _file_stamps(name)
+              and ent["sig"] == _signature(step, kwargs, nchains, likelihood, ent["engine"]))
+    except OSError:
+        ok = False
+    if not ok:
+        ent["engine"].close()
+        return None
+    return ent["engine"]
+
+
+def release_engines():
+    """free the engines kept for run_dream(restart=True) (their archives stay in HBM until then, or until the process ends)"""
+    while _parked:
+        _parked.popitem()[1]["engine"].close()
 
 
 def _sample_dream_pt_batched(eng, step, nchains, niterations, verbose):
@@ -185,6 +264,11 @@ def _sample_dream_batched(eng, step, niterations, verbose, nverbose):
         pin.join()
         if pinned and pinned[0]:
             eng.host_unregister(S)
+    from .convergence import SampledList
+    sampled = SampledList(sampled)
+    if chunk >= niterations >= 2 and eng.nl == eng.N and hasattr(eng, "get_rhat"):
+        # the whole run is still in the device trace: the reference's diagnostic (convergence.py:3-20) over all chains, made there
+        sampled.gelman_rubin = eng.get_rhat()
     if step.save_history:
         _save_history_to_disc(eng, step)
     return sampled, log_ps
@@ -243,8 +327,9 @@ def _mp_dream_init(engine, nchains):
 
 
 def _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=None, mp_context=None, seed=None, device=0,
-                         chain_offset=0, nchains_local=None, engine_cls=None, history_lag=0):
-    """Validate, size and allocate the shared sampler state (core.py:250-314) -- in HBM."""
+                         chain_offset=0, nchains_local=None, engine_cls=None, history_lag=0, live=None):
+    """Validate, size and allocate the shared sampler state (core.py:250-314) -- in HBM.
+    `live`: the engine of the run whose files this restart would load (run_dream): continued in place, nothing uploaded."""
     min_njobs = (2 * len(step_instance.DEpairs)) + 1
     if nchains < min_njobs:
         raise Exception('Dream should be run with at least (2*DEpairs)+1 number of chains.  For current algorithmic settings, set njobs>=%s.' % str(min_njobs))
@@ -253,7 +338,11 @@ def _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=None, mp_
         seed = int.from_bytes(os.urandom(8), 'little')
     rng = np.random.RandomState(seed % (2 ** 32))
     Dream_shared_vars.rng = rng
-    if step_instance.history_file != False:          # noqa: E712  (core.py:255-259)
+    nrows_live = live.history_rows() if live is not None else None
+    if live is not None:                              # the history file's content is the live engine's archive
+        seed_rows = None
+        step_instance.nseedchains = nrows_live
+    elif step_instance.history_file != False:        # noqa: E712  (core.py:255-259)
         old_history = np.load(step_instance.history_file)
         seed_rows = np.asarray(old_history, dtype=float).reshape(-1, d)
         step_instance.nseedchains = len(seed_rows)
@@ -262,7 +351,7 @@ def _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=None, mp_
     min_nseedchains = 2 * len(step_instance.DEpairs) * nchains
     if step_instance.nseedchains < min_nseedchains:
         raise Exception('The size of the seeded starting history is insufficient.  Increase nseedchains>=%s.' % str(min_nseedchains))
-    if seed_rows is None:                             # Dream.py:203-214: seed the history with draws from the prior
+    if seed_rows is None and live is None:            # Dream.py:203-214: seed the history with draws from the prior
         seed_rows = np.array([Dream_shared_vars.draw_from_prior(step_instance.variables) for _ in range(int(step_instance.nseedchains))])
     if step_instance.crossover_burnin is None:        # core.py:299-300
         step_instance.crossover_burnin = int(np.floor(niterations / 10))
@@ -277,7 +366,10 @@ def _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=None, mp_
     ld = (d + 15) // 16 * 16
     # the device keeps whole chunks of the trace (up to 64 GiB of the 288 GB by default): normally the entire run
     trace_cap = int(max(1, min(niterations, int(os.environ.get('DREAMZS_TRACE_BYTES', 64 << 30)) // (nl * ld * 8))))
-    eng = (engine_cls or _capi.Engine)(nchains=nchains, nchains_local=nl, chain_offset=chain_offset, ndim=d, multitry=int(step_instance.multitry),
+    if live is not None:
+        live.continue_run(nrows_live + nchains * n_appends, trace_cap, int(seed), int(min(step_instance.crossover_burnin, 2 ** 31 - 1)))
+        live.nseed = nrows_live
+    eng = live if live is not None else (engine_cls or _capi.Engine)(nchains=nchains, nchains_local=nl, chain_offset=chain_offset, ndim=d, multitry=int(step_instance.multitry),
                        depairs=len(step_instance.DEpairs), ncr=int(step_instance.nCR), ngamma=int(step_instance.ngamma),
                        history_thin=int(thin), crossover_burnin=int(min(step_instance.crossover_burnin, 2 ** 31 - 1)),
                        adapt_crossover=int(bool(step_instance.adapt_crossover)), adapt_gamma=int(bool(step_instance.adapt_gamma)),
@@ -285,22 +377,24 @@ def _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=None, mp_
                        history_capacity=len(seed_rows) + nchains * n_appends, trace_capacity=trace_cap, seed=int(seed),
                        lamb=float(step_instance.lamb), zeta=float(step_instance.zeta), snooker=float(step_instance.snooker),
                        p_gamma_unity=float(step_instance.p_gamma_unity))
-    eng.nseed = len(seed_rows)
-    if step_instance.boundaries:
-        eng.set_bounds(step_instance.mins, step_instance.maxs)
-    eng.set_gamma_table(step_instance.gamma_arr)
-    eng.set_history(seed_rows)
-    eng.set_cr_probs(np.asarray(step_instance.CR_probabilities, dtype=float))
-    eng.set_gamma_probs(np.asarray(step_instance.gamma_probabilities, dtype=float))
+    if live is None:
+        eng.nseed = len(seed_rows)
+        if step_instance.boundaries:
+            eng.set_bounds(step_instance.mins, step_instance.maxs)
+        eng.set_gamma_table(step_instance.gamma_arr)
+        eng.set_history(seed_rows)
+        eng.set_cr_probs(np.asarray(step_instance.CR_probabilities, dtype=float))
+        eng.set_gamma_probs(np.asarray(step_instance.gamma_probabilities, dtype=float))
 
     model = step_instance.model
     dev_prior = model.device_prior() if step_instance.variables is model.sampled_parameters or list(step_instance.variables) == list(model.sampled_parameters) else None
-    if dev_prior is not None:
+    if dev_prior is not None and live is None:
         eng.set_prior(*dev_prior)
     like = model.likelihood
     host_eval = None
     if hasattr(like, "_dz_apply") and dev_prior is not None:
-        like._dz_apply(eng)                           # likelihood AND priors on the device
+        if live is None:
+            like._dz_apply(eng)                       # likelihood AND priors on the device
     else:
         from .model import HostEvaluator
         host_eval = HostEvaluator(model, dev_prior is None, nchains, mp_context=mp_context, force=bool(getattr(step_instance, 'parallel', False)))

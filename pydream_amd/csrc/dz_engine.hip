@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -1373,6 +1374,63 @@ int dz_get_swaps(dz_engine* e, int64_t g0, int64_t ng, int32_t* out)
     if (!e->d_tswap || g0 < 0 || ng < 0 || g0 + ng > e->ntrace) return fail("swap log range");
     DZCK(sync_all(e));
     HIPCK(hipMemcpy(out, e->d_tswap + 3 * g0, sizeof(int32_t) * 3 * (size_t)ng, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// A new run on the live engine, as run_dream(restart=True) starts one from the files the previous run left (core.py:46-62, 255-263;
+// Dream.py:128-147): the archive as it stands is the new run's seed history (it is what the history file holds), the crossover /
+// gamma-level probabilities stay (the two probability files), their accumulators start from zero (core.py:287-293), the generation
+// counter restarts (Dream.iter = 0: generation 0 appends, the crossover burn-in runs again), the random contract takes the new key.
+// Chain states come from dz_set_state afterwards.  Nothing is uploaded: a grown archive is copied device to device.
+int dz_continue_run(dz_engine* e, int64_t history_capacity, int64_t trace_capacity, uint64_t seed, int32_t crossover_burnin)
+{
+    if (!e) return fail("null engine");
+    HIPCK(hipSetDevice(e->c.device));
+    if (e->peer_on || e->comm || e->world > 1) return fail("dz_continue_run: not on a sharded engine");
+    if (e->tempering || e->p.Tc) return fail("dz_continue_run: not on a tempering engine");
+    DZCK(sync_all(e));
+    if (e->copy_stream) HIPCK(hipStreamSynchronize(e->copy_stream));
+    dz::Params& p = e->p;
+    if (history_capacity < e->M) return fail("dz_continue_run: capacity below the rows already in the archive");
+    auto swap_buffer = [&](auto** slot, size_t count, size_t keep) -> int {
+        using T = std::remove_pointer_t<std::remove_pointer_t<decltype(slot)>>;
+        T* fresh = nullptr;
+        DZCK(dalloc(&fresh, count));
+        if (keep && hipMemcpy(fresh, *slot, sizeof(T) * keep, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(fresh); return fail("dz_continue_run: device copy failed"); }
+        auto it = std::find(e->to_free.begin(), e->to_free.end(), (void*)*slot);
+        if (it != e->to_free.end()) e->to_free.erase(it);
+        (void)hipFree((void*)*slot);
+        *slot = fresh; e->to_free.push_back((void*)fresh);
+        return 0;
+    };
+    if (history_capacity > e->c.history_capacity) {
+        DZCK(swap_buffer(&p.Z, (size_t)history_capacity * p.ld, (size_t)e->M * p.ld));
+        e->c.history_capacity = history_capacity;
+    }
+    if (trace_capacity > e->c.trace_capacity) {
+        const size_t tc = (size_t)trace_capacity, nl = (size_t)p.nl;
+        if (!e->c.trace_capacity) {
+            DZCK(ealloc(e, &p.tX, tc * nl * p.ld)); DZCK(ealloc(e, &p.tlogp, tc * nl)); DZCK(ealloc(e, &p.tmoved, tc * nl));
+            DZCK(ealloc(e, &p.tsnk, tc * nl)); DZCK(ealloc(e, &p.ttry, tc * nl)); DZCK(ealloc(e, &p.tcr, tc * nl));
+        } else {
+            DZCK(swap_buffer(&p.tX, tc * nl * p.ld, 0)); DZCK(swap_buffer(&p.tlogp, tc * nl, 0)); DZCK(swap_buffer(&p.tmoved, tc * nl, 0));
+            DZCK(swap_buffer(&p.tsnk, tc * nl, 0)); DZCK(swap_buffer(&p.ttry, tc * nl, 0)); DZCK(swap_buffer(&p.tcr, tc * nl, 0));
+        }
+        p.tcap = (long long)tc; e->c.trace_capacity = trace_capacity;
+    }
+    e->c.seed = seed; p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32);
+    e->c.crossover_burnin = crossover_burnin; p.burnin = crossover_burnin;
+    // delta_m / ncr_updates and the gamma analogue start from zero; the probabilities stay (layout: cr_probs|cr_delta|cr_n|g_probs|g_delta|g_n)
+    HIPCK(hipMemset(p.cr_delta, 0, sizeof(double) * 2 * (size_t)p.ncr));
+    HIPCK(hipMemset(p.g_delta, 0, sizeof(double) * 2 * (size_t)p.ngamma));
+    if (e->d_redraw_count) HIPCK(hipMemset(e->d_redraw_count, 0, sizeof(unsigned long long)));
+    HIPCK(hipStreamSynchronize(nullptr));
+    e->gen = 0; std::fill(e->gen_c.begin(), e->gen_c.end(), (int64_t)0);
+    e->napp = 0; e->ntrace = 0; e->draws_gen = -1; e->pending_accept = false; e->pending_slot = -1; e->stream_prop_gen = -1;
+    e->have_logp = false; e->need_join = true; e->redraw_rounds = 0;
+    std::fill(e->own_init.begin(), e->own_init.end(), 0);
+    if (e->adapt) { p.cp_prev = e->d_cp[0]; p.cp_new = e->d_cp[1]; e->cp_idx = 1; }
+    e->params_uploaded = false;
     return 0;
 }
 

@@ -175,3 +175,23 @@ def test_open_uniform_prior_run_on_the_oracle_stays_inside_its_support(tmp_path,
     assert np.all(S >= lower) and np.all(S <= upper) and np.all(np.isfinite(np.concatenate(log_ps)))
     assert len(np.unique(S[:, 0])) > 50
 
+
+
+def test_gelman_rubin_on_run_dream_shaped_results_copies_nothing():
+    """run_dream returns the chains of ONE [chain, iteration, d] array (core.py:98/:127's list of per-chain arrays as views): the
+    diagnostic recognises that and works on the array in place, a block of chains at a time -- same numbers as chain by chain (the
+    reference's own order, convergence.py:8-14), no stacked copy of the run."""
+    import tracemalloc
+    from pydream_amd.convergence import _common_base
+    rng = np.random.default_rng(3)
+    S = rng.normal(size=(256, 3001, 20)).cumsum(axis=1)            # 123 MB
+    views = [S[c] for c in range(len(S))]
+    assert _common_base(views) is S
+    assert _common_base(views[::-1]) is None and _common_base([v.copy() for v in views]) is None and _common_base(views[:-1]) is None
+    tracemalloc.start()
+    r = Gelman_Rubin(views)
+    peak = tracemalloc.get_traced_memory()[1]
+    tracemalloc.stop()
+    assert peak < 48 << 20                                         # (np.stack alone would be S.nbytes; the blocks' temporaries are ~32 MB)
+    np.testing.assert_array_equal(r, Gelman_Rubin([v.copy() for v in views]))
+    assert r.shape == (20,) and np.all(r > 1.0)

@@ -440,3 +440,63 @@ def test_restart_continues_bit_for_bit_like_the_oracle(tmp_path):
     hist2 = np.load("rs_DREAM_chain_history.npy").reshape(-1, d)
     assert len(hist2) == len(hist) + N * 2
     np.testing.assert_array_equal(hist2[:len(hist)], hist)
+
+
+def test_the_convergence_loop_of_the_examples_continues_on_the_live_engine(tmp_path, monkeypatch):
+    """dream_ex_ndim_gaussian.py:79-102 as a user runs it: run_dream, Gelman_Rubin, then run_dream(restart=True, model_name=...) again
+    and again.  The restart continues on the engine of the run before (history and adapted probabilities still in HBM: no engine is
+    built, nothing is read from the .npy files or uploaded) and gives, bit for bit, what the same calls give when every restart
+    rebuilds the engine from the files (DREAMZS_KEEP_ENGINE=0); the files are written either way; files touched in between, or another
+    sampler, and the restart goes back to the files.  The result carries the device-made diagnostic of the run."""
+    from pydream_amd import _capi, core
+    from pydream_amd.convergence import Gelman_Rubin_device
+    os.chdir(tmp_path)
+    d, N, G = 12, 16, 60
+    like = MVNormalLogLike(H.mvn_precision(d), factorize=False)
+    params = [FlatParam(np.zeros(d))]
+    Z0 = H.seed_history(10 * d, d, 5)
+    np.save("seed.npy", Z0)
+    kw = dict(multitry=5, adapt_crossover=True, history_thin=5, verbose=False, save_history=True)
+    built = []
+    real = _capi.Engine.__init__
+    monkeypatch.setattr(_capi.Engine, "__init__", lambda self, **k: (built.append(1), real(self, **k))[1])
+
+    def loop(name, keep):
+        monkeypatch.setenv("DREAMZS_KEEP_ENGINE", "1" if keep else "0")
+        out = []
+        s, l = run_dream(params, like, nchains=N, niterations=G, start=[Z0[i] for i in range(N)], history_file="seed.npy", model_name=name, seed=11, **kw)
+        out.append((np.array(s), np.array(l), s.gelman_rubin))
+        for rnd in range(3):
+            starts = [x[-1, :] for x in s]
+            s, l = run_dream(params, like, nchains=N, niterations=G + 20 * rnd, start=starts, restart=True, model_name=name, seed=12 + rnd, **kw)
+            out.append((np.array(s), np.array(l), s.gelman_rubin))
+        core.release_engines()
+        return out
+    built.clear()
+    a = loop("live", True)
+    assert len(built) == 1                                     # one engine for the four calls ...
+    built.clear()
+    b = loop("files", False)
+    assert len(built) == 4                                     # ... against one per call
+    for (sa, la, ra), (sb, lb, rb) in zip(a, b):
+        np.testing.assert_array_equal(sa, sb)
+        np.testing.assert_array_equal(la, lb)
+        np.testing.assert_array_equal(ra, rb)
+        np.testing.assert_allclose(ra, Gelman_Rubin(list(sa)), rtol=1e-10)          # the device diagnostic is the reference's
+    for tail in ("DREAM_chain_history.npy", "DREAM_chain_adapted_crossoverprob.npy", "DREAM_chain_adapted_gammalevelprob.npy"):
+        np.testing.assert_array_equal(np.load("live_" + tail), np.load("files_" + tail))
+    assert len(np.load("live_DREAM_chain_history.npy")) == (len(Z0) + N * (12 + 12 + 16 + 20)) * d
+    # a history file the user has replaced is read again; so is everything when the sampler differs
+    monkeypatch.setenv("DREAMZS_KEEP_ENGINE", "1")
+    s, _ = run_dream(params, like, nchains=N, niterations=G, start=[Z0[i] for i in range(N)], history_file="seed.npy", model_name="t", seed=11, **kw)
+    assert "t" in core._parked
+    hist = np.load("t_DREAM_chain_history.npy")
+    np.save("t_DREAM_chain_history.npy", hist[:len(Z0) * d + N * d * 4])
+    built.clear()
+    s2, _ = run_dream(params, like, nchains=N, niterations=30, start=[x[-1] for x in s], restart=True, model_name="t", seed=5, **kw)
+    assert len(built) == 1 and len(np.load("t_DREAM_chain_history.npy")) == (len(Z0) + N * 4 + N * 6) * d
+    built.clear()
+    run_dream(params, like, nchains=N, niterations=30, start=[x[-1] for x in s2], restart=True, model_name="t", seed=6, **dict(kw, snooker=0.3))
+    assert len(built) == 1
+    core.release_engines()
+    assert Gelman_Rubin_device(s2) is not s2.gelman_rubin and np.array_equal(Gelman_Rubin_device(s2), s2.gelman_rubin)

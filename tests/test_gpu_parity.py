@@ -510,7 +510,7 @@ def test_eval_logp_scratch_buffers_survive_growth(G, O):
 def test_c3_full_size_mixture_with_adaptation(G, O):
     """BASELINE configs[2] at full size: 4096 chains x 100-D mixture of three Gaussians (examples/mixturemodel/mixturemodel.py:18-48
     generalised: weights 1/6, 1/3, 1/2, means -5, 0, +5 in every dimension), crossover adaptation on.
-    (a) the first 30 generations (all inside the crossover burn-in: multi-kernel path with the adaptation kernels) equal the
+    (a) the first 30 generations (all inside the crossover burn-in: the persistent mixture kernel, one generation per launch, followed by the adaptation launches) equal the
         oracle bit for bit, adapted probabilities included;
     (b) size-independent properties of the long run (burn-in ends inside it, the persistent mixture kernel takes over), from a
         seed archive and starts spread over all three modes: every chain ends inside a mode's shell (|x - mu_j|^2 / d ~ 1) and

@@ -180,6 +180,7 @@ int dz_trace_download_wait(dz_engine* e);
 int dz_host_register(void* ptr, int64_t bytes);
 int dz_host_unregister(void* ptr);
 int dz_get_history(dz_engine* e, double* Z, int64_t cap_rows, int64_t* rows);       /* Dream_shared_vars.history / count */
+int dz_get_history_range(dz_engine* e, int64_t row0, int64_t nrows, double* Z /* [nrows, d] */);   /* rows [row0, row0 + nrows) only */
 /* A 64-bit checksum of the archive as dz_get_history would return it ([rows, d], every appended row of every rank waited for), made on the
  * device: the sum modulo 2^64 over all elements of mix64(bits(Z[r][j]) + (r d + j + 1) 0x9E3779B97F4A7C15), mix64 = the splitmix64 finaliser.
  * What the ranks of a sharded run compare afterwards: the reference's chains all see ONE history (the shared array of core.py:281-283),

@@ -37,7 +37,7 @@ SYMBOLS = [
     "dz_version", "dz_last_error", "dz_device_count", "dz_create", "dz_destroy", "dz_set_bounds", "dz_set_gamma_table",
     "dz_set_history", "dz_set_state", "dz_set_cr_probs", "dz_set_gamma_probs", "dz_set_prior", "dz_set_likelihood_mvn",
     "dz_set_likelihood_mixture", "dz_set_likelihood_host", "dz_hip_library", "dz_comm_library", "dz_comm_unique_id", "dz_comm_init_rccl", "dz_comm_barrier", "dz_set_exchange", "dz_peer_export", "dz_peer_attach", "dz_peer_detach", "dz_exchange_stats", "dz_set_temperatures", "dz_get_swaps",
-    "dz_step", "dz_continue_run", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_get_chain_probs", "dz_sync", "dz_trace_reset", "dz_generation", "dz_redraw_rounds", "dz_last_kernel_variant", "dz_get_state", "dz_get_trace", "dz_get_trace_chains", "dz_trace_download_begin", "dz_trace_download_wait", "dz_host_register", "dz_host_unregister", "dz_get_history", "dz_history_checksum",
+    "dz_step", "dz_continue_run", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_get_chain_probs", "dz_sync", "dz_trace_reset", "dz_generation", "dz_redraw_rounds", "dz_last_kernel_variant", "dz_get_state", "dz_get_trace", "dz_get_trace_chains", "dz_trace_download_begin", "dz_trace_download_wait", "dz_host_register", "dz_host_unregister", "dz_get_history", "dz_get_history_range", "dz_history_checksum",
     "dz_get_cr_state", "dz_get_gamma_state", "dz_get_rhat", "dz_get_chain_moments", "dz_eval_logp", "dz_debug_propose",
     "dz_profile_enable", "dz_profile_get", "dz_profile_reset", "dz_profile_get_list",
 ]
@@ -99,6 +99,7 @@ def load_library():
     L.dz_get_trace.argtypes = [V, C.c_int64, C.c_int64] + [V] * 6
     L.dz_get_history.argtypes = [V, V, C.c_int64, V]
     L.dz_history_checksum.argtypes = [V, V, V]
+    L.dz_get_history_range.argtypes = [V, C.c_int64, C.c_int64, V]
     L.dz_get_cr_state.argtypes = [V, V, V, V]
     L.dz_get_gamma_state.argtypes = [V, V, V, V]
     L.dz_get_rhat.argtypes = [V, V]
@@ -405,10 +406,15 @@ class Engine:
     def host_unregister(self, arr):
         self.L.dz_host_unregister(C.c_void_p(arr.ctypes.data))
 
-    def get_history(self):
+    def get_history(self, row0=0):
+        """the archive [rows, d] (from row `row0` on)"""
         rows = C.c_int64()
         self._chk(self.L.dz_get_history(self.h, None, 0, C.byref(rows)))
-        Z = np.zeros((rows.value, self.d))
+        if row0:
+            Z = np.empty((rows.value - row0, self.d))
+            self._chk(self.L.dz_get_history_range(self.h, int(row0), rows.value - row0, _p(Z)))
+            return Z
+        Z = np.empty((rows.value, self.d))
         self._chk(self.L.dz_get_history(self.h, _p(Z), rows.value, C.byref(rows)))
         return Z
 

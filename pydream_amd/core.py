@@ -270,11 +270,42 @@ def _sample_dream_batched(eng, step, niterations, verbose, nverbose):
         # the whole run is still in the device trace: the reference's diagnostic (convergence.py:3-20) over all chains, made there
         sampled.gelman_rubin = eng.get_rhat()
     if step.save_history:
-        _save_history_to_disc(eng, step)
+        _save_history_to_disc(eng, step, appended_from=getattr(eng, "continued_from_file_rows", None))
     return sampled, log_ps
 
 
-def _save_history_to_disc(eng, step):
+_NPY_HEADER_BYTES = 256          # room for any row count: the shape can be rewritten in place when rows are appended
+
+
+def _npy_header(nvalues):
+    """a version-1.0 .npy header for a flat float64 array of `nvalues`, padded to _NPY_HEADER_BYTES (np.load reads any valid length)"""
+    body = "{'descr': '<f8', 'fortran_order': False, 'shape': (%d,), }" % nvalues
+    pad = _NPY_HEADER_BYTES - 10 - len(body) - 1
+    return b"\x93NUMPY\x01\x00" + (_NPY_HEADER_BYTES - 10).to_bytes(2, "little") + (body + " " * pad + "\n").encode("latin1")
+
+
+def _write_history_file(filename, eng, d, appended_from=None):
+    """Dream.save_history_to_disc's history file (Dream.py:947-959: the WHOLE flat history, every time).  A run continued on the live
+    engine of the run that wrote `filename` (run_dream checked that the file is untouched since) appends its new rows behind the old
+    ones and rewrites the row count in the header instead of downloading and writing gigabytes that are already there."""
+    rows = eng.history_rows()
+    if appended_from is not None and 0 < appended_from <= rows:
+        try:
+            with open(filename, "r+b") as f:
+                if f.read(_NPY_HEADER_BYTES) == _npy_header(appended_from * d) and os.fstat(f.fileno()).st_size == _NPY_HEADER_BYTES + 8 * appended_from * d:
+                    f.seek(0, 2)
+                    eng.get_history(appended_from).tofile(f)
+                    f.seek(0)
+                    f.write(_npy_header(rows * d))
+                    return
+        except OSError:
+            pass
+    with open(filename, "wb") as f:
+        f.write(_npy_header(rows * d))
+        eng.get_history().tofile(f)
+
+
+def _save_history_to_disc(eng, step, appended_from=None):
     """Dream.save_history_to_disc (Dream.py:947-969): the three .npy files a restart reads back."""
     if not step.model_name:
         prefix = datetime.now().strftime('%Y_%m_%d_%H:%M:%S') + '_'
@@ -283,7 +314,10 @@ def _save_history_to_disc(eng, step):
     filename = prefix + 'DREAM_chain_history.npy'
     if step.verbose:
         print('Saving history to file: ', filename)
-    np.save(filename, eng.get_history().reshape(-1))
+    if isinstance(eng, _capi.Engine):
+        _write_history_file(filename, eng, step.total_var_dimension, appended_from)
+    else:
+        np.save(filename, eng.get_history().reshape(-1))
     cr = eng.get_cr_state()[0]
     filename = prefix + 'DREAM_chain_adapted_crossoverprob.npy'
     if step.verbose:
@@ -369,6 +403,7 @@ def _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=None, mp_
     if live is not None:
         live.continue_run(nrows_live + nchains * n_appends, trace_cap, int(seed), int(min(step_instance.crossover_burnin, 2 ** 31 - 1)))
         live.nseed = nrows_live
+        live.continued_from_file_rows = nrows_live       # (the history file of the run before holds exactly these rows: run_dream checked)
     eng = live if live is not None else (engine_cls or _capi.Engine)(nchains=nchains, nchains_local=nl, chain_offset=chain_offset, ndim=d, multitry=int(step_instance.multitry),
                        depairs=len(step_instance.DEpairs), ncr=int(step_instance.nCR), ngamma=int(step_instance.ngamma),
                        history_thin=int(thin), crossover_burnin=int(min(step_instance.crossover_burnin, 2 ** 31 - 1)),

@@ -114,7 +114,7 @@ struct dz_engine {
     int nlanes = 1; hipStream_t lane_stream[8] = {nullptr}; hipEvent_t lane_ev[8] = {nullptr}; bool need_join = true;
     // bounded host run-ahead: a marker every ra_stride generations, the host never gets more than 3 markers ahead
     dz::Params p_shadow; bool params_uploaded = false;    // what d_params holds
-    void* h_pin = nullptr;          // page-locked bounce buffer for downloads into pageable memory (d2h_2d)
+    void* h_pin = nullptr; hipEvent_t pin_ev[2] = {nullptr, nullptr};          // page-locked bounce buffer (two halves) for downloads into pageable memory (d2h_2d)
     double* d_bar = nullptr;                // dz_comm_barrier's all-gather buffer (one element per rank)
     double* d_qpart = nullptr; size_t qpart_len = 0; bool force_big = false; bool logp_gemm = true; int logp_bm = 0;    // DZ_LOGP_GEMM=0: no LDS-tiled product; row-tile sums of the tiled large-d likelihood; DZ_LOGP_BIG=1: the one-wave-per-tile kernel
     int logp_waves = 0;      // DZ_LOGP_WAVES: force the block size of k_logp_mvn_lds (tuning)
@@ -243,16 +243,28 @@ int sync_all(dz_engine* e)
 int d2h_2d(dz_engine* e, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height)
 {
     if (!width || !height) return 0;
-    constexpr size_t CAP = (size_t)32 << 20;
+    constexpr size_t CAP = (size_t)64 << 20, HALF = CAP / 2;
     if (!e->h_pin) { if (hipHostMalloc(&e->h_pin, CAP, hipHostMallocDefault) != hipSuccess) { e->h_pin = nullptr; return fail("hipHostMalloc (bounce buffer) failed"); } }
-    if (width > CAP) return fail("row too long for the bounce buffer");
-    const size_t rows_per = std::max<size_t>(1, CAP / width);
-    for (size_t r0 = 0; r0 < height; r0 += rows_per) {
+    if (width > HALF) return fail("row too long for the bounce buffer");
+    // two halves: the DMA of the next batch of rows runs while the host copies the batch before out of the other half
+    const size_t rows_per = std::max<size_t>(1, HALF / width);
+    auto issue = [&](size_t r0, int half) -> hipError_t {
         const size_t nr = std::min(rows_per, height - r0);
-        HIPCK(hipMemcpy2DAsync(e->h_pin, width, (const char*)src + r0 * spitch, spitch, width, nr, hipMemcpyDeviceToHost, e->stream));
-        HIPCK(hipStreamSynchronize(e->stream));
-        for (size_t r = 0; r < nr; ++r) memcpy((char*)dst + (r0 + r) * dpitch, (const char*)e->h_pin + r * width, width);
+        return hipMemcpy2DAsync((char*)e->h_pin + (size_t)half * HALF, width, (const char*)src + r0 * spitch, spitch, width, nr, hipMemcpyDeviceToHost, e->stream);
+    };
+    if (!e->pin_ev[0]) for (int i = 0; i < 2; ++i) HIPCK(hipEventCreateWithFlags(&e->pin_ev[i], hipEventDisableTiming));
+    HIPCK(issue(0, 0));
+    HIPCK(hipEventRecord(e->pin_ev[0], e->stream));
+    int half = 0;
+    for (size_t r0 = 0; r0 < height; r0 += rows_per, half ^= 1) {
+        const size_t nr = std::min(rows_per, height - r0);
+        if (r0 + rows_per < height) { HIPCK(issue(r0 + rows_per, half ^ 1)); HIPCK(hipEventRecord(e->pin_ev[half ^ 1], e->stream)); }
+        HIPCK(hipEventSynchronize(e->pin_ev[half]));
+        const char* from = (const char*)e->h_pin + (size_t)half * HALF;
+        if (dpitch == width) memcpy((char*)dst + r0 * dpitch, from, nr * width);
+        else for (size_t r = 0; r < nr; ++r) memcpy((char*)dst + (r0 + r) * dpitch, from + r * width, width);
     }
+    HIPCK(hipStreamSynchronize(e->stream));
     return 0;
 }
 
@@ -1038,6 +1050,7 @@ int dz_destroy(dz_engine* e)
     if (e->d_scratch) (void)hipFree(e->d_scratch);
     if (e->d_qpart) (void)hipFree(e->d_qpart);
     if (e->h_pin) (void)hipHostFree(e->h_pin);
+    for (hipEvent_t x : e->pin_ev) if (x) (void)hipEventDestroy(x);
     if (e->h_redo) (void)hipHostFree(e->h_redo);
     if (e->h_redo_list) (void)hipHostFree(e->h_redo_list);
     if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
@@ -1696,6 +1709,14 @@ int dz_get_history(dz_engine* e, double* Z, int64_t cap_rows, int64_t* rows)
         DZCK(peer_check(e));
     }
     return 0;
+}
+
+int dz_get_history_range(dz_engine* e, int64_t row0, int64_t nrows, double* Z)
+{   // rows [row0, row0 + nrows) of the archive (what a continued run appends to the history file of the run before)
+    HIPCK(hipSetDevice(e->c.device));
+    if (row0 < 0 || nrows < 0 || row0 + nrows > e->M || !Z) return fail("history range");
+    if (e->peer_on && e->z_gated < e->napp) { DZCK(peer_gate(e, XK_Z, (unsigned long long)e->napp)); e->z_gated = e->napp; }
+    return download_rows(e, Z, e->p.Z + (size_t)row0 * e->p.ld, (size_t)nrows);
 }
 
 int dz_history_checksum(dz_engine* e, uint64_t* sum, int64_t* rows)

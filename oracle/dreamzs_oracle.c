@@ -808,6 +808,67 @@ static int adapt_gamma_now(const orc_engine* e, uint32_t g, int gamma_unity, int
     return g > 10 && (int64_t)g < e->c.crossover_burnin && !gamma_unity && !snk;
 }
 
+/* Adaptation of a LOCKSTEP generation (schedule S2), reduction contract v3.  The reference adds, chain by chain,
+ * delta_m[m] += sum_j ((q_new - q0)_j / sd_j)^2 with sd = np.std(current_positions, axis=0) (:476-481, :522-527).  With every chain
+ * of the generation updating at once the same quantity is  sum_j D[m][j] / sd_j^2,  D[m][j] = sum over the chains of bin m of
+ * (q_new - q0)_j^2 -- column sums that do NOT need sd, so they are taken in the same pass over the positions as the sums sd itself
+ * needs (one grid-wide reduction on the GPU instead of three: mean, deviations, bins):
+ *   s_j   = cp_prev[chain 0][j]                          a shift near the population (any value is exact in exact arithmetic)
+ *   S1_j  = sum_c (x_cj - s_j),  S2_j = sum_c (x_cj - s_j)^2 [fma],  Dc[m][j] / Dg[m][j] = sum_{c in bin m} (x_cj - xprev_cj)^2 [fma]
+ *   every sum over chains: units of 16 consecutive global chains added in chain order from 0.0, groups of 16 units added in order,
+ *   then the groups in order;
+ *   a_j = S1_j / N,  var_j = fma(-a_j, a_j, S2_j / N) clamped at 0,  sd_j = sqrt(var_j);  crossover: sd_j == 0 -> 1e-12 (:479)
+ *   w_j = 1 / (sd_j sd_j);  delta_m[m] += nan_to_num(sum_j Dc[m][j] w_j)  (lane/butterfly order, fma), ncr_updates[m] += the bin's count.
+ * Differences from the chain-by-chain form: rounding (1e-15 relative), and nan_to_num applied once per bin instead of once per chain
+ * -- visible only when a coordinate has population sd exactly 0 in the gamma statistic or a jump overflows. */
+static void adapt_lockstep(orc_engine* e, const int* binc, const int* bing)
+{
+    const int N = e->N, d = e->d, ncr = e->c.ncr, ng = e->c.ngamma, nq = 2 + ncr + ng;
+    double* tot = zalloc(sizeof(double) * (size_t)nq * d); double* cnt = zalloc(sizeof(double) * (size_t)(ncr + ng));
+    const double* shift = e->cp_prev;                                   /* row of global chain 0 */
+    for (int q = 0; q < nq; ++q)
+        for (int j = 0; j < d; ++j) {
+            double t = 0.0;
+            for (int G = 0; G < N; G += 256) {
+                double gs = 0.0;
+                for (int u = G; u < N && u < G + 256; u += 16) {
+                    double us = 0.0;
+                    for (int c = u; c < N && c < u + 16; ++c) {
+                        const double x = e->cp_new[(size_t)c * d + j];
+                        if (q == 0) us = us + (x - shift[j]);
+                        else if (q == 1) { const double v = x - shift[j]; us = fma(v, v, us); }
+                        else {
+                            const int m = q - 2, in = m < ncr ? binc[c] == m : bing[c] == m - ncr;
+                            if (in) { const double df = x - e->cp_prev[(size_t)c * d + j]; us = fma(df, df, us); }
+                        }
+                    }
+                    gs = gs + us;
+                }
+                t = t + gs;
+            }
+            tot[(size_t)q * d + j] = t;
+        }
+    for (int c = 0; c < N; ++c) { if (binc[c] >= 0) cnt[binc[c]] += 1.0; if (bing[c] >= 0) cnt[ncr + bing[c]] += 1.0; }
+    double* wc = zalloc(sizeof(double) * d); double* wg = zalloc(sizeof(double) * d);
+    for (int j = 0; j < d; ++j) {
+        const double a = tot[j] / (double)N;
+        double var = fma(-a, a, tot[(size_t)d + j] / (double)N);
+        if (!(var > 0.0)) var = 0.0;
+        const double sd = sqrt(var), sdc = sd == 0.0 ? 1e-12 : sd;      /* :479 (crossover only) */
+        wc[j] = 1.0 / (sdc * sdc); wg[j] = 1.0 / (sd * sd);
+    }
+    int anyc = 0, anyg = 0;
+    for (int m = 0; m < ncr; ++m) if (cnt[m] > 0.0) {
+        e->cr_delta[m] = e->cr_delta[m] + nan_to_num(orc_wave_dot(tot + (size_t)(2 + m) * d, wc, d)); e->cr_n[m] += cnt[m]; anyc = 1;
+    }
+    for (int m = 0; m < ng; ++m) if (cnt[ncr + m] > 0.0) {
+        e->g_delta[m] = e->g_delta[m] + nan_to_num(orc_wave_dot(tot + (size_t)(2 + ncr + m) * d, wg, d)); e->g_n[m] += cnt[ncr + m]; anyg = 1;
+    }
+    if (anyc) renorm_probs(e->cr_probs, e->cr_delta, e->cr_n, ncr, N);
+    if (anyg) renorm_probs(e->g_probs, e->g_delta, e->g_n, ng, N);
+    free(tot); free(cnt); free(wc); free(wg);
+}
+
 /* chain flags of ANY global chain at generation g, recomputed from the random
  * contract (used for chains owned by other ranks in schedule S2). */
 static void chain_flags(const orc_engine* e, uint32_t gc, uint32_t g, int* snk, int* cr_idx, int* glev, int* gamma_unity)
@@ -899,33 +960,15 @@ static int generation_s2(orc_engine* e)
         double* t = e->cp_prev; e->cp_prev = e->cp_new; e->cp_new = t;
         rc = exchange(e, e->X, e->cp_new, d);
         if (rc) { free(Xn); free(R); return rc; }
-        /* estimate_crossover_probabilities / estimate_gamma_level_probs for all N chains */
-        double* sd = zalloc(sizeof(double) * d); double* sdg = zalloc(sizeof(double) * d); double* tmp = zalloc(sizeof(double) * d);
-        double* dl = zalloc(sizeof(double) * N); double* dlg = zalloc(sizeof(double) * N);
+        /* estimate_crossover_probabilities / estimate_gamma_level_probs for all N chains of the lockstep generation */
         int* binc = zalloc(sizeof(int) * N); int* bing = zalloc(sizeof(int) * N);
-        std_by_dim(e->cp_new, N, d, 64, sdg);
-        for (int j = 0; j < d; ++j) sd[j] = sdg[j] == 0.0 ? 1e-12 : sdg[j];      /* :479 (crossover only) */
         for (int gcn = 0; gcn < N; ++gcn) {
             int snk, cr, gl, gu; chain_flags(e, (uint32_t)gcn, g, &snk, &cr, &gl, &gu);
             binc[gcn] = adapt_cr_now(e, g, gu) ? (snk ? e->c.ncr - 1 : cr) : -1;     /* :374-378 */
             bing[gcn] = adapt_gamma_now(e, g, gu, snk) ? gl - 1 : -1;
-            if (binc[gcn] >= 0) dl[gcn] = jump_norm(e->cp_new + (size_t)gcn * d, e->cp_prev + (size_t)gcn * d, sd, d, tmp);
-            if (bing[gcn] >= 0) dlg[gcn] = jump_norm(e->cp_new + (size_t)gcn * d, e->cp_prev + (size_t)gcn * d, sdg, d, tmp);
         }
-        int anyc = 0, anyg = 0;
-        for (int m = 0; m < e->c.ncr; ++m) {
-            double tot = 0.0; int cnt = 0;
-            for (int s = 0; s < N; s += 64) { double ps = 0.0; for (int c = s; c < N && c < s + 64; ++c) if (binc[c] == m) { ps = ps + dl[c]; cnt++; } tot = tot + ps; }
-            if (cnt) { e->cr_delta[m] = e->cr_delta[m] + tot; e->cr_n[m] += cnt; anyc = 1; }
-        }
-        for (int m = 0; m < e->c.ngamma; ++m) {
-            double tot = 0.0; int cnt = 0;
-            for (int s = 0; s < N; s += 64) { double ps = 0.0; for (int c = s; c < N && c < s + 64; ++c) if (bing[c] == m) { ps = ps + dlg[c]; cnt++; } tot = tot + ps; }
-            if (cnt) { e->g_delta[m] = e->g_delta[m] + tot; e->g_n[m] += cnt; anyg = 1; }
-        }
-        if (anyc) renorm_probs(e->cr_probs, e->cr_delta, e->cr_n, e->c.ncr, N);
-        if (anyg) renorm_probs(e->g_probs, e->g_delta, e->g_n, e->c.ngamma, N);
-        free(sd); free(sdg); free(tmp); free(dl); free(dlg); free(binc); free(bing);
+        adapt_lockstep(e, binc, bing);
+        free(binc); free(bing);
     }
     /* record_history :360-362, :919-938 */
     if (g % (uint32_t)e->c.history_thin == 0) {

@@ -147,6 +147,9 @@ struct dz_engine {
     double *d_partial = nullptr, *d_mean = nullptr, *d_sd = nullptr, *d_sdc = nullptr, *d_dl = nullptr, *d_dlg = nullptr;
     int *d_binc = nullptr, *d_bing = nullptr;
     double* d_binsum = nullptr;     // k_adapt_update's scratch: [strips of 64 chains][ncr + ngamma] sums, then the same shape of counts
+    // lockstep adaptation, contract v3 (dz_kernels.h adapt_unit_sums): the units' sums [units][nq][ld] and counts [units][ncr + ngamma], their totals
+    double *d_PR = nullptr, *d_PC = nullptr, *d_TOT = nullptr, *d_CNT = nullptr;
+    bool adapt_fused = true;        // the persistent kernels make their block's unit sums themselves (DZ_ADAPT_FUSED=0: k_adapt_partials does)
     dz::Params* d_params = nullptr;  // device copy of `p` for kernels that take it by pointer
     double *d_scratch = nullptr; size_t scratch_rows = 0;   // debug / eval staging [rows, ld]
     double *d_cmean = nullptr, *d_cvar = nullptr, *d_rhat = nullptr;
@@ -499,29 +502,42 @@ int exchange_rows(dz_engine* e, int kind, double* buf, size_t row0)
     return 0;
 }
 
-int adapt_generation(dz_engine* e, uint32_t g, int gc0, int ngc)
+// the totals of the units' sums and the update (k_adapt_totals, k_adapt_apply): the tail of a lockstep generation's adaptation
+int adapt_finish(dz_engine* e)
+{
+    const dz::Params& p = e->p;
+    const int nq = 2 + p.ncr + p.ngamma, units = (p.N + 15) / 16, groups = (units + 15) / 16;
+    hipLaunchKernelGGL(dz::k_adapt_totals, dim3((nq * p.d + 63) / 64), dim3(1024), sizeof(double) * 64 * (size_t)groups, e->stream, p, (const double*)e->d_PR, (const double*)e->d_PC, units, e->d_TOT, e->d_CNT);
+    NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_adapt_apply<NCH>, dim3(1), dim3(64), 0, e->stream, p, (const double*)e->d_TOT, (const double*)e->d_CNT));
+    return launch_check("adaptation kernels");
+}
+
+// fused = the generation's persistent launch has already left its units' sums in d_PR / d_PC (adapt_unit_sums in its epilogue)
+int adapt_generation(dz_engine* e, uint32_t g, int gc0, int ngc, bool fused = false)
 {
     ProfScope ps(e, PR_ADAPT);
     const dz::Params& p = e->p;
-    // lockstep generations: strips of 64 chains, then the strips in order (the reduction contract); a single chain's update (Dream.astep,
-    // schedule S1): all rows in row order, numpy's own
+    // lockstep generations (schedule S2): reduction contract v3 -- one pass over the positions makes, per unit of 16 chains, the column
+    // sums the standard deviations need AND the per-bin column sums of squared jumps; their totals; the update.
+    // A single chain's update (Dream.astep, schedule S1): the reference's own chain-by-chain form, all rows in row order (numpy's).
     const bool single = ngc != p.N;
-    const int strip = single ? p.N : 64, nstrips = (p.N + strip - 1) / strip;
+    if (!single) {
+        if (!fused) {
+            hipLaunchKernelGGL(dz::k_adapt_partials, dim3((p.N + 15) / 16), dim3(1024), 0, e->stream, p, g, e->d_PR, e->d_PC);
+            DZCK(launch_check("k_adapt_partials"));
+        }
+        return adapt_finish(e);
+    }
+    const int strip = p.N, nstrips = 1;
     const dim3 b(128), gcol((p.d + 127) / 128, nstrips);
-    // four launches: strip sums -> (column means, made by every block for itself) strip sums of squared deviations -> (standard
-    // deviations, likewise) normalised jumps per chain -> accumulators and probabilities.  The same additions in the same order as the
-    // six-launch form of round 2 with its two one-block finishing kernels; a kernel boundary is the cheapest grid-wide
-    // synchronisation on this chip (an agent-scope fence costs more), so what is left is one per true dependency.
     double* partial1 = e->d_partial + (size_t)((p.N + 63) / 64) * p.ld;
-    hipLaunchKernelGGL(dz::k_strip_partial, gcol, b, 0, e->stream, p.cp_new, p.N, p.d, p.ld, e->d_mean, 0, e->d_partial, strip, single ? 1 : 0);
-    hipLaunchKernelGGL(dz::k_strip_dev, gcol, b, 0, e->stream, p.cp_new, p.N, p.d, p.ld, (const double*)e->d_partial, nstrips, partial1, e->d_mean, strip, single ? 1 : 0);
-    const int nstrips64 = (p.N + 63) / 64;          // (the bins are always summed by strips of 64 chains, then the strips in order)
+    hipLaunchKernelGGL(dz::k_strip_partial, gcol, b, 0, e->stream, p.cp_new, p.N, p.d, p.ld, e->d_mean, 0, e->d_partial, strip, 1);
+    hipLaunchKernelGGL(dz::k_strip_dev, gcol, b, 0, e->stream, p.cp_new, p.N, p.d, p.ld, (const double*)e->d_partial, nstrips, partial1, e->d_mean, strip, 1);
     NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_jump<NCH>, dim3((p.N + dz::JUMP_CHAINS - 1) / dz::JUMP_CHAINS), dim3(64 * dz::JUMP_CHAINS), 0, e->stream, p, g, gc0, ngc,
                                        (const double*)partial1, nstrips, e->d_sd, e->d_sdc, e->d_dl, e->d_dlg, e->d_binc, e->d_bing));
-    (void)nstrips64;
     hipLaunchKernelGGL(dz::k_adapt_update, dim3(1), dim3(1024), (size_t)(dz::ADAPT_CHUNK + dz::ADAPT_CHUNK / 64) * 24, e->stream, p,
                        (const double*)e->d_dl, (const double*)e->d_dlg, (const int*)e->d_binc, (const int*)e->d_bing, e->d_binsum);
-    if (single && e->d_own_cr)      // the chains that updated the shared probabilities adopt them (Dream.py:375, :383, :409-415)
+    if (e->d_own_cr)      // the chains that updated the shared probabilities adopt them (Dream.py:375, :383, :409-415)
         hipLaunchKernelGGL(dz::k_own_probs, dim3((ngc + 63) / 64), dim3(64), 0, e->stream, p, gc0 - p.off, ngc, (const int*)e->d_binc, (const int*)e->d_bing, 0, e->d_own_cr, e->d_own_g);
     return launch_check("adaptation kernels");
 }
@@ -824,9 +840,12 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
         DZCK(exchange_rows(e, XK_POS, p.cp_new, 0));
     }
     if (publish) { e->cp_idx = (e->cp_idx + 1) % 3; p.cp_prev = p.cp_new; p.cp_new = e->d_cp[e->cp_idx]; }
-    double* pubto = publish ? p.cp_new : nullptr;
+    dz::Publish pub; pub.to = publish ? p.cp_new : nullptr; pub.shift = nullptr; pub.PR = nullptr; pub.PC = nullptr;
+    // crossover burn-in on one GPU: a block of 16 chains is one unit of the adaptation's column sums (contract v3) and makes them itself
+    bool fused = false;
+    auto fuse_adapt = [&]() { fused = true; pub.shift = p.cp_prev; pub.PR = e->d_PR; pub.PC = e->d_PC; };
     auto after_launch = [&]() -> int {      // end of the generation(s): positions -> adaptation -> history append (schedule S2)
-        if (publish) { DZCK(exchange_rows(e, XK_POS, p.cp_new, 0)); DZCK(adapt_generation(e, g, 0, p.N)); }
+        if (publish) { DZCK(exchange_rows(e, XK_POS, p.cp_new, 0)); DZCK(adapt_generation(e, g, 0, p.N, fused)); }
         if (append_last) { DZCK(exchange_rows(e, XK_Z, p.Z, (size_t)e->M)); e->M += p.N; e->napp += 1; }
         e->need_join = true;
         e->draws_gen = -1;
@@ -837,9 +856,11 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
     const int64_t slot0 = e->c.trace_capacity ? e->ntrace : -1;
     if (e->lk == LK_MIX) {
         DZCK(upload_params(e));
-        const dim3 gridm((p.nl + dz::MIXW - 1) / dz::MIXW), blockm(64 * dz::MIXW);
-        const size_t ldsm = sizeof(double) * (size_t)dz::MIXW * dz::mega_mix_wave_doubles(p.d, p.k, p.J);
-        DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, dz::k_generations_mix, gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, pubto);
+        int mw = dz::MIXW;
+        if (publish && e->adapt_fused && e->world == 1 && p.k >= 3 && sizeof(double) * (size_t)16 * dz::mega_mix_wave_doubles(p.d, p.k, p.J) <= (size_t)160 * 1024) { mw = 16; fuse_adapt(); }
+        const dim3 gridm((p.nl + mw - 1) / mw), blockm(64 * mw);
+        const size_t ldsm = sizeof(double) * (size_t)mw * dz::mega_mix_wave_doubles(p.d, p.k, p.J);
+        DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, dz::k_generations_mix, gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, pub);
         DZCK(launch_check("k_generations_mix"));
         e->last_variant = "k_generations_mix";
         DZCK(after_launch());
@@ -858,12 +879,13 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
     const bool pb = p.hard || p.have_prior || p.depairs > 1 || mega_redo(e);      // the instantiations with the full proposal code
     const size_t lds = mega_lds_bytes(e, xlds);
     DZCK(upload_params(e));
+    if (publish && e->adapt_fused && e->world == 1 && ch == 16 && wpc == 1 && !k1 && p.k >= 3) fuse_adapt();
     {
         // the instantiations live in one translation unit per row-tile count (dz_mega_tu.hip)
         dz::MegaLaunch ml;
         ml.tri = p.tri != 0; ml.xlds = pb ? true : xlds; ml.pb = pb; ml.k1 = k1; ml.ch = ch; ml.wpc = wpc; ml.redo = mega_redo(e);
         ml.grid = grid; ml.block = block; ml.lds = lds; ml.st = e->stream; ml.ka = nullptr; ml.kb = nullptr;
-        ml.pp = (const dz::Params*)e->d_params; ml.g = g; ml.n = n; ml.M = (uint32_t)visible_rows(e); ml.slot0 = slot0; ml.zappend = append_last ? e->M : (int64_t)-1; ml.publish = pubto;
+        ml.pp = (const dz::Params*)e->d_params; ml.g = g; ml.n = n; ml.M = (uint32_t)visible_rows(e); ml.slot0 = slot0; ml.zappend = append_last ? e->M : (int64_t)-1; ml.publish = &pub;
         if (e->prof) { ml.ka = prof_event(e); ml.kb = prof_event(e); e->ev[PR_GENERATIONS].emplace_back(ml.ka, ml.kb); }
         const char* name = nullptr;
         switch (nrt) {
@@ -923,6 +945,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     if (const char* kv = getenv("DZ_MEGA_MAXGEN")) e->mega_max_gen = std::max(1, atoi(kv));
     if (const char* kv = getenv("DZ_MEGA_BURNIN")) e->mega_burnin = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_REDO")) e->mega_redo_on = atoi(kv) != 0;
+    if (const char* kv = getenv("DZ_ADAPT_FUSED")) e->adapt_fused = atoi(kv) != 0;
     static_assert(dz::DZ_MAX_REDRAWS_DEV == DZ_MAX_REDRAWS && dz::DZ_REDRAW_KEY_STEP_DEV == DZ_REDRAW_KEY_STEP, "redraw constants");
     if (const char* kv = getenv("DZ_QFIN")) e->q_defer = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_FUSE_STREAM")) e->fuse_stream = atoi(kv) != 0;
@@ -995,6 +1018,9 @@ int dz_create(const dz_config* cfg, dz_engine** out)
         rc |= ealloc(e, &e->d_mean, ld); rc |= ealloc(e, &e->d_sd, ld); rc |= ealloc(e, &e->d_sdc, ld);
         rc |= ealloc(e, &e->d_dl, N); rc |= ealloc(e, &e->d_dlg, N); rc |= ealloc(e, &e->d_binc, N); rc |= ealloc(e, &e->d_bing, N);
         rc |= ealloc(e, &e->d_binsum, (size_t)2 * ((N + 63) / 64) * (cfg->ncr + cfg->ngamma));
+        const size_t nq = 2 + (size_t)cfg->ncr + cfg->ngamma, units = (N + 15) / 16;
+        rc |= ealloc(e, &e->d_PR, units * nq * ld); rc |= ealloc(e, &e->d_PC, units * (size_t)(cfg->ncr + cfg->ngamma));
+        rc |= ealloc(e, &e->d_TOT, nq * ld); rc |= ealloc(e, &e->d_CNT, (size_t)(cfg->ncr + cfg->ngamma));
     }
     if (tc) {
         p.tcap = (long long)tc;

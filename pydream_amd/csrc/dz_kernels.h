@@ -63,6 +63,12 @@ struct Params {
     int pb_lds;      // persistent kernel, full-code instantiations: the prior / boundary constants are staged in LDS (PBConsts; set by the host when they fit)
     unsigned long long* dbg;  // cycle-stamp buffer of instrumented builds (-DDZ_EXPERIMENTS, dz_experiments.h); null otherwise
 };
+// What a persistent launch inside the crossover burn-in (one generation per launch) leaves behind besides the new states:
+// to: the published positions (set_current_position_arr, Dream.py:364-366, :447-449: [N][ld], row = global chain), or null outside the
+// burn-in; PR / PC / shift: when set, the block also makes the adaptation sums of its unit of 16 chains (adapt_unit_sums; contract v3),
+// shift = the previous published positions (row 0 is the shift of the column sums).
+struct Publish { double* to; const double* shift; double* PR; double* PC; };
+
 // per-phase cycle stamps: defined by dz_experiments.h in instrumented builds only (tools/variants.sh), no-ops in the product
 #ifdef DZ_EXPERIMENTS
 #include "dz_experiments.h"
@@ -1942,7 +1948,87 @@ __global__ __launch_bounds__(1024) void k_jump(Params p, uint32_t g, int gc0, in
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Adaptation of a LOCKSTEP generation, reduction contract v3 (oracle: adapt_lockstep).
+//   delta_m[m] += sum_j D[m][j] / sd_j^2,  D[m][j] = sum over the chains of bin m of (x_new - x_prev)_j^2:
+// the per-bin column sums of squared jumps do not need sd, so they are taken in the same pass over the positions as the sums sd
+// itself needs (S1_j = sum (x - s_j), S2_j = sum (x - s_j)^2 around the shift s = previous position of global chain 0) -- ONE
+// grid-wide reduction where the chain-by-chain form (k_strip_* / k_jump / k_adapt_update, kept for Dream.astep's schedule S1)
+// needs three.  Sums over chains: units of 16 consecutive global chains in chain order from 0.0 (adapt_unit_sums: one block of
+// the persistent kernels, or k_adapt_partials), groups of 16 units in order, then the groups in order (k_adapt_totals);
+// k_adapt_apply makes sd, the weights 1 / sd^2, the nb dot products and the new probabilities.
+// Partial rows: PR[unit][q][ld], q = 0: S1, 1: S2, 2 + m: crossover bin m, 2 + ncr + m: gamma-level bin m; PC[unit][ncr + ngamma]: counts.
+// ------------------------------------------------------------------------------------------
+DZ_DEV int adapt_nq(const Params& p) { return 2 + p.ncr + p.ngamma; }
+
+// the bins of GLOBAL chain gcn at generation g (:371-383, :385-401), by its wave: lanes 0, 1 make the control stream's idx 0, 1
+// (set_snooker / set_CR, set_DEpair / set_gamma_level), lanes 2 .. 2 + n - 1 the gamma-unity draws of the tries of the LAST
+// generate_proposal_points call (:705 / :730: the reference set's, or the single try's) -- ONE Philox call per wave
+DZ_DEV void adapt_bins(const Params& p, uint32_t g, int gcn, int lane, int& binc, int& bing)
+{
+    const int phase = p.k > 1 ? 1 : 0, n = p.k > 1 ? p.k - 1 : 1;
+    u32x4 w = u32x4{0, 0, 0, 0};
+    if (lane < 2 + n) w = lane < 2 ? philox(p.k0, p.k1, (uint32_t)lane, stream_id(K_CTRL, 0, 0), (uint32_t)gcn, g)
+                                   : philox(p.k0, p.k1, 0u, stream_id(K_PT, (uint32_t)(lane - 2), (uint32_t)phase), (uint32_t)gcn, g);
+    Ctrl u;
+    u.u_snk = u53(__shfl(w.x, 0, 64), __shfl(w.y, 0, 64)); u.u_cr = u53(__shfl(w.z, 0, 64), __shfl(w.w, 0, 64));
+    u.u_de = u53(__shfl(w.x, 1, 64), __shfl(w.y, 1, 64)); u.u_glev = u53(__shfl(w.z, 1, 64), __shfl(w.w, 1, 64));
+    u.u_sel = 0.0; u.u_acc = 0.0;
+    const StepFlags f = step_flags(p, u);                                  // (lockstep: every chain decides with the shared probabilities)
+    const bool gu = !f.snk && __any(lane >= 2 && lane < 2 + n && u53(w.x, w.y) < p.pgu);
+    const bool at_end = (int)g == p.burnin;
+    const bool window = g > 10 && (int)g < p.burnin;
+    const bool do_c = p.adapt_cr && (at_end || (window && !gu));               // :371, :395
+    const bool do_g = p.adapt_g && (at_end || (window && !gu && !f.snk));      // :381, :391
+    binc = do_c ? (f.snk ? p.ncr - 1 : f.cr_idx) : -1;                         // :374-378
+    bing = do_g ? f.glev - 1 : -1;
+}
+
+// The sums of ONE unit (16 consecutive global chains, nc of them present) by the threads of a block: xn / xp = the chains' new /
+// previous positions, [16][ldx] (LDS or global), bin(isg, c) = chain c's crossover (isg = false) / gamma-level bin or -1.
+// Thread (q, j) adds its column's terms in chain order.
+template <class BIN>
+DZ_DEV void adapt_unit_sums(const Params& p, const double* xn, const double* xp, int ldx, int nc, BIN bin, const double* __restrict__ shift,
+                            double* __restrict__ pr /* [nq][ld] */, double* __restrict__ pc /* [ncr + ngamma] */, int tid, int nthreads)
+{
+    const int d = p.d, nq = adapt_nq(p);
+    for (int idx = tid; idx < nq * d; idx += nthreads) {
+        const int q = idx / d, j = idx - q * d;
+        double us = 0.0;
+        if (q < 2) {
+            const double sj = shift[j];
+            for (int c = 0; c < nc; ++c) { const double v = xn[(size_t)c * ldx + j] - sj; us = q == 0 ? us + v : fma(v, v, us); }
+        } else {
+            const int m = q - 2; const bool isg = m >= p.ncr; const int mm = isg ? m - p.ncr : m;
+            for (int c = 0; c < nc; ++c) if (bin(isg, c) == mm) { const double df = xn[(size_t)c * ldx + j] - xp[(size_t)c * ldx + j]; us = fma(df, df, us); }
+        }
+        pr[(size_t)q * p.ld + j] = us;
+    }
+    if (tid < p.ncr + p.ngamma) {
+        const bool isg = tid >= p.ncr; const int mm = isg ? tid - p.ncr : tid;
+        int cnt = 0;
+        for (int c = 0; c < nc; ++c) cnt += bin(isg, c) == mm ? 1 : 0;
+        pc[tid] = (double)cnt;
+    }
+}
+
 #ifndef DZ_TEMPLATES_ONLY   // plain (non-template) kernels: defined once, in dz_engine.hip's translation unit
+// The general form: the units' sums from the replicated published positions of ALL N chains (sharded runs, the multi-kernel path, blocks
+// of fewer than 16 chains); block = one unit, wave w = global chain 16 unit + w (its bins), then thread (q, j) the sums.
+__global__ __launch_bounds__(1024) void k_adapt_partials(Params p, uint32_t g, double* __restrict__ PR, double* __restrict__ PC)
+{
+    __shared__ int s_bc[16], s_bg[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, unit = blockIdx.x;
+    const int gcn = 16 * unit + wv;
+    int bc = -1, bg = -1;
+    if (gcn < p.N) adapt_bins(p, g, gcn, lane, bc, bg);
+    if (lane == 0) { s_bc[wv] = bc; s_bg[wv] = bg; }
+    __syncthreads();
+    const int nc = min(16, p.N - 16 * unit), nq = adapt_nq(p);
+    adapt_unit_sums(p, p.cp_new + (size_t)16 * unit * p.ld, p.cp_prev + (size_t)16 * unit * p.ld, p.ld, nc, [&](bool isg, int c) { return isg ? s_bg[c] : s_bc[c]; }, p.cp_prev,
+                    PR + (size_t)unit * nq * p.ld, PC + (size_t)unit * (p.ncr + p.ngamma), threadIdx.x, 1024);
+}
+
 // Single block of 1024 threads.  Step 1: the chains' jumps and bins are staged in LDS with coalesced loads, 4096 chains at a time (a
 // thread reading its strip straight from memory makes 128 line requests of its own: 34 us for 4096 chains, measured), and thread
 // (strip s, bin b) adds the jumps of the strip's 64 chains that fell into the bin, in chain order (crossover bins first, then the
@@ -2003,6 +2089,109 @@ __global__ __launch_bounds__(1024) void k_adapt_update(Params p, const double* _
     if (t < 2 && any[t]) {     // :487-493 / :531-536
         const int nbb = t ? p.ngamma : p.ncr;
         double* probs = t ? p.g_probs : p.cr_probs; const double* delta = t ? p.g_delta : p.cr_delta; const double* n = t ? p.g_n : p.cr_n;
+        bool all = true;
+        for (int m = 0; m < nbb; ++m) if (delta[m] == 0.0) all = false;
+        if (all) {
+            double S = 0.0;
+            for (int m = 0; m < nbb; ++m) { probs[m] = (delta[m] / n[m]) * (double)p.N; S = S + probs[m]; }
+            for (int m = 0; m < nbb; ++m) probs[m] = probs[m] / S;
+        }
+    }
+}
+
+// Totals of the units' sums: block = 64 columns (q, j) of the nq d; wave w adds the units of groups w, w + 16, ... (16 units each, in
+// order, all 16 loads in flight), then wave 0 adds the groups in order.  Block 0 also adds the counts (small integers: exact in any order).
+__global__ __launch_bounds__(1024) void k_adapt_totals(Params p, const double* __restrict__ PR, const double* __restrict__ PC, int nunits,
+                                                       double* __restrict__ TOT /* [nq][ld] */, double* __restrict__ CNT /* [ncr + ngamma] */)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_gs[];       // [groups][64]
+    __shared__ double s_cnt[64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int d = p.d, nq = adapt_nq(p), ncol = nq * d, col = blockIdx.x * 64 + lane;
+    const int ngroups = (nunits + 15) / 16;
+    const bool on = col < ncol;
+    const int q = on ? col / d : 0, j = on ? col - q * d : 0;
+    const double* src = PR + (size_t)q * p.ld + j;
+    const size_t ustride = (size_t)nq * p.ld;
+    for (int G = wv; G < ngroups; G += 16) {
+        const int u0 = 16 * G, nu = min(16, nunits - u0);
+        double v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = (on && i < nu) ? src[(size_t)(u0 + i) * ustride] : 0.0;
+        double gs = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) if (i < nu) gs = gs + v[i];
+        s_gs[G * 64 + lane] = gs;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) s_cnt[threadIdx.x] = 0.0;
+    __syncthreads();
+    if (wv == 0 && on) {
+        double t = 0.0;
+        for (int G = 0; G < ngroups; ++G) t = t + s_gs[G * 64 + lane];
+        TOT[(size_t)q * p.ld + j] = t;
+    }
+    if (blockIdx.x == 0) {
+        const int nb = p.ncr + p.ngamma;
+        for (int b = 0; b < nb; ++b) {
+            double c = 0.0;
+            for (int u = threadIdx.x; u < nunits; u += 1024) c += PC[(size_t)u * nb + b];
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+            if (lane == 0 && c != 0.0) atomicAdd(&s_cnt[b], c);
+        }
+        __syncthreads();
+        if (threadIdx.x < nb) CNT[threadIdx.x] = s_cnt[threadIdx.x];
+    }
+}
+
+// sd, the weights, the bins' dot products and the new probabilities (:476-493, :522-536) from the totals: one wave.
+template <int NCH>
+__global__ __launch_bounds__(64) void k_adapt_apply(Params p, const double* __restrict__ TOT, const double* __restrict__ CNT)
+{
+    const int lane = threadIdx.x, d = p.d, ld = p.ld;
+    const double invN = (double)p.N;
+    double wc[NCH][2], wg[NCH][2];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int j = 128 * it + 2 * lane + s;
+            wc[it][s] = 0.0; wg[it][s] = 0.0;
+            if (j < d) {
+                const double a = TOT[j] / invN;
+                double var = fma(-a, a, TOT[(size_t)ld + j] / invN);
+                if (!(var > 0.0)) var = 0.0;
+                const double sd = sqrt(var), sdc = sd == 0.0 ? 1e-12 : sd;      // :479 (crossover only)
+                wc[it][s] = 1.0 / (sdc * sdc); wg[it][s] = 1.0 / (sd * sd);
+            }
+        }
+    const int nb = p.ncr + p.ngamma;
+    bool anyc = false, anyg = false;
+    for (int b = 0; b < nb; ++b) {
+        const bool isg = b >= p.ncr; const int m = isg ? b - p.ncr : b;
+        const double cnt = CNT[b];
+        if (!(cnt > 0.0)) continue;                                           // (wave-uniform)
+        const double* D = TOT + (size_t)(2 + b) * ld;
+        double acc = 0.0;
+#pragma unroll
+        for (int it = 0; it < NCH; ++it)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int j = 128 * it + 2 * lane + s;
+                if (j < d) acc = fma(D[j], isg ? wg[it][s] : wc[it][s], acc);
+            }
+        const double tot = nan_to_num(wave_bfly(acc));
+        if (lane == 0) {
+            double* delta = isg ? p.g_delta : p.cr_delta; double* n = isg ? p.g_n : p.cr_n;
+            delta[m] = delta[m] + tot; n[m] += cnt;
+        }
+        if (isg) anyg = true; else anyc = true;
+    }
+    __threadfence_block();
+    if (lane < 2 && (lane ? anyg : anyc)) {     // :487-493 / :531-536
+        const int t = lane;
+        const int nbb = t ? p.ngamma : p.ncr;
+        double* probs = t ? p.g_probs : p.cr_probs; const double* delta = t ? p.g_delta : p.cr_delta; const double* n = t ? p.g_n : p.cr_n;
+        // (lane 0 wrote delta / n above; lane 1 reads the gamma ones: same wave, program order + the fence)
         bool all = true;
         for (int m = 0; m < nbb; ++m) if (delta[m] == 0.0) all = false;
         if (all) {

@@ -21,12 +21,12 @@ static const char* launch_one(const MegaLaunch& a)
     if constexpr (PB && !K1) {
         if (a.redo) {
             hipExtLaunchKernelGGL((k_generations<DZ_TU_NRT, TRI, X, CH, WPC, PB, K1, true>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0,
-                                  a.pp, a.g, a.n, a.M, a.slot0, a.zappend, a.publish);
+                                  a.pp, a.g, a.n, a.M, a.slot0, a.zappend, *a.publish);
             return TRI ? "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,full,redo>" : "k_generations<" DZ_STR(DZ_TU_NRT) ",dense,xlds,%d,%d,full,redo>";
         }
     }
     hipExtLaunchKernelGGL((k_generations<DZ_TU_NRT, TRI, X, CH, WPC, PB, K1>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0,
-                          a.pp, a.g, a.n, a.M, a.slot0, a.zappend, a.publish);
+                          a.pp, a.g, a.n, a.M, a.slot0, a.zappend, *a.publish);
     // (NRT, matrix, chain states, chains per block, waves per chain, proposal code)
     return TRI ? (X ? (PB ? (K1 ? "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,full,k1>" : "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,full>")
                           : (K1 ? "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,lean,k1>" : "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,lean>"))

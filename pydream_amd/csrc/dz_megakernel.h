@@ -233,8 +233,9 @@ DZ_DEV void propose_de_pf(const Params& p, int phase, uint32_t g, uint32_t M, in
 // the chains that need it propose again, every wave takes part in the barriers and the likelihood units (the other chains' points have not
 // changed: their sums come out the same), and the block leaves the loop when none of its chains needs another round (DZ_MAX_REDRAWS caps it).
 template <int NRT, bool TRI, bool XLDS, int CH, int WPC, bool PB, bool K1 = false, bool REDO = false>
-__global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int64_t zappend, double* __restrict__ publish)
+__global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int64_t zappend, Publish pub)
 {
+    double* const publish = pub.to;
     const Params& p = *pp;       // read through the scalar cache on demand: keeps the ~70 fields out of the SGPR file
     constexpr int NCH = 1;
     // WPC waves per chain (1 at 16 chains per block; 2 / 4 at 8 / 4 chains per block, i.e. when there are fewer than 16 chains
@@ -547,6 +548,23 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 }
             }
             if (lane == 0) { st[4 * cl] = npri; st[4 * cl + 1] = nlik; }
+            if (CH == 16 && WPC == 1 && !K1 && pub.PR) {
+                // crossover burn-in (one generation per launch): the chain's new and old state go to two dead rows of the point area (the
+                // reference points' tiles), its bins to the rows' pad elements; behind the barrier the block adds its unit's sums
+                int bc, bg;
+                adapt_bins(p, g, (int)gc, lane, bc, bg);
+                double* sn = Pt + (size_t)(16 + cl) * L.LDP; double* so = Pt + (size_t)(32 + cl) * L.LDP;
+                if (jj < d) { sn[jj] = xn.x; so[jj] = xo.x; }
+                if (jj + 1 < d) { sn[jj + 1] = xn.y; so[jj + 1] = xo.y; }
+                if (lane == 0) { sn[L.LDP - 1] = (double)bc; so[L.LDP - 1] = (double)bg; }
+            }
+        }
+        if (CH == 16 && WPC == 1 && !K1 && pub.PR) {
+            __syncthreads();
+            const double* sn = Pt + (size_t)16 * L.LDP; const double* so = Pt + (size_t)32 * L.LDP;
+            const int LDPc = L.LDP;
+            adapt_unit_sums(p, sn, so, LDPc, min(16, p.nl - 16 * (int)blockIdx.x), [&](bool isg, int c_) { return (int)(isg ? so : sn)[(size_t)c_ * LDPc + LDPc - 1]; }, pub.shift,
+                            pub.PR + (size_t)blockIdx.x * adapt_nq(p) * p.ld, pub.PC + (size_t)blockIdx.x * (p.ncr + p.ngamma), (int)threadIdx.x, NT);
         }
         DZ_MSTAMP(9);
         // one wave per chain: no barrier here -- the next generation's first phase only touches each wave's own chain's rows
@@ -566,8 +584,10 @@ constexpr int MIXW = 4;       // waves (= chains) per block
 
 __host__ __device__ inline int mega_mix_wave_doubles(int d, int k, int J) { return k * (4 * ((d + 3) / 4) + 1) + 5 * k + k * J + 8 + (k & 1); }
 
-__global__ __launch_bounds__(64 * MIXW) void k_generations_mix(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int64_t zappend, double* __restrict__ publish)
+// (blocks of MIXW waves; blocks of 16 -- one adaptation unit -- inside the crossover burn-in, where the block adds its unit's sums)
+__global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int64_t zappend, Publish pub)
 {
+    double* const publish = pub.to;
     const Params& p = *pp;
     constexpr int NCH = 1;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -578,7 +598,8 @@ __global__ __launch_bounds__(64 * MIXW) void k_generations_mix(const Params* __r
     double* sP = region + (size_t)k * LDP; double* sS = sP + k; double* sL = sS + k; double* rS = sL + k; double* rL = rS + k;
     double* lh = rL + k;                                                    // [k][J] mixture component terms; then [8] decisions
     double* dec = lh + (size_t)k * p.J;
-    const int cg = blockIdx.x * MIXW + wv;
+    const int nwv = blockDim.x >> 6;
+    const int cg = blockIdx.x * nwv + wv;
     const bool active = cg < p.nl;
     const int c = min(cg, p.nl - 1);
     const uint32_t gc = (uint32_t)(p.off + c);
@@ -708,6 +729,21 @@ __global__ __launch_bounds__(64 * MIXW) void k_generations_mix(const Params* __r
                 }
             }
             lpri = npri; llik = nlik;
+            if (pub.PR) {   // crossover burn-in, blocks of 16 chains, k >= 3: new and old state into the chain's (now dead) rows 1 and 2, bins into their pad elements
+                int bc, bg;
+                adapt_bins(p, g, (int)gc, lane, bc, bg);
+                double* sn = region + LDP; double* so = region + 2 * LDP;
+                if (jj < d) { sn[jj] = xn.x; so[jj] = xo.x; }
+                if (jj + 1 < d) { sn[jj + 1] = xn.y; so[jj + 1] = xo.y; }
+                if (lane == 0) { sn[LDP - 1] = (double)bc; so[LDP - 1] = (double)bg; }
+            }
+        }
+        if (pub.PR) {       // (block-uniform; one generation per launch)
+            __syncthreads();
+            const int W = mega_mix_wave_doubles(d, k, p.J);
+            const double* sn = smem + LDP; const double* so = smem + 2 * LDP;
+            adapt_unit_sums(p, sn, so, W, min(16, p.nl - 16 * (int)blockIdx.x), [&](bool isg, int c_) { return (int)(isg ? so : sn)[(size_t)c_ * W + LDP - 1]; }, pub.shift,
+                            pub.PR + (size_t)blockIdx.x * adapt_nq(p) * p.ld, pub.PC + (size_t)blockIdx.x * (p.ncr + p.ngamma), (int)threadIdx.x, (int)blockDim.x);
         }
     }
 }

@@ -143,7 +143,9 @@ struct dz_engine {
     // owned device buffers (also referenced from p)
     double *d_mins = nullptr, *d_maxs = nullptr, *d_gtab = nullptr, *d_mu = nullptr, *d_Mt = nullptr, *d_Mtp = nullptr, *d_mixF = nullptr;
     double *d_pa = nullptr, *d_pb = nullptr, *d_plogb = nullptr; int32_t* d_pkind = nullptr;
-    double *d_shared = nullptr;      // cr_probs|cr_delta|cr_n|g_probs|g_delta|g_n
+    double *d_shared = nullptr;      // cr_probs|cr_delta|cr_n|g_probs|g_delta|g_n -- two copies: e->p points at the current one (sh_cur); a persistent launch
+    int sh_cur = 0;                  // that applies pending adaptation totals in its prologue reads the current copy and leaves the new state in the other
+    bool adapt_pending = false;      // d_TOT / d_CNT hold totals that no launch has applied yet (only between two launches inside dz_step)
     double *d_partial = nullptr, *d_mean = nullptr, *d_sd = nullptr, *d_sdc = nullptr, *d_dl = nullptr, *d_dlg = nullptr;
     int *d_binc = nullptr, *d_bing = nullptr;
     double* d_binsum = nullptr;     // k_adapt_update's scratch: [strips of 64 chains][ncr + ngamma] sums, then the same shape of counts
@@ -502,18 +504,34 @@ int exchange_rows(dz_engine* e, int kind, double* buf, size_t row0)
     return 0;
 }
 
-// the totals of the units' sums and the update (k_adapt_totals, k_adapt_apply): the tail of a lockstep generation's adaptation
-int adapt_finish(dz_engine* e)
+void point_shared(dz_engine* e)
+{   // e->p's six pointers at the current copy of the shared adaptation state
+    dz::Params& p = e->p; const int ncr = e->c.ncr, ng = e->c.ngamma;
+    p.cr_probs = e->d_shared + (size_t)e->sh_cur * 3 * (ncr + ng); p.cr_delta = p.cr_probs + ncr; p.cr_n = p.cr_delta + ncr;
+    p.g_probs = p.cr_n + ncr; p.g_delta = p.g_probs + ng; p.g_n = p.g_delta + ng;
+}
+// totals left by the last generation's adaptation that no launch has applied yet: the update on its own
+int adapt_flush(dz_engine* e)
+{
+    if (!e->adapt_pending) return 0;
+    NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_adapt_apply<NCH>, dim3(1), dim3(64), 0, e->stream, e->p, (const double*)e->d_TOT, (const double*)e->d_CNT));
+    e->adapt_pending = false;
+    return launch_check("k_adapt_apply");
+}
+// the totals of the units' sums (k_adapt_totals); the update itself (adapt_apply_wave) is left to the next persistent launch's prologue
+// when `defer` says one follows, else made at once (k_adapt_apply)
+int adapt_finish(dz_engine* e, bool defer)
 {
     const dz::Params& p = e->p;
     const int nq = 2 + p.ncr + p.ngamma, units = (p.N + 15) / 16, groups = (units + 15) / 16;
-    hipLaunchKernelGGL(dz::k_adapt_totals, dim3((nq * p.d + 63) / 64), dim3(1024), sizeof(double) * 64 * (size_t)groups, e->stream, p, (const double*)e->d_PR, (const double*)e->d_PC, units, e->d_TOT, e->d_CNT);
-    NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_adapt_apply<NCH>, dim3(1), dim3(64), 0, e->stream, p, (const double*)e->d_TOT, (const double*)e->d_CNT));
-    return launch_check("adaptation kernels");
+    hipLaunchKernelGGL(dz::k_adapt_totals, dim3((nq * p.d + 63) / 64 + 1), dim3(1024), sizeof(double) * 64 * (size_t)groups, e->stream, p, (const double*)e->d_PR, (const double*)e->d_PC, units, e->d_TOT, e->d_CNT);
+    DZCK(launch_check("k_adapt_totals"));
+    e->adapt_pending = true;
+    return defer ? 0 : adapt_flush(e);
 }
 
 // fused = the generation's persistent launch has already left its units' sums in d_PR / d_PC (adapt_unit_sums in its epilogue)
-int adapt_generation(dz_engine* e, uint32_t g, int gc0, int ngc, bool fused = false)
+int adapt_generation(dz_engine* e, uint32_t g, int gc0, int ngc, bool fused = false, bool defer = false)
 {
     ProfScope ps(e, PR_ADAPT);
     const dz::Params& p = e->p;
@@ -526,7 +544,7 @@ int adapt_generation(dz_engine* e, uint32_t g, int gc0, int ngc, bool fused = fa
             hipLaunchKernelGGL(dz::k_adapt_partials, dim3((p.N + 15) / 16), dim3(1024), 0, e->stream, p, g, e->d_PR, e->d_PC);
             DZCK(launch_check("k_adapt_partials"));
         }
-        return adapt_finish(e);
+        return adapt_finish(e, defer);
     }
     const int strip = p.N, nstrips = 1;
     const dim3 b(128), gcol((p.d + 127) / 128, nstrips);
@@ -623,6 +641,7 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
     const bool full = (c0 == 0 && nc == p.nl);
     if (!full && e->world > 1) return fail("single-chain stepping is not available on a sharded engine");
     if (!full && e->c.history_lag) return fail("single-chain stepping (Dream.astep) appends with immediate effect: history_lag must be 0");
+    DZCK(adapt_flush(e));               // (these kernels read the shared probabilities in place)
     DZCK(ensure_visible(e));
     const uint32_t Mv = (uint32_t)visible_rows(e);
     const int L = (full && e->lk != LK_HOST && !redo_possible(e)) ? e->nlanes : 1;     // the host-callback likelihood is synchronous anyway; redraw rounds use shared buffers
@@ -806,6 +825,7 @@ int upload_params(dz_engine* e)
     dz::Params q = e->p;
     q.cp_prev = nullptr; q.cp_new = nullptr; q.draws = nullptr; q.draws_next = nullptr; q.ctl = nullptr; q.ctl_next = nullptr;
     q.own_cr = nullptr; q.own_g = nullptr; q.redo = nullptr; q.redo_list = nullptr;
+    q.cr_probs = nullptr; q.cr_delta = nullptr; q.cr_n = nullptr; q.g_probs = nullptr; q.g_delta = nullptr; q.g_n = nullptr;     // (the persistent kernels get the state through Publish::sh)
     if (e->params_uploaded && memcmp(&e->p_shadow, &q, sizeof(dz::Params)) == 0) return 0;
     // (through a staging copy that outlives the call: the source of an asynchronous copy from pageable memory must not be a local)
     memcpy(&e->p_shadow, &q, sizeof(dz::Params));
@@ -826,7 +846,7 @@ int mega_segment(const dz_engine* e, uint32_t g, int64_t remaining)
     }
     return n;
 }
-int run_mega_segment(dz_engine* e, uint32_t g, int n)
+int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
 {
     dz::Params& p = e->p;
     const bool append_last = ((g + (uint32_t)n - 1) % (uint32_t)p.thin) == 0;
@@ -841,11 +861,15 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
     }
     if (publish) { e->cp_idx = (e->cp_idx + 1) % 3; p.cp_prev = p.cp_new; p.cp_new = e->d_cp[e->cp_idx]; }
     dz::Publish pub; pub.to = publish ? p.cp_new : nullptr; pub.shift = nullptr; pub.PR = nullptr; pub.PC = nullptr;
+    pub.sh = p.cr_probs; pub.sh_out = nullptr; pub.TOT = nullptr; pub.CNT = nullptr;
+    const bool applies = e->adapt_pending;      // the previous generation's adaptation totals: applied by this launch's prologue, new state into the other copy
+    if (applies) { pub.TOT = e->d_TOT; pub.CNT = e->d_CNT; pub.sh_out = e->d_shared + (size_t)(e->sh_cur ^ 1) * 3 * (p.ncr + p.ngamma); }
+    auto launched = [&]() { if (applies) { e->sh_cur ^= 1; point_shared(e); e->adapt_pending = false; } };
     // crossover burn-in on one GPU: a block of 16 chains is one unit of the adaptation's column sums (contract v3) and makes them itself
     bool fused = false;
     auto fuse_adapt = [&]() { fused = true; pub.shift = p.cp_prev; pub.PR = e->d_PR; pub.PC = e->d_PC; };
     auto after_launch = [&]() -> int {      // end of the generation(s): positions -> adaptation -> history append (schedule S2)
-        if (publish) { DZCK(exchange_rows(e, XK_POS, p.cp_new, 0)); DZCK(adapt_generation(e, g, 0, p.N, fused)); }
+        if (publish) { DZCK(exchange_rows(e, XK_POS, p.cp_new, 0)); DZCK(adapt_generation(e, g, 0, p.N, fused, mega_follows)); }
         if (append_last) { DZCK(exchange_rows(e, XK_Z, p.Z, (size_t)e->M)); e->M += p.N; e->napp += 1; }
         e->need_join = true;
         e->draws_gen = -1;
@@ -857,11 +881,13 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
     if (e->lk == LK_MIX) {
         DZCK(upload_params(e));
         int mw = dz::MIXW;
-        if (publish && e->adapt_fused && e->world == 1 && p.k >= 3 && sizeof(double) * (size_t)16 * dz::mega_mix_wave_doubles(p.d, p.k, p.J) <= (size_t)160 * 1024) { mw = 16; fuse_adapt(); }
+        const size_t lds_probs = sizeof(double) * (size_t)((p.ncr + p.ngamma + 1) & ~1);
+        if (publish && e->adapt_fused && e->world == 1 && p.k >= 3 && sizeof(double) * (size_t)16 * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs <= (size_t)160 * 1024) { mw = 16; fuse_adapt(); }
         const dim3 gridm((p.nl + mw - 1) / mw), blockm(64 * mw);
-        const size_t ldsm = sizeof(double) * (size_t)mw * dz::mega_mix_wave_doubles(p.d, p.k, p.J);
+        const size_t ldsm = sizeof(double) * (size_t)mw * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs;
         DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, dz::k_generations_mix, gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, pub);
         DZCK(launch_check("k_generations_mix"));
+        launched();
         e->last_variant = "k_generations_mix";
         DZCK(after_launch());
         if (slot0 >= 0) e->ntrace += n;
@@ -899,6 +925,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n)
         e->last_variant = buf;
     }
     DZCK(launch_check("k_generations"));
+    launched();
     DZCK(after_launch());
     if (slot0 >= 0) e->ntrace += n;
     return 0;
@@ -1009,7 +1036,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     rc |= ealloc(e, &e->d_redraw_count, 1); p.redraw_count = e->d_redraw_count;
     rc |= ealloc(e, &e->d_mins, ld); rc |= ealloc(e, &e->d_maxs, ld);
     rc |= ealloc(e, &e->d_gtab, (size_t)cfg->ngamma * cfg->depairs * p.d);
-    rc |= ealloc(e, &e->d_shared, (size_t)3 * (cfg->ncr + cfg->ngamma));
+    rc |= ealloc(e, &e->d_shared, (size_t)2 * 3 * (cfg->ncr + cfg->ngamma));
     rc |= ealloc(e, &e->d_pkind, ld); rc |= ealloc(e, &e->d_pa, ld); rc |= ealloc(e, &e->d_pb, ld); rc |= ealloc(e, &e->d_plogb, ld);
     if (e->adapt) {
         for (int i = 0; i < 3; ++i) rc |= ealloc(e, &e->d_cp[i], N * ld);
@@ -1030,8 +1057,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     rc |= ealloc(e, &e->d_cmean, nl * (size_t)p.d); rc |= ealloc(e, &e->d_cvar, nl * (size_t)p.d); rc |= ealloc(e, &e->d_rhat, (size_t)p.d);
     if (rc) { dz_destroy(e); return -1; }
     p.mins = e->d_mins; p.maxs = e->d_maxs; p.gtab = e->d_gtab;
-    p.cr_probs = e->d_shared; p.cr_delta = p.cr_probs + cfg->ncr; p.cr_n = p.cr_delta + cfg->ncr;
-    p.g_probs = p.cr_n + cfg->ncr; p.g_delta = p.g_probs + cfg->ngamma; p.g_n = p.g_delta + cfg->ngamma;
+    point_shared(e);
     p.pkind = e->d_pkind; p.pa = e->d_pa; p.pb = e->d_pb; p.plogb = e->d_plogb; p.have_prior = 0;
     // defaults: unbounded, uniform CR / gamma-level probabilities (Dream.py:134, :143), computed gamma table
     {
@@ -1493,7 +1519,7 @@ int dz_step(dz_engine* e, int64_t generations)
     for (int64_t i = 0; i < generations;) {
         DZCK(peer_check(e));            // a gate that gave up is fatal: nothing more is queued behind it
         const int n = mega ? mega_segment(e, (uint32_t)e->gen, generations - i) : 0;
-        if (n > 0) { DZCK(run_mega_segment(e, (uint32_t)e->gen, n)); i += n; }
+        if (n > 0) { DZCK(run_mega_segment(e, (uint32_t)e->gen, n, i + n < generations && mega_segment(e, (uint32_t)e->gen + (uint32_t)n, 1) > 0)); i += n; }
         else { DZCK(one_generation(e, 0, e->p.nl, (uint32_t)e->gen, true, i + 1 < generations && !(mega && mega_segment(e, (uint32_t)e->gen + 1, 1) > 0))); i += 1; }
         if (e->ra_stride > 0 && (++e->ra_n % e->ra_stride) == 0) {
             // keep the launch queue short: thousands of queued dispatches exhaust the runtime's kernarg/signal pools
@@ -1504,7 +1530,7 @@ int dz_step(dz_engine* e, int64_t generations)
             if (e->ra_used[oldest]) HIPCK(hipEventSynchronize(e->ra_ev[oldest]));
         }
     }
-    return 0;
+    return adapt_flush(e);          // (adaptation totals are left pending only between two launches of this loop)
 }
 
 int dz_step_range(dz_engine* e, int32_t c0, int32_t nc)

@@ -67,7 +67,11 @@ struct Params {
 // to: the published positions (set_current_position_arr, Dream.py:364-366, :447-449: [N][ld], row = global chain), or null outside the
 // burn-in; PR / PC / shift: when set, the block also makes the adaptation sums of its unit of 16 chains (adapt_unit_sums; contract v3),
 // shift = the previous published positions (row 0 is the shift of the column sums).
-struct Publish { double* to; const double* shift; double* PR; double* PC; };
+// sh: the shared adaptation state the launch's chains decide with (cr_probs|cr_delta|cr_n|g_probs|g_delta|g_n, core.py:287-293).
+// TOT / CNT: when set, the totals of the PREVIOUS generation's sums, not applied yet: every block makes the update for itself in its
+// prologue (adapt_apply_wave: sd, weights, the bins' dot products, the new probabilities -- the same arithmetic everywhere, so every
+// block decides with the same bits) and block 0 leaves the new state in sh_out (another buffer than sh: blocks start at different times).
+struct Publish { double* to; const double* shift; double* PR; double* PC; const double* sh; double* sh_out; const double* TOT; const double* CNT; };
 
 // per-phase cycle stamps: defined by dz_experiments.h in instrumented builds only (tools/variants.sh), no-ops in the product
 #ifdef DZ_EXPERIMENTS
@@ -1964,7 +1968,7 @@ DZ_DEV int adapt_nq(const Params& p) { return 2 + p.ncr + p.ngamma; }
 // the bins of GLOBAL chain gcn at generation g (:371-383, :385-401), by its wave: lanes 0, 1 make the control stream's idx 0, 1
 // (set_snooker / set_CR, set_DEpair / set_gamma_level), lanes 2 .. 2 + n - 1 the gamma-unity draws of the tries of the LAST
 // generate_proposal_points call (:705 / :730: the reference set's, or the single try's) -- ONE Philox call per wave
-DZ_DEV void adapt_bins(const Params& p, uint32_t g, int gcn, int lane, int& binc, int& bing)
+DZ_DEV void adapt_bins(const Params& p, uint32_t g, int gcn, int lane, int& binc, int& bing, const double* cr_probs, const double* g_probs)
 {
     const int phase = p.k > 1 ? 1 : 0, n = p.k > 1 ? p.k - 1 : 1;
     u32x4 w = u32x4{0, 0, 0, 0};
@@ -1974,7 +1978,7 @@ DZ_DEV void adapt_bins(const Params& p, uint32_t g, int gcn, int lane, int& binc
     u.u_snk = u53(__shfl(w.x, 0, 64), __shfl(w.y, 0, 64)); u.u_cr = u53(__shfl(w.z, 0, 64), __shfl(w.w, 0, 64));
     u.u_de = u53(__shfl(w.x, 1, 64), __shfl(w.y, 1, 64)); u.u_glev = u53(__shfl(w.z, 1, 64), __shfl(w.w, 1, 64));
     u.u_sel = 0.0; u.u_acc = 0.0;
-    const StepFlags f = step_flags(p, u);                                  // (lockstep: every chain decides with the shared probabilities)
+    const StepFlags f = step_flags_from(p, u, cr_probs, g_probs);          // (lockstep: every chain decides with the shared probabilities)
     const bool gu = !f.snk && __any(lane >= 2 && lane < 2 + n && u53(w.x, w.y) < p.pgu);
     const bool at_end = (int)g == p.burnin;
     const bool window = g > 10 && (int)g < p.burnin;
@@ -2012,6 +2016,65 @@ DZ_DEV void adapt_unit_sums(const Params& p, const double* xn, const double* xp,
     }
 }
 
+// sd, the weights 1 / sd^2, the bins' dot products and the new probabilities (:476-493, :522-536) from the totals, by ONE wave: lane b keeps
+// bin b's accumulators (crossover bins first, then the gamma-level bins).  sh_in: the state before (cr_probs|cr_delta|cr_n|g_probs|g_delta|
+// g_n); probs_out: [ncr + ngamma] the new probabilities (LDS of a persistent kernel) or null; sh_out: the whole new state or null (may be sh_in).
+template <int NCH>
+DZ_DEV void adapt_apply_wave(const Params& p, const double* __restrict__ TOT, const double* __restrict__ CNT, const double* sh_in, double* probs_out, double* sh_out, int lane)
+{
+    const int d = p.d, ld = p.ld, ncr = p.ncr, ng = p.ngamma, nb = ncr + ng;
+    const double Nd = (double)p.N;
+    double wc[NCH][2], wg[NCH][2];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int j = 128 * it + 2 * lane + s;
+            wc[it][s] = 0.0; wg[it][s] = 0.0;
+            if (j < d) {
+                const double a = TOT[j] / Nd;
+                double var = fma(-a, a, TOT[(size_t)ld + j] / Nd);
+                if (!(var > 0.0)) var = 0.0;
+                const double sd = sqrt(var), sdc = sd == 0.0 ? 1e-12 : sd;      // :479 (crossover only)
+                wc[it][s] = 1.0 / (sdc * sdc); wg[it][s] = 1.0 / (sd * sd);
+            }
+        }
+    const bool mine = lane < nb, isg_l = lane >= ncr;
+    const int m_l = isg_l ? lane - ncr : lane;
+    const int o_probs = isg_l ? 3 * ncr + m_l : m_l, o_delta = isg_l ? 3 * ncr + ng + m_l : ncr + m_l, o_n = isg_l ? 3 * ncr + 2 * ng + m_l : 2 * ncr + m_l;
+    double my_delta = mine ? sh_in[o_delta] : 1.0, my_n = mine ? sh_in[o_n] : 1.0;
+    const double my_old = mine ? sh_in[o_probs] : 0.0, my_cnt = mine ? CNT[lane] : 0.0;
+    for (int b = 0; b < nb; ++b) {
+        const double cnt = readlane_f64(my_cnt, b);
+        if (!(cnt > 0.0)) continue;                                           // (wave-uniform)
+        const bool isg = b >= ncr;
+        const double* D = TOT + (size_t)(2 + b) * ld;
+        double acc = 0.0;
+#pragma unroll
+        for (int it = 0; it < NCH; ++it)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int j = 128 * it + 2 * lane + s;
+                if (j < d) acc = fma(D[j], isg ? wg[it][s] : wc[it][s], acc);
+            }
+        const double tot = nan_to_num(wave_bfly(acc));
+        if (lane == b) { my_delta = my_delta + tot; my_n += cnt; }
+    }
+    // :487-493 / :531-536: a kind whose bins got anything is renormalised once every one of its bins has a non-zero delta
+    const bool anyc = __any(lane < ncr && my_cnt > 0.0), anyg = __any(mine && isg_l && my_cnt > 0.0);
+    const bool allc = !__any(lane < ncr && my_delta == 0.0), allg = !__any(mine && isg_l && my_delta == 0.0);
+    const double pm = (my_delta / my_n) * Nd;
+    double Sc = 0.0, Sg = 0.0;
+    for (int m = 0; m < ncr; ++m) Sc = Sc + readlane_f64(pm, m);
+    for (int m = ncr; m < nb; ++m) Sg = Sg + readlane_f64(pm, m);
+    const bool renorm = isg_l ? (anyg && allg) : (anyc && allc);
+    const double newp = renorm ? pm / (isg_l ? Sg : Sc) : my_old;
+    if (mine) {
+        if (probs_out) probs_out[lane] = newp;
+        if (sh_out) { sh_out[o_probs] = newp; sh_out[o_delta] = my_delta; sh_out[o_n] = my_n; }
+    }
+}
+
 #ifndef DZ_TEMPLATES_ONLY   // plain (non-template) kernels: defined once, in dz_engine.hip's translation unit
 // The general form: the units' sums from the replicated published positions of ALL N chains (sharded runs, the multi-kernel path, blocks
 // of fewer than 16 chains); block = one unit, wave w = global chain 16 unit + w (its bins), then thread (q, j) the sums.
@@ -2021,7 +2084,7 @@ __global__ __launch_bounds__(1024) void k_adapt_partials(Params p, uint32_t g, d
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, unit = blockIdx.x;
     const int gcn = 16 * unit + wv;
     int bc = -1, bg = -1;
-    if (gcn < p.N) adapt_bins(p, g, gcn, lane, bc, bg);
+    if (gcn < p.N) adapt_bins(p, g, gcn, lane, bc, bg, p.cr_probs, p.g_probs);
     if (lane == 0) { s_bc[wv] = bc; s_bg[wv] = bg; }
     __syncthreads();
     const int nc = min(16, p.N - 16 * unit), nq = adapt_nq(p);
@@ -2100,13 +2163,22 @@ __global__ __launch_bounds__(1024) void k_adapt_update(Params p, const double* _
 }
 
 // Totals of the units' sums: block = 64 columns (q, j) of the nq d; wave w adds the units of groups w, w + 16, ... (16 units each, in
-// order, all 16 loads in flight), then wave 0 adds the groups in order.  Block 0 also adds the counts (small integers: exact in any order).
+// order, all 16 loads in flight), then wave 0 adds the groups in order.  One more block adds the counts.
 __global__ __launch_bounds__(1024) void k_adapt_totals(Params p, const double* __restrict__ PR, const double* __restrict__ PC, int nunits,
                                                        double* __restrict__ TOT /* [nq][ld] */, double* __restrict__ CNT /* [ncr + ngamma] */)
 {
     extern __shared__ __attribute__((aligned(16))) double s_gs[];       // [groups][64]
-    __shared__ double s_cnt[64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (blockIdx.x == gridDim.x - 1) {       // the last block: the bins' counts (small integers: exact in any order), wave b = bin b, b + 16, ...
+        const int nb = p.ncr + p.ngamma;
+        for (int b = wv; b < nb; b += 16) {
+            double c = 0.0;
+            for (int u = lane; u < nunits; u += 64) c += PC[(size_t)u * nb + b];
+            c = wave_bfly(c);
+            if (lane == 0) CNT[b] = c;
+        }
+        return;
+    }
     const int d = p.d, nq = adapt_nq(p), ncol = nq * d, col = blockIdx.x * 64 + lane;
     const int ngroups = (nunits + 15) / 16;
     const bool on = col < ncol;
@@ -2123,83 +2195,20 @@ __global__ __launch_bounds__(1024) void k_adapt_totals(Params p, const double* _
         for (int i = 0; i < 16; ++i) if (i < nu) gs = gs + v[i];
         s_gs[G * 64 + lane] = gs;
     }
-    if (blockIdx.x == 0 && threadIdx.x < 64) s_cnt[threadIdx.x] = 0.0;
     __syncthreads();
     if (wv == 0 && on) {
         double t = 0.0;
         for (int G = 0; G < ngroups; ++G) t = t + s_gs[G * 64 + lane];
         TOT[(size_t)q * p.ld + j] = t;
     }
-    if (blockIdx.x == 0) {
-        const int nb = p.ncr + p.ngamma;
-        for (int b = 0; b < nb; ++b) {
-            double c = 0.0;
-            for (int u = threadIdx.x; u < nunits; u += 1024) c += PC[(size_t)u * nb + b];
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-            if (lane == 0 && c != 0.0) atomicAdd(&s_cnt[b], c);
-        }
-        __syncthreads();
-        if (threadIdx.x < nb) CNT[threadIdx.x] = s_cnt[threadIdx.x];
-    }
 }
 
-// sd, the weights, the bins' dot products and the new probabilities (:476-493, :522-536) from the totals: one wave.
+// the update on its own (adapt_apply_wave), in place on the engine's current state: behind the multi-kernel path's generations, sharded
+// runs, and whenever totals are still pending when a launch that cannot apply them follows
 template <int NCH>
 __global__ __launch_bounds__(64) void k_adapt_apply(Params p, const double* __restrict__ TOT, const double* __restrict__ CNT)
 {
-    const int lane = threadIdx.x, d = p.d, ld = p.ld;
-    const double invN = (double)p.N;
-    double wc[NCH][2], wg[NCH][2];
-#pragma unroll
-    for (int it = 0; it < NCH; ++it)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int j = 128 * it + 2 * lane + s;
-            wc[it][s] = 0.0; wg[it][s] = 0.0;
-            if (j < d) {
-                const double a = TOT[j] / invN;
-                double var = fma(-a, a, TOT[(size_t)ld + j] / invN);
-                if (!(var > 0.0)) var = 0.0;
-                const double sd = sqrt(var), sdc = sd == 0.0 ? 1e-12 : sd;      // :479 (crossover only)
-                wc[it][s] = 1.0 / (sdc * sdc); wg[it][s] = 1.0 / (sd * sd);
-            }
-        }
-    const int nb = p.ncr + p.ngamma;
-    bool anyc = false, anyg = false;
-    for (int b = 0; b < nb; ++b) {
-        const bool isg = b >= p.ncr; const int m = isg ? b - p.ncr : b;
-        const double cnt = CNT[b];
-        if (!(cnt > 0.0)) continue;                                           // (wave-uniform)
-        const double* D = TOT + (size_t)(2 + b) * ld;
-        double acc = 0.0;
-#pragma unroll
-        for (int it = 0; it < NCH; ++it)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int j = 128 * it + 2 * lane + s;
-                if (j < d) acc = fma(D[j], isg ? wg[it][s] : wc[it][s], acc);
-            }
-        const double tot = nan_to_num(wave_bfly(acc));
-        if (lane == 0) {
-            double* delta = isg ? p.g_delta : p.cr_delta; double* n = isg ? p.g_n : p.cr_n;
-            delta[m] = delta[m] + tot; n[m] += cnt;
-        }
-        if (isg) anyg = true; else anyc = true;
-    }
-    __threadfence_block();
-    if (lane < 2 && (lane ? anyg : anyc)) {     // :487-493 / :531-536
-        const int t = lane;
-        const int nbb = t ? p.ngamma : p.ncr;
-        double* probs = t ? p.g_probs : p.cr_probs; const double* delta = t ? p.g_delta : p.cr_delta; const double* n = t ? p.g_n : p.cr_n;
-        // (lane 0 wrote delta / n above; lane 1 reads the gamma ones: same wave, program order + the fence)
-        bool all = true;
-        for (int m = 0; m < nbb; ++m) if (delta[m] == 0.0) all = false;
-        if (all) {
-            double S = 0.0;
-            for (int m = 0; m < nbb; ++m) { probs[m] = (delta[m] / n[m]) * (double)p.N; S = S + probs[m]; }
-            for (int m = 0; m < nbb; ++m) probs[m] = probs[m] / S;
-        }
-    }
+    adapt_apply_wave<NCH>(p, TOT, CNT, p.cr_probs, nullptr, p.cr_probs, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------

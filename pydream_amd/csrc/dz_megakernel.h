@@ -292,8 +292,12 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     }
     for (int i = threadIdx.x; i < L.rows * L.LDP; i += NT) Pt[i] = 0.0;
     if (threadIdx.x < 4 * ((d + 3) / 4) + 4) mus[threadIdx.x] = threadIdx.x < d ? p.mu[threadIdx.x] : 0.0;
-    if (threadIdx.x < p.ncr) probs[threadIdx.x] = p.cr_probs[threadIdx.x];
-    if (threadIdx.x < p.ngamma) probs[p.ncr + threadIdx.x] = p.g_probs[threadIdx.x];
+    if (pub.TOT) {      // the previous generation's adaptation totals are still to be applied: every block makes the update for itself (wave 0)
+        if (wv == 0) adapt_apply_wave<1>(p, pub.TOT, pub.CNT, pub.sh, probs, blockIdx.x == 0 ? pub.sh_out : nullptr, lane);
+    } else {
+        if (threadIdx.x < p.ncr) probs[threadIdx.x] = pub.sh[threadIdx.x];
+        if (threadIdx.x < p.ngamma) probs[p.ncr + threadIdx.x] = pub.sh[3 * p.ncr + threadIdx.x];
+    }
     for (int i = threadIdx.x; i < p.ngamma * d; i += NT) gts[i] = p.gtab[(size_t)(i / d) * p.depairs * d + (i % d)];
     if (pbl && (int)threadIdx.x < L.pcn) {
         const int j = threadIdx.x;
@@ -552,7 +556,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 // crossover burn-in (one generation per launch): the chain's new and old state go to two dead rows of the point area (the
                 // reference points' tiles), its bins to the rows' pad elements; behind the barrier the block adds its unit's sums
                 int bc, bg;
-                adapt_bins(p, g, (int)gc, lane, bc, bg);
+                adapt_bins(p, g, (int)gc, lane, bc, bg, probs, probs + p.ncr);
                 double* sn = Pt + (size_t)(16 + cl) * L.LDP; double* so = Pt + (size_t)(32 + cl) * L.LDP;
                 if (jj < d) { sn[jj] = xn.x; so[jj] = xo.x; }
                 if (jj + 1 < d) { sn[jj + 1] = xn.y; so[jj + 1] = xo.y; }
@@ -599,6 +603,15 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
     double* lh = rL + k;                                                    // [k][J] mixture component terms; then [8] decisions
     double* dec = lh + (size_t)k * p.J;
     const int nwv = blockDim.x >> 6;
+    // the crossover / gamma-level probabilities the launch decides with: behind the waves' regions; made by wave 0 when the previous
+    // generation's adaptation totals are still to be applied (Publish::TOT)
+    double* probs = smem + (size_t)nwv * mega_mix_wave_doubles(d, k, p.J);
+    if (pub.TOT) { if (wv == 0) adapt_apply_wave<1>(p, pub.TOT, pub.CNT, pub.sh, probs, blockIdx.x == 0 ? pub.sh_out : nullptr, lane); }
+    else {
+        if ((int)threadIdx.x < p.ncr) probs[threadIdx.x] = pub.sh[threadIdx.x];
+        if ((int)threadIdx.x < p.ngamma) probs[p.ncr + threadIdx.x] = pub.sh[3 * p.ncr + threadIdx.x];
+    }
+    __syncthreads();
     const int cg = blockIdx.x * nwv + wv;
     const bool active = cg < p.nl;
     const int c = min(cg, p.nl - 1);
@@ -621,7 +634,7 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
                 const u32x4 w0 = uniform_draw(p, ds, 0, gc, g), w1 = uniform_draw(p, ds, 1, gc, g), w2 = uniform_draw(p, ds, 2, gc, g);
                 u.u_snk = u53(w0.x, w0.y); u.u_cr = u53(w0.z, w0.w); u.u_de = u53(w1.x, w1.y); u.u_glev = u53(w1.z, w1.w);
                 u.u_sel = u53(w2.x, w2.y); u.u_acc = u53(w2.z, w2.w);
-                f = step_flags(p, u);                                               // Dream.py:246-256
+                f = step_flags_from(p, u, probs, probs + p.ncr);                    // Dream.py:246-256
                 if (lane == 0) { dec[0] = u.u_sel; dec[1] = u.u_acc; dec[2] = f.snk ? 1.0 : 0.0; dec[3] = (double)f.cr_idx; dec[4] = (double)f.glev; }
                 base[0][0] = xs[0][0]; base[0][1] = xs[0][1];
             } else {
@@ -731,7 +744,7 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
             lpri = npri; llik = nlik;
             if (pub.PR) {   // crossover burn-in, blocks of 16 chains, k >= 3: new and old state into the chain's (now dead) rows 1 and 2, bins into their pad elements
                 int bc, bg;
-                adapt_bins(p, g, (int)gc, lane, bc, bg);
+                adapt_bins(p, g, (int)gc, lane, bc, bg, probs, probs + p.ncr);
                 double* sn = region + LDP; double* so = region + 2 * LDP;
                 if (jj < d) { sn[jj] = xn.x; so[jj] = xo.x; }
                 if (jj + 1 < d) { sn[jj + 1] = xn.y; so[jj + 1] = xo.y; }

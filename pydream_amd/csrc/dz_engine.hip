@@ -523,8 +523,8 @@ int adapt_flush(dz_engine* e)
 int adapt_finish(dz_engine* e, bool defer)
 {
     const dz::Params& p = e->p;
-    const int nq = 2 + p.ncr + p.ngamma, units = (p.N + 15) / 16, groups = (units + 15) / 16;
-    hipLaunchKernelGGL(dz::k_adapt_totals, dim3((nq * p.d + 63) / 64 + 1), dim3(1024), sizeof(double) * 64 * (size_t)groups, e->stream, p, (const double*)e->d_PR, (const double*)e->d_PC, units, e->d_TOT, e->d_CNT);
+    const int nq = 2 + p.ncr + p.ngamma, units = (p.N + 15) / 16;
+    hipLaunchKernelGGL(dz::k_adapt_totals, dim3((nq * p.d + 15) / 16 + 1), dim3(256), 0, e->stream, (const double*)e->d_PR, (const double*)e->d_PC, units, nq, p.d, p.ld, p.ncr + p.ngamma, e->d_TOT, e->d_CNT);
     DZCK(launch_check("k_adapt_totals"));
     e->adapt_pending = true;
     return defer ? 0 : adapt_flush(e);

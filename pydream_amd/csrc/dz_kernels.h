@@ -2162,45 +2162,51 @@ __global__ __launch_bounds__(1024) void k_adapt_update(Params p, const double* _
     }
 }
 
-// Totals of the units' sums: block = 64 columns (q, j) of the nq d; wave w adds the units of groups w, w + 16, ... (16 units each, in
-// order, all 16 loads in flight), then wave 0 adds the groups in order.  One more block adds the counts.
-__global__ __launch_bounds__(1024) void k_adapt_totals(Params p, const double* __restrict__ PR, const double* __restrict__ PC, int nunits,
-                                                       double* __restrict__ TOT /* [nq][ld] */, double* __restrict__ CNT /* [ncr + ngamma] */)
+// Totals of the units' sums.  Block = 16 columns (q, j) of the nq d (one 128-byte segment of every unit's row: 32 blocks pull the
+// 1 MB of 256 units x 500 columns through 32 CUs' paths to L2); thread (i, column) fetches unit i of every group (16 loads in flight),
+// thread (group, column) adds the group's 16 units in order, thread column adds the groups in order.  One more block adds the counts.
+__global__ __launch_bounds__(256) void k_adapt_totals(const double* __restrict__ PR, const double* __restrict__ PC, int nunits, int nq, int d, int ld, int nb,
+                                                      double* __restrict__ TOT /* [nq][ld] */, double* __restrict__ CNT /* [nb] */)
 {
-    extern __shared__ __attribute__((aligned(16))) double s_gs[];       // [groups][64]
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (blockIdx.x == gridDim.x - 1) {       // the last block: the bins' counts (small integers: exact in any order), wave b = bin b, b + 16, ...
-        const int nb = p.ncr + p.ngamma;
-        for (int b = wv; b < nb; b += 16) {
+    __shared__ double s_v[16][16][17];
+    __shared__ double s_g[16][17];
+    const int tid = threadIdx.x, cl = tid & 15, hi = tid >> 4;
+    if (blockIdx.x == gridDim.x - 1) {       // the bins' counts (small integers: exact in any order): wave w = bins w, w + 4, ...
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int b2 = wv; b2 < nb; b2 += 4) {
             double c = 0.0;
-            for (int u = lane; u < nunits; u += 64) c += PC[(size_t)u * nb + b];
+            for (int u = lane; u < nunits; u += 64) c += PC[(size_t)u * nb + b2];
             c = wave_bfly(c);
-            if (lane == 0) CNT[b] = c;
+            if (lane == 0) CNT[b2] = c;
         }
         return;
     }
-    const int d = p.d, nq = adapt_nq(p), ncol = nq * d, col = blockIdx.x * 64 + lane;
-    const int ngroups = (nunits + 15) / 16;
-    const bool on = col < ncol;
+    const int col = blockIdx.x * 16 + cl;
+    const bool on = col < nq * d;
     const int q = on ? col / d : 0, j = on ? col - q * d : 0;
-    const double* src = PR + (size_t)q * p.ld + j;
-    const size_t ustride = (size_t)nq * p.ld;
-    for (int G = wv; G < ngroups; G += 16) {
-        const int u0 = 16 * G, nu = min(16, nunits - u0);
+    const double* src = PR + (size_t)q * ld + j;
+    const size_t ustride = (size_t)nq * ld;
+    const int ngroups = (nunits + 15) / 16;
+    double t = 0.0;
+    for (int G0 = 0; G0 < ngroups; G0 += 16) {
         double v[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = (on && i < nu) ? src[(size_t)(u0 + i) * ustride] : 0.0;
-        double gs = 0.0;
+        for (int gg = 0; gg < 16; ++gg) { const int u = 16 * (G0 + gg) + hi; v[gg] = (on && u < nunits) ? src[(size_t)u * ustride] : 0.0; }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) if (i < nu) gs = gs + v[i];
-        s_gs[G * 64 + lane] = gs;
+        for (int gg = 0; gg < 16; ++gg) s_v[gg][hi][cl] = v[gg];
+        __syncthreads();
+        {
+            const int nu = min(16, nunits - 16 * (G0 + hi));             // (thread (group hi, column cl))
+            double gs = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) if (i < nu) gs = gs + s_v[hi][i][cl];
+            s_g[hi][cl] = gs;
+        }
+        __syncthreads();
+        if (tid < 16) for (int gg = 0; gg < 16 && G0 + gg < ngroups; ++gg) t = t + s_g[gg][tid];
+        __syncthreads();
     }
-    __syncthreads();
-    if (wv == 0 && on) {
-        double t = 0.0;
-        for (int G = 0; G < ngroups; ++G) t = t + s_gs[G * 64 + lane];
-        TOT[(size_t)q * p.ld + j] = t;
-    }
+    if (tid < 16 && on) TOT[(size_t)q * ld + j] = t;
 }
 
 // the update on its own (adapt_apply_wave), in place on the engine's current state: behind the multi-kernel path's generations, sharded

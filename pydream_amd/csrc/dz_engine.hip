@@ -882,9 +882,10 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         DZCK(upload_params(e));
         int mw = dz::MIXW;
         const size_t lds_probs = sizeof(double) * (size_t)((p.ncr + p.ngamma + 1) & ~1);
-        if (publish && e->adapt_fused && e->world == 1 && p.k >= 3 && sizeof(double) * (size_t)16 * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs <= (size_t)160 * 1024) { mw = 16; fuse_adapt(); }
+        const size_t lds_xo = sizeof(double) * (size_t)16 * (4 * ((p.d + 3) / 4) + 1);
+        if (publish && e->adapt_fused && e->world == 1 && p.k >= 3 && sizeof(double) * (size_t)16 * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs + lds_xo <= (size_t)160 * 1024) { mw = 16; fuse_adapt(); }
         const dim3 gridm((p.nl + mw - 1) / mw), blockm(64 * mw);
-        const size_t ldsm = sizeof(double) * (size_t)mw * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs;
+        const size_t ldsm = sizeof(double) * (size_t)mw * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs + (fused ? lds_xo : 0);
         DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, dz::k_generations_mix, gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, pub);
         DZCK(launch_check("k_generations_mix"));
         launched();
@@ -905,12 +906,16 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
     const bool pb = p.hard || p.have_prior || p.depairs > 1 || mega_redo(e);      // the instantiations with the full proposal code
     const size_t lds = mega_lds_bytes(e, xlds);
     DZCK(upload_params(e));
-    if (publish && e->adapt_fused && e->world == 1 && ch == 16 && wpc == 1 && !k1 && p.k >= 3) fuse_adapt();
+    size_t lds_launch = lds;
+    if (publish && e->adapt_fused && e->world == 1 && ch == 16 && wpc == 1 && !k1 && p.k >= 3 && (pb || xlds)) {      // (the new and old states are read from LDS)
+        const size_t with_xo = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, true, ch, p.pb_lds != 0, true).total;
+        if (with_xo <= (size_t)160 * 1024) { fuse_adapt(); lds_launch = with_xo; }
+    }
     {
         // the instantiations live in one translation unit per row-tile count (dz_mega_tu.hip)
         dz::MegaLaunch ml;
         ml.tri = p.tri != 0; ml.xlds = pb ? true : xlds; ml.pb = pb; ml.k1 = k1; ml.ch = ch; ml.wpc = wpc; ml.redo = mega_redo(e);
-        ml.grid = grid; ml.block = block; ml.lds = lds; ml.st = e->stream; ml.ka = nullptr; ml.kb = nullptr;
+        ml.grid = grid; ml.block = block; ml.lds = lds_launch; ml.st = e->stream; ml.ka = nullptr; ml.kb = nullptr;
         ml.pp = (const dz::Params*)e->d_params; ml.g = g; ml.n = n; ml.M = (uint32_t)visible_rows(e); ml.slot0 = slot0; ml.zappend = append_last ? e->M : (int64_t)-1; ml.publish = &pub;
         if (e->prof) { ml.ka = prof_event(e); ml.kb = prof_event(e); e->ev[PR_GENERATIONS].emplace_back(ml.ka, ml.kb); }
         const char* name = nullptr;

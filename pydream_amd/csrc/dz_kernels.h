@@ -1989,10 +1989,10 @@ DZ_DEV void adapt_bins(const Params& p, uint32_t g, int gcn, int lane, int& binc
 }
 
 // The sums of ONE unit (16 consecutive global chains, nc of them present) by the threads of a block: xn / xp = the chains' new /
-// previous positions, [16][ldx] (LDS or global), bin(isg, c) = chain c's crossover (isg = false) / gamma-level bin or -1.
+// previous positions, [16][ldx] / [16][ldxp] (LDS or global), bin(isg, c) = chain c's crossover (isg = false) / gamma-level bin or -1.
 // Thread (q, j) adds its column's terms in chain order.
 template <class BIN>
-DZ_DEV void adapt_unit_sums(const Params& p, const double* xn, const double* xp, int ldx, int nc, BIN bin, const double* __restrict__ shift,
+DZ_DEV void adapt_unit_sums(const Params& p, const double* xn, int ldx, const double* xp, int ldxp, int nc, BIN bin, const double* __restrict__ shift,
                             double* __restrict__ pr /* [nq][ld] */, double* __restrict__ pc /* [ncr + ngamma] */, int tid, int nthreads)
 {
     const int d = p.d, nq = adapt_nq(p);
@@ -2004,7 +2004,7 @@ DZ_DEV void adapt_unit_sums(const Params& p, const double* xn, const double* xp,
             for (int c = 0; c < nc; ++c) { const double v = xn[(size_t)c * ldx + j] - sj; us = q == 0 ? us + v : fma(v, v, us); }
         } else {
             const int m = q - 2; const bool isg = m >= p.ncr; const int mm = isg ? m - p.ncr : m;
-            for (int c = 0; c < nc; ++c) if (bin(isg, c) == mm) { const double df = xn[(size_t)c * ldx + j] - xp[(size_t)c * ldx + j]; us = fma(df, df, us); }
+            for (int c = 0; c < nc; ++c) if (bin(isg, c) == mm) { const double df = xn[(size_t)c * ldx + j] - xp[(size_t)c * ldxp + j]; us = fma(df, df, us); }
         }
         pr[(size_t)q * p.ld + j] = us;
     }
@@ -2088,7 +2088,7 @@ __global__ __launch_bounds__(1024) void k_adapt_partials(Params p, uint32_t g, d
     if (lane == 0) { s_bc[wv] = bc; s_bg[wv] = bg; }
     __syncthreads();
     const int nc = min(16, p.N - 16 * unit), nq = adapt_nq(p);
-    adapt_unit_sums(p, p.cp_new + (size_t)16 * unit * p.ld, p.cp_prev + (size_t)16 * unit * p.ld, p.ld, nc, [&](bool isg, int c) { return isg ? s_bg[c] : s_bc[c]; }, p.cp_prev,
+    adapt_unit_sums(p, p.cp_new + (size_t)16 * unit * p.ld, p.ld, p.cp_prev + (size_t)16 * unit * p.ld, p.ld, nc, [&](bool isg, int c) { return isg ? s_bg[c] : s_bc[c]; }, p.cp_prev,
                     PR + (size_t)unit * nq * p.ld, PC + (size_t)unit * (p.ncr + p.ngamma), threadIdx.x, 1024);
 }
 

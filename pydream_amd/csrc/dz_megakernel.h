@@ -30,7 +30,7 @@ constexpr int DZ_MAX_REDRAWS_DEV = 64;                                  // == DZ
 constexpr unsigned long long DZ_REDRAW_KEY_STEP_DEV = 0x9E3779B97F4A7C15ull;   // == DZ_REDRAW_KEY_STEP
 constexpr int MEGA_CHAINS = 16;      // chains (= waves) per block at full size; 8 or 4 when there are too few chains to give every CU a block
 
-struct MegaLayout { int LDM, LDP, rows, off_P, off_q, off_sP, off_sS, off_sL, off_rP, off_rS, off_mu, off_pr, off_st, off_dec, off_gt, off_X, off_pc, pcn, total; };
+struct MegaLayout { int LDM, LDP, rows, off_P, off_q, off_sP, off_sS, off_sL, off_rP, off_rS, off_mu, off_pr, off_st, off_dec, off_gt, off_X, off_pc, pcn, off_Xo, total; };
 
 // point rows of a block: try i of chain c at row i*ch + c; tiles are 16 consecutive rows, from row 0 (k tries) or from
 // row ch (the k-1 reference tries); rows past the last point stay zero
@@ -41,7 +41,8 @@ __host__ __device__ inline int mega_rows(int k, int ch)
 }
 // pb: room for the per-dimension prior / boundary constants of the full-code instantiations (PBConsts: five double arrays and one int
 // array of pcn = 16 nrt entries)
-__host__ __device__ inline MegaLayout mega_layout(int d, int k, int nrt, int ncr, int ngamma, bool tri, bool xlds, int ch = MEGA_CHAINS, bool pb = false)
+// xo: room for the chains' states as they were at the start of the launch (crossover burn-in: the block's adaptation sums need the jumps)
+__host__ __device__ inline MegaLayout mega_layout(int d, int k, int nrt, int ncr, int ngamma, bool tri, bool xlds, int ch = MEGA_CHAINS, bool pb = false, bool xo = false)
 {
     MegaLayout L;
     const int ks4 = 4 * ((d + 3) / 4);
@@ -65,6 +66,9 @@ __host__ __device__ inline MegaLayout mega_layout(int d, int k, int nrt, int ncr
     L.total += L.total & 1;
     L.off_pc = L.total; L.pcn = 16 * nrt;
     if (pb) L.total += 5 * L.pcn + L.pcn / 2;
+    L.total += L.total & 1;
+    L.off_Xo = L.total;
+    if (xo) L.total += ch * L.LDP + ((ch * L.LDP) & 1);
     return L;
 }
 
@@ -247,7 +251,8 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int d = p.d, k = K1 ? 1 : p.k, ld = p.ld;
     const bool pbl = PB && p.pb_lds != 0;
-    const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, XLDS, CH, pbl);
+    const bool fuse_adapt = CH == 16 && WPC == 1 && !K1 && XLDS && pub.PR != nullptr;
+    const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, XLDS, CH, pbl, fuse_adapt);
     double* Ms = smem;
     double* Pt = smem + L.off_P;
     double* qb = smem + L.off_q;
@@ -309,7 +314,11 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     }
     if (lane == 0 && sub == 0) { st[4 * cl] = p.lprior[c]; st[4 * cl + 1] = p.llike[c]; st[4 * cl + 2] = 0.0; }
     if (XLDS && sub == 0) {
-        for (int j = lane; j < L.LDP; j += 64) Xs[cl * L.LDP + j] = j < d ? p.X[(size_t)c * ld + j] : 0.0;
+        for (int j = lane; j < L.LDP; j += 64) {
+            const double v = j < d ? p.X[(size_t)c * ld + j] : 0.0;
+            Xs[cl * L.LDP + j] = v;
+            if (fuse_adapt) smem[L.off_Xo + cl * L.LDP + j] = v;
+        }
     }
     __syncthreads();
 
@@ -552,28 +561,23 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 }
             }
             if (lane == 0) { st[4 * cl] = npri; st[4 * cl + 1] = nlik; }
-            if (CH == 16 && WPC == 1 && !K1 && pub.PR) {
-                // crossover burn-in (one generation per launch): the chain's new and old state go to two dead rows of the point area (the
-                // reference points' tiles), its bins to the rows' pad elements; behind the barrier the block adds its unit's sums
-                int bc, bg;
-                adapt_bins(p, g, (int)gc, lane, bc, bg, probs, probs + p.ncr);
-                double* sn = Pt + (size_t)(16 + cl) * L.LDP; double* so = Pt + (size_t)(32 + cl) * L.LDP;
-                if (jj < d) { sn[jj] = xn.x; so[jj] = xo.x; }
-                if (jj + 1 < d) { sn[jj + 1] = xn.y; so[jj + 1] = xo.y; }
-                if (lane == 0) { sn[L.LDP - 1] = (double)bc; so[L.LDP - 1] = (double)bg; }
-            }
-        }
-        if (CH == 16 && WPC == 1 && !K1 && pub.PR) {
-            __syncthreads();
-            const double* sn = Pt + (size_t)16 * L.LDP; const double* so = Pt + (size_t)32 * L.LDP;
-            const int LDPc = L.LDP;
-            adapt_unit_sums(p, sn, so, LDPc, min(16, p.nl - 16 * (int)blockIdx.x), [&](bool isg, int c_) { return (int)(isg ? so : sn)[(size_t)c_ * LDPc + LDPc - 1]; }, pub.shift,
-                            pub.PR + (size_t)blockIdx.x * adapt_nq(p) * p.ld, pub.PC + (size_t)blockIdx.x * (p.ncr + p.ngamma), (int)threadIdx.x, NT);
         }
         DZ_MSTAMP(9);
         // one wave per chain: no barrier here -- the next generation's first phase only touches each wave's own chain's rows
         // and scalars, and the shared q buffer is not written again before the next barrier
         if (WPC > 1) __syncthreads();                                                // the chain's other waves read the new state
+    }
+    // Crossover burn-in (one generation per launch), a block of 16 chains = one unit of the adaptation's column sums (contract v3): the
+    // chains' new states sit in LDS, so do the ones they started the launch with (off_Xo); every wave makes its chain's
+    // bins, then the block adds its unit's sums (adapt_unit_sums).  Kept outside the generation loop: nothing of it lives in registers there.
+    if (fuse_adapt) {
+        int bc, bg;
+        adapt_bins(p, g0, (int)gc, lane, bc, bg, probs, probs + p.ncr);
+        if (lane == 0) { dec[8 * cl + 6] = (double)bc; dec[8 * cl + 7] = (double)bg; }
+        __syncthreads();
+        const int unit = blockIdx.x;
+        adapt_unit_sums(p, Xs, L.LDP, smem + L.off_Xo, L.LDP, min(16, p.nl - 16 * unit), [&](bool isg, int c_) { return (int)dec[8 * c_ + (isg ? 7 : 6)]; }, pub.shift,
+                        pub.PR + (size_t)unit * adapt_nq(p) * ld, pub.PC + (size_t)unit * (p.ncr + p.ngamma), (int)threadIdx.x, NT);
     }
 }
 
@@ -618,6 +622,8 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
     const uint32_t gc = (uint32_t)(p.off + c);
     double xs[NCH][2];                                                      // the chain's state lives in registers
     load_row<NCH>(p.X + (size_t)c * ld, ld, lane, xs);
+    double* xo_area = probs + ((p.ncr + p.ngamma + 1) & ~1);                // (crossover burn-in, blocks of 16: the states the launch started with, [16][LDP])
+    if (pub.PR) { if (2 * lane < d) xo_area[wv * LDP + 2 * lane] = xs[0][0]; if (2 * lane + 1 < d) xo_area[wv * LDP + 2 * lane + 1] = xs[0][1]; }
     double lpri = p.lprior[c], llik = p.llike[c];
     for (int gi = 0; gi < ngen; ++gi) {
         const uint32_t g = g0 + (uint32_t)gi;
@@ -742,22 +748,20 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
                 }
             }
             lpri = npri; llik = nlik;
-            if (pub.PR) {   // crossover burn-in, blocks of 16 chains, k >= 3: new and old state into the chain's (now dead) rows 1 and 2, bins into their pad elements
-                int bc, bg;
-                adapt_bins(p, g, (int)gc, lane, bc, bg, probs, probs + p.ncr);
-                double* sn = region + LDP; double* so = region + 2 * LDP;
-                if (jj < d) { sn[jj] = xn.x; so[jj] = xo.x; }
-                if (jj + 1 < d) { sn[jj + 1] = xn.y; so[jj + 1] = xo.y; }
-                if (lane == 0) { sn[LDP - 1] = (double)bc; so[LDP - 1] = (double)bg; }
-            }
         }
-        if (pub.PR) {       // (block-uniform; one generation per launch)
-            __syncthreads();
-            const int W = mega_mix_wave_doubles(d, k, p.J);
-            const double* sn = smem + LDP; const double* so = smem + 2 * LDP;
-            adapt_unit_sums(p, sn, so, W, min(16, p.nl - 16 * (int)blockIdx.x), [&](bool isg, int c_) { return (int)(isg ? so : sn)[(size_t)c_ * W + LDP - 1]; }, pub.shift,
-                            pub.PR + (size_t)blockIdx.x * adapt_nq(p) * p.ld, pub.PC + (size_t)blockIdx.x * (p.ncr + p.ngamma), (int)threadIdx.x, (int)blockDim.x);
-        }
+    }
+    if (pub.PR) {   // crossover burn-in, blocks of 16 chains (one adaptation unit), k >= 3: the new state into the chain's (dead) row 1, its bins into that row's pad
+        int bc, bg;
+        adapt_bins(p, g0, (int)gc, lane, bc, bg, probs, probs + p.ncr);
+        double* sn = region + LDP;
+        if (2 * lane < d) sn[2 * lane] = xs[0][0];
+        if (2 * lane + 1 < d) sn[2 * lane + 1] = xs[0][1];
+        if (lane == 0) { sn[LDP - 1] = (double)bc; sn[LDP] = (double)bg; }          // (the first element of row 2 is dead as well)
+        __syncthreads();
+        const int W = mega_mix_wave_doubles(d, k, p.J), unit = blockIdx.x;
+        const double* s0 = smem + LDP;
+        adapt_unit_sums(p, s0, W, xo_area, LDP, min(16, p.nl - 16 * unit), [&](bool isg, int c_) { return (int)s0[(size_t)c_ * W + LDP - 1 + (isg ? 1 : 0)]; }, pub.shift,
+                        pub.PR + (size_t)unit * adapt_nq(p) * ld, pub.PC + (size_t)unit * (p.ncr + p.ngamma), (int)threadIdx.x, (int)blockDim.x);
     }
 }
 #endif  // DZ_TEMPLATES_ONLY

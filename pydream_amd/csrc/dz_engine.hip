@@ -142,7 +142,7 @@ struct dz_engine {
     double* d_cp[3] = {nullptr, nullptr, nullptr}; int cp_idx = 1;      // published positions rotate through three buffers (a peer may run one generation ahead)
     // owned device buffers (also referenced from p)
     double *d_mins = nullptr, *d_maxs = nullptr, *d_gtab = nullptr, *d_mu = nullptr, *d_Mt = nullptr, *d_Mtp = nullptr, *d_mixF = nullptr;
-    double *d_pa = nullptr, *d_pb = nullptr, *d_plogb = nullptr; int32_t* d_pkind = nullptr;
+    double *d_pa = nullptr, *d_pb = nullptr, *d_plogb = nullptr, *d_pc2 = nullptr; int32_t* d_pkind = nullptr;
     double *d_shared = nullptr;      // cr_probs|cr_delta|cr_n|g_probs|g_delta|g_n -- two copies: e->p points at the current one (sh_cur); a persistent launch
     int sh_cur = 0;                  // that applies pending adaptation totals in its prologue reads the current copy and leaves the new state in the other
     bool adapt_pending = false;      // d_TOT / d_CNT hold totals that no launch has applied yet (only between two launches inside dz_step)
@@ -792,6 +792,12 @@ void mega_set_pb_lds(dz_engine* e)
 {
     const bool pb = e->p.hard || e->p.have_prior || e->p.depairs > 1 || (redo_possible(e) && e->lk == LK_MVN && e->p.k > 1 && e->mega_redo_on);
     e->p.pb_lds = 0;
+    {   // uniform / flat priors whose supports contain the hard boundaries' box: the log prior of every proposal is one constant
+        bool cst = e->p.have_prior && e->p.prior_nonormal && e->p.hard && !getenv("DZ_PRIOR_CONST_OFF");
+        for (size_t j = 0; cst && j < e->h_pkind.size(); ++j)
+            if (e->h_pkind[j] == 2 && !(j < e->h_mins.size() && e->h_mins[j] >= e->h_pa[j] && e->h_maxs[j] <= e->h_pa[j] + e->h_pb[j])) cst = false;
+        e->p.prior_const = cst ? 1 : 0;
+    }
     if (!pb) return;
     e->p.pb_lds = 1;
     if (mega_lds_bytes(e, true) > (size_t)160 * 1024) e->p.pb_lds = 0;
@@ -1042,7 +1048,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     rc |= ealloc(e, &e->d_mins, ld); rc |= ealloc(e, &e->d_maxs, ld);
     rc |= ealloc(e, &e->d_gtab, (size_t)cfg->ngamma * cfg->depairs * p.d);
     rc |= ealloc(e, &e->d_shared, (size_t)2 * 3 * (cfg->ncr + cfg->ngamma));
-    rc |= ealloc(e, &e->d_pkind, ld); rc |= ealloc(e, &e->d_pa, ld); rc |= ealloc(e, &e->d_pb, ld); rc |= ealloc(e, &e->d_plogb, ld);
+    rc |= ealloc(e, &e->d_pkind, ld); rc |= ealloc(e, &e->d_pa, ld); rc |= ealloc(e, &e->d_pb, ld); rc |= ealloc(e, &e->d_plogb, ld); rc |= ealloc(e, &e->d_pc2, ld);
     if (e->adapt) {
         for (int i = 0; i < 3; ++i) rc |= ealloc(e, &e->d_cp[i], N * ld);
         p.cp_prev = e->d_cp[0]; p.cp_new = e->d_cp[1]; e->cp_idx = 1;
@@ -1063,7 +1069,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     if (rc) { dz_destroy(e); return -1; }
     p.mins = e->d_mins; p.maxs = e->d_maxs; p.gtab = e->d_gtab;
     point_shared(e);
-    p.pkind = e->d_pkind; p.pa = e->d_pa; p.pb = e->d_pb; p.plogb = e->d_plogb; p.have_prior = 0;
+    p.pkind = e->d_pkind; p.pa = e->d_pa; p.pb = e->d_pb; p.plogb = e->d_plogb; p.pc2 = e->d_pc2; p.have_prior = 0; p.prior_nonormal = 1;
     // defaults: unbounded, uniform CR / gamma-level probabilities (Dream.py:134, :143), computed gamma table
     {
         std::vector<double> lo(ld, -HUGE_VAL), hi(ld, HUGE_VAL);
@@ -1202,6 +1208,14 @@ int dz_set_prior(dz_engine* e, const int32_t* kind, const double* a, const doubl
     HIPCK(hipMemcpy(e->d_pkind, kind, sizeof(int32_t) * d, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(e->d_pa, a, sizeof(double) * d, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(e->d_pb, b, sizeof(double) * d, hipMemcpyHostToDevice));
+    {   // Params::pc2: normal: the reciprocal of the scale; uniform: the upper end of the support
+        std::vector<double> c2((size_t)d, 0.0);
+        bool normal = false;
+        for (int j = 0; j < d; ++j) { c2[j] = kind[j] == 1 ? 1.0 / b[j] : (kind[j] == 2 ? a[j] + b[j] : 0.0); normal = normal || kind[j] == 1; }
+        HIPCK(hipMemcpy(e->d_pc2, c2.data(), sizeof(double) * d, hipMemcpyHostToDevice));
+        e->p.prior_nonormal = normal ? 0 : 1;
+        if (const char* kv = getenv("DZ_PRIOR_NONORMAL")) if (!atoi(kv)) e->p.prior_nonormal = 0;      // (measurement: the general butterfly form)
+    }
     hipLaunchKernelGGL(dz::k_prior_consts, dim3((d + 127) / 128), dim3(128), 0, e->stream, (const double*)e->d_pb, d, e->d_plogb);
     DZCK(launch_check("k_prior_consts"));
     e->p.have_prior = any ? 1 : 0;

@@ -33,6 +33,12 @@ struct Params {
     long long tcap;      // trace capacity in generations; tX is CHAIN-major [nl][tcap][ld] (a chain's samples are one block, as run_dream returns them)
     // likelihood / prior
     const int32_t* pkind; const double *pa, *pb, *plogb; int have_prior;      // plogb[j] = dlog(pb[j]), made once by k_prior_consts
+    // pc2[j]: the second constant a prior evaluation needs -- normal (kind 1): 1 / scale (z = (x - loc) pc2: no division per try and
+    // dimension); uniform (kind 2): loc + scale, the upper end of the support.  prior_nonormal: no dimension has a normal prior: the log
+    // prior of a point is either -inf or ONE constant (the sum of -log scale over the uniform dimensions)
+    const double* pc2; int prior_nonormal;
+    int prior_const;     // ... and every uniform support contains the hard boundaries' box: after the boundary handling a proposal is inside every support,
+                         // its log prior is that constant (set by the host per launch: mega_set_pb_lds)
     const double *mu, *Mt; double logF; int tri; int J; const double* mixF;
     // triangular factor, packed for k_logp_mvn_lds: k-row r keeps its first 16*(r/16+1) columns (the row tiles that
     // use it), rows back to back; mtp_len doubles (even)
@@ -329,7 +335,7 @@ DZ_DEV void reduce_rows(const ZRows<NCH>& zr, bool snk, RowTerms<NCH>& rt)
 struct SetConsts { uint32_t thr; unsigned long long pgu_thr; double zeta, ec1, ec0; int npt, slot0; };
 // Per-dimension constants of the priors (SampledParam: kind, loc, scale, log scale) and the hard boundaries, staged in LDS by the
 // persistent kernel's full-code instantiations ([ld] each): a try then costs LDS reads instead of eight dependent global loads.
-struct PBConsts { const double *a, *b, *logb, *lo, *hi; const int* kind; };
+struct PBConsts { const double *a, *b, *logb, *lo, *hi; const int* kind; const double* inside; };      // (b: Params::pc2; inside: the log prior of a point inside every support, one LDS word)
 DZ_DEV SetConsts set_consts(const Params& p, int phase, int cr_idx)
 {
     SetConsts s;
@@ -498,16 +504,17 @@ DZ_DEV double prior_of_point(const Params& p, const double (&x)[NCH][2], int lan
             if (j < p.d) {
                 const int kd = p.pkind[j];
                 double t = 0.0;
-                if (kd == 1) { const double z = (x[it][s] - p.pa[j]) / p.pb[j]; t = (-(z * z) / 2.0 - 0.91893853320467274178) - p.plogb[j]; }
-                else if (kd == 2) t = (x[it][s] >= p.pa[j] && x[it][s] <= p.pa[j] + p.pb[j]) ? -p.plogb[j] : -__builtin_huge_val();
+                if (kd == 1) { const double z = (x[it][s] - p.pa[j]) * p.pc2[j]; t = (-(z * z) / 2.0 - 0.91893853320467274178) - p.plogb[j]; }
+                else if (kd == 2) t = (x[it][s] >= p.pa[j] && x[it][s] <= p.pc2[j]) ? -p.plogb[j] : -__builtin_huge_val();
                 acc = acc + t;
             }
         }
     return wave_bfly(acc);
 }
 DZ_DEV double nan_to_ninf(double x) { return x != x ? -__builtin_huge_val() : x; }
-// ... the same with the constants from LDS (PBConsts) and the point in registers (NCH == 1: the persistent kernels)
-DZ_DEV double prior_of_point_lds(const Params& p, const PBConsts& pc, const double (&x)[1][2], int lane)
+// ... the same with the constants from LDS (PBConsts; b = Params::pc2) and the point in registers (NCH == 1: the persistent kernels).
+// prior_lane_lds: the lane's partial sum (its two dimensions in order); the butterfly over the lanes finishes it.
+DZ_DEV double prior_lane_lds(const Params& p, const PBConsts& pc, const double (&x)[1][2], int lane)
 {
     double acc = 0.0;
 #pragma unroll
@@ -515,14 +522,35 @@ DZ_DEV double prior_of_point_lds(const Params& p, const PBConsts& pc, const doub
         const int j = 2 * lane + s;
         if (j < p.d) {
             const int kd = pc.kind[j];
-            const double a = pc.a[j], b = pc.b[j], lb = pc.logb[j];
+            const double a = pc.a[j], c2 = pc.b[j], lb = pc.logb[j];
             double t = 0.0;
-            if (kd == 1) { const double z = (x[0][s] - a) / b; t = (-(z * z) / 2.0 - 0.91893853320467274178) - lb; }
-            else if (kd == 2) t = (x[0][s] >= a && x[0][s] <= a + b) ? -lb : -__builtin_huge_val();
+            if (kd == 1) { const double z = (x[0][s] - a) * c2; t = (-(z * z) / 2.0 - 0.91893853320467274178) - lb; }
+            else if (kd == 2) t = (x[0][s] >= a && x[0][s] <= c2) ? -lb : -__builtin_huge_val();
             acc = acc + t;
         }
     }
-    return wave_bfly(acc);
+    return acc;
+}
+DZ_DEV double prior_of_point_lds(const Params& p, const PBConsts& pc, const double (&x)[1][2], int lane) { return wave_bfly(prior_lane_lds(p, pc, x, lane)); }
+// No normal prior anywhere (Params::prior_nonormal): a point's log prior is -inf if any uniform dimension is outside its support,
+// else the constant `inside_value` = the same sum with every point inside (made once per launch by the same code) -- a ballot
+// instead of a butterfly per try.
+DZ_DEV double prior_of_point_nonormal(const Params& p, const PBConsts& pc, const double (&x)[1][2], int lane, double inside_value)
+{
+    bool out = false;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int j = 2 * lane + s;
+        if (j < p.d) out = out || (pc.kind[j] == 2 && !(x[0][s] >= pc.a[j] && x[0][s] <= pc.b[j]));
+    }
+    return __any(out) ? -__builtin_huge_val() : inside_value;
+}
+// the log prior of a try of the persistent kernels' full-code instantiations (wave-uniform); pc.inside: see prior_of_point_nonormal
+DZ_DEV double prior_try_lds(const Params& p, const PBConsts& pc, const double (&x)[1][2], int lane)
+{
+    if (p.prior_const) return *pc.inside;
+    if (p.prior_nonormal) return prior_of_point_nonormal(p, pc, x, lane, *pc.inside);
+    return nan_to_ninf(prior_of_point_lds(p, pc, x, lane));
 }
 // Q = q_0 + q_1 + ... in ascending row tile t (the MVN contract, v2) for point `pt` of the scratch array [row tile][npts] the tiled
 // likelihood kernels leave -- what k_q_finish does, for the kernels that take the sums over themselves (Params::qfin_*).  32 loads in
@@ -677,7 +705,7 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
             const double sq = propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, grow, rt, out + (size_t)i * out_stride, csn, snk_, cr_idx, delta_, glev, dsrc, nullptr, nullptr, pc, pv);
             if (prior_out) {
                 double pr = 0.0;
-                if (p.have_prior) { const double (&pv1)[1][2] = reinterpret_cast<const double (&)[1][2]>(pv); pr = nan_to_ninf(prior_of_point_lds(p, *pc, pv1, lane)); }
+                if (p.have_prior) { const double (&pv1)[1][2] = reinterpret_cast<const double (&)[1][2]>(pv); pr = prior_try_lds(p, *pc, pv1, lane); }
                 if (lane == 0) prior_out[i] = pr;
             }
             return sq;

@@ -39,6 +39,9 @@ static const char* launch_one(const MegaLaunch& a)
 template <bool TRI, bool X, bool PB>
 static const char* launch_ch(const MegaLaunch& a)
 {
+#ifdef DZ_TU_FAST      // experiment builds (tools/fastbuild.sh): 16 chains per block, multi-try only -- a fifth of the instantiations
+    return launch_one<TRI, X, 16, 1, PB, false>(a);
+#endif
     if (a.k1) {
         if (a.ch == 16) return launch_one<TRI, X, 16, 1, PB, true>(a);
         if (a.ch == 8) return launch_one<TRI, X, 8, 1, PB, true>(a);

@@ -58,7 +58,7 @@ __host__ __device__ inline MegaLayout mega_layout(int d, int k, int nrt, int ncr
     L.off_rS = L.off_rP + ch * k;
     L.off_mu = L.off_rS + ch * k;
     L.off_pr = L.off_mu + ks4 + 4;               // (mu zero padded to the k-steps) crossover / gamma-level probabilities
-    L.off_st = L.off_pr + ncr + ngamma;          // per chain: lprior, llike, sel|fin
+    L.off_st = L.off_pr + ncr + ngamma + 2 - ((ncr + ngamma) & 1);      // (the offsets behind stay even; one word of the gap: the log prior of a point inside every uniform support, PBConsts::inside) per chain: lprior, llike, sel|fin
     L.off_dec = L.off_st + 4 * ch;      // per chain and generation: u_sel, u_acc, snooker, CR index, gamma level
     L.off_gt = L.off_dec + 8 * ch;      // gamma_arr[level-1][0][:]
     L.off_X = L.off_gt + ngamma * d + (d & 1);   // chain states (XLDS)
@@ -194,6 +194,8 @@ DZ_DEV void propose_de_pf(const Params& p, int phase, uint32_t g, uint32_t M, in
                           double* out, int out_stride, double* sl, double* prior_out, RowPair& A, RowPair& B, RowPair& C, const PBConsts* pc = nullptr)
 {
     const SetConsts sc = set_consts(p, phase, cr_idx);
+    // (the tries' prior butterflies batched three at a time through wave_bfly4 -- lane partial sums kept across a round -- made the
+    //  full-code kernel spill twice as much, 88 -> 180 bytes per lane, and cost 18 %: not kept)
     auto body = [&](int i, const RowPair& R) {
         RowTerms<1> rt;
         rt.a[0][0] = R.a.x - R.b.x; rt.a[0][1] = R.a.y - R.b.y; rt.b[0][0] = 0.0; rt.b[0][1] = 0.0;       // chain_differences :692
@@ -201,7 +203,7 @@ DZ_DEV void propose_de_pf(const Params& p, int phase, uint32_t g, uint32_t M, in
             double pv[1][2];
             propose_point<1, false, LEAN>(p, phase, g, M, c, i, n, lane, xb, grow, rt, out + (size_t)i * out_stride, nullptr, false, cr_idx, 1, glev, ds, nullptr, &sc, pc, pv);
             if (prior_out) {
-                const double pr = p.have_prior ? nan_to_ninf(prior_of_point_lds(p, *pc, pv, lane)) : 0.0;
+                const double pr = p.have_prior ? prior_try_lds(p, *pc, pv, lane) : 0.0;
                 if (lane == 0) prior_out[i] = pr;
             }
             return;
@@ -211,6 +213,17 @@ DZ_DEV void propose_de_pf(const Params& p, int phase, uint32_t g, uint32_t M, in
     };
     const int rs = sc.slot0 + 1;                          // pt_slot(phase, i, 1) = rs + i npt
     const double* Zb = p.Z; const uint32_t ldb = 8u * (uint32_t)p.ld;
+    if (!LEAN) {      // full code: two row buffers -- the rows of try i + 1 in flight during try i (the caller requested tries i0 and i0 + 1)
+        for (int i = i0; i < i1; i += 2) {
+            body(i, A);
+            if (i + 1 >= i1) break;
+            if (i + 2 < i1) request_pair<XF>(p, ds, rs + (i + 2) * sc.npt, gc, g, M, lane, A, Zb, ldb);
+            body(i + 1, B);
+            if (i + 3 < i1) request_pair<XF>(p, ds, rs + (i + 3) * sc.npt, gc, g, M, lane, B, Zb, ldb);
+        }
+        if (lane >= i0 && lane < i1) sl[lane] = 0.0;
+        return;
+    }
     for (int i = i0; i < i1; i += 3) {
         if (i + 2 < i1) request_pair<XF>(p, ds, rs + (i + 2) * sc.npt, gc, g, M, lane, C, Zb, ldb);
         body(i, A);
@@ -269,6 +282,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
         double* q = smem + L.off_pc;
         pcs.a = q; pcs.b = q + L.pcn; pcs.logb = q + 2 * L.pcn; pcs.lo = q + 3 * L.pcn; pcs.hi = q + 4 * L.pcn;
         pcs.kind = reinterpret_cast<const int*>(q + 5 * L.pcn);
+        pcs.inside = smem + L.off_pr + p.ncr + p.ngamma;
     }
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;       // (scalar: everything derived from the wave number stays on the scalar unit)
     const int cl = WPC == 1 ? wv : wv % CH;                              // chain inside the block
@@ -308,7 +322,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
         const int j = threadIdx.x;
         double* q = smem + L.off_pc;
         const bool hp = p.have_prior && j < d, hb = p.hard && j < d;
-        q[j] = hp ? p.pa[j] : 0.0; q[L.pcn + j] = hp ? p.pb[j] : 1.0; q[2 * L.pcn + j] = hp ? p.plogb[j] : 0.0;
+        q[j] = hp ? p.pa[j] : 0.0; q[L.pcn + j] = hp ? p.pc2[j] : 1.0; q[2 * L.pcn + j] = hp ? p.plogb[j] : 0.0;
         q[3 * L.pcn + j] = hb ? p.mins[j] : -__builtin_huge_val(); q[4 * L.pcn + j] = hb ? p.maxs[j] : __builtin_huge_val();
         reinterpret_cast<int*>(q + 5 * L.pcn)[j] = hp ? p.pkind[j] : 0;
     }
@@ -321,6 +335,16 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
         }
     }
     __syncthreads();
+    if (PB && pbl && p.have_prior && p.prior_nonormal) {      // the log prior of a point inside every uniform support: the sum every such try would make
+        if (wv == 0) {
+            double acc = 0.0;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { const int j = 2 * lane + s; if (j < d) acc = acc + (pcs.kind[j] == 2 ? -pcs.logb[j] : 0.0); }
+            acc = wave_bfly(acc);
+            if (lane == 0) smem[L.off_pr + p.ncr + p.ngamma] = acc;
+        }
+        __syncthreads();
+    }
 
     // A generation's wave-uniform draws: lane s holds slot s (both phases read them; four registers across the likelihood pass are
     // cheaper than a second Philox call).  They are made at the end of the PREVIOUS generation's second proposal phase, together
@@ -328,11 +352,12 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     // (the full-code instantiations read the raw draws: several pairs per try; with one try per generation -- multitry off -- or one or
     //  two tries per wave -- four waves per chain, every one of which would make the pass -- it costs more than it saves: 583 -> 557 M/s
     //  and 320 -> 301 M/s at 1024 chains)
+    // (not in the full-code instantiations: measured there at -2.5 % -- the pass's registers -- with three row buffers, +-0 with two)
     constexpr bool XF = !PB && !K1 && WPC == 1;
     auto generation_draws = [&](uint32_t g_) {
         DrawSrc q; q.have = true; q.mine = make_uint4(0, 0, 0, 0);
         if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g_); q.mine = make_uint4(w.x, w.y, w.z, w.w); }
-        if (XF) {
+        if (XF && !multipair) {
             const uint32_t hx = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.mine.x), hy = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.mine.y);
             finish_draws(p, q, u53_below(hx, hy, p.snk_thr), M, lane);               // (slot 0 = lane 0: set_snooker's draw)
         }
@@ -350,8 +375,13 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
         const u32x4 w0 = uniform_draw(p, q, 0, gc, g_);
         return u53_below(w0.x, w0.y, p.snk_thr);
     };
+    // The full-code instantiations live at the register limit (128 per wave at 16 waves per block: they spill): there the rows of a
+    // phase's first tries are requested at the START of the phase, not a phase ahead -- 16 registers less across the likelihood pass and
+    // the barriers -- and two row buffers rotate instead of three (propose_de_pf).  Measured together: uniform priors + hard boundaries
+    // 508 -> 612 M proposals/s, normal priors 522 -> 572 (spilled registers are reloaded on the generation's critical path).
+    constexpr bool PF_AHEAD = !PB;
     DrawSrc dsn = generation_draws(g0);
-    if (!multipair && !draws_say_snooker(dsn, g0)) prefetch_first(dsn, 0, g0);
+    if (PF_AHEAD && !multipair && !draws_say_snooker(dsn, g0)) prefetch_first(dsn, 0, g0);
 
     for (int gi = 0; gi < ngen; ++gi) {
         const uint32_t g = g0 + (uint32_t)gi;
@@ -444,13 +474,13 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
             };
             for (;;) {
                 if (mine) {
-                    if (REDO && round > 0 && !snk_s && !multipair) prefetch_first(dcur, 0, g);      // (round 0's first rows were requested a phase ahead)
+                    if (((REDO && round > 0) || !PF_AHEAD) && !snk_s && !multipair) prefetch_first(dcur, phase, g);      // (round 0's first rows were requested a phase ahead)
                     propose_range(i0, i1, RA, RB, RC);
-                    if (phase == 0 && round == 0 && !snk_s && !multipair) prefetch_first(ds, 1, g);  // the reference set's first rows, ahead of the likelihood pass
+                    if (PF_AHEAD && phase == 0 && round == 0 && !snk_s && !multipair) prefetch_first(ds, 1, g);  // the reference set's first rows, ahead of the likelihood pass
                 }
                 if (round == 0 && phase == nph - 1 && !last) {                       // the next generation's draws and first rows
                     dsn = generation_draws(g + 1u);
-                    if (!multipair && !draws_say_snooker(dsn, g + 1u)) prefetch_first(dsn, 0, g + 1u);
+                    if (PF_AHEAD && !multipair && !draws_say_snooker(dsn, g + 1u)) prefetch_first(dsn, 0, g + 1u);
                 }
                 DZ_MSTAMP(1 + 4 * phase);
                 __syncthreads();                                                     // points visible
@@ -482,9 +512,11 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                     dcur.rekey = true; dcur.k0 = (uint32_t)key; dcur.k1 = (uint32_t)(key >> 32);
                     dcur.mine = make_uint4(0, 0, 0, 0);
                     if (lane < p.nslots) { const u32x4 w = slot_counter_draw_key(p, lane, gc, g, dcur.k0, dcur.k1); dcur.mine = make_uint4(w.x, w.y, w.z, w.w); }
+                    dcur.xf = false;
+                    if (XF && !multipair) finish_draws(p, dcur, snk_s, M, lane);
                 }
             }
-            if (REDO && phase == 0 && redrew && !snk_s && !multipair) prefetch_first(ds, 1, g);      // (the redraw rounds used the row buffers)
+            if (PF_AHEAD && REDO && phase == 0 && redrew && !snk_s && !multipair) prefetch_first(ds, 1, g);      // (the redraw rounds used the row buffers)
             DZ_MSTAMP(4 + 4 * phase);
         }
         // ---- Metropolis step (:305-347), trace (core.py:114-116), record_history (:919-938)

@@ -17,7 +17,7 @@ for name, k, depairs, prior in (("flat, k=5", 5, 1, None), ("uniform priors + ha
                                 ("DEpairs=3, multitry off", 1, 3, None)):
     if len(sys.argv) > 1 and sys.argv[1] not in name:          # (python tools/variant_rates.py "redraw": that case only, e.g. under rocprofv3)
         continue
-    e = G.Engine(nchains=N, ndim=d, multitry=k, depairs=depairs, hardboundaries=0 if prior == "uniform-open" else 1, history_capacity=len(Z0) + N * (gens // 10 + 30), trace_capacity=0, seed=5)
+    e = G.Engine(nchains=N, ndim=d, multitry=k, depairs=depairs, hardboundaries=0 if prior == "uniform-open" else 1, history_capacity=len(Z0) + N * (gens // 10 + 30), trace_capacity=0, seed=5, snooker=float(os.environ.get("DZ_VR_SNOOKER", "0.1")))
     if depairs > 1:
         e.set_gamma_table(np.array([[2.38 / np.sqrt(2.0 * (dl + 1) * np.arange(1, d + 1)) for dl in range(depairs)]]))
     if prior == "uniform":

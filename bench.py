@@ -576,6 +576,19 @@ def main():
                                "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                                "algorithmic_flops_per_launch": fl,
                                "whole_generation_achieved": whole, "whole_generation_frac": whole / FP64_MFMA_PEAK_TFLOPS}
+            # the other third of a streamed generation, priced as what it is -- HBM traffic: algorithmic bytes / the AVERAGE event-timed
+            # launch (no ramp subtracted).  Per try: base row + the archive rows read, the proposal written = 8d (rows_z + 2); the
+            # Metropolis step's own bytes ride in the launch that carries the next proposal set (k_accept_propose).
+            rows_z = 2 * (1 - args.snooker) + 3 * args.snooker
+            try_b = 8.0 * args.dim * (rows_z + 2.0)
+            others = {}
+            for cls, name, nbytes in (("accept", "k_accept_propose / k_accept (Metropolis step + the next generation's proposal set)", ab["accept"] + n_local * args.multitry * try_b),
+                                      ("propose", "k_propose_stream (reference set)", n_local * (args.multitry - 1) * try_b)):
+                v = prof.get(cls)
+                if v and v["launches"]:
+                    gbps = nbytes / (v["avg_us"] * 1e-6) / 1e9
+                    others[cls] = {"kernel": name, "algorithmic_bytes_per_launch": nbytes, "avg_us": v["avg_us"], "achieved_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBS}
+            out["roofline"]["other_kernels_hbm"] = others
         else:
             achieved = ab[dom] / launch_s / 1e9
             traffic, tsrc = measured_traffic(args, n_local, dom, gens_per_launch)

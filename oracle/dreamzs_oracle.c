@@ -1120,18 +1120,23 @@ int orc_gelman_rubin(const double* tr, int nchains, int nsamples, int d, double*
     int nb = nsamples / 2, n2 = nsamples - nb;
     double* means = zalloc(sizeof(double) * nchains);
     for (int j = 0; j < d; ++j) {
-        double W = 0.0;
+        /* sums over chains (W, the mean of the chain means, B): strips of 64 chains in chain order, then the strips in order -- what lets
+         * the GPU give every strip its own thread (k_rhat) */
+        double W = 0.0, Ws = 0.0;
         for (int c = 0; c < nchains; ++c) {
             const double* x = tr + ((size_t)c * nsamples + nb) * d + j;
             double s = 0.0; for (int t = 0; t < n2; ++t) s = s + x[(size_t)t * d];
             double mean = s / (double)n2; means[c] = mean;
             double v = 0.0; for (int t = 0; t < n2; ++t) { double q = x[(size_t)t * d] - mean; v = v + q * q; }
-            W = W + v / (double)n2;
+            Ws = Ws + v / (double)n2;
+            if ((c & 63) == 63 || c == nchains - 1) { W = W + Ws; Ws = 0.0; }
         }
         W = W / (double)nchains;
-        double mm = 0.0; for (int c = 0; c < nchains; ++c) mm = mm + means[c];
+        double mm = 0.0;
+        for (int s = 0; s < nchains; s += 64) { double ps = 0.0; for (int c = s; c < nchains && c < s + 64; ++c) ps = ps + means[c]; mm = mm + ps; }
         mm = mm / (double)nchains;
-        double B = 0.0; for (int c = 0; c < nchains; ++c) { double q = means[c] - mm; B = B + q * q; }
+        double B = 0.0;
+        for (int s = 0; s < nchains; s += 64) { double ps = 0.0; for (int c = s; c < nchains && c < s + 64; ++c) { double q = means[c] - mm; ps = ps + q * q; } B = B + ps; }
         B = B / (double)nchains;
         double var_est = W * (1.0 - 1.0 / (double)nsamples) + B;
         rhat[j] = sqrt(var_est / W);

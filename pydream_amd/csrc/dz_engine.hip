@@ -1852,7 +1852,7 @@ int dz_get_rhat(dz_engine* e, double* rhat)
     HIPCK(hipSetDevice(e->c.device));
     DZCK(chain_moments(e));
     const dz::Params& p = e->p;
-    hipLaunchKernelGGL(dz::k_rhat, dim3((p.d + 127) / 128), dim3(128), 0, e->stream, e->d_cmean, e->d_cvar, p.nl, p.d, (int)e->ntrace, e->d_rhat);
+    hipLaunchKernelGGL(dz::k_rhat, dim3((p.d + 15) / 16), dim3(1024), sizeof(double) * 16 * (size_t)((p.nl + 63) / 64), e->stream, e->d_cmean, e->d_cvar, p.nl, p.d, (int)e->ntrace, e->d_rhat);
     DZCK(launch_check("rhat"));
     DZCK(sync_all(e));
     HIPCK(hipMemcpy(rhat, e->d_rhat, sizeof(double) * p.d, hipMemcpyDeviceToHost));

@@ -2260,16 +2260,37 @@ __global__ void k_chain_moments(const double* __restrict__ tX, int nl, int d, in
     const double v = strided_sum<2>(x, (size_t)ld, n2, m);
     mean[(size_t)c * d + j] = m; var[(size_t)c * d + j] = v / (double)n2;
 }
-__global__ void k_rhat(const double* __restrict__ mean, const double* __restrict__ var, int nch, int d, int nsamples, double* __restrict__ rhat)
+// block = 16 dimensions x 64 strip slots: thread (dimension, slot) adds the strips slot, slot + 64, ... of 64 chains each (in chain order),
+// then thread (dimension, 0) adds the strips in order -- W, the mean of the chain means, B in three such passes (round 3's form: one
+// thread per dimension walking all chains three times, two waves for the whole job)
+__global__ __launch_bounds__(1024) void k_rhat(const double* __restrict__ mean, const double* __restrict__ var, int nch, int d, int nsamples, double* __restrict__ rhat)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= d) return;
-    double W = strided_sum<0>(var + j, (size_t)d, nch, 0.0), mm = strided_sum<0>(mean + j, (size_t)d, nch, 0.0);
-    W = W / (double)nch; mm = mm / (double)nch;
-    double B = strided_sum<2>(mean + j, (size_t)d, nch, mm);
-    B = B / (double)nch;
-    const double var_est = W * (1.0 - 1.0 / (double)nsamples) + B;
-    rhat[j] = sqrt(var_est / W);
+    extern __shared__ __attribute__((aligned(16))) double sp[];            // [strips][16]
+    __shared__ double s_mm[16];
+    const int jl = threadIdx.x & 15, slot = threadIdx.x >> 4, j = blockIdx.x * 16 + jl;
+    const bool on = j < d;
+    const int ns = (nch + 63) / 64;
+    auto strips = [&](const double* src, int mode, double m) {
+        for (int s = slot; s < ns; s += 64) {
+            const int n = min(64, nch - 64 * s);
+            const double* q = src + (size_t)64 * s * d + j;
+            sp[s * 16 + jl] = !on ? 0.0 : (mode == 0 ? strided_sum<0>(q, (size_t)d, n, 0.0) : strided_sum<2>(q, (size_t)d, n, m));
+        }
+        __syncthreads();
+        double t = 0.0;
+        if (slot == 0) for (int s = 0; s < ns; ++s) t = t + sp[s * 16 + jl];
+        __syncthreads();
+        return t;
+    };
+    const double W = strips(var, 0, 0.0) / (double)nch;
+    const double mm = strips(mean, 0, 0.0) / (double)nch;
+    if (slot == 0) s_mm[jl] = mm;
+    __syncthreads();
+    const double B = strips(mean, 2, s_mm[jl]) / (double)nch;
+    if (slot == 0 && on) {
+        const double var_est = W * (1.0 - 1.0 / (double)nsamples) + B;
+        rhat[j] = sqrt(var_est / W);
+    }
 }
 #endif  // DZ_TEMPLATES_ONLY
 

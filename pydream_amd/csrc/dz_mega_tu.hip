@@ -39,7 +39,8 @@ static const char* launch_one(const MegaLaunch& a)
 template <bool TRI, bool X, bool PB>
 static const char* launch_ch(const MegaLaunch& a)
 {
-#ifdef DZ_TU_FAST      // experiment builds (tools/fastbuild.sh): 16 chains per block, multi-try only -- a fifth of the instantiations
+#ifdef DZ_TU_FAST      // experiment builds (tools/fastbuild.sh): multi-try only, 16 chains per block or 4 x 4 waves -- a third of the instantiations
+    if (a.ch == 4) return launch_one<TRI, X, 4, 4, PB, false>(a);
     return launch_one<TRI, X, 16, 1, PB, false>(a);
 #endif
     if (a.k1) {

@@ -454,3 +454,118 @@ def test_rccl_next_to_the_engines_hip_runtime_in_bench_load_order():
     hip, rccl = line[1], line[3]
     assert os.path.dirname(os.path.realpath(hip)) == os.path.dirname(os.path.realpath(rccl)) and "torch" not in rccl, line
     assert "equal: True" in res.stdout
+
+
+def test_socket_group_wire_format_round_trips_and_names_no_code():
+    """The control plane's values (None, ints beyond 64 bits, floats, bytes, text, arrays, nested lists / tuples) survive the tagged framing;
+    anything else is refused at the sender, an unknown tag or a bad length at the receiver -- nothing on the wire can name code (the
+    advisor's finding against pickle)."""
+    from pydream_amd.distributed import _decode, _encode
+    vals = [None, True, 7, -2 ** 70, 1.5, b"\x00\xff", "hé", [1, (2.0, None), b"x"], (np.arange(6.0).reshape(2, 3), np.ones(3, np.uint8)), np.zeros((0, 4))]
+    for v in vals:
+        buf = bytearray(); _encode(v, buf)
+        out, pos = _decode(bytes(buf))
+        assert pos == len(buf)
+        if isinstance(v, np.ndarray):
+            assert out.dtype == v.dtype and out.shape == v.shape and np.array_equal(out, v)
+        elif isinstance(v, tuple) and isinstance(v[0], np.ndarray):
+            assert all(np.array_equal(a, b) for a, b in zip(out, v)) and isinstance(out, tuple)
+        else:
+            assert out == v and type(out) is type(v)
+    with pytest.raises(TypeError):
+        _encode(object(), bytearray())
+    with pytest.raises(TypeError):
+        _encode(np.array(["a"]), bytearray())
+    with pytest.raises(ValueError):
+        _decode(b"Z")
+    with pytest.raises(ValueError):
+        _decode(b"B" + (10 ** 6).to_bytes(8, "little") + b"ab")
+    import pickle
+    with pytest.raises(ValueError):
+        _decode(pickle.dumps([1, 2, 3]))
+
+
+def _sg_rank(rank, world, port, token, q):
+    sys.path.insert(0, ROOT)
+    from pydream_amd.distributed import SocketGroup
+    g = SocketGroup(rank, world, "127.0.0.1", port, timeout=30.0, token=token)
+    q.put((rank, g.all_gather_object("r%d" % rank), g.all_reduce_max([float(rank)])))
+    g.close()
+
+
+def test_socket_group_seats_only_ranks_that_know_the_token():
+    """Rank 0 listens on loopback; a stranger (wrong token), a rank number out of range and a second claimant of a seated rank are dropped, the
+    collective then completes with the real ranks; a non-loopback address is refused outright."""
+    import multiprocessing as mp
+    import socket as S
+    import struct
+    from pydream_amd.distributed import SocketGroup, new_token
+    with pytest.raises(ValueError):
+        SocketGroup(0, 2, "0.0.0.0", 1, token=new_token())
+    port, token = _free_port(), new_token()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    hub = ctx.Process(target=_sg_rank, args=(0, 3, port, token, q)); hub.start()
+    time.sleep(0.5)
+
+    def knock(rank, tok):
+        c = S.create_connection(("127.0.0.1", port), timeout=5.0)
+        c.sendall(b"DZRDV1" + struct.pack("<i", rank) + tok)
+        c.settimeout(3.0)
+        try:
+            return c.recv(1)
+        except OSError:
+            return b""
+        finally:
+            c.close()
+    assert knock(1, bytes(32)) == b""                               # wrong token
+    assert knock(7, bytes.fromhex(token)) == b""                    # rank out of range
+    others = [ctx.Process(target=_sg_rank, args=(r, 3, port, token, q)) for r in (1, 2)]
+    for pr in others:
+        pr.start()
+    res = sorted(q.get(timeout=60) for _ in range(3))
+    for pr in [hub] + others:
+        pr.join(30); assert pr.exitcode == 0
+    assert [r[1] for r in res] == [["r0", "r1", "r2"]] * 3 and [r[2] for r in res] == [[2.0]] * 3
+
+
+_GATE_TIMEOUT_RANK = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from pydream_amd import _capi
+from pydream_amd.distributed import attach_transport, socket_group_from_env
+from tests import helpers as H
+rank, world = int(os.environ["RANK"]), 2
+group = socket_group_from_env(timeout=60.0)
+d, N = 16, 16
+Z0 = H.seed_history(64, d, 4)
+e = _capi.Engine(nchains=N, nchains_local=N // 2, chain_offset=rank * (N // 2), ndim=d, multitry=5, history_capacity=64 + N * 8, trace_capacity=40, seed=5, history_thin=5)
+e.set_history(Z0); e.set_state(Z0[rank * (N // 2):(rank + 1) * (N // 2)]); e.set_likelihood_mvn(np.zeros(d), H.mvn_precision(d), 0, 0.0)
+attach_transport(e, rank, world, transport="peer", group=group)
+if rank == 1:                       # this rank never steps: its rows never arrive
+    time.sleep(8.0)
+    os._exit(0)
+t0 = time.time()
+try:
+    for _ in range(40):
+        e.step(1); e.sync()
+    print("NO ERROR", flush=True)
+except _capi.DreamZSError as exc:
+    print("stopped after %.1f s: %s" % (time.time() - t0, exc), flush=True)
+os._exit(0)
+"""
+
+
+@pytest.mark.gpu
+def test_a_peer_gate_that_times_out_stops_the_run(tmp_path):
+    """A rank whose peer never delivers its rows does not sample an archive with holes in it: the gate kernel gives up after
+    DZ_PEER_TIMEOUT_S, and from then on dz_step queues nothing and every synchronising call fails, naming the silent rank (advisor,
+    round 3: the time-out used to be recorded and found at the end of the run, if at all)."""
+    import subprocess
+    port = str(_free_port())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DZ_PEER_TIMEOUT_S="2", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    procs = [subprocess.Popen([sys.executable, "-c", _GATE_TIMEOUT_RANK, ROOT], cwd=str(tmp_path), env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [pr.communicate(timeout=120) for pr in procs]
+    assert "stopped after" in outs[0][0] and "rank 1" in outs[0][0] and "NO ERROR" not in outs[0][0], outs[0]

@@ -586,3 +586,40 @@ def test_c5_shard_512_chains_1000d_against_oracle(G, O, monkeypatch):
     for other in out[:2]:
         assert_traces_identical(other[0], out[2][0])
         np.testing.assert_array_equal(other[1], out[2][1])
+
+
+@pytest.mark.parametrize("variant", ["flat", "uniform_bounds", "normal", "unfused", "dense"])
+def test_crossover_burnin_at_4096_chains_against_oracle(G, O, variant, monkeypatch):
+    """The crossover burn-in at the headline size (4096 chains x 100-D MVN, 16 chains per block): the persistent kernel makes its
+    block's unit sums of the adaptation (reduction contract v3: DESIGN.md section 5) and applies the previous generation's totals in its
+    prologue (round 4) -- 45 generations with the burn-in ending inside them (the hand-over at generation 30, then whole thin-cycles per
+    launch) equal the oracle bit for bit, adapted probabilities and accumulators included; with uniform priors + hard boundaries (the log
+    prior is one constant there), with normal priors (reciprocal scale), with the sums made by k_adapt_partials instead
+    (DZ_ADAPT_FUSED=0) and with the dense matrix (chain states in HBM: no fused sums)."""
+    if variant == "unfused":
+        monkeypatch.setenv("DZ_ADAPT_FUSED", "0")
+    N, d, n, seed = 4096, 100, 45, 31
+    P = H.mvn_precision(d)
+    U = np.linalg.cholesky((P + P.T) / 2).T
+    Z0 = H.seed_history(2 * N, d, 6)
+    out = []
+    for Cls in (G.Engine, O.Engine):
+        e = Cls(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
+                adapt_crossover=1, crossover_burnin=30)
+        if variant == "uniform_bounds":
+            e.set_prior(np.full(d, 2, np.int32), np.full(d, -10.0), np.full(d, 30.0)); e.set_bounds(np.full(d, -10.0), np.full(d, 20.0))
+        elif variant == "normal":
+            e.set_prior(np.full(d, 1, np.int32), np.linspace(-1.0, 1.0, d), np.linspace(20.0, 40.0, d))
+        e.set_history(Z0); e.set_state(Z0[:N])
+        if variant == "dense":
+            e.set_likelihood_mvn(np.zeros(d), P, 0, 0.0)
+        else:
+            e.set_likelihood_mvn(np.zeros(d), U, 1, 0.0)
+        e.step(n)
+        out.append((e.get_trace(0, n), e.get_cr_state(), e.get_history(), e.last_kernel_variant() if Cls is G.Engine else ""))
+    assert_traces_identical(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    assert not np.allclose(out[0][1][0], 1 / 3.) and out[0][3].startswith("k_generations<7,")
+    assert ("full" in out[0][3]) == (variant in ("uniform_bounds", "normal"))

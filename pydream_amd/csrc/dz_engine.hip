@@ -807,7 +807,7 @@ bool mega_xlds(const dz_engine* e) { return mega_lds_bytes(e, true) <= (size_t)1
 bool mega_mix_eligible(const dz_engine* e)
 {
     const dz::Params& p = e->p;
-    return e->mega && !p.Tc && e->lk == LK_MIX && !redo_possible(e) && !p.hard && !p.have_prior && p.ld <= 128 && (p.k == 1 || p.k >= 3) && p.k <= dz::MAXK && p.depairs == 1 &&
+    return e->mega && e->lk == LK_MIX && !redo_possible(e) && !p.hard && !p.have_prior && p.ld <= 128 && (p.k == 1 || p.k >= 3) && p.k <= dz::MAXK && p.depairs == 1 &&
            p.nslots <= 64 && p.J <= 32;
 }
 // redraw rounds inside the persistent kernel: the instantiations with the full proposal code, multi-try, device MVN likelihood
@@ -819,7 +819,7 @@ bool mega_eligible(dz_engine* e)
     if (redo_possible(e) && !mega_redo(e)) return false;
     if (mega_mix_eligible(e)) return true;
     if ((p.hard || p.have_prior || p.depairs > 1 || mega_redo(e)) && !mega_xlds(e)) return false;      // (the full-code instantiations keep the states in LDS)
-    return e->mega && !p.Tc && e->lk == LK_MVN && p.ld <= 128 && (p.k == 1 || p.k >= 3) && p.k <= dz::MAXK &&
+    return e->mega && e->lk == LK_MVN && p.ld <= 128 && (p.k == 1 || p.k >= 3) && p.k <= dz::MAXK &&
            p.nslots <= 64 && (!p.tri || p.Mtp) && mega_lds_bytes(e, false) <= (size_t)160 * 1024;
 }
 // number of generations, starting at g, that one launch may cover: none of them publishes positions
@@ -844,6 +844,7 @@ int mega_segment(const dz_engine* e, uint32_t g, int64_t remaining)
 {
     // crossover burn-in: the positions are published and the probabilities adapted after every generation -- one generation per launch
     if (publishing(e, g)) return (e->mega_burnin && remaining > 0) ? 1 : 0;
+    if (e->tempering) return remaining > 0 ? 1 : 0;       // parallel tempering: a temperature swap follows every generation (core.py:185-221)
     int n = 0;
     for (uint32_t gg = g; n < remaining && n < e->mega_max_gen; ++gg) {
         if (publishing(e, gg)) break;
@@ -866,6 +867,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         DZCK(exchange_rows(e, XK_POS, p.cp_new, 0));
     }
     if (publish) { e->cp_idx = (e->cp_idx + 1) % 3; p.cp_prev = p.cp_new; p.cp_new = e->d_cp[e->cp_idx]; }
+    const int64_t slot0 = e->c.trace_capacity ? e->ntrace : -1;
     dz::Publish pub; pub.to = publish ? p.cp_new : nullptr; pub.shift = nullptr; pub.PR = nullptr; pub.PC = nullptr;
     pub.sh = p.cr_probs; pub.sh_out = nullptr; pub.TOT = nullptr; pub.CNT = nullptr;
     const bool applies = e->adapt_pending;      // the previous generation's adaptation totals: applied by this launch's prologue, new state into the other copy
@@ -877,13 +879,16 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
     auto after_launch = [&]() -> int {      // end of the generation(s): positions -> adaptation -> history append (schedule S2)
         if (publish) { DZCK(exchange_rows(e, XK_POS, p.cp_new, 0)); DZCK(adapt_generation(e, g, 0, p.N, fused, mega_follows)); }
         if (append_last) { DZCK(exchange_rows(e, XK_Z, p.Z, (size_t)e->M)); e->M += p.N; e->napp += 1; }
+        if (e->tempering) {          // (then n == 1) the temperature swap: after every chain's step and the updates above, as on the multi-kernel path
+            NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_pt_swap<NCH>, dim3(1), dim3(64), 0, e->stream, p, g, slot0, publish ? 1 : 0));
+            DZCK(launch_check("k_pt_swap"));
+        }
         e->need_join = true;
         e->draws_gen = -1;
         e->gen = (int64_t)g + n;
         for (auto& gcv : e->gen_c) gcv = e->gen;
         return 0;
     };
-    const int64_t slot0 = e->c.trace_capacity ? e->ntrace : -1;
     if (e->lk == LK_MIX) {
         DZCK(upload_params(e));
         int mw = dz::MIXW;

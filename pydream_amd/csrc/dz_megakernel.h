@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
         q[3 * L.pcn + j] = hb ? p.mins[j] : -__builtin_huge_val(); q[4 * L.pcn + j] = hb ? p.maxs[j] : __builtin_huge_val();
         reinterpret_cast<int*>(q + 5 * L.pcn)[j] = hp ? p.pkind[j] : 0;
     }
-    if (lane == 0 && sub == 0) { st[4 * cl] = p.lprior[c]; st[4 * cl + 1] = p.llike[c]; st[4 * cl + 2] = 0.0; }
+    if (lane == 0 && sub == 0) { st[4 * cl] = p.lprior[c]; st[4 * cl + 1] = p.llike[c]; st[4 * cl + 2] = 0.0; dec[8 * cl + 7] = chain_T(p, c); }      // (the chain's temperature: Dream.astep's T, core.py:133-136)
     if (XLDS && sub == 0) {
         for (int j = lane; j < L.LDP; j += 64) {
             const double v = j < d ? p.X[(size_t)c * ld + j] : 0.0;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                     for (int t = 0; t < NRT; ++t) Q = Q + qt[t];
                     const double lk = nan_to_ninf(p.logF - 0.5 * Q);
                     if (sub == 0) sL[cl * k + lane] = lk;
-                    lp = sP[cl * k + lane] + p.T * lk;
+                    lp = sP[cl * k + lane] + dec[8 * cl + 7] * lk;
                 }
                 bool fin;
                 DZ_MSTAMP(11);
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                     double Q = 0.0;
 #pragma unroll
                     for (int t = 0; t < NRT; ++t) Q = Q + qb[pt * NRT + t];
-                    lpv = sP[cl * k + lane] + p.T * nan_to_ninf(p.logF - 0.5 * Q);
+                    lpv = sP[cl * k + lane] + dec[8 * cl + 7] * nan_to_ninf(p.logF - 0.5 * Q);
                 }
                 const bool need = __any(lane < k && is_finite(lpv)) == 0 && round < DZ_MAX_REDRAWS_DEV;
                 if (!__syncthreads_or(need ? 1 : 0)) break;
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
             const double u_acc = dc[1];
             const bool snk = dc[2] != 0.0;
             const int cr_idx = (int)dc[3];
-            const double lpri = st[4 * cl], llik = st[4 * cl + 1];
+            const double lpri = st[4 * cl], llik = st[4 * cl + 1], Tch = dec[8 * cl + 7];
             const int sf = (int)st[4 * cl + 2]; const int sel = sf & 255; const bool fin = (sf & 256) != 0;
             double val = -__builtin_huge_val();
             if (K1) {                                                           // single try: the proposal's density straight from the q sums (:271-275)
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 val = nan_to_ninf(p.logF - 0.5 * Q);                                 // (every lane: the same sums)
                 sL[cl] = val;
             } else if (lane < k) {
-                val = sP[cl * k + lane] + p.T * sL[cl * k + lane];                                       // :279
+                val = sP[cl * k + lane] + Tch * sL[cl * k + lane];                                       // :279
                 if (snk) val = val + sS[cl * k + lane];                                                  // :307
             } else if (lane >= 16 && lane < 16 + k) {
                 const int i = lane - 16;
@@ -550,14 +550,14 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                     double Q = 0.0;
 #pragma unroll
                     for (int t = 0; t < NRT; ++t) Q = Q + qt[t];
-                    val = p.T * nan_to_ninf(p.logF - 0.5 * Q) + rP[cl * (k - 1) + i];                     // :303
-                } else val = p.T * llik + lpri;                                                          // :877-879
+                    val = Tch * nan_to_ninf(p.logF - 0.5 * Q) + rP[cl * (k - 1) + i];                     // :303
+                } else val = Tch * llik + lpri;                                                          // :877-879
                 if (snk) { const double sr = i < k - 1 ? rS[cl * (k - 1) + i] : 0.0; val = (val + sr) + sS[cl * k + i]; }   // :312-313
             }
             DZ_MSTAMP(14);
             double lu, ratio;
             if (K1) {
-                const double q_logp = p.T * val + sP[cl], last_logp = p.T * llik + lpri;                 // :274, :243
+                const double q_logp = Tch * val + sP[cl], last_logp = Tch * llik + lpri;                 // :274, :243
                 if (snk) ratio = nan_to_num((q_logp + sS[cl]) - (last_logp + st[4 * cl + 3]));           // :326-332
                 else ratio = nan_to_num(q_logp) - nan_to_num(last_logp);                                 // :334
                 lu = dlog(u_acc);
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 if (lane == 0) {
                     if (trace_slot0 >= 0) {
                         const size_t o = (size_t)(trace_slot0 + gi) * p.nl + c;
-                        p.tlogp[o] = nlik + npri;                                    // core.py:115
+                        p.tlogp[o] = Tch * nlik + npri;                              // core.py:115; with a temperature ladder core.py:178 (1.0 * x == x)
                         p.tmoved[o] = moved ? 1 : 0; p.ttry[o] = sel; p.tcr[o] = cr_idx; p.tsnk[o] = snk ? 1 : 0;
                     }
                     if (last) { p.lprior[c] = npri; p.llike[c] = nlik; }
@@ -605,10 +605,10 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     if (fuse_adapt) {
         int bc, bg;
         adapt_bins(p, g0, (int)gc, lane, bc, bg, probs, probs + p.ncr);
-        if (lane == 0) { dec[8 * cl + 6] = (double)bc; dec[8 * cl + 7] = (double)bg; }
+        if (lane == 0) { st[4 * cl + 3] = (double)bc; dec[8 * cl + 6] = (double)bg; }      // (st[.. + 3] is the multitry-off kernels' word; dec[.. + 7] holds the temperature)
         __syncthreads();
         const int unit = blockIdx.x;
-        adapt_unit_sums(p, Xs, L.LDP, smem + L.off_Xo, L.LDP, min(16, p.nl - 16 * unit), [&](bool isg, int c_) { return (int)dec[8 * c_ + (isg ? 7 : 6)]; }, pub.shift,
+        adapt_unit_sums(p, Xs, L.LDP, smem + L.off_Xo, L.LDP, min(16, p.nl - 16 * unit), [&](bool isg, int c_) { return (int)(isg ? dec[8 * c_ + 6] : st[4 * c_ + 3]); }, pub.shift,
                         pub.PR + (size_t)unit * adapt_nq(p) * ld, pub.PC + (size_t)unit * (p.ncr + p.ngamma), (int)threadIdx.x, NT);
     }
 }
@@ -657,6 +657,7 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
     double* xo_area = probs + ((p.ncr + p.ngamma + 1) & ~1);                // (crossover burn-in, blocks of 16: the states the launch started with, [16][LDP])
     if (pub.PR) { if (2 * lane < d) xo_area[wv * LDP + 2 * lane] = xs[0][0]; if (2 * lane + 1 < d) xo_area[wv * LDP + 2 * lane + 1] = xs[0][1]; }
     double lpri = p.lprior[c], llik = p.llike[c];
+    if (lane == 0) dec[6] = chain_T(p, c);                                  // the chain's temperature (Dream.astep's T)
     for (int gi = 0; gi < ngen; ++gi) {
         const uint32_t g = g0 + (uint32_t)gi;
         const bool last = gi == ngen - 1;
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
             } else {
                 f.snk = dec[2] != 0.0; f.cr_idx = (int)dec[3]; f.delta = 1; f.glev = (int)dec[4];
                 double lp = -__builtin_huge_val();
-                if (lane < k) lp = sP[lane] + p.T * sL[lane];                       // :279, mt_choose_proposal_pt :291
+                if (lane < k) lp = sP[lane] + dec[6] * sL[lane];                    // :279, mt_choose_proposal_pt :291
                 sel = mt_select_vals(k, lp, dec[0], lane, &fin);
                 const double* row = region + (size_t)sel * LDP;
                 base[0][0] = 2 * lane < d ? row[2 * lane] : 0.0; base[0][1] = 2 * lane + 1 < d ? row[2 * lane + 1] : 0.0;
@@ -738,16 +739,16 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
             const int cr_idx = (int)dec[3];
             double val = -__builtin_huge_val();
             if (lane < k) {
-                val = sP[lane] + p.T * sL[lane];                                    // :279
+                val = sP[lane] + dec[6] * sL[lane];                                 // :279
                 if (snk) val = val + sS[lane];                                      // :307
             } else if (lane >= 16 && lane < 16 + k) {
                 const int i = lane - 16;
-                val = i < k - 1 ? p.T * rL[i] + 0.0 : p.T * llik + lpri;            // :303, :877-879 (flat priors)
+                val = i < k - 1 ? dec[6] * rL[i] + 0.0 : dec[6] * llik + lpri;      // :303, :877-879 (flat priors)
                 if (snk) { const double sr = i < k - 1 ? rS[i] : 0.0; val = (val + sr) + sS[i]; }   // :312-313
             }
             double lu, ratio;
             if (k == 1) {
-                const double q_logp = p.T * sL[0] + sP[0], last_logp = p.T * llik + lpri;                // :274, :243
+                const double q_logp = dec[6] * sL[0] + sP[0], last_logp = dec[6] * llik + lpri;          // :274, :243
                 if (snk) ratio = nan_to_num((q_logp + sS[0]) - (last_logp + dec[5]));                    // :326-332
                 else ratio = nan_to_num(q_logp) - nan_to_num(last_logp);                                 // :334
                 lu = dlog(u_acc);
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
                 if (lane == 0) {
                     if (trace_slot0 >= 0) {
                         const size_t o = (size_t)(trace_slot0 + gi) * p.nl + c;
-                        p.tlogp[o] = nlik + npri;                                   // core.py:115
+                        p.tlogp[o] = dec[6] * nlik + npri;                          // core.py:115 / :178
                         p.tmoved[o] = moved ? 1 : 0; p.ttry[o] = sel; p.tcr[o] = cr_idx; p.tsnk[o] = snk ? 1 : 0;
                     }
                     if (last) { p.lprior[c] = npri; p.llike[c] = nlik; }

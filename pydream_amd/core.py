@@ -87,7 +87,7 @@ def run_dream(parameters, likelihood, nchains=5, niterations=50000, start=None, 
     return sampled_params, log_ps
 
 
-# ---- engines kept alive between run_dream calls (one per model name) ----
+# ---- the engine kept alive between run_dream calls (the one of the last run that saved its history under a model name) ----
 _parked = {}
 
 
@@ -115,6 +115,8 @@ def _park(pool, step, kwargs, nchains, likelihood):
     old = _parked.pop(name, None)
     if old is not None and old["engine"] is not pool.engine:
         old["engine"].close()
+    while _parked:                          # ONE parked engine per process: a parked archive is gigabytes of HBM that only a restart under
+        _parked.popitem()[1]["engine"].close()      # its own model name would use again
     if Dream_shared_vars.engine is pool.engine:
         Dream_shared_vars.engine = None
     try:

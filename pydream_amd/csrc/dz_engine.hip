@@ -168,6 +168,7 @@ struct dz_engine {
     bool mega = true;               // the persistent generation kernel serves every eligible configuration (mega_eligible); DZ_MEGA=0 forces the multi-kernel path
     bool mega_redo_on = true;       // redraw rounds (Dream.py:281-289) inside the persistent kernel; DZ_MEGA_REDO=0: such configurations take the multi-kernel path
     unsigned long long* d_redraw_count = nullptr;
+    bool mega_mix_pb = true;        // the mixture kernel's full-code instantiation (priors, boundaries, several pairs); DZ_MEGA_MIX_PB=0: multi-kernel path there
     bool mega_burnin = true;        // ... the generations of the crossover burn-in too, one per launch (positions published by the kernel); DZ_MEGA_BURNIN=0: multi-kernel path there
     int mega_max_gen = 1 << 20;     // DZ_MEGA_MAXGEN: generations per launch cap (measurement)
     int mega_ch = 0;                // DZ_MEGA_CHAINS: force 16 / 8 / 4 chains per block (0: by chain count)
@@ -807,7 +808,8 @@ bool mega_xlds(const dz_engine* e) { return mega_lds_bytes(e, true) <= (size_t)1
 bool mega_mix_eligible(const dz_engine* e)
 {
     const dz::Params& p = e->p;
-    return e->mega && e->lk == LK_MIX && !redo_possible(e) && !p.hard && !p.have_prior && p.ld <= 128 && (p.k == 1 || p.k >= 3) && p.k <= dz::MAXK && p.depairs == 1 &&
+    const bool pbm = p.hard || p.have_prior || p.depairs > 1;
+    return e->mega && e->lk == LK_MIX && !redo_possible(e) && (!pbm || e->mega_mix_pb) && p.ld <= 128 && (p.k == 1 || p.k >= 3) && p.k <= dz::MAXK &&
            p.nslots <= 64 && p.J <= 32;
 }
 // redraw rounds inside the persistent kernel: the instantiations with the full proposal code, multi-try, device MVN likelihood
@@ -897,10 +899,12 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         if (publish && e->adapt_fused && e->world == 1 && p.k >= 3 && sizeof(double) * (size_t)16 * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs + lds_xo <= (size_t)160 * 1024) { mw = 16; fuse_adapt(); }
         const dim3 gridm((p.nl + mw - 1) / mw), blockm(64 * mw);
         const size_t ldsm = sizeof(double) * (size_t)mw * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs + (fused ? lds_xo : 0);
-        DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, dz::k_generations_mix, gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, pub);
+        const bool pbm = p.hard || p.have_prior || p.depairs > 1;
+        if (pbm) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, dz::k_generations_mix<true>, gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, pub);
+        else DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, dz::k_generations_mix<false>, gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, pub);
         DZCK(launch_check("k_generations_mix"));
         launched();
-        e->last_variant = "k_generations_mix";
+        e->last_variant = pbm ? "k_generations_mix<full>" : "k_generations_mix";
         DZCK(after_launch());
         if (slot0 >= 0) e->ntrace += n;
         return 0;
@@ -989,6 +993,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     if (const char* kv = getenv("DZ_MEGA_BURNIN")) e->mega_burnin = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_REDO")) e->mega_redo_on = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_ADAPT_FUSED")) e->adapt_fused = atoi(kv) != 0;
+    if (const char* kv = getenv("DZ_MEGA_MIX_PB")) e->mega_mix_pb = atoi(kv) != 0;
     static_assert(dz::DZ_MAX_REDRAWS_DEV == DZ_MAX_REDRAWS && dz::DZ_REDRAW_KEY_STEP_DEV == DZ_REDRAW_KEY_STEP, "redraw constants");
     if (const char* kv = getenv("DZ_QFIN")) e->q_defer = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_FUSE_STREAM")) e->fuse_stream = atoi(kv) != 0;

@@ -622,9 +622,12 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int MIXW = 4;       // waves (= chains) per block
 
-__host__ __device__ inline int mega_mix_wave_doubles(int d, int k, int J) { return k * (4 * ((d + 3) / 4) + 1) + 5 * k + k * J + 8 + (k & 1); }
+__host__ __device__ inline int mega_mix_wave_doubles(int d, int k, int J) { const int n = k * (4 * ((d + 3) / 4) + 1) + 6 * k + k * J + 8; return n + (n & 1); }
 
 // (blocks of MIXW waves; blocks of 16 -- one adaptation unit -- inside the crossover burn-in, where the block adds its unit's sums)
+// PB (round 4): per-dimension priors, hard boundaries, several DE pairs -- the full proposal code and the prior evaluation (constants from
+// global memory: this kernel has no block-wide staging); the flat, unbounded, one-pair case keeps the lean instantiation.
+template <bool PB>
 __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int64_t zappend, Publish pub)
 {
     double* const publish = pub.to;
@@ -638,6 +641,7 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
     double* sP = region + (size_t)k * LDP; double* sS = sP + k; double* sL = sS + k; double* rS = sL + k; double* rL = rS + k;
     double* lh = rL + k;                                                    // [k][J] mixture component terms; then [8] decisions
     double* dec = lh + (size_t)k * p.J;
+    double* rP = dec + 8;                                                   // [k] (PB) log priors of the reference points
     const int nwv = blockDim.x >> 6;
     // the crossover / gamma-level probabilities the launch decides with: behind the waves' regions; made by wave 0 when the previous
     // generation's adaptation totals are still to be applied (Publish::TOT)
@@ -674,10 +678,10 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
                 u.u_snk = u53(w0.x, w0.y); u.u_cr = u53(w0.z, w0.w); u.u_de = u53(w1.x, w1.y); u.u_glev = u53(w1.z, w1.w);
                 u.u_sel = u53(w2.x, w2.y); u.u_acc = u53(w2.z, w2.w);
                 f = step_flags_from(p, u, probs, probs + p.ncr);                    // Dream.py:246-256
-                if (lane == 0) { dec[0] = u.u_sel; dec[1] = u.u_acc; dec[2] = f.snk ? 1.0 : 0.0; dec[3] = (double)f.cr_idx; dec[4] = (double)f.glev; }
+                if (lane == 0) { dec[0] = u.u_sel; dec[1] = u.u_acc; dec[2] = f.snk ? 1.0 : 0.0; dec[3] = (double)f.cr_idx; dec[4] = (double)f.glev; if (PB) dec[7] = (double)f.delta; }
                 base[0][0] = xs[0][0]; base[0][1] = xs[0][1];
             } else {
-                f.snk = dec[2] != 0.0; f.cr_idx = (int)dec[3]; f.delta = 1; f.glev = (int)dec[4];
+                f.snk = dec[2] != 0.0; f.cr_idx = (int)dec[3]; f.delta = PB ? (int)dec[7] : 1; f.glev = (int)dec[4];
                 double lp = -__builtin_huge_val();
                 if (lane < k) lp = sP[lane] + dec[6] * sL[lane];                    // :279, mt_choose_proposal_pt :291
                 sel = mt_select_vals(k, lp, dec[0], lane, &fin);
@@ -686,11 +690,13 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
                 if (2 * lane < d) region[2 * lane] = base[0][0];                    // the selected proposal now sits in row 0
                 if (2 * lane + 1 < d) region[2 * lane + 1] = base[0][1];
             }
-            const double* grow = gamma_row(p, f.glev, 1);
+            const double* grow = gamma_row(p, f.glev, PB ? f.delta : 1);
             const int n = k - phase;
             double* rows = region + (size_t)phase * LDP;
-            propose_set<NCH, false, false, 2>(p, phase, g, M, c, gc, 0, n, n, lane, base, grow, f.snk, f.cr_idx, 1, f.glev, ds,
-                                              rows, LDP, (phase ? rS : sS), (k == 1 ? dec + 5 : nullptr), (phase ? lh : sP));   // (flat priors: in phase 1 the prior slot is scratch)
+            if (PB) propose_set<NCH, false, true, 0>(p, phase, g, M, c, gc, 0, n, n, lane, base, grow, f.snk, f.cr_idx, f.delta, f.glev, ds,
+                                                     rows, LDP, (phase ? rS : sS), (k == 1 ? dec + 5 : nullptr), (phase ? rP : sP));
+            else propose_set<NCH, false, false, 2>(p, phase, g, M, c, gc, 0, n, n, lane, base, grow, f.snk, f.cr_idx, 1, f.glev, ds,
+                                                   rows, LDP, (phase ? rS : sS), (k == 1 ? dec + 5 : nullptr), (phase ? lh : sP));   // (flat priors: in phase 1 the prior slot is scratch)
             // mt_evaluate_logps :278, :302 -- by this wave, for its own points.  The squared distances to the J means need the
             // whole wave (one butterfly each); the log-sum-exp of a point is scalar work, so lane i does it for point i and
             // the n points cost one pass of exp / log instead of n (same operations per point as k_logp_mix).
@@ -743,7 +749,7 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
                 if (snk) val = val + sS[lane];                                      // :307
             } else if (lane >= 16 && lane < 16 + k) {
                 const int i = lane - 16;
-                val = i < k - 1 ? dec[6] * rL[i] + 0.0 : dec[6] * llik + lpri;      // :303, :877-879 (flat priors)
+                val = i < k - 1 ? dec[6] * rL[i] + (PB ? rP[i] : 0.0) : dec[6] * llik + lpri;      // :303, :877-879
                 if (snk) { const double sr = i < k - 1 ? rS[i] : 0.0; val = (val + sr) + sS[i]; }   // :312-313
             }
             double lu, ratio;

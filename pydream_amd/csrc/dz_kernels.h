@@ -761,6 +761,18 @@ DZ_DEV void propose_set(const Params& p, int phase, uint32_t g, uint32_t M, int 
             // (unconditional: after the last try the same rows are requested again and never used -- a conditional request makes
             //  the compiler keep the old and the new rows apart and copy one set into the other every try)
             request(min(i + 1, i1 - 1));
+            if (NCH == 1 && !LEAN && pc) {      // constants through PBConsts: the prior on the values in registers (no read-back of the row)
+                double pv[NCH][2];
+                propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, grow, rt, out + (size_t)i * out_stride, csn, false, cr_idx, 1, glev, dsrc,
+                                               AHEAD ? &wcur : nullptr, nullptr, pc, pv);
+                if (lane == 0) sl[i] = 0.0;
+                if (prior_out) {
+                    double pr = 0.0;
+                    if (p.have_prior) { const double (&pv1)[1][2] = reinterpret_cast<const double (&)[1][2]>(pv); pr = prior_try_lds(p, *pc, pv1, lane); }
+                    if (lane == 0) prior_out[i] = pr;
+                }
+                continue;
+            }
             propose_point<NCH, AL16, LEAN>(p, phase, g, M, c, i, n, lane, xb, grow, rt, out + (size_t)i * out_stride, csn, false, cr_idx, 1, glev, dsrc,
                                            AHEAD ? &wcur : nullptr);
             if (lane == 0) sl[i] = 0.0;

@@ -662,6 +662,18 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
     if (pub.PR) { if (2 * lane < d) xo_area[wv * LDP + 2 * lane] = xs[0][0]; if (2 * lane + 1 < d) xo_area[wv * LDP + 2 * lane + 1] = xs[0][1]; }
     double lpri = p.lprior[c], llik = p.llike[c];
     if (lane == 0) dec[6] = chain_T(p, c);                                  // the chain's temperature (Dream.astep's T)
+    // (PB) the prior / boundary constants straight from global memory through the PBConsts interface of the block-staged kernels: the prior
+    // is evaluated on the values in registers, and where the supports contain the boundaries' box (Params::prior_const) it is one constant --
+    // made here by the wave itself, kept in the word of rP the reference set never uses
+    PBConsts pcs;
+    pcs.a = p.pa; pcs.b = p.pc2; pcs.logb = p.plogb; pcs.lo = p.mins; pcs.hi = p.maxs; pcs.kind = p.pkind; pcs.inside = rP + (k - 1);
+    if (PB && p.have_prior && p.prior_nonormal) {
+        double acc = 0.0;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) { const int j = 2 * lane + s2; if (j < d) acc = acc + (p.pkind[j] == 2 ? -p.plogb[j] : 0.0); }
+        acc = wave_bfly(acc);
+        if (lane == 0) rP[k - 1] = acc;
+    }
     for (int gi = 0; gi < ngen; ++gi) {
         const uint32_t g = g0 + (uint32_t)gi;
         const bool last = gi == ngen - 1;
@@ -694,7 +706,7 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
             const int n = k - phase;
             double* rows = region + (size_t)phase * LDP;
             if (PB) propose_set<NCH, false, true, 0>(p, phase, g, M, c, gc, 0, n, n, lane, base, grow, f.snk, f.cr_idx, f.delta, f.glev, ds,
-                                                     rows, LDP, (phase ? rS : sS), (k == 1 ? dec + 5 : nullptr), (phase ? rP : sP));
+                                                     rows, LDP, (phase ? rS : sS), (k == 1 ? dec + 5 : nullptr), (phase ? rP : sP), &pcs);
             else propose_set<NCH, false, false, 2>(p, phase, g, M, c, gc, 0, n, n, lane, base, grow, f.snk, f.cr_idx, 1, f.glev, ds,
                                                    rows, LDP, (phase ? rS : sS), (k == 1 ? dec + 5 : nullptr), (phase ? lh : sP));   // (flat priors: in phase 1 the prior slot is scratch)
             // mt_evaluate_logps :278, :302 -- by this wave, for its own points.  The squared distances to the J means need the

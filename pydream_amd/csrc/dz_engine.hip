@@ -774,13 +774,19 @@ int mega_chains(const dz_engine* e)
     // a block of 8 chains needs 0.67 and one of 4 chains (four waves per chain) 0.49 of the time of a block of 16.  The
     // smallest product wins, the larger block on a tie: 4096 chains -> 16, 3072 -> 16 (192 CUs at full speed beat 384 blocks
     // of 8 in two rounds: 431 vs 333 M proposals/s), 2048 -> 8, 1024 -> 4.
+    // ... among the block sizes whose LDS layout fits at all (round 4): at 113..128 dimensions the point tiles of 16 chains no longer fit
+    // next to the matrix, those of 8 do -- 4096 chains x 128-D ran the multi-kernel path at 300 M proposals/s for want of that
     const int ncu = e->num_cu > 0 ? e->num_cu : 1;
     const double cost[3] = {1.0, 0.67, 0.49};
-    int best = dz::MEGA_CHAINS; double tb = 0.0;
+    const dz::Params& p = e->p;
+    const bool need_x = p.hard || p.have_prior || p.depairs > 1;          // (the full-code instantiations keep the states in LDS)
+    int best = dz::MEGA_CHAINS; double tb = -1.0;
     for (int i = 0, ch = dz::MEGA_CHAINS; i < 3; ++i, ch >>= 1) {
-        const int blocks = (e->p.nl + ch - 1) / ch, rounds = (blocks + ncu - 1) / ncu;
+        const size_t lds = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, p.tri != 0, need_x, ch, need_x && p.pb_lds != 0).total;
+        if (lds > (size_t)160 * 1024) continue;
+        const int blocks = (p.nl + ch - 1) / ch, rounds = (blocks + ncu - 1) / ncu;
         const double t = rounds * cost[i];
-        if (i == 0 || t < tb - 1e-9) { best = ch; tb = t; }
+        if (tb < 0.0 || t < tb - 1e-9) { best = ch; tb = t; }
     }
     return best;
 }

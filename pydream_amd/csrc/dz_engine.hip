@@ -169,6 +169,7 @@ struct dz_engine {
     bool mega_redo_on = true;       // redraw rounds (Dream.py:281-289) inside the persistent kernel; DZ_MEGA_REDO=0: such configurations take the multi-kernel path
     unsigned long long* d_redraw_count = nullptr;
     bool mega_mix_pb = true;        // the mixture kernel's full-code instantiation (priors, boundaries, several pairs); DZ_MEGA_MIX_PB=0: multi-kernel path there
+    bool mega_split = true;         // a remainder of chains beyond whole rounds of 16-chain blocks goes in a second launch of smaller blocks; DZ_MEGA_SPLIT=0: off
     bool mega_burnin = true;        // ... the generations of the crossover burn-in too, one per launch (positions published by the kernel); DZ_MEGA_BURNIN=0: multi-kernel path there
     int mega_max_gen = 1 << 20;     // DZ_MEGA_MAXGEN: generations per launch cap (measurement)
     int mega_ch = 0;                // DZ_MEGA_CHAINS: force 16 / 8 / 4 chains per block (0: by chain count)
@@ -877,7 +878,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
     if (publish) { e->cp_idx = (e->cp_idx + 1) % 3; p.cp_prev = p.cp_new; p.cp_new = e->d_cp[e->cp_idx]; }
     const int64_t slot0 = e->c.trace_capacity ? e->ntrace : -1;
     dz::Publish pub; pub.to = publish ? p.cp_new : nullptr; pub.shift = nullptr; pub.PR = nullptr; pub.PC = nullptr;
-    pub.sh = p.cr_probs; pub.sh_out = nullptr; pub.TOT = nullptr; pub.CNT = nullptr;
+    pub.sh = p.cr_probs; pub.sh_out = nullptr; pub.TOT = nullptr; pub.CNT = nullptr; pub.c0 = 0; pub.c1 = p.nl;
     const bool applies = e->adapt_pending;      // the previous generation's adaptation totals: applied by this launch's prologue, new state into the other copy
     if (applies) { pub.TOT = e->d_TOT; pub.CNT = e->d_CNT; pub.sh_out = e->d_shared + (size_t)(e->sh_cur ^ 1) * 3 * (p.ncr + p.ngamma); }
     auto launched = [&]() { if (applies) { e->sh_cur ^= 1; point_shared(e); e->adapt_pending = false; } };
@@ -921,23 +922,36 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
     // side (1024 chains: 238 -> 249 M proposals/s, 512: 120 -> 131); at 8 chains per block two waves per chain lose (405 -> 368).
     // multitry off: one try, one wave per chain whatever the block size
     const bool k1 = p.k == 1;
-    const int wpc = (ch == 4 && !k1) ? 4 : 1;
-    const dim3 grid((p.nl + ch - 1) / ch), block(64 * ch * wpc);
     const bool xlds = mega_xlds(e);
     const bool pb = p.hard || p.have_prior || p.depairs > 1 || mega_redo(e);      // the instantiations with the full proposal code
-    const size_t lds = mega_lds_bytes(e, xlds);
     DZCK(upload_params(e));
-    size_t lds_launch = lds;
-    if (publish && e->adapt_fused && e->world == 1 && ch == 16 && wpc == 1 && !k1 && p.k >= 3 && (pb || xlds)) {      // (the new and old states are read from LDS)
-        const size_t with_xo = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, true, ch, p.pb_lds != 0, true).total;
-        if (with_xo <= (size_t)160 * 1024) { fuse_adapt(); lds_launch = with_xo; }
+    // A generation is ceil(blocks / CUs) rounds of blocks (one block per CU is resident), so a chain count just above a whole number of
+    // rounds -- 5000 chains: 313 blocks of 16 -- pays a whole round for its remainder.  The remainder then goes in a SECOND launch of
+    // smaller blocks (8 chains: 0.67, 4 chains x 4 waves: 0.49 of a 16-chain block's time) when that is cheaper than one more round.
+    int split_c = p.nl, ch_b = 0;
+    if (ch == 16 && !k1 && e->mega_split) {
+        const int ncu = e->num_cu > 0 ? e->num_cu : 1, blocks = (p.nl + 15) / 16;
+        if (blocks > ncu && blocks % ncu != 0) {
+            const int full = (blocks / ncu) * ncu * 16, r = p.nl - full;
+            const double c8 = (double)(((r + 7) / 8 + ncu - 1) / ncu) * 0.67, c4 = (double)(((r + 3) / 4 + ncu - 1) / ncu) * 0.49;
+            if (std::min(c8, c4) < 1.0 - 1e-9) { split_c = full; ch_b = c4 < c8 ? 4 : 8; }
+        }
     }
-    {
+    std::string variant;
+    auto launch_part = [&](int c0, int c1, int chp) -> int {
+        const int wpcp = (chp == 4 && !k1) ? 4 : 1;
+        size_t ldsp = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, pb ? true : xlds, chp, p.pb_lds != 0).total;
+        dz::Publish pp = pub; pp.c0 = c0; pp.c1 = c1;
+        if (split_c != p.nl) { pp.PR = nullptr; pp.PC = nullptr; pp.shift = nullptr; }      // (a split generation's unit sums come from k_adapt_partials)
+        else if (publish && e->adapt_fused && e->world == 1 && chp == 16 && wpcp == 1 && !k1 && p.k >= 3 && (pb || xlds)) {      // (the new and old states are read from LDS)
+            const size_t with_xo = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, true, chp, p.pb_lds != 0, true).total;
+            if (with_xo <= (size_t)160 * 1024) { fuse_adapt(); pp.shift = pub.shift; pp.PR = pub.PR; pp.PC = pub.PC; ldsp = with_xo; }
+        }
         // the instantiations live in one translation unit per row-tile count (dz_mega_tu.hip)
         dz::MegaLaunch ml;
-        ml.tri = p.tri != 0; ml.xlds = pb ? true : xlds; ml.pb = pb; ml.k1 = k1; ml.ch = ch; ml.wpc = wpc; ml.redo = mega_redo(e);
-        ml.grid = grid; ml.block = block; ml.lds = lds_launch; ml.st = e->stream; ml.ka = nullptr; ml.kb = nullptr;
-        ml.pp = (const dz::Params*)e->d_params; ml.g = g; ml.n = n; ml.M = (uint32_t)visible_rows(e); ml.slot0 = slot0; ml.zappend = append_last ? e->M : (int64_t)-1; ml.publish = &pub;
+        ml.tri = p.tri != 0; ml.xlds = pb ? true : xlds; ml.pb = pb; ml.k1 = k1; ml.ch = chp; ml.wpc = wpcp; ml.redo = mega_redo(e);
+        ml.grid = dim3((c1 - c0 + chp - 1) / chp); ml.block = dim3(64 * chp * wpcp); ml.lds = ldsp; ml.st = e->stream; ml.ka = nullptr; ml.kb = nullptr;
+        ml.pp = (const dz::Params*)e->d_params; ml.g = g; ml.n = n; ml.M = (uint32_t)visible_rows(e); ml.slot0 = slot0; ml.zappend = append_last ? e->M : (int64_t)-1; ml.publish = &pp;
         if (e->prof) { ml.ka = prof_event(e); ml.kb = prof_event(e); e->ev[PR_GENERATIONS].emplace_back(ml.ka, ml.kb); }
         const char* name = nullptr;
         switch (nrt) {
@@ -947,9 +961,13 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
             case 7: name = dz::mega_launch_nrt7(ml); break; case 8: name = dz::mega_launch_nrt8(ml); break;
             default: return fail("persistent kernel: ld > 128");
         }
-        char buf[96]; snprintf(buf, sizeof buf, name, ch, wpc);
-        e->last_variant = buf;
-    }
+        char buf[96]; snprintf(buf, sizeof buf, name, chp, wpcp);
+        variant += (variant.empty() ? "" : " + ") + std::string(buf);
+        return 0;
+    };
+    DZCK(launch_part(0, split_c, ch));
+    if (ch_b) DZCK(launch_part(split_c, p.nl, ch_b));
+    e->last_variant = variant;
     DZCK(launch_check("k_generations"));
     launched();
     DZCK(after_launch());
@@ -1000,6 +1018,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     if (const char* kv = getenv("DZ_MEGA_REDO")) e->mega_redo_on = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_ADAPT_FUSED")) e->adapt_fused = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_MIX_PB")) e->mega_mix_pb = atoi(kv) != 0;
+    if (const char* kv = getenv("DZ_MEGA_SPLIT")) e->mega_split = atoi(kv) != 0;
     static_assert(dz::DZ_MAX_REDRAWS_DEV == DZ_MAX_REDRAWS && dz::DZ_REDRAW_KEY_STEP_DEV == DZ_REDRAW_KEY_STEP, "redraw constants");
     if (const char* kv = getenv("DZ_QFIN")) e->q_defer = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_FUSE_STREAM")) e->fuse_stream = atoi(kv) != 0;

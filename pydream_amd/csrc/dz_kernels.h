@@ -77,7 +77,9 @@ struct Params {
 // TOT / CNT: when set, the totals of the PREVIOUS generation's sums, not applied yet: every block makes the update for itself in its
 // prologue (adapt_apply_wave: sd, weights, the bins' dot products, the new probabilities -- the same arithmetic everywhere, so every
 // block decides with the same bits) and block 0 leaves the new state in sh_out (another buffer than sh: blocks start at different times).
-struct Publish { double* to; const double* shift; double* PR; double* PC; const double* sh; double* sh_out; const double* TOT; const double* CNT; };
+// c0: the first local chain of this launch (a generation may be two launches: whole rounds of 16-chain blocks, then the remainder in smaller
+// blocks -- run_mega_segment); the launch's chains end at the engine's nl or, for the first part, at c1.
+struct Publish { double* to; const double* shift; double* PR; double* PC; const double* sh; double* sh_out; const double* TOT; const double* CNT; int c0, c1; };
 
 // per-phase cycle stamps: defined by dz_experiments.h in instrumented builds only (tools/variants.sh), no-ops in the product
 #ifdef DZ_EXPERIMENTS

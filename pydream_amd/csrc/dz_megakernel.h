@@ -287,9 +287,9 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;       // (scalar: everything derived from the wave number stays on the scalar unit)
     const int cl = WPC == 1 ? wv : wv % CH;                              // chain inside the block
     const int sub = WPC == 1 ? 0 : wv / CH;                              // this wave's number among the chain's waves
-    const int cg = blockIdx.x * CH + cl;
-    const bool active = cg < p.nl;
-    const int c = min(cg, p.nl - 1);
+    const int cg = pub.c0 + blockIdx.x * CH + cl;
+    const bool active = cg < pub.c1;
+    const int c = min(cg, pub.c1 - 1);
     const uint32_t gc = (uint32_t)(p.off + c);
     const int tstride = CH * L.LDP;                                      // try i of chain cl: Pt + (CH i + cl) LDP
     // DEpairs > 1 (set_DEpair :571-583, several archive-row pairs per try): served by the PB instantiations, which carry the full
@@ -652,9 +652,9 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
         if ((int)threadIdx.x < p.ngamma) probs[p.ncr + threadIdx.x] = pub.sh[3 * p.ncr + threadIdx.x];
     }
     __syncthreads();
-    const int cg = blockIdx.x * nwv + wv;
-    const bool active = cg < p.nl;
-    const int c = min(cg, p.nl - 1);
+    const int cg = pub.c0 + blockIdx.x * nwv + wv;
+    const bool active = cg < pub.c1;
+    const int c = min(cg, pub.c1 - 1);
     const uint32_t gc = (uint32_t)(p.off + c);
     double xs[NCH][2];                                                      // the chain's state lives in registers
     load_row<NCH>(p.X + (size_t)c * ld, ld, lane, xs);

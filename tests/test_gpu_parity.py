@@ -623,3 +623,26 @@ def test_crossover_burnin_at_4096_chains_against_oracle(G, O, variant, monkeypat
     np.testing.assert_array_equal(out[0][2], out[1][2])
     assert not np.allclose(out[0][1][0], 1 / 3.) and out[0][3].startswith("k_generations<7,")
     assert ("full" in out[0][3]) == (variant in ("uniform_bounds", "normal"))
+
+
+@pytest.mark.parametrize("adapt", [0, 1])
+def test_a_chain_count_just_above_whole_rounds_of_blocks_against_oracle(G, O, adapt):
+    """4196 chains are 263 blocks of 16: one more than the CUs hold at once.  The generation then goes in two launches -- 4096 chains in
+    blocks of 16, the remaining 100 in blocks of 4 chains x 4 waves (run_mega_segment; 5000 chains: 460 -> 574 M proposals/s) -- and
+    still equals the oracle bit for bit, with and without the crossover burn-in (whose unit sums then come from k_adapt_partials)."""
+    N, d, n, seed = 4196, 100, 25, 17
+    P = H.mvn_precision(d)
+    U = np.linalg.cholesky((P + P.T) / 2).T
+    Z0 = H.seed_history(2 * N, d, 8)
+    out = []
+    for Cls in (G.Engine, O.Engine):
+        e = Cls(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
+                adapt_crossover=adapt, crossover_burnin=15 if adapt else 0)
+        e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), U, 1, 0.0)
+        e.step(n)
+        out.append((e.get_trace(0, n), e.get_cr_state(), e.get_history(), e.last_kernel_variant() if Cls is G.Engine else ""))
+    assert_traces_identical(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    assert out[0][3] == "k_generations<7,tri,xlds,16,1,lean> + k_generations<7,tri,xlds,4,4,lean>", out[0][3]

@@ -18,9 +18,10 @@
 // Arithmetic is the multi-kernel path's, function for function (propose_set, mt_select_vals, mt_log_ratio,
 // the MFMA contract), so results are bit-identical to it and to the oracle.
 //
-// Eligibility (checked on the host, everything else runs the multi-kernel path): MVN likelihood, ld <= 128,
-// multitry 1 or >= 3, draw slots <= 64 (priors / hard boundaries / DEpairs > 1: the PB instantiation), no position publishing (i.e. outside
-// the crossover burn-in), LDS budget met.
+// Eligibility (checked on the host, everything else runs the multi-kernel path): MVN likelihood, ld <= 128, multitry 1 or 3..15 (draw
+// slots <= 64), a block size whose LDS layout fits (16, 8 or 4 chains).  Priors / hard boundaries / DEpairs > 1 / redraw rounds: the PB
+// instantiations.  Inside the crossover burn-in and under parallel tempering a launch covers ONE generation (positions published, the
+// block's adaptation sums made, the previous generation's totals applied in the prologue; the swap kernel follows).
 #pragma once
 #include "dz_kernels.h"
 
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
 // The same persistent scheme for a likelihood a single wave evaluates on its own (Gaussian mixture): nothing is shared
 // between the chains of a block, so there are no tiles and no barriers at all -- every wave carries its chain through the
 // generations of the launch independently (its k points in an LDS region it alone touches, its state in registers).
-// Eligibility: flat priors, no bounds, DEpairs = 1, multitry 1 or >= 3, ld <= 128, outside the crossover burn-in.
+// Eligibility: multitry 1 or >= 3, ld <= 128, up to 32 components; priors / boundaries / several pairs run the <true> instantiation.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int MIXW = 4;       // waves (= chains) per block
 

@@ -145,9 +145,13 @@ def _claim_parked(step, kwargs, nchains, niterations, likelihood, tempering):
 
 
 def release_engines():
-    """free the engines kept for run_dream(restart=True) (their archives stay in HBM until then, or until the process ends)"""
+    """free the engine kept for run_dream(restart=True) (its archive stays in HBM until then, or until the process ends)"""
     while _parked:
         _parked.popitem()[1]["engine"].close()
+
+
+import atexit                                   # noqa: E402
+atexit.register(release_engines)                # (a parked engine is destroyed while the HIP runtime is still up, not by a late __del__)
 
 
 def _sample_dream_pt_batched(eng, step, nchains, niterations, verbose):

@@ -116,6 +116,11 @@ int dz_peer_export(dz_engine* e, void* blob /* DZ_PEER_BLOB_BYTES */);
 int dz_peer_attach(dz_engine* e, int32_t rank, int32_t world, const void* blobs /* world x DZ_PEER_BLOB_BYTES */);
 int dz_peer_detach(dz_engine* e);      /* stop using it (e.g. another rank could not attach and all ranks fall back to the same other transport) */
 int dz_exchange_stats(dz_engine* e, int64_t* exchanges, int64_t* gates, double* gate_wait_us);
+/* Bytes this rank has handed to the transport for EACH other rank so far (any transport), by what they were: appended history rows
+ * (record_history, Dream.py:919-945), published positions (set_current_position_arr, Dream.py:424-449) and -- ranks that own whole groups
+ * of 256 chains -- the crossover burn-in's group sums (estimate_crossover_probabilities, Dream.py:451-499: (2 + nCR + ngamma) ld + 16
+ * doubles per group and generation instead of the group's 256 position rows; then the positions travel only once, at generation 0). */
+int dz_exchange_bytes(dz_engine* e, int64_t* history_bytes, int64_t* position_bytes, int64_t* sums_bytes);
 int dz_comm_barrier(dz_engine* e);     /* device-side rendezvous of the ranks (RCCL: a one-element all-gather; peer transport: every rank pushes a flag word to every peer and a gate kernel waits for theirs; then a stream sync) -- the ranks leave it within microseconds of each other, which a timed region of a few hundred microseconds wants in front of it; no transport: a sync */
 
 /* Parallel tempering (core.py:131-236).  T[nchains]: the temperature of every (global) chain -- Dream.astep's T argument

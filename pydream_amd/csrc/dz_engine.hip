@@ -132,9 +132,9 @@ struct dz_engine {
     ncclComm_t comm = nullptr; int rank = 0, world = 1;
     // peer transport (dz_peer_export / dz_peer_attach): the other ranks' archives, position buffers and flag words mapped into this
     // process; rows travel on copy streams (one per peer: xGMI is point to point), never through a kernel
-    struct Peer { double* Z = nullptr; double* cp[3] = {nullptr, nullptr, nullptr}; unsigned long long* flags = nullptr; hipStream_t st = nullptr; };
+    struct Peer { double* Z = nullptr; double* cp[3] = {nullptr, nullptr, nullptr}; double* gs[2] = {nullptr, nullptr}; unsigned long long* flags = nullptr; hipStream_t st = nullptr; };
     std::vector<Peer> peers; bool peer_on = false;
-    unsigned long long* d_flags = nullptr;      // [3][world]: exchange number received from every rank -- [0] history appends, [1] published positions, [2] the attach-time self-test
+    unsigned long long* d_flags = nullptr;      // [4][world]: exchange number received from every rank -- [0] history appends, [1] published positions, [2] the attach-time self-test, [3] adaptation group sums
     unsigned long long* d_seq = nullptr; int64_t seq_cap = 0;     // seq[i] = i: the source of the flag pushes
     unsigned long long* h_gate = nullptr;       // host-mapped: ticks waited, gates passed, error (k_peer_gate)
     hipEvent_t push_ev[8] = {nullptr}; int push_n = 0;
@@ -152,6 +152,12 @@ struct dz_engine {
     // lockstep adaptation, contract v3 (dz_kernels.h adapt_unit_sums): the units' sums [units][nq][ld] and counts [units][ncr + ngamma], their totals
     double *d_PR = nullptr, *d_PC = nullptr, *d_TOT = nullptr, *d_CNT = nullptr;
     bool adapt_fused = true;        // the persistent kernels make their block's unit sums themselves (DZ_ADAPT_FUSED=0: k_adapt_partials does)
+    // sharded crossover burn-in (round 5): a rank that owns whole groups of 256 chains exchanges its groups' sums (dz_kernels.h k_adapt_groups /
+    // k_group_totals) instead of its positions.  d_GS[parity of the generation]: [world][gs_rec] records (two buffers: a peer may be one
+    // generation ahead); d_shift[parity]: global chain 0's position after that generation (the shift of the next one's column sums)
+    bool adapt_groups = false; double* d_GS[2] = {nullptr, nullptr}; double* d_shift[2] = {nullptr, nullptr}; size_t gs_rec = 0; int gs_nbp = 0;
+    int64_t gs_pushed = 0, gs_last_gen = -1;
+    int64_t bytes_z = 0, bytes_pos = 0, bytes_sums = 0;      // bytes this rank has sent to EACH other rank, by kind (dz_exchange_bytes)
     dz::Params* d_params = nullptr;  // device copy of `p` for kernels that take it by pointer
     double *d_scratch = nullptr; size_t scratch_rows = 0;   // debug / eval staging [rows, ld]
     double *d_cmean = nullptr, *d_cvar = nullptr, *d_rhat = nullptr;
@@ -418,7 +424,7 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
     return launch_check("logp kernel");
 }
 
-enum { XK_Z = 0, XK_POS = 1, XK_HELLO = 2, XK_KINDS = 3 };
+enum { XK_Z = 0, XK_POS = 1, XK_HELLO = 2, XK_SUMS = 3, XK_KINDS = 4 };
 double gate_timeout_s()
 {
     // (liveness of the other ranks is the control plane's business; the bound only keeps a kernel from spinning for ever -- a rank with
@@ -428,16 +434,18 @@ double gate_timeout_s()
 }
 // peer transport: this rank's rows of `buf` (global layout [N,ld], rows [off, off+nl) at `row0`) go to every peer's copy of the
 // buffer, each followed by this rank's flag word for exchange number `seq` of that kind
+// (XK_SUMS: `buf` = d_GS[which_cp], this rank's record of gs_rec doubles at rank * gs_rec)
 int peer_push(dz_engine* e, int kind, double* buf, int which_cp, size_t row0, unsigned long long seq)
 {
     if ((int64_t)seq >= e->seq_cap) return fail("peer exchange: sequence capacity exceeded");
     hipEvent_t ev = e->push_ev[e->push_n++ & 7];
     HIPCK(hipEventRecord(ev, e->stream));
-    const size_t first = (row0 + (size_t)e->p.off) * e->p.ld, cnt = (size_t)e->p.nl * e->p.ld;
+    const size_t first = kind == XK_SUMS ? (size_t)e->rank * e->gs_rec : (row0 + (size_t)e->p.off) * e->p.ld;
+    const size_t cnt = kind == XK_SUMS ? e->gs_rec : (size_t)e->p.nl * e->p.ld;
     for (int r = 0; r < e->world; ++r) {
         if (r == e->rank) continue;
         dz_engine::Peer& pr = e->peers[r];
-        double* dst = kind == XK_Z ? pr.Z : pr.cp[which_cp];
+        double* dst = kind == XK_Z ? pr.Z : (kind == XK_SUMS ? pr.gs[which_cp] : pr.cp[which_cp]);
         HIPCK(hipStreamWaitEvent(pr.st, ev, 0));
         if (kind != XK_HELLO) HIPCK(hipMemcpyAsync(dst + first, buf + first, sizeof(double) * cnt, hipMemcpyDeviceToDevice, pr.st));
         HIPCK(hipMemcpyAsync(pr.flags + (size_t)kind * e->world + e->rank, e->d_seq + seq, sizeof(unsigned long long), hipMemcpyDeviceToDevice, pr.st));
@@ -477,15 +485,21 @@ int ensure_visible(dz_engine* e)
 //   RCCL: in-place ncclAllGather on the engine's stream;  host: staged through the exchange callback (tests, gloo);
 //   peer: pushed by the copy engines into the peers' mapped buffers -- history appends are waited for only when their rows become
 //   sampleable (ensure_visible: with history_lag >= 1 a whole thin-cycle later), published positions at once.
-int exchange_rows(dz_engine* e, int kind, double* buf, size_t row0)
+// XK_SUMS (sharded crossover burn-in): buf = d_GS[which], [world][gs_rec]; this rank's record is replicated, waited for at once.
+int exchange_rows(dz_engine* e, int kind, double* buf, size_t row0, int which = 0)
 {
     if (!e->comm && !e->peer_on && e->p.nl == e->p.N) return 0;     // single GPU, no communicator: the kernels wrote the rows in place
     ProfScope ps(e, PR_EXCHANGE);
-    const size_t cnt = (size_t)e->p.nl * e->p.ld;
-    double* base = buf + row0 * e->p.ld;
-    double* mine = base + (size_t)e->p.off * e->p.ld;
+    const size_t cnt = kind == XK_SUMS ? e->gs_rec : (size_t)e->p.nl * e->p.ld;
+    double* base = kind == XK_SUMS ? buf : buf + row0 * e->p.ld;
+    double* mine = kind == XK_SUMS ? buf + (size_t)e->rank * e->gs_rec : base + (size_t)e->p.off * e->p.ld;
+    (kind == XK_Z ? e->bytes_z : kind == XK_SUMS ? e->bytes_sums : e->bytes_pos) += (int64_t)(sizeof(double) * cnt);
     if (e->peer_on) {
         if (kind == XK_Z) { DZCK(peer_push(e, XK_Z, buf, 0, row0, (unsigned long long)(e->z_pushed + 1))); e->z_pushed++; return 0; }
+        if (kind == XK_SUMS) {
+            DZCK(peer_push(e, XK_SUMS, buf, which, 0, (unsigned long long)(e->gs_pushed + 1))); e->gs_pushed++;
+            return peer_gate(e, XK_SUMS, (unsigned long long)e->gs_pushed);
+        }
         DZCK(peer_push(e, XK_POS, buf, e->cp_idx, row0, (unsigned long long)(e->pos_pushed + 1))); e->pos_pushed++;
         return peer_gate(e, XK_POS, (unsigned long long)e->pos_pushed);
     }
@@ -532,6 +546,12 @@ int adapt_finish(dz_engine* e, bool defer)
     return defer ? 0 : adapt_flush(e);
 }
 
+// the row the column sums of generation g are taken around: global chain 0's previous published position (contract v3).  Ranks that exchange
+// group sums instead of positions get it with the records of generation g - 1 (k_group_totals), generation 0's from the start positions
+const double* adapt_shift(const dz_engine* e, uint32_t g)
+{
+    return (e->adapt_groups && g > 0) ? e->d_shift[(g - 1u) & 1u] : e->p.cp_prev;
+}
 // fused = the generation's persistent launch has already left its units' sums in d_PR / d_PC (adapt_unit_sums in its epilogue)
 int adapt_generation(dz_engine* e, uint32_t g, int gc0, int ngc, bool fused = false, bool defer = false)
 {
@@ -541,9 +561,29 @@ int adapt_generation(dz_engine* e, uint32_t g, int gc0, int ngc, bool fused = fa
     // sums the standard deviations need AND the per-bin column sums of squared jumps; their totals; the update.
     // A single chain's update (Dream.astep, schedule S1): the reference's own chain-by-chain form, all rows in row order (numpy's).
     const bool single = ngc != p.N;
+    if (!single && e->adapt_groups) {
+        // sharded, whole groups per rank: own units' sums -> own groups' sums -> every rank's record everywhere -> the totals (the same
+        // additions in the same order as k_adapt_totals makes them from all units: dz_kernels.h)
+        const int units_l = p.nl / 16, gl = p.nl / 256, nq = 2 + p.ncr + p.ngamma, nb = p.ncr + p.ngamma, nbp = e->gs_nbp, par = (int)(g & 1u);
+        if (g > 0 && e->gs_last_gen != (int64_t)g - 1) return fail("sharded adaptation: the previous burn-in generation left no shift row");
+        if (!fused) {
+            hipLaunchKernelGGL(dz::k_adapt_partials, dim3(units_l), dim3(1024), 0, e->stream, p, g, e->d_PR, e->d_PC, p.off / 16, adapt_shift(e, g));
+            DZCK(launch_check("k_adapt_partials"));
+        }
+        hipLaunchKernelGGL(dz::k_adapt_groups, dim3((gl * nq * p.d + gl * nbp + p.ld + 255) / 256), dim3(256), 0, e->stream, (const double*)e->d_PR, (const double*)e->d_PC, units_l, nq, p.d, p.ld, nb, nbp,
+                           (const double*)(p.cp_new + (size_t)p.off * p.ld), e->d_GS[par] + (size_t)e->rank * e->gs_rec);
+        DZCK(launch_check("k_adapt_groups"));
+        DZCK(exchange_rows(e, XK_SUMS, e->d_GS[par], 0, par));
+        hipLaunchKernelGGL(dz::k_group_totals, dim3((nq * p.d + nb + p.ld + 255) / 256), dim3(256), 0, e->stream, (const double*)e->d_GS[par], e->world, e->gs_rec, gl, nq, p.d, p.ld, nb, nbp,
+                           e->d_TOT, e->d_CNT, e->d_shift[par]);
+        DZCK(launch_check("k_group_totals"));
+        e->gs_last_gen = (int64_t)g;
+        e->adapt_pending = true;
+        return defer ? 0 : adapt_flush(e);
+    }
     if (!single) {
         if (!fused) {
-            hipLaunchKernelGGL(dz::k_adapt_partials, dim3((p.N + 15) / 16), dim3(1024), 0, e->stream, p, g, e->d_PR, e->d_PC);
+            hipLaunchKernelGGL(dz::k_adapt_partials, dim3((p.N + 15) / 16), dim3(1024), 0, e->stream, p, g, e->d_PR, e->d_PC, 0, (const double*)nullptr);
             DZCK(launch_check("k_adapt_partials"));
         }
         return adapt_finish(e, defer);
@@ -746,7 +786,7 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
     if (publish || append) {         // shared state changed: the lanes meet before anything reads it
         if (L > 1) DZCK(join_all(e));
         if (publish) {
-            if (full) DZCK(exchange_rows(e, XK_POS, p.cp_new, 0));
+            if (full && !e->adapt_groups) DZCK(exchange_rows(e, XK_POS, p.cp_new, 0));      // (ranks that own whole groups exchange their groups' sums: adapt_generation)
             DZCK(adapt_generation(e, g, full ? 0 : p.off + c0, full ? p.N : nc));
         }
         if (append) { if (full) DZCK(exchange_rows(e, XK_Z, p.Z, (size_t)e->M)); e->M += nrows; e->napp += 1; }
@@ -884,9 +924,12 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
     auto launched = [&]() { if (applies) { e->sh_cur ^= 1; point_shared(e); e->adapt_pending = false; } };
     // crossover burn-in on one GPU: a block of 16 chains is one unit of the adaptation's column sums (contract v3) and makes them itself
     bool fused = false;
-    auto fuse_adapt = [&]() { fused = true; pub.shift = p.cp_prev; pub.PR = e->d_PR; pub.PC = e->d_PC; };
+    auto fuse_adapt = [&]() { fused = true; pub.shift = adapt_shift(e, g); pub.PR = e->d_PR; pub.PC = e->d_PC; };
     auto after_launch = [&]() -> int {      // end of the generation(s): positions -> adaptation -> history append (schedule S2)
-        if (publish) { DZCK(exchange_rows(e, XK_POS, p.cp_new, 0)); DZCK(adapt_generation(e, g, 0, p.N, fused, mega_follows)); }
+        if (publish) {
+            if (!e->adapt_groups) DZCK(exchange_rows(e, XK_POS, p.cp_new, 0));      // (ranks that own whole groups exchange their groups' sums instead: adapt_generation)
+            DZCK(adapt_generation(e, g, 0, p.N, fused, mega_follows));
+        }
         if (append_last) { DZCK(exchange_rows(e, XK_Z, p.Z, (size_t)e->M)); e->M += p.N; e->napp += 1; }
         if (e->tempering) {          // (then n == 1) the temperature swap: after every chain's step and the updates above, as on the multi-kernel path
             NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_pt_swap<NCH>, dim3(1), dim3(64), 0, e->stream, p, g, slot0, publish ? 1 : 0));
@@ -903,7 +946,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         int mw = dz::MIXW;
         const size_t lds_probs = sizeof(double) * (size_t)((p.ncr + p.ngamma + 1) & ~1);
         const size_t lds_xo = sizeof(double) * (size_t)16 * (4 * ((p.d + 3) / 4) + 1);
-        if (publish && e->adapt_fused && e->world == 1 && p.k >= 3 && sizeof(double) * (size_t)16 * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs + lds_xo <= (size_t)160 * 1024) { mw = 16; fuse_adapt(); }
+        if (publish && e->adapt_fused && (e->world == 1 || e->adapt_groups) && p.k >= 3 && sizeof(double) * (size_t)16 * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs + lds_xo <= (size_t)160 * 1024) { mw = 16; fuse_adapt(); }
         const dim3 gridm((p.nl + mw - 1) / mw), blockm(64 * mw);
         const size_t ldsm = sizeof(double) * (size_t)mw * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs + (fused ? lds_xo : 0);
         const bool pbm = p.hard || p.have_prior || p.depairs > 1;
@@ -943,7 +986,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         size_t ldsp = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, pb ? true : xlds, chp, p.pb_lds != 0).total;
         dz::Publish pp = pub; pp.c0 = c0; pp.c1 = c1;
         if (split_c != p.nl) { pp.PR = nullptr; pp.PC = nullptr; pp.shift = nullptr; }      // (a split generation's unit sums come from k_adapt_partials)
-        else if (publish && e->adapt_fused && e->world == 1 && chp == 16 && wpcp == 1 && !k1 && p.k >= 3 && (pb || xlds)) {      // (the new and old states are read from LDS)
+        else if (publish && e->adapt_fused && (e->world == 1 || e->adapt_groups) && chp == 16 && wpcp == 1 && !k1 && p.k >= 3 && (pb || xlds)) {      // (the new and old states are read from LDS)
             const size_t with_xo = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, true, chp, p.pb_lds != 0, true).total;
             if (with_xo <= (size_t)160 * 1024) { fuse_adapt(); pp.shift = pub.shift; pp.PR = pub.PR; pp.PC = pub.PC; ldsp = with_xo; }
         }
@@ -1094,6 +1137,14 @@ int dz_create(const dz_config* cfg, dz_engine** out)
         const size_t nq = 2 + (size_t)cfg->ncr + cfg->ngamma, units = (N + 15) / 16;
         rc |= ealloc(e, &e->d_PR, units * nq * ld); rc |= ealloc(e, &e->d_PC, units * (size_t)(cfg->ncr + cfg->ngamma));
         rc |= ealloc(e, &e->d_TOT, nq * ld); rc |= ealloc(e, &e->d_CNT, (size_t)(cfg->ncr + cfg->ngamma));
+        // sharded, and this rank owns whole groups of 256 chains (then every rank does: equal shards): the burn-in exchanges group sums
+        const bool groups_on = !(getenv("DZ_ADAPT_GROUPS") && atoi(getenv("DZ_ADAPT_GROUPS")) == 0);
+        if (e->world > 1 && groups_on && p.off % 256 == 0 && p.nl % 256 == 0) {
+            e->adapt_groups = true;
+            e->gs_nbp = (cfg->ncr + cfg->ngamma + 15) / 16 * 16;
+            e->gs_rec = (size_t)(p.nl / 256) * (nq * ld + (size_t)e->gs_nbp) + ld;
+            for (int i = 0; i < 2; ++i) { rc |= ealloc(e, &e->d_GS[i], (size_t)e->world * e->gs_rec); rc |= ealloc(e, &e->d_shift[i], ld); }
+        }
     }
     if (tc) {
         p.tcap = (long long)tc;
@@ -1141,6 +1192,7 @@ int dz_destroy(dz_engine* e)
         if (pr.Z) (void)hipIpcCloseMemHandle(pr.Z);
         if (pr.flags) (void)hipIpcCloseMemHandle(pr.flags);
         for (double* q : pr.cp) if (q) (void)hipIpcCloseMemHandle(q);
+        for (double* q : pr.gs) if (q) (void)hipIpcCloseMemHandle(q);
     }
     for (hipEvent_t x : e->push_ev) if (x) (void)hipEventDestroy(x);
     if (e->h_gate) (void)hipHostFree(e->h_gate);
@@ -1350,7 +1402,7 @@ int dz_set_exchange(dz_engine* e, dz_exchange_cb cb, void* user) { e->xcb = cb; 
 namespace {
 struct PeerBlob {          // what a rank publishes about itself (DZ_PEER_BLOB_BYTES)
     uint32_t magic, nchains, nchains_local, ld; int64_t capacity; int32_t has_cp, rank;
-    hipIpcMemHandle_t z, flags, cp[3];
+    hipIpcMemHandle_t z, flags, cp[3], gs[2];      // (has_cp: 1 = position buffers, 3 = ... and the group-sum records of the sharded burn-in)
 };
 static_assert(sizeof(PeerBlob) <= DZ_PEER_BLOB_BYTES, "PeerBlob does not fit DZ_PEER_BLOB_BYTES");
 }  // namespace
@@ -1386,10 +1438,11 @@ int dz_peer_export(dz_engine* e, void* blob)
     }
     PeerBlob b; memset(&b, 0, sizeof b);
     b.magic = 0x445a5058u; b.nchains = (uint32_t)e->p.N; b.nchains_local = (uint32_t)e->p.nl; b.ld = (uint32_t)e->p.ld; b.capacity = e->c.history_capacity;
-    b.has_cp = e->adapt ? 1 : 0; b.rank = e->rank;
+    b.has_cp = e->adapt ? (e->adapt_groups ? 3 : 1) : 0; b.rank = e->rank;
     HIPCK(hipIpcGetMemHandle(&b.z, e->p.Z));
     HIPCK(hipIpcGetMemHandle(&b.flags, e->d_flags));
     if (e->adapt) for (int i = 0; i < 3; ++i) HIPCK(hipIpcGetMemHandle(&b.cp[i], e->d_cp[i]));
+    if (e->adapt_groups) for (int i = 0; i < 2; ++i) HIPCK(hipIpcGetMemHandle(&b.gs[i], e->d_GS[i]));
     memset(blob, 0, DZ_PEER_BLOB_BYTES);
     memcpy(blob, &b, sizeof b);
     return 0;
@@ -1406,12 +1459,13 @@ int dz_peer_attach(dz_engine* e, int32_t rank, int32_t world, const void* blobs)
         if (r == rank) continue;
         PeerBlob b; memcpy(&b, (const char*)blobs + (size_t)r * DZ_PEER_BLOB_BYTES, sizeof b);
         if (b.magic != 0x445a5058u || b.rank != r) return fail("dz_peer_attach: blob " + std::to_string(r) + " is not rank " + std::to_string(r) + "'s export");
-        if ((int)b.nchains != e->p.N || (int)b.nchains_local != e->p.nl || (int)b.ld != e->p.ld || b.capacity != e->c.history_capacity || b.has_cp != (e->adapt ? 1 : 0))
+        if ((int)b.nchains != e->p.N || (int)b.nchains_local != e->p.nl || (int)b.ld != e->p.ld || b.capacity != e->c.history_capacity || b.has_cp != (e->adapt ? (e->adapt_groups ? 3 : 1) : 0))
             return fail("dz_peer_attach: rank " + std::to_string(r) + " was created with a different configuration");
         dz_engine::Peer& pr = e->peers[r];
         HIPCK(hipIpcOpenMemHandle((void**)&pr.Z, b.z, hipIpcMemLazyEnablePeerAccess));
         HIPCK(hipIpcOpenMemHandle((void**)&pr.flags, b.flags, hipIpcMemLazyEnablePeerAccess));
         if (e->adapt) for (int i = 0; i < 3; ++i) HIPCK(hipIpcOpenMemHandle((void**)&pr.cp[i], b.cp[i], hipIpcMemLazyEnablePeerAccess));
+        if (e->adapt_groups) for (int i = 0; i < 2; ++i) HIPCK(hipIpcOpenMemHandle((void**)&pr.gs[i], b.gs[i], hipIpcMemLazyEnablePeerAccess));
         HIPCK(hipStreamCreateWithFlags(&pr.st, hipStreamNonBlocking));
     }
     for (int i = 0; i < 8; ++i) HIPCK(hipEventCreateWithFlags(&e->push_ev[i], hipEventDisableTiming));
@@ -1446,9 +1500,18 @@ int dz_peer_detach(dz_engine* e)
 
 int dz_exchange_stats(dz_engine* e, int64_t* exchanges, int64_t* gates, double* gate_wait_us)
 {   // (k_peer_gate's counters; call after dz_sync)
-    if (exchanges) *exchanges = e->z_pushed + e->pos_pushed;
+    if (exchanges) *exchanges = e->z_pushed + e->pos_pushed + e->gs_pushed;
     if (gates) *gates = e->h_gate ? (int64_t)e->h_gate[1] : 0;
     if (gate_wait_us) *gate_wait_us = e->h_gate ? (double)e->h_gate[0] * 0.01 : 0.0;      // 100 MHz ticks
+    return 0;
+}
+
+int dz_exchange_bytes(dz_engine* e, int64_t* history_bytes, int64_t* position_bytes, int64_t* sums_bytes)
+{   // bytes this rank has handed to the transport FOR EACH other rank so far, by what they were
+    if (!e) return fail("null engine");
+    if (history_bytes) *history_bytes = e->bytes_z;
+    if (position_bytes) *position_bytes = e->bytes_pos;
+    if (sums_bytes) *sums_bytes = e->bytes_sums;
     return 0;
 }
 

@@ -2118,20 +2118,98 @@ DZ_DEV void adapt_apply_wave(const Params& p, const double* __restrict__ TOT, co
 }
 
 #ifndef DZ_TEMPLATES_ONLY   // plain (non-template) kernels: defined once, in dz_engine.hip's translation unit
-// The general form: the units' sums from the replicated published positions of ALL N chains (sharded runs, the multi-kernel path, blocks
-// of fewer than 16 chains); block = one unit, wave w = global chain 16 unit + w (its bins), then thread (q, j) the sums.
-__global__ __launch_bounds__(1024) void k_adapt_partials(Params p, uint32_t g, double* __restrict__ PR, double* __restrict__ PC)
+// The general form: the units' sums from the published positions (the multi-kernel path, blocks of fewer than 16 chains, and sharded runs
+// whose ranks do not own whole groups: then from the replicated positions of ALL N chains); block = one unit, wave w = global chain
+// 16 unit + w (its bins), then thread (q, j) the sums.  unit0: the first GLOBAL unit of this launch (a rank that owns whole groups makes
+// only its own units' sums: rows PR[0 ..] = units unit0 ..); shift: the row the column sums are taken around -- the previous published
+// position of global chain 0 -- or null: row 0 of p.cp_prev.
+__global__ __launch_bounds__(1024) void k_adapt_partials(Params p, uint32_t g, double* __restrict__ PR, double* __restrict__ PC, int unit0, const double* __restrict__ shift)
 {
     __shared__ int s_bc[16], s_bg[16];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, unit = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, unit = unit0 + blockIdx.x;
     const int gcn = 16 * unit + wv;
     int bc = -1, bg = -1;
     if (gcn < p.N) adapt_bins(p, g, gcn, lane, bc, bg, p.cr_probs, p.g_probs);
     if (lane == 0) { s_bc[wv] = bc; s_bg[wv] = bg; }
     __syncthreads();
     const int nc = min(16, p.N - 16 * unit), nq = adapt_nq(p);
-    adapt_unit_sums(p, p.cp_new + (size_t)16 * unit * p.ld, p.ld, p.cp_prev + (size_t)16 * unit * p.ld, p.ld, nc, [&](bool isg, int c) { return isg ? s_bg[c] : s_bc[c]; }, p.cp_prev,
-                    PR + (size_t)unit * nq * p.ld, PC + (size_t)unit * (p.ncr + p.ngamma), threadIdx.x, 1024);
+    adapt_unit_sums(p, p.cp_new + (size_t)16 * unit * p.ld, p.ld, p.cp_prev + (size_t)16 * unit * p.ld, p.ld, nc, [&](bool isg, int c) { return isg ? s_bg[c] : s_bc[c]; }, shift ? shift : p.cp_prev,
+                    PR + (size_t)blockIdx.x * nq * p.ld, PC + (size_t)blockIdx.x * (p.ncr + p.ngamma), threadIdx.x, 1024);
+}
+
+// ---- sharded crossover burn-in (round 5): the ranks exchange their GROUPS' sums, not their positions.  Contract v3 adds the units' sums
+// in groups of 16 units (256 consecutive global chains) in order, then the groups in order; a rank that owns whole groups (chain offset and
+// local chain count multiples of 256) makes its groups' sums from its own units' sums -- the same additions in the same order as
+// k_adapt_totals' middle stage -- and every rank then adds ALL groups in order from the exchanged records: the same totals, bit for bit, at
+// every world size, for (2 + nCR + ngamma) ld + 16 doubles per group instead of 256 ld per group of positions (4096 chains per GPU,
+// 100-D, nCR = 3: 86 KB per rank and generation instead of 3.7 MB).  (What replaces the shared current_positions array of core.py:296 /
+// Dream.py:447-449 under sharding; Dream.py:451-499 is the arithmetic.)
+// A rank's record (rec doubles): [groups][nq][ld] sums | [groups][nbp] bin counts (nbp = nb rounded up to 16) | [ld] the new position of
+// the rank's first chain (rank 0's is global chain 0's: the shift of the NEXT generation's column sums).
+// thread (group, column): the group's units in order from 0.0
+__global__ __launch_bounds__(256) void k_adapt_groups(const double* __restrict__ PR, const double* __restrict__ PC, int nunits, int nq, int d, int ld, int nb, int nbp,
+                                                      const double* __restrict__ x0, double* __restrict__ rec)
+{
+    const int ngroups = (nunits + 15) / 16, ncol = nq * d;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const size_t ustride = (size_t)nq * ld;
+    if (idx < ngroups * ncol) {
+        const int gq = idx / ncol, col = idx - gq * ncol, q = col / d, j = col - q * d;
+        const double* src = PR + (size_t)16 * gq * ustride + (size_t)q * ld + j;
+        const int nu = min(16, nunits - 16 * gq);
+        double v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = i < nu ? src[(size_t)i * ustride] : 0.0;
+        double gs = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) if (i < nu) gs = gs + v[i];
+        rec[(size_t)gq * ustride + (size_t)q * ld + j] = gs;
+        return;
+    }
+    int r = idx - ngroups * ncol;
+    if (r < ngroups * nbp) {           // the bins' counts (small integers: exact)
+        const int gq = r / nbp, b = r - gq * nbp;
+        double c = 0.0;
+        if (b < nb) for (int i = 0; i < 16 && 16 * gq + i < nunits; ++i) c += PC[(size_t)(16 * gq + i) * nb + b];
+        rec[(size_t)ngroups * ustride + (size_t)gq * nbp + b] = c;
+        return;
+    }
+    r -= ngroups * nbp;
+    if (r < ld) rec[(size_t)ngroups * ustride + (size_t)ngroups * nbp + r] = x0[r];
+}
+// ... and every rank's totals from all ranks' records: thread column adds the groups in global order (rank by rank) from 0.0 -- k_adapt_totals'
+// last stage --; the counts; the next generation's shift (rank 0's first chain)
+__global__ __launch_bounds__(256) void k_group_totals(const double* __restrict__ GS, int world, size_t rec, int gl, int nq, int d, int ld, int nb, int nbp,
+                                                      double* __restrict__ TOT, double* __restrict__ CNT, double* __restrict__ shift_out)
+{
+    const int ncol = nq * d;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const size_t ustride = (size_t)nq * ld;
+    if (idx < ncol) {
+        const int q = idx / d, j = idx - q * d;
+        double t = 0.0;
+        for (int r = 0; r < world; ++r) {
+            const double* src = GS + (size_t)r * rec + (size_t)q * ld + j;
+            for (int g0 = 0; g0 < gl; g0 += 16) {
+                double v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = g0 + i < gl ? src[(size_t)(g0 + i) * ustride] : 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) if (g0 + i < gl) t = t + v[i];
+            }
+        }
+        TOT[(size_t)q * ld + j] = t;
+        return;
+    }
+    int r2 = idx - ncol;
+    if (r2 < nb) {
+        double c = 0.0;
+        for (int r = 0; r < world; ++r) for (int gq = 0; gq < gl; ++gq) c += GS[(size_t)r * rec + (size_t)gl * ustride + (size_t)gq * nbp + r2];
+        CNT[r2] = c;
+        return;
+    }
+    r2 -= nb;
+    if (r2 < ld) shift_out[r2] = GS[(size_t)gl * ustride + (size_t)gl * nbp + r2];
 }
 
 // Single block of 1024 threads.  Step 1: the chains' jumps and bins are staged in LDS with coalesced loads, 4096 chains at a time (a

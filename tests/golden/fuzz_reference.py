@@ -6,6 +6,13 @@ machinery it uses): random small configurations are run through the reference's 
 probabilities).  Nothing is written to tests/golden; the point is that the pinning does not hang on the dozen committed cases.
 
     PYTHONPATH=/root/reference python tests/golden/fuzz_reference.py --n 200 --seed 1
+    PYTHONPATH=/root/reference python tests/golden/fuzz_reference.py --n 300 --seed 1 --tri
+
+--tri (round 5): the triangular arm.  Every case has the MVN target, at dimensions up to 100, and after the comparison with the dense
+precision matrix (the reference's own formula, dream_ex_ndim_gaussian.py:49-52) the oracle runs the case AGAIN with the matrix handed over
+as its triangular factor (kind 1: log p = log_F - |U x|^2 / 2 -- what bench.py's headline times) and is compared with the same reference
+output: the two forms differ in the last bits of log p, so this measures whether such a difference ever flips a selection (Dream.py:908)
+or an accept (:993).  A flip is reported as a mismatch, with the case.
 """
 import argparse
 import os
@@ -63,6 +70,22 @@ def draw_case(rng):
                 rng_seed=int(rng.integers(0, 2 ** 31 - 1)), history_lag=lag)
 
 
+def draw_tri_case(rng):
+    """MVN target only, dimensions up to the headline's 100 (the reference's astep takes ~1 ms a call: the large ones are short)"""
+    c = draw_case(rng)
+    while c["prior"].startswith("uniform"):
+        c = draw_case(rng)
+    d = int(rng.choice([2, 3, 5, 8, 12, 17, 33, 64, 100]))
+    c["d"] = d
+    c["dream_kwargs"]["nCR"] = int(min(d, c["dream_kwargs"]["nCR"]))
+    c["target"] = ("mvn",)
+    c["tri"] = True
+    if d > 20:
+        thin = c["dream_kwargs"]["history_thin"]
+        c["G"] = thin * int(np.ceil(min(c["G"], 16) / thin))
+    return c
+
+
 def draw_pt_case(rng):
     """parallel tempering through the reference's own _sample_dream_pt (make_golden.run_reference_pt): MVN target, reference defaults"""
     G = int(rng.choice([20, 30, 40]))
@@ -89,6 +112,7 @@ def run_case(c):
         return run_pt_case(c)
     captured = {}
     MG.save = lambda name, **arrs: captured.update({k: np.asarray(v) for k, v in arrs.items()})       # (trace_case hands its arrays to save)
+    c = dict(c); tri = c.pop("tri", False)
     MG.trace_case("fuzz", **c)
     fx = captured
     if int(fx["redraws"].max()) >= 64:         # beyond DZ_MAX_REDRAWS the engines give the step up as a rejection (DESIGN.md deviation D1): not comparable
@@ -107,6 +131,14 @@ def run_case(c):
         _, dm, nu = e.get_gamma_state()
         np.testing.assert_allclose(dm, fx["delta_m_gamma"], rtol=1e-11)
         np.testing.assert_array_equal(nu, fx["ngamma_updates"])
+    if tri:
+        assert str(fx["lk_kind"]) == "mvn"
+        e = H.engine_from_trace_fixture(O.Engine, fx, mvn_kind="tri")
+        e.step(G)
+        try:
+            H.compare_with_reference(e.get_trace(0, G), fx, e.get_history(), e.get_cr_state()[0], e.get_gamma_state()[0] if int(fx["cfg_adapt_gamma"]) else None)
+        except AssertionError as ex:
+            raise AssertionError("TRIANGULAR FACTOR: " + str(ex).strip().split("\n")[0])
     return int((fx["redraws"] > 0).sum())
 
 
@@ -114,12 +146,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--tri", action="store_true", help="the triangular arm: MVN cases up to 100-D, each also run with the triangular factor")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     bad = 0; redrawn = 0; skipped = 0; t0 = time.time()
     devnull = open(os.devnull, "w")
     for i in range(args.n):
-        c = draw_pt_case(rng) if rng.random() < 0.1 else draw_case(rng)
+        c = draw_tri_case(rng) if args.tri else (draw_pt_case(rng) if rng.random() < 0.1 else draw_case(rng))
         out = sys.stdout
         try:
             sys.stdout = devnull
@@ -132,8 +165,8 @@ def main():
             print("MISMATCH #%d: %s\n   %s" % (i, str(ex).strip().split("\n")[0][:300], c), flush=True)
         finally:
             sys.stdout = out
-    print("fuzz vs reference: %d cases, %d mismatches, %d with redraw rounds, %d skipped (a step of the reference took 64 or more redraw rounds: deviation D1), %.0f s (seed %d)"
-          % (args.n, bad, redrawn, skipped, time.time() - t0, args.seed))
+    print("fuzz vs reference%s: %d cases, %d mismatches, %d with redraw rounds, %d skipped (a step of the reference took 64 or more redraw rounds: deviation D1), %.0f s (seed %d)"
+          % (" (triangular arm: every case also with the factor U of the precision matrix)" if args.tri else "", args.n, bad, redrawn, skipped, time.time() - t0, args.seed))
     return 1 if bad else 0
 
 

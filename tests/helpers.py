@@ -16,7 +16,15 @@ def simple_logp(X):
     return np.zeros(len(X)), np.sum(X + 3, axis=1)
 
 
-def engine_from_trace_fixture(EngineCls, fx, schedule=None, trace=True, **over):
+def tri_factor(P):
+    """The upper-triangular factor U of a precision matrix, P = U^T U -- what pydream_amd.likelihoods.MVNormalLogLike builds and
+    bench.py's headline times (`--mvn-kind tri`): log p = log_F - |U x|^2 / 2, half the flops of x.(P x)."""
+    return np.linalg.cholesky((P + P.T) / 2).T
+
+
+def engine_from_trace_fixture(EngineCls, fx, schedule=None, trace=True, mvn_kind="dense", **over):
+    """mvn_kind="tri": the fixture's MVN likelihood handed over as the triangular factor of its precision matrix (kind 1) instead of the
+    dense matrix the reference itself multiplied with (kind 0)."""
     d, N, G, k = int(fx["cfg_d"]), int(fx["cfg_N"]), int(fx["cfg_G"]), int(fx["cfg_k"])
     thin = int(fx["cfg_history_thin"])
     Z0 = fx["Z0"]
@@ -39,7 +47,9 @@ def engine_from_trace_fixture(EngineCls, fx, schedule=None, trace=True, **over):
     if "restart_cr_probs" in fx:                       # a restarted run: Dream's `crossover_file` (Dream.py:128-134)
         e.set_cr_probs(fx["restart_cr_probs"])
     lk = str(fx["lk_kind"])
-    if lk == "mvn":
+    if lk == "mvn" and mvn_kind == "tri":
+        e.set_likelihood_mvn(np.zeros(d), tri_factor(fx["invC"]), 1, float(fx["log_F"]))
+    elif lk == "mvn":
         e.set_likelihood_mvn(np.zeros(d), fx["invC"], 0, float(fx["log_F"]))
     elif lk == "mix":
         e.set_likelihood_mixture(fx["mix_mu"], fx["mix_logF"])

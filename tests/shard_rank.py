@@ -23,7 +23,14 @@ sys.path.insert(0, ROOT)
 CONFIGS = {   # (chains, d, mvn kind)
     "c3": (32768, 100, "tri"), "c4": (4096, 1000, "tri"),
     "c3s": (4096, 100, "tri"), "c4s": (512, 1000, "tri"),
+    # crossover adaptation on (the reference's default, Dream.py:63-67): a burn-in of BURNIN generations inside the run, so that the ranks
+    # exchange adaptation statistics every generation -- group sums where a rank owns whole groups of 256 chains, positions otherwise
+    "a512": (512, 100, "tri"), "a1k": (1024, 100, "tri"), "a2k": (2048, 100, "tri"), "a2k_mix": (2048, 100, "mix"), "a512_k1": (512, 100, "tri"),
+    "a768": (768, 100, "tri"),        # 2 ranks x 384 chains: NOT whole groups -- the positions travel (the round-4 path)
+    "a2k_d200": (2048, 200, "tri"),   # the multi-kernel path's generations (d > 128) with the group exchange
 }
+ADAPT = {"a512": 5, "a1k": 5, "a2k": 5, "a2k_mix": 5, "a512_k1": 1, "a768": 5, "a2k_d200": 5}       # config -> multitry
+BURNIN = 24
 SEED, K, THIN = 20260930, 5, 10
 
 
@@ -33,21 +40,29 @@ def matrix(config):
     from tests import helpers as H
     N, d, kind = CONFIGS[config]
     P = H.mvn_precision(d)
-    return np.linalg.cholesky((P + P.T) / 2).T if kind == "tri" else P
+    return np.linalg.cholesky((P + P.T) / 2).T if kind != "dense" else P
 
 
-def build(config, rank, world, generations, lag, device=0, M=None):
-    from pydream_amd import _capi
+def build(config, rank, world, generations, lag, device=0, M=None, engine_cls=None):
+    """engine_cls: the test's comparand may be the ORACLE (tests only) instead of the HIP engine"""
+    if engine_cls is None:
+        from pydream_amd import _capi
+        engine_cls = _capi.Engine
     N, d, kind = CONFIGS[config]
     nl = N // world
     m0 = max(10 * d, 2 * N)                                  # Dream.py:168-170, core.py:270-273
     Z0 = np.random.default_rng(SEED).uniform(-5.0, 15.0, (m0, d))
-    e = _capi.Engine(nchains=N, nchains_local=nl, chain_offset=rank * nl, ndim=d, multitry=K, history_thin=THIN,
-                     history_capacity=m0 + N * (generations // THIN + 2), trace_capacity=generations, seed=SEED, device=device,
-                     history_lag=lag)
+    extra = dict(adapt_crossover=1, crossover_burnin=BURNIN) if config in ADAPT else {}
+    e = engine_cls(nchains=N, nchains_local=nl, chain_offset=rank * nl, ndim=d, multitry=ADAPT.get(config, K), history_thin=THIN,
+                   history_capacity=m0 + N * (generations // THIN + 2), trace_capacity=generations, seed=SEED, device=device,
+                   history_lag=lag, **extra)
     e.set_history(Z0)
     e.set_state(Z0[rank * nl:(rank + 1) * nl])
-    e.set_likelihood_mvn(np.zeros(d), matrix(config) if M is None else M, 1 if kind == "tri" else 0, 0.0)
+    if kind == "mix":
+        mu = np.array([np.full(d, m) for m in (-5.0, 0.0, 5.0)])
+        e.set_likelihood_mixture(mu, np.log(np.array([1 / 6., 1 / 3., 1 / 2.])) - (d / 2.) * np.log(2 * np.pi))
+    else:
+        e.set_likelihood_mvn(np.zeros(d), matrix(config) if M is None else M, 1 if kind == "tri" else 0, 0.0)
     return e
 
 
@@ -56,7 +71,9 @@ def results(e, generations, with_history):
     tr = e.get_trace(0, generations, with_X=False)
     h, rows = e.history_checksum()
     out = dict(X=X, prior=pr, like=lk, logp=tr["logp"], moved=tr["moved"], try_idx=tr["try_idx"], cr_idx=tr["cr_idx"], snooker=tr["snooker"],
-               checksum=np.array([h], dtype=np.uint64), rows=np.array([rows]), variant=np.array(e.last_kernel_variant()))
+               checksum=np.array([h], dtype=np.uint64), rows=np.array([rows]), variant=np.array(e.last_kernel_variant()),
+               cr_probs=e.get_cr_state()[0], cr_delta=e.get_cr_state()[1], cr_n=e.get_cr_state()[2],
+               xbytes=np.array(e.exchange_bytes() if hasattr(e, "exchange_bytes") else (0, 0, 0), dtype=np.int64))
     if with_history:
         out["Z"] = e.get_history()
     return out

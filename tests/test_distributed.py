@@ -231,6 +231,72 @@ def test_baseline_multi_gpu_configs_at_full_size_equal_the_unsharded_engine(tmp_
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("config,world,transport,lag,against,env", [
+    ("a512", 2, "peer", 1, "oracle", {}),                           # one group of 256 chains per rank, fused unit sums inside k_generations
+    ("a1k", 2, "peer", 1, "oracle", {}),                            # >= 1024 chains, 2 ranks, peer, lag 1, against the ORACLE (round-4 verdict 1c)
+    ("a1k", 4, "host", 0, "oracle", {"DZ_ADAPT_FUSED": "0"}),       # the units' sums by k_adapt_partials over the rank's OWN units
+    ("a512_k1", 2, "peer", 0, "oracle", {}),                        # multitry off: no fused sums
+    ("a2k", 8, "peer", 1, "engine", {}),                            # eight ranks
+    ("a2k_mix", 8, "peer", 0, "engine", {}),                        # the mixture kernel's 16-wave burn-in blocks
+    ("a2k_d200", 8, "peer", 1, "engine", {}),                       # d > 128: the multi-kernel path's generations
+    ("a768", 2, "peer", 1, "oracle", {}),                           # 384 chains per rank: not whole groups, the positions travel
+    ("a1k", 2, "peer", 1, "engine", {"DZ_ADAPT_GROUPS": "0"})])     # the position exchange forced where groups would do
+def test_sharded_crossover_burnin_exchanges_group_sums(tmp_path, config, world, transport, lag, against, env):
+    """The crossover burn-in of a sharded run (estimate_crossover_probabilities, Dream.py:451-499, over ALL chains' positions -- the shared
+    current_positions array of core.py:296): a rank that owns whole groups of 256 chains sends its groups' column sums (reduction
+    contract v3: units of 16 chains -> groups of 16 units -> total, in order) instead of its positions, every rank adds all groups in
+    order -- the same totals bit for bit at every world size.  Checked: every rank's states, log densities, decision sequences, adapted
+    probabilities AND their accumulators (delta_m, ncr_updates) over a run whose burn-in (24 generations) ends inside it, against the
+    ORACLE (<= 1024 chains) or the unsharded engine; all archive replicas identical; the bytes per rank and burn-in generation
+    (dz_exchange_bytes): group sums, and the positions only once."""
+    from tests import shard_rank as SR
+    G = 37
+    renv = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DZ_PEER_TIMEOUT_S="200", DZ_SHARD_DEVICE="0", **env)
+    M = SR.matrix(config)
+    np.save(tmp_path / "matrix.npy", M)
+    _launch_ranks([os.path.join(ROOT, "tests", "shard_rank.py"), config, str(tmp_path), transport, str(lag), str(G)], world, renv, str(tmp_path), timeout=300)
+    N, d, _ = SR.CONFIGS[config]
+    if against == "oracle":
+        from oracle import oracle as O
+        o = SR.build(config, 0, 1, G, lag, M=M, engine_cls=O.Engine)
+        o.step(G)
+        X, pr, lk = o.get_state()
+        tr = o.get_trace(0, G)
+        ref = dict(X=X, prior=pr, like=lk, logp=tr["logp"], moved=tr["moved"], try_idx=tr["try_idx"], cr_idx=tr["cr_idx"], snooker=tr["snooker"], Z=o.get_history())
+        ref["cr_probs"], ref["cr_delta"], ref["cr_n"] = o.get_cr_state()
+    else:
+        e = SR.build(config, 0, 1, G, lag, M=M)
+        e.step(G)
+        ref = SR.results(e, G, with_history=True)
+        e.close()
+    assert not np.allclose(ref["cr_probs"], 1 / 3.) and ref["cr_n"].sum() > N          # the adaptation did run
+    nl = N // world
+    sums0 = None
+    for r in range(world):
+        got = np.load(tmp_path / ("rank%d.npz" % r))
+        sl = slice(r * nl, (r + 1) * nl)
+        for key in ("X", "prior", "like"):
+            np.testing.assert_array_equal(got[key], ref[key][sl], err_msg="%s of rank %d" % (key, r))
+        for key in ("logp", "moved", "try_idx", "cr_idx", "snooker"):
+            np.testing.assert_array_equal(got[key], ref[key][:, sl], err_msg="%s of rank %d" % (key, r))
+        for key in ("cr_probs", "cr_delta", "cr_n"):
+            np.testing.assert_array_equal(got[key], ref[key], err_msg="%s of rank %d" % (key, r))
+        if r == 0:
+            np.testing.assert_array_equal(got["Z"], ref["Z"])
+            sums0 = (int(got["checksum"][0]), int(got["rows"][0]))
+        assert (int(got["checksum"][0]), int(got["rows"][0])) == sums0, "archive replica of rank %d" % r
+        zb, pb, sb = (int(x) for x in got["xbytes"])
+        ld = (d + 15) // 16 * 16
+        assert zb == 4 * nl * ld * 8                                                        # four appends in 37 generations
+        groups = nl % 256 == 0 and env.get("DZ_ADAPT_GROUPS") != "0"
+        if groups:          # 25 burn-in generations of (2 + nCR + ngamma) ld + 16 doubles per group, + one row; the positions once (generation 0's start)
+            assert pb == nl * ld * 8 and sb == 25 * ((nl // 256) * (6 * ld + 16) + ld) * 8
+            assert sb // 25 <= 100 * 1024 * max(1, nl // 4096 + (nl % 4096 > 0))
+        else:
+            assert sb == 0 and pb == 26 * nl * ld * 8
+
+
+@pytest.mark.gpu
 def test_history_checksum_is_the_documented_sum_and_sees_a_single_changed_element():
     from pydream_amd import _capi
     from tests import helpers as H

@@ -52,6 +52,29 @@ def test_golden_traces(name, G, O):
         np.testing.assert_array_equal(a, b)
 
 
+MVN_S2_TRACES = [n for n in S2_TRACES if str(H.load(n)["lk_kind"]) == "mvn"]
+
+
+@pytest.mark.parametrize("name", MVN_S2_TRACES)
+def test_golden_traces_with_the_triangular_factor(name, G, O):
+    """The likelihood form the driver's headline times (the triangular factor of the precision matrix, kind 1) on the HIP engine against
+    the decision sequences the REFERENCE made with its dense formula (dream_ex_ndim_gaussian.py:49-52; Dream.py:908, :993): snooker flags,
+    CR indices, selected tries and accept flags exact, log p to 1e-10 -- and bit for bit against the oracle given the same factor."""
+    fx = H.load(name)
+    n = int(fx["cfg_G"])
+    e = H.engine_from_trace_fixture(G.Engine, fx, mvn_kind="tri")
+    e.step(n)
+    tr = e.get_trace(0, n)
+    gp = e.get_gamma_state()[0] if int(fx["cfg_adapt_gamma"]) else None
+    H.compare_with_reference(tr, fx, e.get_history(), e.get_cr_state()[0], gp)
+    o = H.engine_from_trace_fixture(O.Engine, fx, mvn_kind="tri")
+    o.step(n)
+    assert_traces_identical(tr, o.get_trace(0, n))
+    np.testing.assert_array_equal(e.get_history(), o.get_history())
+    for a, b in zip(e.get_cr_state(), o.get_cr_state()):
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("tag", ["d100k5", "d4k5b", "d4k1b", "d10k1"])
 def test_generate_proposal_points(tag, G, O):
     fx = H.load("proposals")
@@ -212,23 +235,29 @@ def test_persistent_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, k, tr
         np.testing.assert_array_equal(a[2], other[2])
 
 
-@pytest.mark.parametrize("N,tri,target,variant", [(4096, 1, "mvn", "k_generations<7,tri,xlds,16,1,lean>"),       # bench.py's headline `value`
-                                                  (4096, 0, "mvn", "k_generations<7,dense,xhbm,16,1,lean>"),    # ... `dense_value`
-                                                  (1024, 1, "mvn", "k_generations<7,tri,xlds,4,4,lean>"),       # BASELINE configs[1]
-                                                  (2048, 1, "mvn", "k_generations<7,tri,xlds,8,1,lean>"),
-                                                  (4096, 1, "mix3", "k_generations_mix")])                      # BASELINE configs[2] after the burn-in
-def test_the_instantiations_the_bench_times_equal_the_oracle(G, O, N, tri, target, variant):
-    """Exactly what bench.py times -- 100-D, multitry 5, flat prior, bench.py's own engine set-up -- against the oracle, bit for bit,
-    over 35 generations (three history appends), with the engine reporting which instantiation ran (dz_last_kernel_variant):
+@pytest.mark.parametrize("N,tri,target,lag,variant", [(4096, 1, "mvn", 1, "k_generations<7,tri,xlds,16,1,lean>"),    # bench.py's headline `value` (history_lag = 1 at every N)
+                                                      (4096, 1, "mvn", 0, "k_generations<7,tri,xlds,16,1,lean>"),    # ... `value_history_lag0`
+                                                      (4096, 0, "mvn", 1, "k_generations<7,dense,xhbm,16,1,lean>"),  # ... `dense_value`
+                                                      (4096, 0, "mvn", 0, "k_generations<7,dense,xhbm,16,1,lean>"),
+                                                      (1024, 1, "mvn", 1, "k_generations<7,tri,xlds,4,4,lean>"),     # BASELINE configs[1] (the `configs` block of the line)
+                                                      (1024, 1, "mvn", 0, "k_generations<7,tri,xlds,4,4,lean>"),
+                                                      (2048, 1, "mvn", 1, "k_generations<7,tri,xlds,8,1,lean>"),
+                                                      (4096, 1, "mix3", 1, "k_generations_mix"),                     # BASELINE configs[2] after the burn-in
+                                                      (4096, 1, "mix3", 0, "k_generations_mix")])
+def test_the_instantiations_the_bench_times_equal_the_oracle(G, O, N, tri, target, lag, variant):
+    """Exactly what bench.py times -- 100-D, multitry 5, flat prior, bench.py's own engine set-up INCLUDING its history_lag (1 for the
+    driver's `value`, 0 for `value_history_lag0`) -- against the oracle, bit for bit, over 45 generations (four history appends, so that
+    with lag 1 three appends have become sampleable), with the engine reporting which instantiation ran (dz_last_kernel_variant):
     16 chains per block with one wave per chain needs >= ~2100 chains, which no other oracle comparison reaches."""
     import argparse
     import bench
-    n = 35
+    n = 45
     args = argparse.Namespace(dim=100, multitry=5, seed=20260929, thin=10, snooker=0.1, target=target, mvn_kind="tri" if tri else "dense",
-                              steps=n, warmup=0)
+                              steps=n, warmup=0, history_lag=lag)
     out = []
     for Cls in (G.Engine, O.Engine):
         e = bench.setup_engine(Cls, args, N, N, 0, n, trace_capacity=n, **({"schedule": 2} if Cls is O.Engine else {}))
+        assert int(e.cfg.history_lag) == lag
         e.step(n)
         if Cls is G.Engine:
             assert e.last_kernel_variant() == variant

@@ -33,6 +33,24 @@ def test_astep_traces_match_reference(name):
         np.testing.assert_array_equal(nu, fx["ngamma_updates"])
 
 
+MVN_TRACES = [n for n in TRACES if str(H.load(n)["lk_kind"]) == "mvn"]
+
+
+@pytest.mark.parametrize("name", MVN_TRACES)
+def test_astep_traces_match_reference_with_the_triangular_factor(name):
+    """The likelihood form bench.py's headline times -- log p = log_F - |U x|^2 / 2 with U the triangular factor of the precision matrix --
+    against the decision sequences the REFERENCE made with its own formula x.(invC.x) (dream_ex_ndim_gaussian.py:49-52): the two forms
+    differ in the last bits of log p, and a difference of 1e-13 can flip `log(u) < ratio` (Dream.py:993) or a multi-try selection (:908).
+    Every reference-made MVN fixture (100-D, 10-D, with lag, adaptation, restart, redraw rounds) is replayed with the factor: snooker
+    flags, CR indices, selected tries and accept flags exact, log p to 1e-10, states to 1e-9."""
+    fx = H.load(name)
+    e = H.engine_from_trace_fixture(O.Engine, fx, mvn_kind="tri")
+    G = int(fx["cfg_G"])
+    e.step(G)
+    gp = e.get_gamma_state()[0] if int(fx["cfg_adapt_gamma"]) else None
+    H.compare_with_reference(e.get_trace(0, G), fx, e.get_history(), e.get_cr_state()[0], gp)
+
+
 @pytest.mark.parametrize("tag", ["d100k5", "d4k5b", "d4k1b", "d10k1"])
 def test_generate_proposal_points_match_reference(tag):
     """Dream.generate_proposal_points / snooker_update (Dream.py:670-837) on hand-built history:

@@ -206,7 +206,7 @@ def timed_blocks(e, K, min_ms, barrier, dist, max_blocks=400):
             return times
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -250,20 +250,42 @@ def main():
                     help="rendezvous of a multi-GPU run: plain TCP (default) or torch.distributed/gloo")
     ap.add_argument("--transport", choices=["peer", "rccl", "host"], default=None,
                     help="row exchange of a multi-GPU run (default: DZ_BENCH_TRANSPORT or peer; falls back peer -> rccl -> host, loudly)")
-    args = ap.parse_args()
+    ap.add_argument("--no-configs", action="store_true",
+                    help="one GPU, default workload: skip the `configs` block (BASELINE configs[1], configs[2] as written, the configs[4] shard, each measured "
+                         "the same way as the headline in the same run)")
+    ap.add_argument("--no-rccl-leg", action="store_true", help="several GPUs: skip the second set of timed blocks over the RCCL all-gather (`rccl_value`)")
+    ap.add_argument("--rccl-leg", action="store_true", help="one GPU: run the RCCL leg too (a communicator of one rank)")
+    args = ap.parse_args(argv)
+    args.rhat_max_given = args.rhat_max_generations is not None
     if args.rhat_max_generations is None:
         args.rhat_max_generations = max(10000, 16 * args.dim)
     if args.spinup is not None:
         args.rhat_min_generations = args.spinup
         args.rhat_max_generations = max(args.spinup, min(args.rhat_max_generations, 4 * args.spinup))
+    if args.history_lag is None:
+        args.history_lag = 1
+    return args
 
+
+def workload_label(args, n_local, world):
+    """which BASELINE.json configuration a workload is"""
+    if args.target == "mvn" and args.dim == 1000 and n_local == 512:
+        return "BASELINE configs[4] per-GPU shard (4096 chains x 1000-D correlated MVN over 8 GPUs)"
+    if args.target == "mvn" and args.dim == 100 and n_local == 1024 and world == 1:
+        return "BASELINE configs[1]"
+    if args.target == "mix3" and args.dim == 100 and n_local == 4096 and world == 1 and getattr(args, "adapt", False):
+        return "BASELINE configs[2] as written"
+    if args.target == "mvn" and args.dim == 100 and n_local == 4096:
+        return "BASELINE north_star target / configs[3] per-GPU shard"
+    return "variant of the BASELINE workloads"
+
+
+def main():
+    args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))        # one process asked for N GPUs: it starts its own N ranks (or fails)
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.history_lag is None:
-        args.history_lag = 1
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
@@ -276,6 +298,68 @@ def main():
         else:
             from pydream_amd.distributed import socket_group_from_env
             dist = socket_group_from_env()
+    out, replicas = measure(args, dist, world, rank)
+    if rank != 0:
+        if dist is not None:
+            dist.close()
+        return
+    default_workload = (args.target == "mvn" and args.dim == 100 and args.chains_per_gpu == 4096 and args.multitry == 5 and not args.adapt)
+    if world == 1 and default_workload and not args.no_configs:
+        out["configs"] = baseline_configs(args)
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.close()
+    if replicas is not None and not replicas["identical"]:
+        sys.stderr.write("bench.py: the ranks' archive replicas DIFFER (see replica_check in the line): the number above is not valid\n")
+        sys.exit(3)
+
+
+def baseline_configs(args):
+    """The other single-GPU BASELINE.json configurations, each measured in this same run the way the headline is (convergence run with
+    the reference's R-hat rule, warm-up, blocks of exactly K generations, an event-timed pass for the roofline) -- without the dense /
+    lag-0 / CPU legs.  -> {"configs[1]": {...}, "configs[2]": {...}, "configs[4] shard": {...}}"""
+    import copy
+    res = {}
+    for key, over in (("configs[1]", dict(chains_per_gpu=1024)),
+                      ("configs[2]", dict(target="mix3", adapt=True, burnin_generations=800)),
+                      ("configs[4] shard", dict(chains_per_gpu=512, dim=1000))):
+        a = copy.copy(args)
+        for k_, v_ in over.items():
+            setattr(a, k_, v_)
+        if not args.rhat_max_given:
+            a.rhat_max_generations = max(10000, 16 * a.dim)
+        a.burnin_generations = min(a.burnin_generations, max(60, a.rhat_max_generations // 4))
+        t0 = time.perf_counter()
+        try:
+            o, _ = measure(a, None, 1, 0, sub=True)
+        except Exception as ex:           # a sub-configuration that fails must not take the headline with it: it is reported as failed
+            res[key] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            continue
+        rf = o.get("roofline", {})
+        c = {"workload": o["config"]["workload"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
+             "kernel_variant": o.get("kernel_variant"), "acceptance_rate": o["acceptance_rate"], "timed_blocks": o["timing"]["timed_blocks"],
+             "rhat_run_so_far": o["convergence"]["history"][-1][1] if o["convergence"]["history"] else None,
+             "rhat_generations": o["convergence"]["generations_run"],
+             "generations_to_rhat_below_1p2": o["convergence"]["generations_to_rhat_below_1p2"],
+             "roofline": {k_: rf.get(k_) for k_ in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_us", "whole_generation_frac", "other_kernels_hbm") if k_ in rf},
+             "generation_hbm_frac_of_8TBps": o.get("generation_hbm", {}).get("frac_of_8TBps"),
+             "seconds": None}
+        if "burnin_value" in o:
+            c["burnin_value"] = o["burnin_value"]
+            c["burnin"] = {k_: o["burnin"][k_] for k_ in ("burnin_generations", "ms_per_step", "kernel_variant", "cr_probs_after_burnin")}
+        c["seconds"] = time.perf_counter() - t0
+        res[key] = c
+    return res
+
+
+def measure(args, dist, world, rank, sub=False):
+    """The whole measurement sequence of one workload (module docstring, parts 1-5) on engines of this process; -> (the line as a dict on
+    rank 0 / None elsewhere, the replica check or None).  sub: one of the `configs` block's workloads -- no dense / lag-0 legs, no fixed
+    R-hat window (the run-so-far R-hat of the convergence run is what is reported)."""
+    from pydream_amd import _capi
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     n_local = args.chains_per_gpu
     n_global = n_local * world
@@ -285,6 +369,23 @@ def main():
     est_block_s = max(K * 15e-6 * max(1.0, (args.dim / 100.0) ** 2) * max(1.0, n_local / 4096.0), 1e-5)
     max_blocks = int(min(400, max(2, args.min_timed_ms * 1e-3 / est_block_s + 2)))
     total = conv_cap + args.rhat_window + args.warmup + K * (max_blocks + 2) + max(K, args.event_generations) + 2 * args.thin + (args.burnin_generations + 40 if args.adapt else 0)
+    # The transport north_star names -- an RCCL all-gather of the appended rows -- gets its own number in every N > 1 line: after the blocks
+    # over the default transport (peer: copy-engine pushes) the SAME engines are re-attached to RCCL and the same blocks are timed again
+    # (`rccl_value`).  --rccl-leg runs it with one rank as well (a world-1 communicator: what a one-GPU box can exercise).
+    want_rccl = not sub and ((world > 1 and not args.no_rccl_leg) or getattr(args, "rccl_leg", False))
+    if want_rccl:
+        total += K * (max_blocks + 2) + max(K, 100) + 4 * args.thin
+        if local_rank == 0:       # librccl.so is 570 MB: one sequential read puts it in the page cache while the first legs run (dlopen's page faults on a cold file took minutes)
+            import threading
+
+            def _warm(path=os.path.join(os.path.dirname(os.path.realpath(_capi.hip_library())), "librccl.so.1")):
+                try:
+                    with open(path, "rb", buffering=0) as f:
+                        while f.read(8 << 20):
+                            pass
+                except OSError:
+                    pass
+            threading.Thread(target=_warm, daemon=True).start()
     # (DZ_BENCH_TRANSPORT=host and DZ_BENCH_DEVICE exist so that the multi-rank control flow can be rehearsed on a
     #  one-GPU box: ranks share the device and exchange through the host; measurements use RCCL, one rank per GPU)
     device = int(os.environ.get("DZ_BENCH_DEVICE", local_rank))
@@ -348,7 +449,7 @@ def main():
                     (conv["generations_to_rhat_below_1p2"] is not None if with_rhat else True):
                 break
         conv["generations_run"] = done
-        if with_rhat:
+        if with_rhat and not sub:
             e.trace_reset()
             e.step(args.rhat_window)
             conv["rhat_window_generations"] = args.rhat_window
@@ -417,9 +518,11 @@ def main():
     prof = {}
     kernel_variant = e.last_kernel_variant()
     xstats = None
+    xbytes = None
     if world > 1:
         e.sync()
         xstats = e.exchange_stats()
+        xbytes = e.exchange_bytes()
     if not args.no_events:
         KE = max(K, args.event_generations)
         KE -= KE % args.thin if KE >= args.thin else 0          # whole thin-cycles: every launch of the persistent kernel is a full one
@@ -459,10 +562,53 @@ def main():
                             "position-keyed hash of every element) and the bytes of its crossover probabilities, all-gathered after the run"}
         e.sync()
         dist.barrier()           # every rank is past its last exchange: only now may a rank unmap its buffers
+    rccl = None
+    if want_rccl:
+        rccl = {"what": "the same engines, after the blocks above, re-attached to RCCL (in-place ncclAllGather of the appended rows on the engine's "
+                        "stream, between two launches) and the same blocks of K generations timed again"}
+        try:
+            if transport == "rccl":
+                rccl.update(value=n_global * args.multitry * K / med, ms_per_step=1e3 * med / K, note="RCCL carried the blocks above: rccl_value == value")
+            else:
+                if transport == "peer":
+                    e.peer_detach()
+                if world > 1:
+                    from pydream_amd.distributed import attach_transport
+                    attach_transport(e, rank, world, transport="rccl", group=dist.group)      # (raises on EVERY rank if any rank failed)
+                else:
+                    e.comm_init_rccl(0, 1, _capi.comm_unique_id())
+
+                def rbarrier():
+                    e.sync()
+                    if dist is not None:
+                        dist.barrier()
+                    e.comm_barrier()
+                e.trace_reset(); e.step(2 * args.thin)
+                rbarrier()
+                rt = timed_blocks(e, K, args.min_timed_ms, rbarrier, dist, max_blocks)
+                rmed = float(np.median(rt))
+                rccl.update(value=n_global * args.multitry * K / rmed, ms_per_step=1e3 * rmed / K, timed_blocks=len(rt), kernel_variant=e.last_kernel_variant())
+                KR = max(K, 100); KR -= KR % args.thin if KR >= args.thin else 0
+                e.profile_enable(True, prealloc_pairs=8 * min(KR, trace_cap)); e.profile_reset()
+                e.trace_reset(); e.step(KR); e.sync()
+                e.profile_enable(False)
+                ex = 1e3 * e.profile_get_list("exchange")
+                rccl["exchange_exposed_us_per_cycle"] = float(ex.mean()) if len(ex) else None
+                rccl["exchanges_timed"] = int(len(ex))
+            rccl["ranks"] = e.comm_count()
+            rccl["library"] = _capi.comm_library()
+            if dist is not None:
+                h, rows = e.history_checksum()
+                got = dist.all_gather_object([h, rows])
+                rccl["replicas_identical"] = all(g[0] == got[0][0] and g[1] == got[0][1] for g in got)
+                e.sync()
+                dist.barrier()
+        except Exception as ex:         # (attach_transport fails on all ranks together; a one-GPU rehearsal cannot give RCCL two ranks on one device)
+            rccl.update(value=None, note="RCCL leg not run: %s" % ex)
     e.close()
 
     dense = None
-    if world == 1 and args.target == "mvn" and args.mvn_kind == "tri" and not args.no_dense:
+    if world == 1 and args.target == "mvn" and args.mvn_kind == "tri" and not args.no_dense and not sub:
         import copy
         a2 = copy.copy(args)
         a2.mvn_kind = "dense"
@@ -473,7 +619,7 @@ def main():
         dense = {"value": n_global * args.multitry * K / m2, "ms_per_step": 1e3 * m2 / K, "timed_blocks": len(t2),
                  "formula": "log_F - x.(invC.x)/2 with the dense precision matrix (dream_ex_ndim_gaussian.py:49-52)", "acceptance_rate": acc2}
     lag0 = None
-    if world == 1 and args.history_lag != 0 and not args.no_lag0:
+    if world == 1 and args.history_lag != 0 and not args.no_lag0 and not sub:
         import copy
         a3 = copy.copy(args)
         a3.history_lag = 0
@@ -486,9 +632,7 @@ def main():
                 "kernel_variant": v3, "what": "the same timed blocks with history_lag = 0: the lockstep schedule (an append is sampled from the "
                                               "next generation on) that most of the reference-made fixtures pin"}
     if rank != 0:
-        if dist is not None:
-            dist.close()
-        return
+        return None, replicas
 
     value = n_global * args.multitry * K / med
     flops_gen = n_local * (2 * args.multitry - 1) * (1.0 if args.mvn_kind == "tri" else 2.0) * float(args.dim) ** 2 if args.target == "mvn" else None
@@ -499,9 +643,10 @@ def main():
         "ms_per_step": 1e3 * med / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%d chains/GPU x %d-D %s target (%s), multitry=%d, DE+snooker(%g), nCR=3, history_thin=%d, "
-                               "seed archive max(10d,2N) rows U(-5,15); BASELINE north_star target / configs[3] per-GPU shard"
+                               "seed archive max(10d,2N) rows U(-5,15); %s"
                                % (n_local, args.dim, "correlated MVN" if args.target == "mvn" else "3-Gaussian mixture",
-                                  args.mvn_kind if args.target == "mvn" else "identity cov", args.multitry, args.snooker, args.thin),
+                                  args.mvn_kind if args.target == "mvn" else "identity cov", args.multitry, args.snooker, args.thin,
+                                  workload_label(args, n_local, world)),
                    "chains_global": n_global, "chains_per_gpu": n_local, "ndim": args.dim, "multitry": args.multitry,
                    "history_lag": args.history_lag,
                    "parallelism": ("chains sharded x%d, history appends replicated on every GPU (transport: %s, history_lag %d)" % (world, transport, args.history_lag))
@@ -513,7 +658,7 @@ def main():
         "logp_points_per_s": n_global * (2 * args.multitry - 1) * K / med,
         "acceptance_rate": acc,
         "generations_executed": conv["generations_run"] + args.rhat_window + args.warmup + K * len(times) + (0 if args.no_events else prof.get("event_pass_generations", 0)),
-        "rhat_max": conv.get("rhat_window_max"),
+        "rhat_max": conv.get("rhat_window_max") if not sub else (conv["history"][-1][1] if conv["history"] else None),
         "convergence": conv,
     }
     if dense is not None:
@@ -531,8 +676,19 @@ def main():
     if replicas is not None:
         out["replicas_identical"] = replicas["identical"]
         out["replica_check"] = replicas
+    if rccl is not None:
+        out["rccl_value"] = rccl.get("value")
+        out["rccl_ranks"] = rccl.get("ranks")
+        out["rccl_exchange_exposed_us_per_cycle"] = rccl.get("exchange_exposed_us_per_cycle")
+        out["rccl"] = rccl
     if world > 1:
         # top level, not buried in config: what carried the rows, and how much of the exchange the generations had to wait for
+        if xbytes is not None:
+            out["exchange_bytes_to_each_peer"] = {"history_rows": xbytes[0], "positions": xbytes[1], "adaptation_group_sums": xbytes[2],
+                                                  "per_burnin_generation": (xbytes[2] / (args.burnin_generations + 1)) if (args.adapt and xbytes[2]) else None,
+                                                  "what": "bytes rank 0 handed to the transport for each other rank over the whole run (dz_exchange_bytes); with crossover "
+                                                          "adaptation a rank that owns whole groups of 256 chains sends its groups' column sums every burn-in generation, "
+                                                          "its positions only once"}
         out["transport"] = transport if transport != "host" else "host-fallback"
         if transport_note:
             out["transport_note"] = transport_note
@@ -622,14 +778,7 @@ def main():
         out["generation_hbm"] = {"algorithmic_bytes_per_generation": gen_bytes,
                                  "achieved_GBps": gen_bytes * K / med / 1e9,
                                  "frac_of_8TBps": gen_bytes * K / med / 1e9 / HBM_PEAK_GBS}
-    if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args)
-    print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.close()
-    if replicas is not None and not replicas["identical"]:
-        sys.stderr.write("bench.py: the ranks' archive replicas DIFFER (see replica_check in the line): the number above is not valid\n")
-        sys.exit(3)
+    return out, replicas
 
 
 def self_launch(args):

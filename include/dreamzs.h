@@ -101,6 +101,7 @@ const char* dz_hip_library(void);      /* path of the HIP runtime this library's
 const char* dz_comm_library(void);     /* path of the librccl in use: the one next to that HIP runtime (and checked to resolve the same one) */
 int dz_comm_unique_id(void* id128);                                                 /* rank 0: 128-byte RCCL unique id */
 int dz_comm_init_rccl(dz_engine* e, int32_t rank, int32_t world, const void* id128);
+int dz_comm_count(dz_engine* e, int32_t* ranks);       /* ncclCommCount of the engine's communicator (0: none): what RCCL itself says about the ranks taking part */
 int dz_set_exchange(dz_engine* e, dz_exchange_cb cb, void* user);
 /* Third transport, "peer": every rank maps the other ranks' archive (and published-position buffers) through HIP IPC and its COPY
  * ENGINES push the rank's rows into them on streams of their own, each push followed by the rank's flag word -- no compute unit is

@@ -36,7 +36,7 @@ XCHG_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 SYMBOLS = [
     "dz_version", "dz_last_error", "dz_device_count", "dz_create", "dz_destroy", "dz_set_bounds", "dz_set_gamma_table",
     "dz_set_history", "dz_set_state", "dz_set_cr_probs", "dz_set_gamma_probs", "dz_set_prior", "dz_set_likelihood_mvn",
-    "dz_set_likelihood_mixture", "dz_set_likelihood_host", "dz_hip_library", "dz_comm_library", "dz_comm_unique_id", "dz_comm_init_rccl", "dz_comm_barrier", "dz_set_exchange", "dz_peer_export", "dz_peer_attach", "dz_peer_detach", "dz_exchange_stats", "dz_exchange_bytes", "dz_set_temperatures", "dz_get_swaps",
+    "dz_set_likelihood_mixture", "dz_set_likelihood_host", "dz_hip_library", "dz_comm_library", "dz_comm_unique_id", "dz_comm_init_rccl", "dz_comm_count", "dz_comm_barrier", "dz_set_exchange", "dz_peer_export", "dz_peer_attach", "dz_peer_detach", "dz_exchange_stats", "dz_exchange_bytes", "dz_set_temperatures", "dz_get_swaps",
     "dz_step", "dz_continue_run", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_get_chain_probs", "dz_sync", "dz_trace_reset", "dz_generation", "dz_redraw_rounds", "dz_last_kernel_variant", "dz_get_state", "dz_get_trace", "dz_get_trace_chains", "dz_trace_download_begin", "dz_trace_download_wait", "dz_host_register", "dz_host_unregister", "dz_get_history", "dz_get_history_range", "dz_history_checksum",
     "dz_get_cr_state", "dz_get_gamma_state", "dz_get_rhat", "dz_get_chain_moments", "dz_eval_logp", "dz_debug_propose",
     "dz_profile_enable", "dz_profile_get", "dz_profile_reset", "dz_profile_get_list",
@@ -87,6 +87,7 @@ def load_library():
     L.dz_peer_attach.argtypes = [V, C.c_int32, C.c_int32, V]
     L.dz_exchange_stats.argtypes = [V, V, V, V]
     L.dz_exchange_bytes.argtypes = [V, V, V, V]
+    L.dz_comm_count.argtypes = [V, V]
     L.dz_peer_detach.argtypes = [V]
     L.dz_step.argtypes = [V, C.c_int64]
     L.dz_sync.argtypes = [V]
@@ -301,6 +302,12 @@ class Engine:
         n, g, us = C.c_int64(), C.c_int64(), C.c_double()
         self._chk(self.L.dz_exchange_stats(self.h, C.byref(n), C.byref(g), C.byref(us)))
         return n.value, g.value, us.value
+
+    def comm_count(self):
+        """ncclCommCount of the engine's RCCL communicator (0: none)"""
+        n = C.c_int32()
+        self._chk(self.L.dz_comm_count(self.h, C.byref(n)))
+        return n.value
 
     def exchange_bytes(self):
         """bytes handed to the transport for EACH other rank so far: (history rows, published positions, adaptation group sums)"""

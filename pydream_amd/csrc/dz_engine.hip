@@ -46,6 +46,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string path, hip_path;
     // RCCL must sit on the SAME HIP runtime as this library: device pointers and streams of one runtime instance mean nothing to
@@ -76,6 +77,7 @@ struct Rccl {
         AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
         CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
         GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        CommCount = (decltype(CommCount))dlsym(lib, "ncclCommCount");
         if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy) { dlclose(lib); lib = nullptr; return fail("librccl lacks required symbols: " + path); }
         Dl_info ri, rh;
         if (dladdr((void*)GetUniqueId, &ri) && ri.dli_fname) path = ri.dli_fname;
@@ -1393,6 +1395,19 @@ int dz_comm_init_rccl(dz_engine* e, int32_t rank, int32_t world, const void* id1
     memcpy(&id, id128, 128);
     ncclResult_t r = g_rccl.CommInitRank(&e->comm, world, id, rank);
     if (r != ncclSuccess) return fail(std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+    return 0;
+}
+
+int dz_comm_count(dz_engine* e, int32_t* ranks)
+{   // ncclCommCount of the engine's communicator: how many ranks RCCL itself says take part (0: no communicator)
+    if (!e || !ranks) return fail("null argument");
+    *ranks = 0;
+    if (!e->comm) return 0;
+    if (!g_rccl.CommCount) return fail("librccl has no ncclCommCount");
+    int n = 0;
+    ncclResult_t r = g_rccl.CommCount(e->comm, &n);
+    if (r != ncclSuccess) return fail(std::string("ncclCommCount: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+    *ranks = n;
     return 0;
 }
 

@@ -435,8 +435,8 @@ def test_bench_line_has_the_contracted_fields(tmp_path):
     import subprocess
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--chains-per-gpu", "512",
                           "--rhat-max-generations", "600", "--rhat-min-generations", "300", "--rhat-chunk", "100", "--rhat-window", "200",
-                          "--min-timed-ms", "5", "--cpu-chains", "128", "--cpu-seconds", "1"],
-                         cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+                          "--min-timed-ms", "5", "--cpu-chains", "128", "--cpu-seconds", "1", "--rccl-leg"],
+                         cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -457,6 +457,63 @@ def test_bench_line_has_the_contracted_fields(tmp_path):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "proposals/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     assert "workload" in d["config"] and "model" not in d["config"]
+    # --rccl-leg: the transport north_star names, through bench.py itself, with the one rank a one-GPU box can give it -- the same engine
+    # re-attached to an RCCL communicator and the same blocks timed again (every N > 1 line carries these keys)
+    assert d["rccl_ranks"] == 1 and d["rccl_value"] > 0 and d["rccl"]["timed_blocks"] >= 1 and d["rccl_exchange_exposed_us_per_cycle"] is not None
+    assert "torch" not in d["rccl"]["library"] and d["rccl"]["kernel_variant"] == d["kernel_variant"]
+    assert "configs" not in d                      # (512 chains per GPU is not the default workload: no configs block)
+
+
+@pytest.mark.gpu
+def test_bench_default_line_carries_every_single_gpu_baseline_config(tmp_path):
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's command; here with a short convergence run): the line's `configs` block
+    holds BASELINE configs[1] (1024 chains x 100-D), configs[2] as written (4096-chain 3-Gaussian mixture with crossover adaptation:
+    the rate inside the burn-in and after it) and the configs[4] per-GPU shard (512 chains x 1000-D), each with its rate, the kernel
+    instantiation that ran, its roofline fraction and the run-so-far R-hat."""
+    import json
+    import subprocess
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                          "--rhat-max-generations", "600", "--rhat-min-generations", "300", "--rhat-chunk", "100", "--rhat-window", "200",
+                          "--min-timed-ms", "5", "--no-cpu-baseline", "--no-dense", "--no-lag0"],
+                         cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith('{"metric"')][0])
+    assert "configs[3] per-GPU shard" in d["config"]["workload"]
+    c = d["configs"]
+    assert set(c) == {"configs[1]", "configs[2]", "configs[4] shard"}
+    for key, variant, label in (("configs[1]", "k_generations<7,tri,xlds,4,4,lean>", "BASELINE configs[1]"),
+                                ("configs[2]", "k_generations_mix", "BASELINE configs[2] as written"),
+                                ("configs[4] shard", "multi-kernel path", "BASELINE configs[4] per-GPU shard")):
+        x = c[key]
+        assert "error" not in x, x
+        assert x["kernel_variant"] == variant and label in x["workload"] and x["value"] > 0 and x["ms_per_step"] > 0
+        assert 0 < x["roofline"]["frac"] < 1 and np.isfinite(x["rhat_run_so_far"]) and x["rhat_generations"] >= 300
+    assert c["configs[1]"]["roofline"]["bound"] == "hbm" and c["configs[4] shard"]["roofline"]["bound"] == "fp64_mfma"
+    assert 0 < c["configs[4] shard"]["roofline"]["whole_generation_frac"] < 1
+    assert c["configs[2]"]["burnin_value"] > 0 and c["configs[2]"]["value"] > c["configs[2]"]["burnin_value"]
+    assert not np.allclose(c["configs[2]"]["burnin"]["cr_probs_after_burnin"], 1 / 3.)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_with_crossover_adaptation_exchange_group_sums(tmp_path):
+    """`bench.py --gpus 2 --adapt` (two ranks sharing device 0, 512 chains each = two whole groups per rank): `burnin_value` is reported,
+    the ranks' replicas and adapted probabilities agree, and what travels per burn-in generation is the groups' sums -- under 100 KB per
+    rank -- while the positions travel once."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DZ_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", DZ_PEER_TIMEOUT_S="120")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--chains-per-gpu", "512", "--adapt",
+                          "--burnin-generations", "160", "--rhat-max-generations", "400", "--rhat-min-generations", "200", "--rhat-chunk", "100", "--rhat-window", "200",
+                          "--min-timed-ms", "20", "--no-cpu-baseline", "--transport", "peer", "--no-rccl-leg"], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith('{"metric"')][0])
+    assert d["n_gpus"] == 2 and d["transport"] == "peer" and d["replicas_identical"] is True
+    assert d["burnin_value"] > 0 and d["burnin"]["kernel_variant"].startswith("k_generations<7,tri,xlds,")
+    assert not np.allclose(d["burnin"]["cr_probs_after_burnin"], 1 / 3.)
+    xb = d["exchange_bytes_to_each_peer"]
+    assert xb["positions"] == 512 * 112 * 8 and 0 < xb["per_burnin_generation"] <= 100 * 1024
+    assert xb["adaptation_group_sums"] == 161 * (2 * (6 * 112 + 16) + 112) * 8
 
 
 @pytest.mark.gpu
@@ -499,6 +556,11 @@ def test_bench_gpus_2_as_one_command_starts_its_own_ranks(tmp_path):
     assert d["exchange"]["gates"] > 0 and d["exchange_exposed_us_per_cycle"] is not None and d["exchange_exposed_us_per_cycle"] >= 0.0
     assert d["kernel_variant"].startswith("k_generations<7,tri,xlds")
     assert np.isfinite(d["rhat_max"]) and d["value"] > 0
+    # the RCCL leg of every N > 1 line: the keys are there; on this box both ranks sit on ONE device, which RCCL refuses -- then the line says so
+    for key in ("rccl_value", "rccl_ranks", "rccl_exchange_exposed_us_per_cycle"):
+        assert key in d, key
+    assert (d["rccl_value"] is None and "RCCL leg not run" in d["rccl"]["note"]) or (d["rccl_value"] > 0 and d["rccl_ranks"] == 2 and d["rccl"]["replicas_identical"])
+    assert d["exchange_bytes_to_each_peer"]["history_rows"] > 0 and d["exchange_bytes_to_each_peer"]["positions"] == 0
     from pydream_amd import _capi
     if _capi.device_count() < 2:                           # the refusal: never fewer ranks than asked for
         env.pop("DZ_BENCH_DEVICE")

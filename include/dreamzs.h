@@ -93,6 +93,21 @@ int dz_set_likelihood_mvn(dz_engine* e, const double* mu, const double* M, int32
 int dz_set_likelihood_mixture(dz_engine* e, int32_t J, const double* mu, const double* log_F);
 /* arbitrary host likelihood (any Python callable behind ctypes) */
 int dz_set_likelihood_host(dz_engine* e, dz_logp_cb cb, void* user);
+/* arbitrary DEVICE likelihood -- the "batched device callback" for a model that is not one of the two descriptors above (the reference takes
+ * any callable: model.py:17-32 `self.likelihood(q0)`).  The caller builds a gfx950 code object (hipcc --offload-arch=gfx950 --genco) that
+ * exports
+ *     extern "C" __global__ void NAME(const double* X, long long n, int d, int ld, double* like, const void* data);
+ * X: the batch's points, row i at X + i * ld (row-major, rows padded to ld doubles); like[i] receives log L(X_i) (may be -inf; nan is
+ * treated as -inf); data: a copy on the device of the `data_bytes` bytes at `data` (model constants, observations; NULL if none).  The
+ * engine launches it once per batch where its own k_logp_* kernels run, with 256 threads per block and
+ *     lanes_per_point = 1:  thread blockIdx.x * 256 + threadIdx.x evaluates point i (grid = ceil(n / 256));
+ *     lanes_per_point = 64: wave (blockIdx.x * 4 + threadIdx.x / 64) evaluates point i with its 64 lanes (grid = ceil(n / 4)).
+ * Priors given by dz_set_prior are added by the engine.  Generations with such a likelihood run the multi-kernel path (the persistent
+ * kernels hold the built-in densities only).  flags: DZ_LIKE_ALWAYS_FINITE promises that the density is finite wherever the priors are, so
+ * the engine need not check every proposal set for "all tries impossible" (Dream.py:281-289) with a read-back per generation. */
+#define DZ_LIKE_ALWAYS_FINITE 1
+int dz_set_likelihood_module(dz_engine* e, const char* code_object_path, const char* kernel_name, int32_t lanes_per_point, int32_t flags,
+                             const void* data, int64_t data_bytes);
 
 /* Multi-GPU: chains are sharded, Z / positions are replicated by an all-gather at the
  * end of appending generations (replaces the multiprocessing shared arrays,

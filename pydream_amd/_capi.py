@@ -36,7 +36,7 @@ XCHG_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 SYMBOLS = [
     "dz_version", "dz_last_error", "dz_device_count", "dz_create", "dz_destroy", "dz_set_bounds", "dz_set_gamma_table",
     "dz_set_history", "dz_set_state", "dz_set_cr_probs", "dz_set_gamma_probs", "dz_set_prior", "dz_set_likelihood_mvn",
-    "dz_set_likelihood_mixture", "dz_set_likelihood_host", "dz_hip_library", "dz_comm_library", "dz_comm_unique_id", "dz_comm_init_rccl", "dz_comm_count", "dz_comm_barrier", "dz_set_exchange", "dz_peer_export", "dz_peer_attach", "dz_peer_detach", "dz_exchange_stats", "dz_exchange_bytes", "dz_set_temperatures", "dz_get_swaps",
+    "dz_set_likelihood_mixture", "dz_set_likelihood_host", "dz_set_likelihood_module", "dz_hip_library", "dz_comm_library", "dz_comm_unique_id", "dz_comm_init_rccl", "dz_comm_count", "dz_comm_barrier", "dz_set_exchange", "dz_peer_export", "dz_peer_attach", "dz_peer_detach", "dz_exchange_stats", "dz_exchange_bytes", "dz_set_temperatures", "dz_get_swaps",
     "dz_step", "dz_continue_run", "dz_step_range", "dz_set_chain_state", "dz_get_chain_state", "dz_get_chain_probs", "dz_sync", "dz_trace_reset", "dz_generation", "dz_redraw_rounds", "dz_last_kernel_variant", "dz_get_state", "dz_get_trace", "dz_get_trace_chains", "dz_trace_download_begin", "dz_trace_download_wait", "dz_host_register", "dz_host_unregister", "dz_get_history", "dz_get_history_range", "dz_history_checksum",
     "dz_get_cr_state", "dz_get_gamma_state", "dz_get_rhat", "dz_get_chain_moments", "dz_eval_logp", "dz_debug_propose",
     "dz_profile_enable", "dz_profile_get", "dz_profile_reset", "dz_profile_get_list",
@@ -77,6 +77,7 @@ def load_library():
     L.dz_set_likelihood_mvn.argtypes = [V, V, V, C.c_int32, C.c_double]
     L.dz_set_likelihood_mixture.argtypes = [V, C.c_int32, V, V]
     L.dz_set_likelihood_host.argtypes = [V, LOGP_CB, V]
+    L.dz_set_likelihood_module.argtypes = [V, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, V, C.c_int64]
     L.dz_comm_unique_id.argtypes = [V]
     L.dz_comm_library.restype = C.c_char_p
     L.dz_hip_library.restype = C.c_char_p
@@ -261,6 +262,14 @@ class Engine:
         cb = LOGP_CB(tramp)
         self._keep.append(cb)
         self._chk(self.L.dz_set_likelihood_host(self.h, cb, None))
+
+    def set_likelihood_module(self, code_object_path, kernel_name, lanes_per_point=1, data=None, always_finite=False):
+        """A user-built gfx950 code object's kernel as the likelihood (include/dreamzs.h dz_set_likelihood_module); data: bytes / a numpy
+        array copied to the device and handed to the kernel."""
+        blob = b"" if data is None else (data if isinstance(data, (bytes, bytearray)) else np.ascontiguousarray(data).tobytes())
+        buf = C.create_string_buffer(bytes(blob), len(blob)) if blob else None
+        self._chk(self.L.dz_set_likelihood_module(self.h, os.fsencode(code_object_path), kernel_name.encode(), int(lanes_per_point),
+                                                   1 if always_finite else 0, buf, len(blob)))
 
     def set_exchange(self, fn):
         """fn(send_bytes, nbytes) -> bytes of all ranks' blocks in rank order (host-staged all-gather)."""

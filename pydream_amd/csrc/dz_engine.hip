@@ -37,7 +37,7 @@ int fail(const std::string& m) { g_err = m; return -1; }
     } while (0)
 #define DZCK(expr) do { int _r = (expr); if (_r) return _r; } while (0)
 
-enum { LK_NONE = 0, LK_MVN = 1, LK_MIX = 2, LK_HOST = 3 };
+enum { LK_NONE = 0, LK_MVN = 1, LK_MIX = 2, LK_HOST = 3, LK_MODULE = 4 };
 enum { PR_PROPOSE = 0, PR_LOGP = 1, PR_ACCEPT = 2, PR_ADAPT = 3, PR_EXCHANGE = 4, PR_GENERATIONS = 5, PR_EMPTY = 6, PR_COUNT = 7 };
 
 struct Rccl {
@@ -130,6 +130,8 @@ struct dz_engine {
     bool have_logp = false, adapt = false;
     int lk = LK_NONE;
     dz_logp_cb cb = nullptr; void* cb_user = nullptr;
+    // a user-supplied DEVICE likelihood (dz_set_likelihood_module): a kernel of a code object the user built, launched where k_logp_* run
+    hipModule_t lk_module = nullptr; hipFunction_t lk_fn = nullptr; void* d_lk_data = nullptr; int lk_lanes = 1; bool lk_finite = false;
     dz_exchange_cb xcb = nullptr; void* xcb_user = nullptr;
     ncclComm_t comm = nullptr; int rank = 0, world = 1;
     // peer transport (dz_peer_export / dz_peer_attach): the other ranks' archives, position buffers and flag words mapped into this
@@ -411,6 +413,16 @@ int eval_logp(dz_engine* e, const double* pts, int n, double* prior, double* lik
         }
     } else if (e->lk == LK_MIX) {
         NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_logp_mix<NCH>, grid, block, 0, st, e->p, pts, n, prior, like));
+    } else if (e->lk == LK_MODULE) {
+        // the user's kernel writes like[n]; the engine zeroes prior[n] first and then adds the device priors and maps nan -> -inf (k_prior_add),
+        // exactly what follows a host callback
+        struct { const double* X; long long n; int d; int ld; double* like; const void* data; } a = {pts, (long long)n, e->p.d, e->p.ld, like, e->d_lk_data};
+        size_t asz = sizeof(a);
+        void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+        HIPCK(hipMemsetAsync(prior, 0, sizeof(double) * (size_t)n, st));
+        const unsigned per_block = e->lk_lanes == 64 ? 4u : 256u;      // one thread or one wave per point, 256 threads per block
+        HIPCK(hipModuleLaunchKernel(e->lk_fn, ((unsigned)n + per_block - 1) / per_block, 1, 1, 256, 1, 1, 0, st, nullptr, extra));
+        NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_prior_add<NCH>, grid, block, 0, st, e->p, pts, n, prior, like));
     } else if (e->lk == LK_HOST) {
         const int d = e->p.d;
         e->h_stage.resize((size_t)n * (d + 2));
@@ -612,6 +624,7 @@ bool redo_possible(const dz_engine* e)
     const dz::Params& p = e->p;
     if (p.k <= 1) return false;
     if (e->lk == LK_HOST) return true;
+    if (e->lk == LK_MODULE && !e->lk_finite) return true;      // (a user's density may be -inf anywhere unless the caller promises otherwise: DZ_LIKE_ALWAYS_FINITE)
     for (size_t j = 0; j < e->h_pkind.size(); ++j) {
         if (e->h_pkind[j] != 2) continue;
         const bool covered = p.hard && j < e->h_mins.size() && e->h_mins[j] >= e->h_pa[j] && e->h_maxs[j] <= e->h_pa[j] + e->h_pb[j];
@@ -1189,6 +1202,8 @@ int dz_destroy(dz_engine* e)
     for (auto& v : e->ev) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t x : e->ev_pool) (void)hipEventDestroy(x);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
+    if (e->lk_module) (void)hipModuleUnload(e->lk_module);
+    if (e->d_lk_data) (void)hipFree(e->d_lk_data);
     for (auto& pr : e->peers) {
         if (pr.st) { (void)hipStreamSynchronize(pr.st); (void)hipStreamDestroy(pr.st); }
         if (pr.Z) (void)hipIpcCloseMemHandle(pr.Z);
@@ -1358,6 +1373,30 @@ int dz_set_likelihood_host(dz_engine* e, dz_logp_cb cb, void* user)
 {
     if (!cb) return fail("null callback");
     e->cb = cb; e->cb_user = user; e->lk = LK_HOST;
+    return 0;
+}
+
+int dz_set_likelihood_module(dz_engine* e, const char* code_object_path, const char* kernel_name, int32_t lanes_per_point, int32_t flags,
+                             const void* data, int64_t data_bytes)
+{
+    if (!e || !code_object_path || !kernel_name) return fail("null argument");
+    if (lanes_per_point != 1 && lanes_per_point != 64) return fail("dz_set_likelihood_module: lanes_per_point must be 1 (a thread per point) or 64 (a wave per point)");
+    if (data_bytes < 0 || (data_bytes > 0 && !data)) return fail("dz_set_likelihood_module: bad data block");
+    HIPCK(hipSetDevice(e->c.device));
+    DZCK(sync_all(e));
+    hipModule_t mod = nullptr; hipFunction_t fn = nullptr;
+    hipError_t err = hipModuleLoad(&mod, code_object_path);
+    if (err != hipSuccess) { (void)hipGetLastError(); return fail(std::string("hipModuleLoad(") + code_object_path + "): " + hipGetErrorString(err) + " (a gfx950 code object is expected: hipcc --offload-arch=gfx950 --genco)"); }
+    err = hipModuleGetFunction(&fn, mod, kernel_name);
+    if (err != hipSuccess) { (void)hipGetLastError(); (void)hipModuleUnload(mod); return fail(std::string("hipModuleGetFunction(") + kernel_name + "): " + hipGetErrorString(err) + " (the kernel must be extern \"C\")"); }
+    if (e->lk_module) (void)hipModuleUnload(e->lk_module);
+    if (e->d_lk_data) { (void)hipFree(e->d_lk_data); e->d_lk_data = nullptr; }
+    if (data_bytes > 0) {
+        HIPCK(hipMalloc(&e->d_lk_data, (size_t)data_bytes));
+        HIPCK(hipMemcpy(e->d_lk_data, data, (size_t)data_bytes, hipMemcpyHostToDevice));
+    }
+    e->lk_module = mod; e->lk_fn = fn; e->lk_lanes = lanes_per_point; e->lk_finite = (flags & DZ_LIKE_ALWAYS_FINITE) != 0;
+    e->lk = LK_MODULE; e->have_logp = false;
     return 0;
 }
 

@@ -54,3 +54,74 @@ class GaussianMixtureLogLike:
 
     def _dz_apply(self, engine):
         engine.set_likelihood_mixture(self.mu, self.log_F)
+
+
+KERNEL_SIGNATURE = 'extern "C" __global__ void NAME(const double* X, long long n, int d, int ld, double* like, const void* data)'
+
+
+def compile_device_kernel(source, out_path=None, extra_flags=()):
+    """HIP source text -> a gfx950 code object (.hsaco) for DeviceKernelLogLike: `hipcc --offload-arch=gfx950 --genco`.
+    -ffp-contract=off is on by default so that a density written with + and * rounds like the same expression in numpy (a host
+    likelihood and its device twin then make the same accept / reject decisions bit for bit); pass extra_flags=("-ffp-contract=fast",)
+    to let the compiler fuse.  Returns the path (a file next to nothing in particular: a private temporary directory unless given)."""
+    import os
+    import subprocess
+    import tempfile
+    if out_path is None:
+        out_path = os.path.join(tempfile.mkdtemp(prefix="dreamzs_kernel_"), "likelihood.hsaco")
+    src = out_path + ".hip"
+    with open(src, "w") as f:
+        if "hip_runtime.h" not in source:
+            f.write("#include <hip/hip_runtime.h>\n")
+        f.write(source)
+    hipcc = next((c for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc") if c and os.path.exists(c)), "hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "--genco", "--no-gpu-bundle-output", "-O3", "-std=c++17", "-ffp-contract=off"] + list(extra_flags) + ["-o", out_path, src]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise Exception("hipcc failed for the device likelihood:\n%s" % res.stderr[-4000:])
+    return out_path
+
+
+class DeviceKernelLogLike:
+    """A user-written HIP kernel as the likelihood -- the batched device callback for ANY model (the reference accepts any callable,
+    pydream/model.py:17-32; a Python callable runs through the host callback at ~40 k proposals/s, this runs where the built-in
+    densities' kernels run).
+
+        like = DeviceKernelLogLike(source=SRC, name="my_logp", ndim=d, data=np.array([...]))     # compiled with hipcc on first use
+        like = DeviceKernelLogLike(path="model.hsaco", name="my_logp", ndim=d)                   # or a code object built beforehand
+        sampled, log_ps = run_dream(parameters, like, nchains=4096, ...)
+
+    The kernel's signature is KERNEL_SIGNATURE: point i is the row X + i * ld, like[i] receives its log likelihood (-inf allowed); `data`
+    is the device copy of the `data` array.  lanes_per_point=1: one thread per point; 64: one wave per point (coalesced row reads, the
+    kernel reduces over its lanes itself).  always_finite=True promises the density is finite wherever the priors are (skips the
+    per-generation "every try impossible?" check of Dream.py:281-289).  host: an optional Python twin f(x[d]) -> float used when the
+    object is called on the host (Model.total_logp); without it a call evaluates the point on the device."""
+
+    def __init__(self, name, ndim, source=None, path=None, data=None, lanes_per_point=1, always_finite=False, host=None, extra_flags=()):
+        if (source is None) == (path is None):
+            raise ValueError("give either the kernel's HIP source or the path of a gfx950 code object")
+        self.name, self.d, self.source, self.path = name, int(ndim), source, path
+        self.data = None if data is None else np.ascontiguousarray(data)
+        self.lanes_per_point, self.always_finite, self.host, self.extra_flags = int(lanes_per_point), bool(always_finite), host, tuple(extra_flags)
+        self._eval_engine = None
+
+    def code_object(self):
+        if self.path is None:
+            self.path = compile_device_kernel(self.source, extra_flags=self.extra_flags)
+        return self.path
+
+    def _dz_apply(self, engine):
+        engine.set_likelihood_module(self.code_object(), self.name, self.lanes_per_point, self.data, self.always_finite)
+
+    def __call__(self, x):
+        if self.host is not None:
+            return self.host(np.asarray(x, dtype=float))
+        if self._eval_engine is None:
+            from . import _capi
+            self._eval_engine = _capi.Engine(nchains=3, ndim=self.d, history_capacity=8)
+            self._dz_apply(self._eval_engine)
+        return float(self._eval_engine.eval_logp(np.asarray(x, dtype=float).reshape(1, self.d))[1][0])
+
+    def __getstate__(self):                      # (the evaluation engine is a device handle: not part of the object's value)
+        st = dict(self.__dict__); st["_eval_engine"] = None
+        return st

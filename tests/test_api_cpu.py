@@ -195,3 +195,23 @@ def test_gelman_rubin_on_run_dream_shaped_results_copies_nothing():
     assert peak < 48 << 20                                         # (np.stack alone would be S.nbytes; the blocks' temporaries are ~32 MB)
     np.testing.assert_array_equal(r, Gelman_Rubin([v.copy() for v in views]))
     assert r.shape == (20,) and np.all(r > 1.0)
+
+
+def test_a_user_kernel_compiles_to_a_gfx950_code_object_that_exports_it(tmp_path):
+    """pydream_amd.likelihoods.compile_device_kernel (hipcc cross-compiles without a GPU): the example's HIP twin of a Python likelihood
+    becomes an ELF code object exporting the extern "C" kernel dz_set_likelihood_module looks up; the host twin is the reference-style
+    callable f(x[d]) -> float (pydream/model.py:31)."""
+    import subprocess
+    from pydream_amd.examples.banana import banana_device as B
+    from pydream_amd.likelihoods import DeviceKernelLogLike, compile_device_kernel
+    out = compile_device_kernel(B.SOURCE, str(tmp_path / "banana.hsaco"))
+    assert open(out, "rb").read(4) == b"\x7fELF"
+    syms = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-s", out], capture_output=True, text=True).stdout
+    assert "banana_logp" in syms and "banana_logp.kd" in syms
+    like = B.make_likelihood(6)
+    x = np.arange(6.0) - 2.0
+    assert like(x) == B.banana_host(x) == B.banana_host_batch(x[None])[1][0]          # the host twin answers a host call
+    with pytest.raises(ValueError):
+        DeviceKernelLogLike("f", 3)                                                  # neither source nor path
+    with pytest.raises(Exception, match="hipcc failed"):
+        compile_device_kernel("this is not HIP", str(tmp_path / "bad.hsaco"))

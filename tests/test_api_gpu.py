@@ -500,3 +500,91 @@ def test_the_convergence_loop_of_the_examples_continues_on_the_live_engine(tmp_p
     assert len(built) == 1
     core.release_engines()
     assert Gelman_Rubin_device(s2) is not s2.gelman_rubin and np.array_equal(Gelman_Rubin_device(s2), s2.gelman_rubin)
+
+
+@pytest.mark.parametrize("prior,finite", [("flat", True), ("flat", False), ("uniform_open", False), ("normal", True)])
+def test_a_user_device_kernel_equals_the_same_function_through_the_host_callback(prior, finite):
+    """dz_set_likelihood_module (the batched device callback for ANY model; the reference takes any callable, pydream/model.py:17-32): the
+    banana density as a user-built HIP kernel on the HIP engine against the same function, operation for operation, through the host
+    callback of the ORACLE -- states, log densities, every decision and the archive equal bit for bit; with a uniform prior narrower than
+    the archive and no hard boundaries whole proposal sets are impossible and are drawn again (Dream.py:281-289) through the user kernel."""
+    from oracle import oracle as O
+    from pydream_amd import _capi as G
+    from pydream_amd.examples.banana import banana_device as B
+    d, N, k, n, seed = 12, 256, 5, 35, 5
+    like = B.make_likelihood(d)
+    Z0 = np.random.default_rng(2).uniform(-8, 8, (10 * d + 2 * N, d))
+    out = []
+    for Cls in (G.Engine, O.Engine):
+        e = Cls(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
+                adapt_crossover=1, crossover_burnin=15, hardboundaries=0 if prior == "uniform_open" else 1)
+        if prior == "uniform_open":
+            e.set_prior(np.full(d, 2, np.int32), np.full(d, -4.0), np.full(d, 8.0))
+        elif prior == "normal":
+            e.set_prior(np.full(d, 1, np.int32), np.linspace(-1.0, 1.0, d), np.full(d, 20.0))
+        e.set_history(Z0)
+        e.set_state(np.clip(Z0[:N], -3.9, 3.9) if prior == "uniform_open" else Z0[:N])
+        if Cls is G.Engine:
+            e.set_likelihood_module(like.code_object(), like.name, 1, like.data, always_finite=finite)
+        else:
+            e.set_likelihood_host(B.banana_host_batch)
+        e.step(n)
+        out.append((e.get_trace(0, n), e.get_history(), e.get_cr_state(), e.redraw_rounds() if Cls is G.Engine else None, e.last_kernel_variant() if Cls is G.Engine else None))
+    for key in ("snooker", "cr_idx", "try_idx", "moved", "X", "logp"):
+        np.testing.assert_array_equal(out[0][0][key], out[1][0][key], err_msg=key)
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    for a, b in zip(out[0][2], out[1][2]):
+        np.testing.assert_array_equal(a, b)
+    assert out[0][4] == "multi-kernel path" and 0.02 < out[0][0]["moved"].mean() < 0.95
+    assert (out[0][3] > 0) == (prior == "uniform_open")
+
+
+def test_run_dream_with_a_user_device_kernel_and_a_wave_per_point(tmp_path):
+    """The drop-in path: run_dream(parameters, DeviceKernelLogLike(...)) -- compiled on first use, SampledParam priors added on the device --
+    gives what run_dream with the Python twin of the kernel as a plain host likelihood gives (same seed: same samples, bit for bit); and
+    the wave-per-point launch shape (lanes_per_point = 64) with a data block, against its own host twin."""
+    from scipy.stats import norm
+    from pydream_amd.examples.banana import banana_device as B
+    from pydream_amd.likelihoods import DeviceKernelLogLike
+    d, N, n = 6, 8, 30
+    hist = str(tmp_path / "seed.npy")
+    np.save(hist, np.random.default_rng(4).uniform(-6, 6, (80, d)))
+    kw = dict(nchains=N, niterations=n, verbose=False, save_history=False, history_file=hist, multitry=3, seed=11, start=[np.full(d, 0.1 * i) for i in range(N)])
+    pri = [SampledParam(norm, loc=np.zeros(d), scale=np.full(d, 10.0))]
+    s_dev, l_dev = run_dream(pri, B.make_likelihood(d), **kw)
+    s_host, l_host = run_dream(pri, lambda x: B.banana_host(x), **kw)
+    np.testing.assert_array_equal(np.array(s_dev), np.array(s_host))
+    np.testing.assert_allclose(np.array(l_dev), np.array(l_host), rtol=0, atol=1e-10)      # (the host path adds scipy's prior, the device its own: 1e-10)
+    # one wave per point: each lane sums its strided share of the squared distances to data[0..d), then a butterfly over the lanes
+    src = r'''
+    extern "C" __global__ void sq_dist(const double* X, long long n, int d, int ld, double* like, const void* data)
+    {
+        const long long i = blockIdx.x * 4ll + (threadIdx.x >> 6);
+        const int lane = threadIdx.x & 63;
+        if (i >= n) return;
+        const double* c = (const double*)data;
+        double acc = 0.0;
+        for (int j = lane; j < d; j += 64) { const double t = X[i * ld + j] - c[j]; acc = acc + t * t; }
+        for (int o = 32; o > 0; o >>= 1) acc = acc + __shfl_xor(acc, o, 64);
+        if (lane == 0) like[i] = -0.5 * acc;
+    }'''
+    d2 = 150
+    c = np.linspace(-1, 1, d2)
+    like = DeviceKernelLogLike("sq_dist", d2, source=src, data=c, lanes_per_point=64)
+    X = np.random.default_rng(0).normal(size=(37, d2))
+
+    def twin(x):          # the same order of additions: lane l adds j = l, l + 64, l + 128; then the xor butterfly 32, 16, .. 1
+        part = np.zeros(64)
+        for j in range(d2):
+            t = x[j] - c[j]; part[j % 64] = part[j % 64] + t * t
+        for o in (32, 16, 8, 4, 2, 1):
+            part = part + part[np.arange(64) ^ o]
+        return -0.5 * part[0]
+    got = np.array([like(x) for x in X[:5]])
+    np.testing.assert_array_equal(got, np.array([twin(x) for x in X[:5]]))
+    from pydream_amd import _capi as G
+    e = G.Engine(nchains=3, ndim=d2, history_capacity=8)
+    like._dz_apply(e)
+    np.testing.assert_array_equal(e.eval_logp(X)[1], np.array([twin(x) for x in X]))
+    with pytest.raises(G.DreamZSError, match="hipModuleGetFunction"):
+        e.set_likelihood_module(like.code_object(), "no_such_kernel")

@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """Which kernel runs, and how fast, across shapes (4096 chains unless given; MVN triangular factor, flat prior, no trace buffer):
-    python tools/shape_scan.py            looks for cliffs -- shapes that fall off the persistent kernel"""
+    python tools/shape_scan.py [chains] [dims, comma separated] [multitry values, comma separated]
+looks for cliffs -- shapes that fall off the persistent kernel"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from pydream_amd import _capi as G
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-for d in (10, 50, 100, 128):
+DIMS = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [10, 50, 100, 128, 160, 200, 256, 512, 1000]
+KS = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else None
+for d in DIMS:
     i = np.arange(1, d + 1.0)
     P = np.linalg.inv((.5 * np.eye(d) + .5) * np.sqrt(np.outer(i, i)))
     U = np.linalg.cholesky((P + P.T) / 2).T
     Z0 = np.random.default_rng(3).uniform(-5, 15, (2 * N, d))
-    for k in (1, 3, 5, 8, 12, 16):
-        gens = 600
+    for k in (KS or ((1, 3, 5, 8, 12, 16) if d <= 128 else (1, 5))):
+        gens = 600 if d <= 256 else 200
         e = G.Engine(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (gens // 10 + 30), trace_capacity=0, seed=5)
         e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), U, 1, 0.0)
         e.step(100); e.sync()

@@ -125,7 +125,8 @@ int dz_set_exchange(dz_engine* e, dz_exchange_cb cb, void* user);
  * (replaces the shared arrays of core.py:281-297 / Dream.py:919-945 like the all-gather does); with history_lag = 1 a whole thin-cycle
  * later, i.e. the exchange is hidden.  Bootstrap: dz_peer_export fills this rank's blob, the control plane all-gathers the blobs (rank
  * order), dz_peer_attach maps them and runs a self-test (every rank pushes one flag word to every peer and waits for theirs: a refusal at
- * attach time instead of a timeout in the middle of a run).  dz_exchange_stats (after dz_sync): exchanges queued, gates passed and the time the gates spent
+ * attach time instead of a timeout in the middle of a run).  A gate that has waited DZ_PEER_TIMEOUT_S seconds (environment; default 600) for a
+ * rank gives up: dz_step queues nothing more and every synchronising call fails naming the silent rank.  dz_exchange_stats (after dz_sync): exchanges queued, gates passed and the time the gates spent
  * waiting -- the exposed part of the exchange. */
 #define DZ_PEER_BLOB_BYTES 512
 int dz_peer_export(dz_engine* e, void* blob /* DZ_PEER_BLOB_BYTES */);

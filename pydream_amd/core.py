@@ -60,15 +60,17 @@ def run_dream(parameters, likelihood, nchains=5, niterations=50000, start=None, 
     # written.  The engine of a run that saved its history under a model name stays alive instead ("parked"), and a restart under the same
     # name with the same sampler and untouched files continues on it (dz_continue_run): history and adapted probabilities are already
     # in HBM.  The files are still written.  release_engines() frees a parked engine's memory; DREAMZS_KEEP_ENGINE=0 turns this off.
-    if restart:
-        live = _claim_parked(step_instance, kwargs, nchains, niterations, likelihood, tempering)
-    else:
-        live = None
-        stale = _parked.pop(kwargs.get('model_name'), None)       # a fresh run under a parked name: that engine's memory is needed now
-        if stale is not None:
-            stale["engine"].close()
-    pool = _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=start, mp_context=mp_context,
-                                seed=kwargs.get('seed'), device=kwargs.get('device', 0), history_lag=kwargs.get('history_lag', 0), live=live)
+    live = _claim_parked(step_instance, kwargs, nchains, niterations, likelihood, tempering) if restart else None
+    # Whatever this call is not going to continue on is released BEFORE the new engine allocates (advisor, round 4): a parked engine holds
+    # its whole archive in HBM, and a run under another name (or none, or with save_history off) would otherwise allocate beside it.
+    release_engines()
+    try:
+        pool = _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=start, mp_context=mp_context,
+                                    seed=kwargs.get('seed'), device=kwargs.get('device', 0), history_lag=kwargs.get('history_lag', 0), live=live)
+    except BaseException:
+        if live is not None:              # (claimed out of the parked table: nobody else would close it -- bad nchains / start shape, an allocation failing in continue_run)
+            live.close()
+        raise
     park = False
     try:
         pool._initializer(*pool._initargs)
@@ -434,8 +436,8 @@ def _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=None, mp_
     like = model.likelihood
     host_eval = None
     if hasattr(like, "_dz_apply") and dev_prior is not None:
-        if live is None:
-            like._dz_apply(eng)                       # likelihood AND priors on the device
+        like._dz_apply(eng)                           # likelihood AND priors on the device (also on a continued engine: the object may have been
+                                                      # changed in place since the run before -- cheap next to the history upload that is saved)
     else:
         from .model import HostEvaluator
         host_eval = HostEvaluator(model, dev_prior is None, nchains, mp_context=mp_context, force=bool(getattr(step_instance, 'parallel', False)))

@@ -190,6 +190,7 @@ struct dz_engine {
     hipStream_t copy_stream = nullptr; hipEvent_t copy_ev[8] = {nullptr};   // dz_trace_download_begin / _wait: trace rows leave while later generations run
     int64_t redraw_rounds = 0;      // redraw launches so far (dz_redraw_rounds)
     double *d_own_cr = nullptr, *d_own_g = nullptr; std::vector<char> own_init;      // per-instance probabilities of single-chain stepping (Params::own_cr)
+    std::string broken;             // non-empty: a failed dz_continue_run left the engine without some of its buffers -- dz_step refuses
     std::string last_variant;       // what the last dz_step launched for its generations (dz_last_kernel_variant)
     bool pending_accept = false;    // generation gen-1's Metropolis step has been deferred into the next proposal kernel
     int64_t pending_slot = -1;
@@ -1628,14 +1629,24 @@ int dz_continue_run(dz_engine* e, int64_t history_capacity, int64_t trace_capaci
     if (e->copy_stream) HIPCK(hipStreamSynchronize(e->copy_stream));
     dz::Params& p = e->p;
     if (history_capacity < e->M) return fail("dz_continue_run: capacity below the rows already in the archive");
+    // keep == 0 (the trace buffers: nothing of the old run's trace is used again): the old buffer is freed BEFORE the new one is allocated,
+    // so the peak is max(old, new), not old + new (advisor, round 4); a failed allocation leaves the slot null and the engine says so
     auto swap_buffer = [&](auto** slot, size_t count, size_t keep) -> int {
         using T = std::remove_pointer_t<std::remove_pointer_t<decltype(slot)>>;
+        auto drop_old = [&]() {
+            auto it = std::find(e->to_free.begin(), e->to_free.end(), (void*)*slot);
+            if (it != e->to_free.end()) e->to_free.erase(it);
+            (void)hipFree((void*)*slot);
+            *slot = nullptr;
+        };
+        if (!keep) drop_old();
         T* fresh = nullptr;
-        DZCK(dalloc(&fresh, count));
+        if (dalloc(&fresh, count)) {
+            if (!keep) { e->c.trace_capacity = 0; e->p.tcap = 0; e->broken = "dz_continue_run could not allocate the new trace buffers; the engine has none now: destroy it"; }
+            return -1;
+        }
         if (keep && hipMemcpy(fresh, *slot, sizeof(T) * keep, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(fresh); return fail("dz_continue_run: device copy failed"); }
-        auto it = std::find(e->to_free.begin(), e->to_free.end(), (void*)*slot);
-        if (it != e->to_free.end()) e->to_free.erase(it);
-        (void)hipFree((void*)*slot);
+        if (keep) drop_old();
         *slot = fresh; e->to_free.push_back((void*)fresh);
         return 0;
     };
@@ -1674,6 +1685,7 @@ int dz_step(dz_engine* e, int64_t generations)
 {
     if (!e) return fail("null engine");
     HIPCK(hipSetDevice(e->c.device));
+    if (!e->broken.empty()) return fail(e->broken);
     if (e->lk == LK_NONE) return fail("no likelihood set");
     if (e->M < 2 * e->c.depairs) return fail("history not seeded");
     if (e->c.trace_capacity && e->ntrace + generations > e->c.trace_capacity) return fail("trace capacity exceeded");

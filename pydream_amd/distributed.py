@@ -147,9 +147,9 @@ class SocketGroup:
         self.rank, self.world = int(rank), int(world)
         self.peers = []
         self.hub = None
-        token = _token_bytes(token)
-        if self.world == 1:
+        if self.world == 1:                # (a single rank needs no token: nothing connects)
             return
+        token = _token_bytes(token)
         if addr not in ("127.0.0.1", "localhost"):
             raise ValueError("SocketGroup is a one-node control plane: it binds and connects on 127.0.0.1 only (got %r)" % (addr,))
         addr = "127.0.0.1"

@@ -21,12 +21,12 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libdreamzs.so")
-HEADERS = [os.path.join(CSRC, h) for h in ("dz_kernels.h", "dz_device.h", "dz_megakernel.h", "dz_mega_launch.h")] + \
+HEADERS = [os.path.join(CSRC, h) for h in ("dz_kernels.h", "dz_device.h", "dz_megakernel.h", "dz_mega_launch.h", "dz_megakernel_w4.h")] + \
           [os.path.join(ROOT, "include", "dreamzs.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 # (object name, source, extra flags, headers it depends on)
 UNITS = [("dz_engine.o", os.path.join(CSRC, "dz_engine.hip"), [], HEADERS)] + \
-        [("dz_mega_nrt%d.o" % n, os.path.join(CSRC, "dz_mega_tu.hip"), ["-DDZ_TU_NRT=%d" % n], HEADERS[:4]) for n in range(1, 9)]
+        [("dz_mega_nrt%d.o" % n, os.path.join(CSRC, "dz_mega_tu.hip"), ["-DDZ_TU_NRT=%d" % n], HEADERS[:5]) for n in range(1, 9)]
 DEPS = sorted({u[1] for u in UNITS} | set(HEADERS))
 
 

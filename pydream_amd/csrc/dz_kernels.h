@@ -88,6 +88,8 @@ struct Publish { double* to; const double* shift; double* PR; double* PC; const 
 #define DZ_STAMP(p_, phase_, c_, i_) do { } while (0)
 #define DZ_LSTAMP(p_, w_, i_) do { } while (0)
 #define DZ_MSTAMP(i_) do { } while (0)
+#define DZ_WSTAMP(i_) do { } while (0)
+#define DZ_W0STAMP(i_) do { } while (0)
 #endif
 
 // offset of k-row r in the packed triangular layout: row block b = r/16 has 16*(b+1) columns

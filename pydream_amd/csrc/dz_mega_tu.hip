@@ -1,6 +1,7 @@
 // dz_mega_tu.hip -- the instantiations of k_generations (dz_megakernel.h) for ONE row-tile count, -DDZ_TU_NRT=1..8.
 #define DZ_TEMPLATES_ONLY
 #include "dz_megakernel.h"
+#include "dz_megakernel_w4.h"
 #include "dz_mega_launch.h"
 #include <hip/hip_ext.h>
 
@@ -39,6 +40,15 @@ static const char* launch_one(const MegaLaunch& a)
 template <bool TRI, bool X, bool PB>
 static const char* launch_ch(const MegaLaunch& a)
 {
+    if constexpr (!PB && X) {
+        if (a.ahead && a.ch == 4 && !a.k1) {      // small populations: four waves per chain, the tries' base-independent halves made ahead (dz_megakernel_w4.h)
+            hipExtLaunchKernelGGL((k_generations_w4<DZ_TU_NRT, TRI>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, a.slot0, a.zappend, *a.publish);
+            return TRI ? "k_generations_w4<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,lean,ahead>" : "k_generations_w4<" DZ_STR(DZ_TU_NRT) ",dense,xlds,%d,%d,lean,ahead>";
+        }
+    }
+#ifdef DZ_TU_W4ONLY    // (compile-time experiments on k_generations_w4 alone)
+    return nullptr;
+#else
 #ifdef DZ_TU_FAST      // experiment builds (tools/fastbuild.sh): multi-try only, 16 chains per block or 4 x 4 waves -- a third of the instantiations
     if (a.ch == 4) return launch_one<TRI, X, 4, 4, PB, false>(a);
     return launch_one<TRI, X, 16, 1, PB, false>(a);
@@ -51,6 +61,7 @@ static const char* launch_ch(const MegaLaunch& a)
     if (a.ch == 16) return launch_one<TRI, X, 16, 1, PB, false>(a);
     if (a.ch == 8) return launch_one<TRI, X, 8, 1, PB, false>(a);
     return launch_one<TRI, X, 4, 4, PB, false>(a);
+#endif
 }
 
 // (priors / boundaries / several pairs: only with the chain states in LDS -- mega_eligible -- which keeps the number of kernels down)

@@ -61,13 +61,13 @@ if __name__ == "__main__":
     import time
     from pydream_amd.core import run_dream
     from pydream_amd.convergence import Gelman_Rubin
-    from pydream_amd.parameters import FlatParam
+    from pydream_amd.parameters import SampledParam
+    from scipy.stats import norm
     d, nchains, niter = 10, 1024, 2000
     like = make_likelihood(d)
-    starts = [np.random.default_rng(i).uniform(-5, 5, d) for i in range(nchains)]
+    params = [SampledParam(norm, loc=np.zeros(d), scale=np.full(d, 50.0))]          # a wide normal prior, evaluated on the device as well
     t0 = time.time()
-    sampled, log_ps = run_dream([FlatParam(test_value=np.zeros(d))], like, nchains=nchains, niterations=niter, start=starts, multitry=5,
-                                start_random=False, save_history=False, verbose=False)
+    sampled, log_ps = run_dream(params, like, nchains=nchains, niterations=niter, multitry=5, nseedchains=2 * nchains, save_history=False, verbose=False)
     dt = time.time() - t0
     print("%d chains x %d iterations x %d-D banana through a user kernel: %.2f s (%.1f M proposals/s incl. set-up and download); max R-hat %.3f"
           % (nchains, niter, d, dt, nchains * 5 * niter / dt / 1e6, float(np.max(Gelman_Rubin(sampled)))))

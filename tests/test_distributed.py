@@ -453,7 +453,7 @@ def test_bench_line_has_the_contracted_fields(tmp_path):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
     assert r["launch_us"] * (20 / r["generations_per_launch"]) <= d["timing"]["block_ms_median"] * 1e3 * (1 + 1e-9)      # a kernel cannot outlast the block around it
-    assert r["launches_timed"] >= 20 and r["kernel_variant"] == d["kernel_variant"] and d["kernel_variant"].startswith("k_generations<7,tri,xlds,")
+    assert r["launches_timed"] >= 20 and r["kernel_variant"] == d["kernel_variant"] and d["kernel_variant"] == "k_generations_w4<7,tri,xlds,4,4,lean,ahead>"
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "proposals/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     assert "workload" in d["config"] and "model" not in d["config"]
@@ -481,7 +481,7 @@ def test_bench_default_line_carries_every_single_gpu_baseline_config(tmp_path):
     assert "configs[3] per-GPU shard" in d["config"]["workload"]
     c = d["configs"]
     assert set(c) == {"configs[1]", "configs[2]", "configs[4] shard"}
-    for key, variant, label in (("configs[1]", "k_generations<7,tri,xlds,4,4,lean>", "BASELINE configs[1]"),
+    for key, variant, label in (("configs[1]", "k_generations_w4<7,tri,xlds,4,4,lean,ahead>", "BASELINE configs[1]"),
                                 ("configs[2]", "k_generations_mix", "BASELINE configs[2] as written"),
                                 ("configs[4] shard", "multi-kernel path", "BASELINE configs[4] per-GPU shard")):
         x = c[key]
@@ -509,7 +509,7 @@ def test_bench_two_ranks_with_crossover_adaptation_exchange_group_sums(tmp_path)
     assert res.returncode == 0, res.stderr[-3000:]
     d = json.loads([l for l in res.stdout.splitlines() if l.startswith('{"metric"')][0])
     assert d["n_gpus"] == 2 and d["transport"] == "peer" and d["replicas_identical"] is True
-    assert d["burnin_value"] > 0 and d["burnin"]["kernel_variant"].startswith("k_generations<7,tri,xlds,")
+    assert d["burnin_value"] > 0 and d["burnin"]["kernel_variant"] == "k_generations_w4<7,tri,xlds,4,4,lean,ahead>"
     assert not np.allclose(d["burnin"]["cr_probs_after_burnin"], 1 / 3.)
     xb = d["exchange_bytes_to_each_peer"]
     assert xb["positions"] == 512 * 112 * 8 and 0 < xb["per_burnin_generation"] <= 100 * 1024
@@ -554,7 +554,7 @@ def test_bench_gpus_2_as_one_command_starts_its_own_ranks(tmp_path):
     assert d["n_gpus"] == 2 and d["transport"] == "peer" and d["history_lag"] == 1, (d.get("transport"), d.get("transport_note"))
     assert d["replicas_identical"] is True and len(set(d["replica_check"]["archive_checksums"])) == 1 and len(d["replica_check"]["archive_rows"]) == 2
     assert d["exchange"]["gates"] > 0 and d["exchange_exposed_us_per_cycle"] is not None and d["exchange_exposed_us_per_cycle"] >= 0.0
-    assert d["kernel_variant"].startswith("k_generations<7,tri,xlds")
+    assert d["kernel_variant"] == "k_generations_w4<7,tri,xlds,4,4,lean,ahead>"
     assert np.isfinite(d["rhat_max"]) and d["value"] > 0
     # the RCCL leg of every N > 1 line: the keys are there; on this box both ranks sit on ONE device, which RCCL refuses -- then the line says so
     for key in ("rccl_value", "rccl_ranks", "rccl_exchange_exposed_us_per_cycle"):

@@ -239,8 +239,9 @@ def test_persistent_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, k, tr
                                                       (4096, 1, "mvn", 0, "k_generations<7,tri,xlds,16,1,lean>"),    # ... `value_history_lag0`
                                                       (4096, 0, "mvn", 1, "k_generations<7,dense,xhbm,16,1,lean>"),  # ... `dense_value`
                                                       (4096, 0, "mvn", 0, "k_generations<7,dense,xhbm,16,1,lean>"),
-                                                      (1024, 1, "mvn", 1, "k_generations<7,tri,xlds,4,4,lean>"),     # BASELINE configs[1] (the `configs` block of the line)
-                                                      (1024, 1, "mvn", 0, "k_generations<7,tri,xlds,4,4,lean>"),
+                                                      (1024, 1, "mvn", 1, "k_generations_w4<7,tri,xlds,4,4,lean,ahead>"),     # BASELINE configs[1] (the `configs` block of the line)
+                                                      (1024, 1, "mvn", 0, "k_generations_w4<7,tri,xlds,4,4,lean,ahead>"),
+                                                      (1024, 0, "mvn", 1, "k_generations_w4<7,dense,xlds,4,4,lean,ahead>"),
                                                       (2048, 1, "mvn", 1, "k_generations<7,tri,xlds,8,1,lean>"),
                                                       (4096, 1, "mix3", 1, "k_generations_mix"),                     # BASELINE configs[2] after the burn-in
                                                       (4096, 1, "mix3", 0, "k_generations_mix")])
@@ -674,4 +675,4 @@ def test_a_chain_count_just_above_whole_rounds_of_blocks_against_oracle(G, O, ad
     for a, b in zip(out[0][1], out[1][1]):
         np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(out[0][2], out[1][2])
-    assert out[0][3] == "k_generations<7,tri,xlds,16,1,lean> + k_generations<7,tri,xlds,4,4,lean>", out[0][3]
+    assert out[0][3] == "k_generations<7,tri,xlds,16,1,lean> + k_generations_w4<7,tri,xlds,4,4,lean,ahead>", out[0][3]

@@ -438,14 +438,25 @@ def broadcast_seed(seed, group=None):
 
 
 def run_dream_sharded(parameters, likelihood, nchains=8, niterations=1000, start=None, verbose=False, nverbose=10,
-                      transport="rccl", device=None, engine_cls=None, group=None, **kwargs):
+                      transport="rccl", device=None, engine_cls=None, group=None, restart=False, **kwargs):
     """run_dream with the chains sharded over the ranks of the (already initialised) process group.
 
     Returns this rank's slice: (sampled_params, log_ps) lists for chains
     [rank*N/W, (rank+1)*N/W), in the same format as run_dream.  `seed` must be the same on all
-    ranks (pass it, or leave it None to have rank 0 draw and broadcast one)."""
+    ranks (pass it, or leave it None to have rank 0 draw and broadcast one).
+    restart=True continues an earlier run the way run_dream does (pydream/core.py:46-62): every rank loads the history and the adapted
+    crossover / gamma-level probabilities from the three files `model_name` names (written by rank 0 of the run before: the archive is
+    replicated) and takes its own slice of `start` -- a list of nchains vectors, the last states of ALL chains."""
     import os
     rank, world = _rank_world(group)
+    if restart:
+        if start is None:
+            raise Exception('Restart run specified but no start positions given.')
+        if 'model_name' not in kwargs:
+            raise Exception('Restart run specified but no model name to load history and crossover value files from given.')
+        kwargs = dict(kwargs, history_file=kwargs['model_name'] + '_DREAM_chain_history.npy',
+                      crossover_file=kwargs['model_name'] + '_DREAM_chain_adapted_crossoverprob.npy',
+                      gamma_file=kwargs['model_name'] + '_DREAM_chain_adapted_gammalevelprob.npy')
     off, nl = shard(nchains, rank, world)
     seed = kwargs.pop('seed', None)
     if seed is None:
@@ -463,6 +474,8 @@ def run_dream_sharded(parameters, likelihood, nchains=8, niterations=1000, start
         save = step.save_history
         step.save_history = save and rank == 0          # the archive is replicated: one writer is enough
         out = _sample_dream_batched(pool.engine, step, niterations, verbose and rank == 0, nverbose)
+        if save and world > 1:
+            _barrier(group)                             # the files are complete before any rank returns (a restart reads them on every rank)
         if transport == "peer" and world > 1:
             pool.engine.sync()
             _barrier(group)                             # a rank's buffers stay mapped until no peer can still be writing into them

@@ -147,6 +147,78 @@ def _run_two_ranks(backend_engine, tmp_path, variant="flat"):
         assert redraws is None or redraws > 0     # (the HIP engine counts its redraw launches)
 
 
+def _restart_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import faulthandler
+    faulthandler.dump_traceback_later(150, exit=True)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from oracle import oracle as O
+    from pydream_amd.distributed import run_dream_sharded
+    from tests import helpers as H
+    os.chdir(outdir)
+    d = 12
+    params, like = _model(d)
+    Z0 = H.seed_history(40, d, 3)
+    np.save("seed_r%d.npy" % rank, Z0)
+    kw = dict(nchains=8, multitry=5, adapt_crossover=True, history_thin=5, engine_cls=O.Engine, transport="host", device=0)
+    s1, l1 = run_dream_sharded(params, like, niterations=30, start=list(Z0[:8]), history_file="seed_r%d.npy" % rank, nseedchains=40, seed=5,
+                               model_name="shard", save_history=True, **kw)
+    last = np.zeros((8, d))
+    last[rank * 4:(rank + 1) * 4] = np.array(s1)[:, -1]
+    import torch
+    t = torch.from_numpy(last); dist.all_reduce(t)                      # every rank needs ALL chains' last states as `start`
+    s2, l2 = run_dream_sharded(params, like, niterations=25, start=list(t.numpy()), restart=True, seed=6, model_name="shard", save_history=True, **kw)
+    np.savez("restart_rank%d.npz" % rank, X1=np.array(s1), X2=np.array(s2), L2=np.array(l2))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_restart_equals_the_unsharded_restart(tmp_path):
+    """run_dream_sharded(restart=True) (pydream/core.py:46-62, :255-263; Dream.py:128-147): a first sharded run leaves the three files, a
+    second one -- two ranks again -- loads history and adapted probabilities from them and continues; equal, bit for bit, to the same two
+    calls of run_dream on one engine (oracle backend, gloo control plane)."""
+    import multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_restart_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(240)
+    assert all(pr.exitcode == 0 for pr in procs), [pr.exitcode for pr in procs]
+    r0, r1 = np.load(tmp_path / "restart_rank0.npz"), np.load(tmp_path / "restart_rank1.npz")
+    # the unsharded comparand: the same two calls through run_dream's own machinery on one oracle engine
+    from oracle import oracle as O
+    from pydream_amd import core
+    from pydream_amd.Dream import Dream
+    from pydream_amd.model import Model
+    from tests import helpers as H
+    d = 12
+    params, like = _model(d)
+    Z0 = H.seed_history(40, d, 3)
+    cwd = os.getcwd()
+    os.makedirs(tmp_path / "single", exist_ok=True)
+    os.chdir(tmp_path / "single")
+    try:
+        np.save("seed.npy", Z0)
+        common = dict(multitry=5, adapt_crossover=True, history_thin=5, model_name="one", save_history=True)
+        step = Dream(model=Model(like, params), history_file="seed.npy", nseedchains=40, **common)
+        pool = core._setup_mp_dream_pool(8, 30, step, start_pt=list(Z0[:8]), seed=5, engine_cls=O.Engine)
+        s1, _ = core._sample_dream_batched(pool.engine, step, 30, False, 10)
+        pool.close(); pool.join()
+        step2 = Dream(model=Model(like, params), history_file="one_DREAM_chain_history.npy", crossover_file="one_DREAM_chain_adapted_crossoverprob.npy",
+                      gamma_file="one_DREAM_chain_adapted_gammalevelprob.npy", **common)
+        pool = core._setup_mp_dream_pool(8, 25, step2, start_pt=[x[-1] for x in s1], seed=6, engine_cls=O.Engine)
+        s2, l2 = core._sample_dream_batched(pool.engine, step2, 25, False, 10)
+        pool.close(); pool.join()
+    finally:
+        os.chdir(cwd)
+    np.testing.assert_array_equal(np.concatenate([r0["X1"], r1["X1"]]), np.array(s1))
+    np.testing.assert_array_equal(np.concatenate([r0["X2"], r1["X2"]]), np.array(s2))
+    np.testing.assert_array_equal(np.concatenate([r0["L2"], r1["L2"]]), np.array(l2))
+    np.testing.assert_array_equal(np.load(tmp_path / "shard_DREAM_chain_history.npy"), np.load(tmp_path / "single" / "one_DREAM_chain_history.npy"))
+
+
 def test_shard_arithmetic():
     from pydream_amd.distributed import shard
     assert shard(32768, 3, 8) == (12288, 4096)

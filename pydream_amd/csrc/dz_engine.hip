@@ -194,6 +194,7 @@ struct dz_engine {
     std::string broken;             // non-empty: a failed dz_continue_run left the engine without some of its buffers -- dz_step refuses
     std::string last_variant;       // what the last dz_step launched for its generations (dz_last_kernel_variant)
     bool pending_accept = false;    // generation gen-1's Metropolis step has been deferred into the next proposal kernel
+    const double* pending_qfin_r = nullptr;      // ... and with it the reference set's row-tile sums (Params::qfin_r), still in the scratch array
     int64_t pending_slot = -1;
     int propose_split = 0;          // waves per chain in k_propose (DZ_PROPOSE_SPLIT); 0 = by problem shape
     int force_pt = 0;               // measurement switch: DZ_MFMA_PT=1|2 forces the point tiles per wave
@@ -759,7 +760,8 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
     const bool defer = full && e->fuse && more_follow && !append && !publish && split == 1 && e->lk != LK_HOST && !e->tempering && !streamed && !redo;
     const int64_t zbase = full ? e->M : e->M - (int64_t)(p.off + c0);
     // large d: the row-tile sums of the likelihood product are added by the kernels that use them (no k_q_finish launches)
-    const bool qdefer = streamed && e->q_defer && e->lk == LK_MVN && p.ld / 16 > 8 && !e->force_big;
+    // (round 5: also the per-chain proposal kernels of 128 < d <= 256 -- the reference example's own d = 200 --: two launches of six fewer)
+    const bool qdefer = e->q_defer && e->lk == LK_MVN && p.ld / 16 > 8 && !e->force_big && (streamed || (full && k >= 3 && !redo_possible(e) && e->nch < 4 && e->nlanes == 1));
     p.qfin_p = nullptr; p.qfin_r = nullptr; p.qfin_nrt = (p.d + 15) / 16;
     for (int s = 0; s < L; ++s) {
         const int lc0 = c0 + (int)((int64_t)nc * s / L), lc1 = c0 + (int)((int64_t)nc * (s + 1) / L), lnc = lc1 - lc0;
@@ -770,7 +772,11 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
         if (streamed && have_prop) { }                      // made by the k_accept_propose launch of the generation before
         else if (streamed && !fused_in) DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose_stream, dim3((lnc * k + 3) / 4), dim3(256), 0, p, 0, g, Mv, lc0, lnc);
         else {
-            if (fused_in) { NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc + wpb - 1) / wpb), dim3(64 * wpb), 0, p, 0, g, Mv, lc0, lnc, 1, 1, e->pending_slot)); }
+            if (fused_in) {      // (the Metropolis step of generation g - 1 in front: its reference set's row-tile sums may still be in the scratch array)
+                p.qfin_r = e->pending_qfin_r; p.qfin_c0 = lc0; p.qfin_nc = lnc;
+                NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc + wpb - 1) / wpb), dim3(64 * wpb), 0, p, 0, g, Mv, lc0, lnc, 1, 1, e->pending_slot));
+                p.qfin_r = nullptr;
+            }
             else { NCH_DISPATCH(e, DZ_KLAUNCH(e, PR_PROPOSE, st, dz::k_propose<NCH>, dim3((lnc * sp0 + wpb - 1) / wpb), dim3(64 * wpb), 0, p, 0, g, Mv, lc0, lnc, sp0, 0, (int64_t)-1)); }
         }
         DZCK(launch_check("propose"));
@@ -799,6 +805,7 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
     }
     if (fuse_next) e->stream_prop_gen = (int64_t)g + 1;
     e->pending_accept = defer; e->pending_slot = defer ? slot : -1;
+    e->pending_qfin_r = (defer && qdefer && k > 1) ? e->last_qpart : nullptr;      // (one chain group when deferred sums are in play: see L below)
     e->draws_gen = (full && !publish) ? (int64_t)g + 1 : -1;   // while adapting, next generation's decisions must wait for the new probabilities
     if (publish || append) {         // shared state changed: the lanes meet before anything reads it
         if (L > 1) DZCK(join_all(e));

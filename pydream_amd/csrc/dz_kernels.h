@@ -860,7 +860,17 @@ __global__ __launch_bounds__(NCH >= 4 ? 256 : 1024) void k_propose(Params p, int
         const double* base;
         if (phase == 0) { base = p.X + (size_t)c * p.ld; out = p.P + (size_t)c * p.k * p.ld; sl = p.p_slogp + (size_t)c * p.k; }
         else {
-            bool fin; const int sel = mt_select(p, c, ct.u_sel, lane, &fin);
+            bool fin; int sel;
+            if (p.qfin_p) {      // the proposal set's row-tile sums are still in the scratch array (no k_q_finish launch): every wave of the chain adds them
+                double lp = -__builtin_huge_val();
+                if (lane < p.k) {
+                    const double like = like_from_q(p, p.qfin_p, (size_t)p.qfin_nc * p.k, (size_t)(c - p.qfin_c0) * p.k + lane);
+                    const double prior = p.have_prior ? p.p_prior[c * p.k + lane] : 0.0;
+                    lp = prior + chain_T(p, c) * like;
+                    if (i0 == 0) { p.p_like[c * p.k + lane] = like; if (!p.have_prior) p.p_prior[c * p.k + lane] = 0.0; }
+                }
+                sel = mt_select_vals(p.k, lp, ct.u_sel, lane, &fin);
+            } else sel = mt_select(p, c, ct.u_sel, lane, &fin);
             if (lane == 0 && i0 == 0) p.sel[c] = sel | (fin ? 256 : 0);
             base = p.P + ((size_t)c * p.k + sel) * p.ld; out = p.R + (size_t)c * (p.k - 1) * p.ld; sl = p.r_slogp + (size_t)c * (p.k - 1);
         }

@@ -562,7 +562,171 @@ def measure(args, dist, world, rank, sub=False):
                             "position-keyed hash of every element) and the bytes of its crossover probabilities, all-gathered after the run"}
         e.sync()
         dist.barrier()           # every rank is past its last exchange: only now may a rank unmap its buffers
-    rccl = None
+    dense = lag0 = rccl = None
+    def assemble():
+        """the JSON line (rank 0) from what has been measured so far"""
+        value = n_global * args.multitry * K / med
+        flops_gen = n_local * (2 * args.multitry - 1) * (1.0 if args.mvn_kind == "tri" else 2.0) * float(args.dim) ** 2 if args.target == "mvn" else None
+        out = {
+            "metric": "proposals/sec (all chains), %dD %s logpdf, MT-DREAM(ZS) multitry=%d, history_lag=%d"
+                      % (args.dim, "MVN" if args.target == "mvn" else "3-Gaussian mixture", args.multitry, args.history_lag),
+            "value": value, "unit": "proposals/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": 1e3 * med / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d chains/GPU x %d-D %s target (%s), multitry=%d, DE+snooker(%g), nCR=3, history_thin=%d, "
+                                   "seed archive max(10d,2N) rows U(-5,15); %s"
+                                   % (n_local, args.dim, "correlated MVN" if args.target == "mvn" else "3-Gaussian mixture",
+                                      args.mvn_kind if args.target == "mvn" else "identity cov", args.multitry, args.snooker, args.thin,
+                                      workload_label(args, n_local, world)),
+                       "chains_global": n_global, "chains_per_gpu": n_local, "ndim": args.dim, "multitry": args.multitry,
+                       "history_lag": args.history_lag,
+                       "parallelism": ("chains sharded x%d, history appends replicated on every GPU (transport: %s, history_lag %d)" % (world, transport, args.history_lag))
+                                      if world > 1 else "single GPU"},
+            "timing": {"timed_blocks": len(times), "block_generations": K, "block_ms_median": 1e3 * med, "block_ms_min": 1e3 * min(times),
+                       "block_ms_max": 1e3 * max(times), "timed_ms_total": 1e3 * sum(times),
+                       "value_from": "median block", "value_best_block": n_global * args.multitry * K / min(times),
+                       "value_worst_block": n_global * args.multitry * K / max(times)},
+            "logp_points_per_s": n_global * (2 * args.multitry - 1) * K / med,
+            "acceptance_rate": acc,
+            "generations_executed": conv["generations_run"] + args.rhat_window + args.warmup + K * len(times) + (0 if args.no_events else prof.get("event_pass_generations", 0)),
+            "rhat_max": conv.get("rhat_window_max") if not sub else (conv["history"][-1][1] if conv["history"] else None),
+            "convergence": conv,
+        }
+        if dense is not None:
+            out["dense_value"] = dense["value"]
+            out["dense"] = dense
+        if lag0 is not None:
+            out["value_history_lag0"] = lag0["value"]
+            out["history_lag0"] = lag0
+        if burn is not None:
+            out["burnin_value"] = burn["value"]
+            out["burnin"] = burn
+            out["config"]["workload"] += "; crossover adaptation ON, crossover_burnin %d: `burnin_value` is the rate inside the burn-in, `value` after it" % args.burnin_generations
+        out["kernel_variant"] = kernel_variant
+        out["history_lag"] = args.history_lag
+        if replicas is not None:
+            out["replicas_identical"] = replicas["identical"]
+            out["replica_check"] = replicas
+        if rccl is not None:
+            out["rccl_value"] = rccl.get("value")
+            out["rccl_ranks"] = rccl.get("ranks")
+            out["rccl_exchange_exposed_us_per_cycle"] = rccl.get("exchange_exposed_us_per_cycle")
+            out["rccl"] = rccl
+        if world > 1:
+            # top level, not buried in config: what carried the rows, and how much of the exchange the generations had to wait for
+            if xbytes is not None:
+                out["exchange_bytes_to_each_peer"] = {"history_rows": xbytes[0], "positions": xbytes[1], "adaptation_group_sums": xbytes[2],
+                                                      "per_burnin_generation": (xbytes[2] / (args.burnin_generations + 1)) if (args.adapt and xbytes[2]) else None,
+                                                      "what": "bytes rank 0 handed to the transport for each other rank over the whole run (dz_exchange_bytes); with crossover "
+                                                              "adaptation a rank that owns whole groups of 256 chains sends its groups' column sums every burn-in generation, "
+                                                              "its positions only once"}
+            out["transport"] = transport if transport != "host" else "host-fallback"
+            if transport_note:
+                out["transport_note"] = transport_note
+            if xstats is not None and transport == "peer":
+                nx, ngate, wait_us = xstats
+                out["exchange"] = {"exchanges": nx, "gates": ngate, "gate_wait_us_total": wait_us,
+                                   "exchange_exposed_us_per_cycle": (wait_us / ngate) if ngate else None,
+                                   "what": "time the one-wave gate kernels in front of the launches spent waiting for the other ranks' rows "
+                                           "(rank 0, whole run incl. convergence and warm-up); bytes per rank and cycle: %d" % (n_local * 8 * ((args.dim + 15) // 16 * 16))}
+                out["exchange_exposed_us_per_cycle"] = out["exchange"]["exchange_exposed_us_per_cycle"]
+        if prof:
+            KE = prof["event_pass_generations"]
+            ab = algorithmic_bytes(args, n_local)
+            if prof.get("generations", {}).get("launches"):
+                # the persistent kernel covers whole generations: SURVEY.md section 8(d) B = 176 d + 152 bytes per chain-generation
+                ab["generations"] = n_local * generation_bytes(args) * KE / prof["generations"]["launches"]
+            cand = {k: v for k, v in prof.items() if isinstance(v, dict) and k in ab and v["launches"]}
+            dom = max(cand, key=lambda k: cand[k]["total_ms"])
+            gens_per_launch = KE / cand[dom]["launches"] if dom == "generations" else 1.0
+            # Duration of one launch of the dominant kernel: the MEDIAN over the event-timed launches (>= 20 of them), never more than the
+            # wall clock allows -- a kernel cannot take longer than the timed block around it (the event pass runs a few percent slower
+            # than the un-instrumented blocks: round 2's line had 314 us per launch inside blocks of 303.6 us per 10 generations).
+            launch_s = cand[dom]["median_us"] * 1e-6
+            launches_per_block = (K / gens_per_launch) if dom == "generations" else K * {"propose": 2.0, "logp": 2.0, "accept": 1.0}.get(dom, 1.0)
+            wall_cap_s = med / max(launches_per_block, 1e-9)
+            events_exceed_wall = launch_s > wall_cap_s
+            if events_exceed_wall and dom == "generations":
+                launch_s = wall_cap_s
+            tmeta = {"launch_us": launch_s * 1e6, "launch_us_from": ("timed blocks (median block / launches per block): the event-timed median %.1f us exceeds it"
+                                                                      % cand[dom]["median_us"]) if (events_exceed_wall and dom == "generations")
+                     else "median of %d event-timed launches" % cand[dom]["launches"],
+                     "launch_us_event_median": cand[dom]["median_us"], "launch_us_event_min": cand[dom]["min_us"],
+                     "launches_timed": cand[dom]["launches"], "generations_per_launch": gens_per_launch}
+            compute_bound = args.dim > 128 and args.target == "mvn" and dom in ("logp", "generations")
+            if compute_bound:
+                # d > 128: the batched quadratic form dominates and is FP64-matrix-bound (SURVEY.md 8(d): ~100 flop/B at d = 1000)
+                fl = flops_gen * (gens_per_launch if dom == "generations" else 0.5)          # logp: two launches per generation
+                achieved = fl / launch_s / 1e12
+                whole = flops_gen * K / med / 1e12                                            # every kernel of the generation in the denominator
+                out["roofline"] = {"bound": "fp64_mfma", "kernel": "k_" + dom, "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                                   "algorithmic_flops_per_launch": fl,
+                                   "whole_generation_achieved": whole, "whole_generation_frac": whole / FP64_MFMA_PEAK_TFLOPS}
+                # the other third of a streamed generation, priced as what it is -- HBM traffic: algorithmic bytes / the AVERAGE event-timed
+                # launch (no ramp subtracted).  Per try: base row + the archive rows read, the proposal written = 8d (rows_z + 2); the
+                # Metropolis step's own bytes ride in the launch that carries the next proposal set (k_accept_propose).
+                rows_z = 2 * (1 - args.snooker) + 3 * args.snooker
+                try_b = 8.0 * args.dim * (rows_z + 2.0)
+                others = {}
+                for cls, name, nbytes in (("accept", "k_accept_propose / k_accept (Metropolis step + the next generation's proposal set)", ab["accept"] + n_local * args.multitry * try_b),
+                                          ("propose", "k_propose_stream (reference set)", n_local * (args.multitry - 1) * try_b)):
+                    v = prof.get(cls)
+                    if v and v["launches"]:
+                        gbps = nbytes / (v["avg_us"] * 1e-6) / 1e9
+                        others[cls] = {"kernel": name, "algorithmic_bytes_per_launch": nbytes, "avg_us": v["avg_us"], "achieved_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBS}
+                out["roofline"]["other_kernels_hbm"] = others
+            else:
+                achieved = ab[dom] / launch_s / 1e9
+                traffic, tsrc = measured_traffic(args, n_local, dom, gens_per_launch)
+                out["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                                   "algorithmic_bytes_per_launch": ab[dom]}
+                pm = measured_pmc(args, n_local)
+                if pm:
+                    out["roofline"].update({k: v for k, v in pm.items() if k != "source"})
+                    out["roofline"]["pmc_source"] = pm["source"]
+                    if dom == "generations" and "mfma_insts_per_wave_generation" in pm:
+                        # What bounds this kernel is instruction issue, not HBM: the vector ALU and the FP64 matrix pipe of a SIMD do not
+                        # overlap on gfx950 (profiles/r02_mfma_valu_overlap.txt), so a generation cannot take fewer cycles than its four
+                        # waves per SIMD need to issue their VALU instructions (4 cycles each) and their FP64 MFMAs (64 cycles each).
+                        wps = 4.0
+                        floor_cycles = wps * (pm["valu_insts_per_wave_generation"] * 4.0 + pm["mfma_insts_per_wave_generation"] * 64.0)
+                        gen_cycles = launch_s / gens_per_launch * ENGINE_CLOCK_HZ
+                        out["roofline"]["issue_floor_frac"] = floor_cycles / gen_cycles
+                        out["roofline"]["issue_floor"] = {
+                            "floor_cycles_per_generation": floor_cycles, "measured_cycles_per_generation": gen_cycles, "clock_hz": ENGINE_CLOCK_HZ,
+                            "formula": "4 waves/SIMD x (VALU instructions x 4 cycles + FP64 MFMA instructions x 64 cycles) per wave-generation "
+                                       "(instruction counts: committed PMC file) / (measured launch duration / generations per launch x clock)",
+                            "reading": "the HBM `frac` above is what BASELINE asks for; this is the fraction of the kernel's time its SIMDs need "
+                                       "just to issue its instructions -- the rest is dependent-latency stalls at four waves per SIMD"}
+                if flops_gen:
+                    out["roofline"]["fp64_matrix_tflops"] = flops_gen * K / med / 1e12
+            out["roofline"].update(tmeta)
+            out["roofline"]["kernel_variant"] = kernel_variant
+            out["kernel_times"] = prof
+            gen_bytes = n_local * generation_bytes(args)             # SURVEY.md section 8(d): B = 176 d + 152 per chain-generation at k = 5, s = 0.1
+            out["generation_hbm"] = {"algorithmic_bytes_per_generation": gen_bytes,
+                                     "achieved_GBps": gen_bytes * K / med / 1e9,
+                                     "frac_of_8TBps": gen_bytes * K / med / 1e9 / HBM_PEAK_GBS}
+        return out
+
+    watchdog = None
+    if want_rccl and rank == 0 and world > 1:
+        # The RCCL leg must never cost the line: if the communicator does not come up (ncclCommInitRank cannot be given a deadline) the
+        # line measured so far is printed without it and the process leaves.
+        import threading
+        T = float(os.environ.get("DZ_BENCH_RCCL_DEADLINE_S", "240"))
+
+        def bail():
+            nonlocal rccl
+            rccl = {"value": None, "note": "RCCL leg not run: it did not finish within %g s (DZ_BENCH_RCCL_DEADLINE_S); the line is printed without it" % T}
+            o = assemble()
+            print(json.dumps(o), flush=True)
+            os._exit(0 if (replicas is None or replicas["identical"]) else 3)
+        watchdog = threading.Timer(T, bail)
+        watchdog.daemon = True
+        watchdog.start()
     if want_rccl:
         rccl = {"what": "the same engines, after the blocks above, re-attached to RCCL (in-place ncclAllGather of the appended rows on the engine's "
                         "stream, between two launches) and the same blocks of K generations timed again"}
@@ -605,9 +769,10 @@ def measure(args, dist, world, rank, sub=False):
                 dist.barrier()
         except Exception as ex:         # (attach_transport fails on all ranks together; a one-GPU rehearsal cannot give RCCL two ranks on one device)
             rccl.update(value=None, note="RCCL leg not run: %s" % ex)
+    if watchdog is not None:
+        watchdog.cancel()
     e.close()
 
-    dense = None
     if world == 1 and args.target == "mvn" and args.mvn_kind == "tri" and not args.no_dense and not sub:
         import copy
         a2 = copy.copy(args)
@@ -618,7 +783,6 @@ def measure(args, dist, world, rank, sub=False):
         m2 = float(np.median(t2))
         dense = {"value": n_global * args.multitry * K / m2, "ms_per_step": 1e3 * m2 / K, "timed_blocks": len(t2),
                  "formula": "log_F - x.(invC.x)/2 with the dense precision matrix (dream_ex_ndim_gaussian.py:49-52)", "acceptance_rate": acc2}
-    lag0 = None
     if world == 1 and args.history_lag != 0 and not args.no_lag0 and not sub:
         import copy
         a3 = copy.copy(args)
@@ -633,152 +797,7 @@ def measure(args, dist, world, rank, sub=False):
                                               "next generation on) that most of the reference-made fixtures pin"}
     if rank != 0:
         return None, replicas
-
-    value = n_global * args.multitry * K / med
-    flops_gen = n_local * (2 * args.multitry - 1) * (1.0 if args.mvn_kind == "tri" else 2.0) * float(args.dim) ** 2 if args.target == "mvn" else None
-    out = {
-        "metric": "proposals/sec (all chains), %dD %s logpdf, MT-DREAM(ZS) multitry=%d, history_lag=%d"
-                  % (args.dim, "MVN" if args.target == "mvn" else "3-Gaussian mixture", args.multitry, args.history_lag),
-        "value": value, "unit": "proposals/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-        "ms_per_step": 1e3 * med / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%d chains/GPU x %d-D %s target (%s), multitry=%d, DE+snooker(%g), nCR=3, history_thin=%d, "
-                               "seed archive max(10d,2N) rows U(-5,15); %s"
-                               % (n_local, args.dim, "correlated MVN" if args.target == "mvn" else "3-Gaussian mixture",
-                                  args.mvn_kind if args.target == "mvn" else "identity cov", args.multitry, args.snooker, args.thin,
-                                  workload_label(args, n_local, world)),
-                   "chains_global": n_global, "chains_per_gpu": n_local, "ndim": args.dim, "multitry": args.multitry,
-                   "history_lag": args.history_lag,
-                   "parallelism": ("chains sharded x%d, history appends replicated on every GPU (transport: %s, history_lag %d)" % (world, transport, args.history_lag))
-                                  if world > 1 else "single GPU"},
-        "timing": {"timed_blocks": len(times), "block_generations": K, "block_ms_median": 1e3 * med, "block_ms_min": 1e3 * min(times),
-                   "block_ms_max": 1e3 * max(times), "timed_ms_total": 1e3 * sum(times),
-                   "value_from": "median block", "value_best_block": n_global * args.multitry * K / min(times),
-                   "value_worst_block": n_global * args.multitry * K / max(times)},
-        "logp_points_per_s": n_global * (2 * args.multitry - 1) * K / med,
-        "acceptance_rate": acc,
-        "generations_executed": conv["generations_run"] + args.rhat_window + args.warmup + K * len(times) + (0 if args.no_events else prof.get("event_pass_generations", 0)),
-        "rhat_max": conv.get("rhat_window_max") if not sub else (conv["history"][-1][1] if conv["history"] else None),
-        "convergence": conv,
-    }
-    if dense is not None:
-        out["dense_value"] = dense["value"]
-        out["dense"] = dense
-    if lag0 is not None:
-        out["value_history_lag0"] = lag0["value"]
-        out["history_lag0"] = lag0
-    if burn is not None:
-        out["burnin_value"] = burn["value"]
-        out["burnin"] = burn
-        out["config"]["workload"] += "; crossover adaptation ON, crossover_burnin %d: `burnin_value` is the rate inside the burn-in, `value` after it" % args.burnin_generations
-    out["kernel_variant"] = kernel_variant
-    out["history_lag"] = args.history_lag
-    if replicas is not None:
-        out["replicas_identical"] = replicas["identical"]
-        out["replica_check"] = replicas
-    if rccl is not None:
-        out["rccl_value"] = rccl.get("value")
-        out["rccl_ranks"] = rccl.get("ranks")
-        out["rccl_exchange_exposed_us_per_cycle"] = rccl.get("exchange_exposed_us_per_cycle")
-        out["rccl"] = rccl
-    if world > 1:
-        # top level, not buried in config: what carried the rows, and how much of the exchange the generations had to wait for
-        if xbytes is not None:
-            out["exchange_bytes_to_each_peer"] = {"history_rows": xbytes[0], "positions": xbytes[1], "adaptation_group_sums": xbytes[2],
-                                                  "per_burnin_generation": (xbytes[2] / (args.burnin_generations + 1)) if (args.adapt and xbytes[2]) else None,
-                                                  "what": "bytes rank 0 handed to the transport for each other rank over the whole run (dz_exchange_bytes); with crossover "
-                                                          "adaptation a rank that owns whole groups of 256 chains sends its groups' column sums every burn-in generation, "
-                                                          "its positions only once"}
-        out["transport"] = transport if transport != "host" else "host-fallback"
-        if transport_note:
-            out["transport_note"] = transport_note
-        if xstats is not None and transport == "peer":
-            nx, ngate, wait_us = xstats
-            out["exchange"] = {"exchanges": nx, "gates": ngate, "gate_wait_us_total": wait_us,
-                               "exchange_exposed_us_per_cycle": (wait_us / ngate) if ngate else None,
-                               "what": "time the one-wave gate kernels in front of the launches spent waiting for the other ranks' rows "
-                                       "(rank 0, whole run incl. convergence and warm-up); bytes per rank and cycle: %d" % (n_local * 8 * ((args.dim + 15) // 16 * 16))}
-            out["exchange_exposed_us_per_cycle"] = out["exchange"]["exchange_exposed_us_per_cycle"]
-    if prof:
-        KE = prof["event_pass_generations"]
-        ab = algorithmic_bytes(args, n_local)
-        if prof.get("generations", {}).get("launches"):
-            # the persistent kernel covers whole generations: SURVEY.md section 8(d) B = 176 d + 152 bytes per chain-generation
-            ab["generations"] = n_local * generation_bytes(args) * KE / prof["generations"]["launches"]
-        cand = {k: v for k, v in prof.items() if isinstance(v, dict) and k in ab and v["launches"]}
-        dom = max(cand, key=lambda k: cand[k]["total_ms"])
-        gens_per_launch = KE / cand[dom]["launches"] if dom == "generations" else 1.0
-        # Duration of one launch of the dominant kernel: the MEDIAN over the event-timed launches (>= 20 of them), never more than the
-        # wall clock allows -- a kernel cannot take longer than the timed block around it (the event pass runs a few percent slower
-        # than the un-instrumented blocks: round 2's line had 314 us per launch inside blocks of 303.6 us per 10 generations).
-        launch_s = cand[dom]["median_us"] * 1e-6
-        launches_per_block = (K / gens_per_launch) if dom == "generations" else K * {"propose": 2.0, "logp": 2.0, "accept": 1.0}.get(dom, 1.0)
-        wall_cap_s = med / max(launches_per_block, 1e-9)
-        events_exceed_wall = launch_s > wall_cap_s
-        if events_exceed_wall and dom == "generations":
-            launch_s = wall_cap_s
-        tmeta = {"launch_us": launch_s * 1e6, "launch_us_from": ("timed blocks (median block / launches per block): the event-timed median %.1f us exceeds it"
-                                                                  % cand[dom]["median_us"]) if (events_exceed_wall and dom == "generations")
-                 else "median of %d event-timed launches" % cand[dom]["launches"],
-                 "launch_us_event_median": cand[dom]["median_us"], "launch_us_event_min": cand[dom]["min_us"],
-                 "launches_timed": cand[dom]["launches"], "generations_per_launch": gens_per_launch}
-        compute_bound = args.dim > 128 and args.target == "mvn" and dom in ("logp", "generations")
-        if compute_bound:
-            # d > 128: the batched quadratic form dominates and is FP64-matrix-bound (~100 flop/B at d = 1000)
-            fl = flops_gen * (gens_per_launch if dom == "generations" else 0.5)          # logp: two launches per generation
-            achieved = fl / launch_s / 1e12
-            whole = flops_gen * K / med / 1e12                                            # every kernel of the generation in the denominator
-            out["roofline"] = {"bound": "fp64_mfma", "kernel": "k_" + dom, "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                               "algorithmic_flops_per_launch": fl,
-                               "whole_generation_achieved": whole, "whole_generation_frac": whole / FP64_MFMA_PEAK_TFLOPS}
-            # the other third of a streamed generation, priced as what it is -- HBM traffic: algorithmic bytes / the AVERAGE event-timed
-            # launch (no ramp subtracted).  Per try: base row + the archive rows read, the proposal written = 8d (rows_z + 2); the
-            # Metropolis step's own bytes ride in the launch that carries the next proposal set (k_accept_propose).
-            rows_z = 2 * (1 - args.snooker) + 3 * args.snooker
-            try_b = 8.0 * args.dim * (rows_z + 2.0)
-            others = {}
-            for cls, name, nbytes in (("accept", "k_accept_propose / k_accept (Metropolis step + the next generation's proposal set)", ab["accept"] + n_local * args.multitry * try_b),
-                                      ("propose", "k_propose_stream (reference set)", n_local * (args.multitry - 1) * try_b)):
-                v = prof.get(cls)
-                if v and v["launches"]:
-                    gbps = nbytes / (v["avg_us"] * 1e-6) / 1e9
-                    others[cls] = {"kernel": name, "algorithmic_bytes_per_launch": nbytes, "avg_us": v["avg_us"], "achieved_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBS}
-            out["roofline"]["other_kernels_hbm"] = others
-        else:
-            achieved = ab[dom] / launch_s / 1e9
-            traffic, tsrc = measured_traffic(args, n_local, dom, gens_per_launch)
-            out["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
-                               "algorithmic_bytes_per_launch": ab[dom]}
-            pm = measured_pmc(args, n_local)
-            if pm:
-                out["roofline"].update({k: v for k, v in pm.items() if k != "source"})
-                out["roofline"]["pmc_source"] = pm["source"]
-                if dom == "generations" and "mfma_insts_per_wave_generation" in pm:
-                    # What bounds this kernel is instruction issue, not HBM: the vector ALU and the FP64 matrix pipe of a SIMD do not
-                    # overlap on gfx950 (profiles/r02_mfma_valu_overlap.txt), so a generation cannot take fewer cycles than its four
-                    # waves per SIMD need to issue their VALU instructions (4 cycles each) and their FP64 MFMAs (64 cycles each).
-                    wps = 4.0
-                    floor_cycles = wps * (pm["valu_insts_per_wave_generation"] * 4.0 + pm["mfma_insts_per_wave_generation"] * 64.0)
-                    gen_cycles = launch_s / gens_per_launch * ENGINE_CLOCK_HZ
-                    out["roofline"]["issue_floor_frac"] = floor_cycles / gen_cycles
-                    out["roofline"]["issue_floor"] = {
-                        "floor_cycles_per_generation": floor_cycles, "measured_cycles_per_generation": gen_cycles, "clock_hz": ENGINE_CLOCK_HZ,
-                        "formula": "4 waves/SIMD x (VALU instructions x 4 cycles + FP64 MFMA instructions x 64 cycles) per wave-generation "
-                                   "(instruction counts: committed PMC file) / (measured launch duration / generations per launch x clock)",
-                        "reading": "the HBM `frac` above is what BASELINE asks for; this is the fraction of the kernel's time its SIMDs need "
-                                   "just to issue its instructions -- the rest is dependent-latency stalls at four waves per SIMD"}
-            if flops_gen:
-                out["roofline"]["fp64_matrix_tflops"] = flops_gen * K / med / 1e12
-        out["roofline"].update(tmeta)
-        out["roofline"]["kernel_variant"] = kernel_variant
-        out["kernel_times"] = prof
-        gen_bytes = n_local * generation_bytes(args)             # B = 176 d + 152 per chain-generation at k = 5, s = 0.1
-        out["generation_hbm"] = {"algorithmic_bytes_per_generation": gen_bytes,
-                                 "achieved_GBps": gen_bytes * K / med / 1e9,
-                                 "frac_of_8TBps": gen_bytes * K / med / 1e9 / HBM_PEAK_GBS}
-    return out, replicas
+    return assemble(), replicas
 
 
 def self_launch(args):

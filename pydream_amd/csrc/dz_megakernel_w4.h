@@ -284,8 +284,13 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
             DZ_W0STAMP(2 + 4 * phase); DZ_WSTAMP(2 + 4 * phase);
             {   // mt_evaluate_logps :278, :302
                 const int row0 = phase ? CH : 0, ntl = (n * CH + 15) / 16;
-                if (p.mu_zero) mfma_units<NRT, TRI, true>(p, Ms, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, L.LDM, L.LDP);
-                else mfma_units<NRT, TRI, false>(p, Ms, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, L.LDM, L.LDP);
+                // The (point tile, row tile) units are dealt heaviest first, one per wave (at most 14 here).  Wave w runs on SIMD w % 4: dealt in
+                // plain order the two heaviest units of every four land on SIMDs 0 and 1 each time (d = 100, triangular factor, 5 tries: 52 / 52 /
+                // 39 / 39 MFMAs per SIMD, reference set 34 / 26 / 18 / 13); in snake order over the SIMDs -- every second group of four waves
+                // reversed -- 47 / 47 / 44 / 44 and 25 / 22 / 22 / 22.
+                const int wu = ((wv >> 2) & 1) ? (wv & ~3) + 3 - (wv & 3) : wv;
+                if (p.mu_zero) mfma_units<NRT, TRI, true>(p, Ms, Pt, mus, qb, row0, ntl, wu, CH * WPC, lane, L.LDM, L.LDP);
+                else mfma_units<NRT, TRI, false>(p, Ms, Pt, mus, qb, row0, ntl, wu, CH * WPC, lane, L.LDM, L.LDP);
             }
             DZ_W0STAMP(3 + 4 * phase); DZ_WSTAMP(3 + 4 * phase);
             __syncthreads();                                               // q visible

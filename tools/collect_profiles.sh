@@ -10,12 +10,12 @@ tag=$1; shift
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
 timeout 600 python bench.py "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_stats -o s --output-format csv -- python bench.py --no-cpu-baseline --no-dense --no-lag0 "$@" > gpurun_out/${tag}_stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_stats -o s --output-format csv -- python bench.py --no-cpu-baseline --no-dense --no-lag0 --no-configs "$@" > gpurun_out/${tag}_stats.log 2>&1
 i=0
 while read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $group -d gpurun_out/${tag}_pmc_$i -o p --output-format csv -- python bench.py --steps 40 --warmup 10 --spinup 200 --min-timed-ms 5 --no-dense --no-lag0 --no-cpu-baseline --no-events "$@" > gpurun_out/${tag}_pmc_$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $group -d gpurun_out/${tag}_pmc_$i -o p --output-format csv -- python bench.py --steps 40 --warmup 10 --spinup 200 --min-timed-ms 5 --no-dense --no-lag0 --no-cpu-baseline --no-events --no-configs "$@" > gpurun_out/${tag}_pmc_$i.log 2>&1
   f=$(find gpurun_out/${tag}_pmc_$i -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && python tools/pmc_summary.py $f gpurun_out/${tag}_pmc_$i.json > /dev/null
 done <<'G'

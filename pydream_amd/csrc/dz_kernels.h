@@ -11,7 +11,7 @@
 
 namespace dz {
 
-constexpr int MAXK = 16;      // multitry limit
+constexpr int MAXK = 32;      // multitry limit (tries 17..32: the multi-kernel path; the persistent kernels hold a generation's draw slots in one wave's lanes: multitry <= 15)
 constexpr int MAXPAIR = 8;    // DEpairs limit
 
 // per-chain control decisions of one generation, computed once (lane-parallel) instead of by every wave
@@ -118,9 +118,13 @@ DZ_DEV StepFlags step_flags_chain(const Params& p, const Ctrl& u, int c)
 
 // mt_choose_proposal_pt :883-917.  Lane i < k evaluates try i's weight (one dexp per wave instead of
 // k); the sums run over the tries in order, so every lane ends with the same scalars.
+// BIG: k may exceed 16 (tries in lanes 0..k-1 <= 31; the multi-kernel path's callers) -- the maximum is exact whatever the order, the
+// sums are sequential in try order, so the bits do not depend on it.
+template <bool BIG = false>
 DZ_DEV int mt_select_vals(int k, double lp, double u_sel, int lane, bool* anyfinite)
 {   // lp: lane i < k holds prior_i + T like_i (:900), other lanes -inf
-    const double mx = readlane_f64(rowmax16(lp), 0);                                   // MAXK = 16 lanes
+    const double rmx = rowmax16(lp);
+    const double mx = BIG ? fmax(readlane_f64(rmx, 0), readlane_f64(rmx, 16)) : readlane_f64(rmx, 0);
     *anyfinite = __any(lane < k && is_finite(lp)) != 0;
     const double w = dexp(lp - mx);
     double S = 0.0;
@@ -141,25 +145,30 @@ DZ_DEV int mt_select(const Params& p, int c, double u_sel, int lane, bool* anyfi
     const int k = p.k;
     double lp = -__builtin_huge_val();
     if (lane < k) lp = p.p_prior[c * k + lane] + chain_T(p, c) * p.p_like[c * k + lane];
-    return mt_select_vals(k, lp, u_sel, lane, anyfinite);
+    return mt_select_vals<true>(k, lp, u_sel, lane, anyfinite);
 }
 
-// log of the multi-try ratio (:305-323).  val: lane i < k holds proposal term A_i, lane 16+i reference term B_i,
+// log of the multi-try ratio (:305-323).  val: lane i < k holds proposal term A_i, lane mt_boff(k) + i reference term B_i,
 // every other lane -inf.
 // u_acc: the Metropolis uniform (:993); its logarithm is evaluated in lane 1 of the same dlog pass (one pass instead of two).
+DZ_DEV int mt_boff(int k) { return k > 16 ? 32 : 16; }
+template <bool BIG = false>
 DZ_DEV double mt_log_ratio(int k, double val, double u_acc, int lane, double* log_u)
 {
     const double rm = rowmax16(val);
-    const double m2 = fmax(readlane_f64(rm, 0), readlane_f64(rm, 16));                                 // :320
+    double m2 = fmax(readlane_f64(rm, 0), readlane_f64(rm, 16));                                       // :320
+    if (BIG) m2 = fmax(m2, fmax(readlane_f64(rm, 32), readlane_f64(rm, 48)));
+    const int boff = BIG ? mt_boff(k) : 16;
     const double ev = dexp(val - m2);                                                                // :321-322
     double SA = 0.0, SB = 0.0;
     for (int i = 0; i < k; ++i) SA = SA + readlane_f64(ev, i);
-    for (int i = 0; i < k; ++i) SB = SB + readlane_f64(ev, 16 + i);
+    for (int i = 0; i < k; ++i) SB = SB + readlane_f64(ev, boff + i);
     const double lg = dlog(lane == 1 ? u_acc : SA / SB);
     *log_u = readlane_f64(lg, 1);
     return nan_to_num(readlane_f64(lg, 0));                                                          // :323
 }
-DZ_DEV double mt_log_ratio(int k, double val) { double lu; return mt_log_ratio(k, val, 0.5, 0, &lu); }
+template <bool BIG = false>
+DZ_DEV double mt_log_ratio(int k, double val) { double lu; return mt_log_ratio<BIG>(k, val, 0.5, 0, &lu); }
 
 // u53(hi, lo) < q for q in [0, 1], as an integer test: u53 = k 2^-53 with k = (hi >> 5) 2^26 + (lo >> 6), so the test is
 // k < ceil(q 2^53) =: thr (made once on the host).  Wave-uniform operands stay on the scalar unit.
@@ -622,8 +631,8 @@ DZ_DEV void accept_chain(const Params& p, uint32_t g, int64_t zbase, int c, int 
         if (lane < k) {
             val = p.p_prior[c * k + lane] + T * p.p_like[c * k + lane];                                    // :279
             if (f.snk) val = val + p.p_slogp[c * k + lane];                                              // :307
-        } else if (lane >= 16 && lane < 16 + k) {
-            const int i = lane - 16;
+        } else if (lane >= mt_boff(k) && lane < mt_boff(k) + k) {
+            const int i = lane - mt_boff(k);
             if (i < k - 1) {
                 double rl, rp;
                 if (p.qfin_r) {      // the reference set's row-tile sums are still in the scratch array: finish them here
@@ -636,7 +645,7 @@ DZ_DEV void accept_chain(const Params& p, uint32_t g, int64_t zbase, int c, int 
             } else val = T * last_like + last_prior;                                                     // :877-879
             if (f.snk) { const double sr = i < k - 1 ? p.r_slogp[c * (k - 1) + i] : 0.0; val = (val + sr) + p.p_slogp[c * k + i]; }   // :312-313
         }
-        ratio = mt_log_ratio(k, val);
+        ratio = mt_log_ratio<true>(k, val);
         if (!fin) ratio = -__builtin_huge_val();                               // DESIGN.md deviation D1 (:282-289)
     }
     const bool accept = is_finite(ratio) && (dlog(u.u_acc) < ratio);           // :993
@@ -869,7 +878,7 @@ __global__ __launch_bounds__(NCH >= 4 ? 256 : 1024) void k_propose(Params p, int
                     lp = prior + chain_T(p, c) * like;
                     if (i0 == 0) { p.p_like[c * p.k + lane] = like; if (!p.have_prior) p.p_prior[c * p.k + lane] = 0.0; }
                 }
-                sel = mt_select_vals(p.k, lp, ct.u_sel, lane, &fin);
+                sel = mt_select_vals<true>(p.k, lp, ct.u_sel, lane, &fin);
             } else sel = mt_select(p, c, ct.u_sel, lane, &fin);
             if (lane == 0 && i0 == 0) p.sel[c] = sel | (fin ? 256 : 0);
             base = p.P + ((size_t)c * p.k + sel) * p.ld; out = p.R + (size_t)c * (p.k - 1) * p.ld; sl = p.r_slogp + (size_t)c * (p.k - 1);
@@ -1017,7 +1026,7 @@ __global__ __launch_bounds__(256) void k_propose_stream(Params p, int phase, uin
                 lp = prior + chain_T(p, c) * like;
                 if (i == 0) { p.p_like[c * k + lane] = like; if (!p.have_prior) p.p_prior[c * k + lane] = 0.0; }
             }
-            sel = mt_select_vals(k, lp, ct.u_sel, lane, &fin);
+            sel = mt_select_vals<true>(k, lp, ct.u_sel, lane, &fin);
         } else sel = mt_select(p, c, ct.u_sel, lane, &fin);
         if (lane == 0 && i == 0) p.sel[c] = sel | (fin ? 256 : 0);
         base = p.P + ((size_t)c * k + sel) * ld; out = p.R + ((size_t)c * (k - 1) + i) * ld; sl = p.r_slogp + (size_t)c * (k - 1);

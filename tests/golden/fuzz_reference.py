@@ -34,7 +34,7 @@ def draw_case(rng):
     prior = str(rng.choice(["flat", "flat", "normal", "uniform", "uniform_wide_history"]))
     d = int(rng.integers(2, 5)) if prior.startswith("uniform") else int(rng.choice([2, 3, 4, 7, 10, 12]))
     N = int(rng.integers(3, 8))
-    k = int(rng.choice([1, 3, 4, 5]))
+    k = int(rng.choice([1, 3, 4, 5, 5, 9, 17, 24, 32]))          # (beyond 16 tries: round 5)
     if prior == "uniform_wide_history" and k == 1:
         k = 3
     schedule = int(rng.choice([1, 2, 2]))

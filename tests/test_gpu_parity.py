@@ -676,3 +676,31 @@ def test_a_chain_count_just_above_whole_rounds_of_blocks_against_oracle(G, O, ad
         np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(out[0][2], out[1][2])
     assert out[0][3] == "k_generations<7,tri,xlds,16,1,lean> + k_generations_w4<7,tri,xlds,4,4,lean,ahead>", out[0][3]
+
+
+@pytest.mark.parametrize("k,d,N,lk", [(16, 100, 300, "tri"), (17, 10, 64, "dense"), (24, 140, 48, "tri"), (32, 33, 40, "mix"), (32, 300, 16, "tri")])
+def test_more_than_sixteen_tries_against_oracle(G, O, k, d, N, lk):
+    """The reference takes any integer as `multitry` (Dream.py:155-161).  Up to 15 tries a generation's draw slots fit one wave's lanes and the
+    persistent kernels run; 16..32 tries run the multi-kernel path (selection and multi-try ratio over 32 + 32 lanes): states, decisions,
+    archive and adapted probabilities equal the oracle's bit for bit, through a crossover burn-in, snooker sets and history appends, for the
+    per-chain (d <= 256) and the streamed (d = 300) proposal kernels."""
+    n, seed = 24, 7
+    Z0 = H.seed_history(max(10 * d, 2 * N), d, seed, lo=-2.0, hi=2.0)          # (near the targets' mass: moves are accepted from the first generations on)
+    out = []
+    for Cls in (G.Engine, O.Engine):
+        e = Cls(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed, snooker=0.2,
+                adapt_crossover=1, crossover_burnin=14)
+        e.set_history(Z0); e.set_state(Z0[:N])
+        if lk == "mix":
+            mu = np.array([np.full(d, m) for m in (-5.0, 0.0, 5.0)])
+            e.set_likelihood_mixture(mu, np.log(np.array([1 / 6., 1 / 3., 1 / 2.])) - (d / 2.) * np.log(2 * np.pi))
+        else:
+            P = H.mvn_precision(d)
+            e.set_likelihood_mvn(np.zeros(d), H.tri_factor(P) if lk == "tri" else P, 1 if lk == "tri" else 0, 0.0)
+        e.step(n)
+        out.append((e.get_trace(0, n), e.get_history(), e.get_cr_state()))
+    assert_traces_identical(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    for a, b in zip(out[0][2], out[1][2]):
+        np.testing.assert_array_equal(a, b)
+    assert out[0][0]["try_idx"].max() >= min(k - 1, 12) and 0.005 < out[0][0]["moved"].mean() < 0.98

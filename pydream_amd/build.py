@@ -7,7 +7,7 @@ with the working tree.  -ffp-contract=off is part of the numerical contract (DES
 every fused multiply-add in the kernels is an explicit fma().
 
 The persistent generation kernel has ~300 template instantiations; they are compiled as one
-translation unit per row-tile count (csrc/dz_mega_tu.hip with -DDZ_TU_NRT=1..8) next to the
+translation unit per row-tile count (csrc/dz_mega_tu.hip with -DDZ_TU_NRT=1..16; 9..16: k_generations_d2, 128 < d <= 256) next to the
 engine's own (csrc/dz_engine.hip), in parallel, into pydream_amd/build/*.o, then linked.
 Objects are rebuilt only when a file they include has changed.
 """
@@ -21,12 +21,12 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libdreamzs.so")
-HEADERS = [os.path.join(CSRC, h) for h in ("dz_kernels.h", "dz_device.h", "dz_megakernel.h", "dz_mega_launch.h", "dz_megakernel_w4.h")] + \
+HEADERS = [os.path.join(CSRC, h) for h in ("dz_kernels.h", "dz_device.h", "dz_megakernel.h", "dz_mega_launch.h", "dz_megakernel_w4.h", "dz_megakernel_d2.h")] + \
           [os.path.join(ROOT, "include", "dreamzs.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 # (object name, source, extra flags, headers it depends on)
 UNITS = [("dz_engine.o", os.path.join(CSRC, "dz_engine.hip"), [], HEADERS)] + \
-        [("dz_mega_nrt%d.o" % n, os.path.join(CSRC, "dz_mega_tu.hip"), ["-DDZ_TU_NRT=%d" % n], HEADERS[:5]) for n in range(1, 9)]
+        [("dz_mega_nrt%d.o" % n, os.path.join(CSRC, "dz_mega_tu.hip"), ["-DDZ_TU_NRT=%d" % n], HEADERS[:6]) for n in range(1, 17)]
 DEPS = sorted({u[1] for u in UNITS} | set(HEADERS))
 
 

@@ -179,6 +179,7 @@ struct dz_engine {
     bool mega_redo_on = true;       // redraw rounds (Dream.py:281-289) inside the persistent kernel; DZ_MEGA_REDO=0: such configurations take the multi-kernel path
     unsigned long long* d_redraw_count = nullptr;
     bool mega_mix_pb = true;        // the mixture kernel's full-code instantiation (priors, boundaries, several pairs); DZ_MEGA_MIX_PB=0: multi-kernel path there
+    bool mega_d2 = true;            // 128 < d <= 256: k_generations_d2 (DZ_MEGA_D2=0: the multi-kernel path there)
     bool mega_w4 = true;            // small populations (4 chains x 4 waves per block), lean, multitry 3..6: k_generations_w4 (DZ_MEGA_W4=0: k_generations<.., 4, 4, lean>)
     bool mega_split = true;         // a remainder of chains beyond whole rounds of 16-chain blocks goes in a second launch of smaller blocks; DZ_MEGA_SPLIT=0: off
     bool mega_burnin = true;        // ... the generations of the crossover burn-in too, one per launch (positions published by the kernel); DZ_MEGA_BURNIN=0: multi-kernel path there
@@ -885,10 +886,25 @@ bool mega_mix_eligible(const dz_engine* e)
 }
 // redraw rounds inside the persistent kernel: the instantiations with the full proposal code, multi-try, device MVN likelihood
 bool mega_redo(const dz_engine* e) { return redo_possible(e) && e->lk == LK_MVN && e->p.k > 1 && e->mega_redo_on; }
+// 128 < d <= 256 (the reference example's d = 200): k_generations_d2 -- lean configurations with the triangular factor (what
+// MVNormalLogLike builds) whose point tiles of 16 chains fit LDS without the matrix (it is read from L2): d <= ~230 at 5 tries.  Measured and
+// left on the multi-kernel path: 8 chains per block (d = 256: 131 against 123 us per generation) and the dense matrix (its 16-chain
+// instantiation spills a hundred registers; at 8 chains per block 156 against 148 us at d = 200).
+int mega_d2_chains(const dz_engine* e)
+{
+    const dz::Params& p = e->p;
+    if (!e->mega || !e->mega_d2 || e->lk != LK_MVN || p.ld <= 128 || p.ld > 256) return 0;
+    if (p.hard || p.have_prior || p.depairs > 1 || redo_possible(e)) return 0;
+    if (p.k < 3 || p.nslots > 64) return 0;
+    if (!p.tri || !p.Mtp) return 0;
+    const size_t lds = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, false, 16, false, false, true).total;
+    return lds <= (size_t)160 * 1024 ? 16 : 0;
+}
 bool mega_eligible(dz_engine* e)
 {
     mega_set_pb_lds(e);
     const dz::Params& p = e->p;
+    if (mega_d2_chains(e) > 0) return true;
     if (redo_possible(e) && !mega_redo(e)) return false;
     if (mega_mix_eligible(e)) return true;
     if ((p.hard || p.have_prior || p.depairs > 1 || mega_redo(e)) && !mega_xlds(e)) return false;      // (the full-code instantiations keep the states in LDS)
@@ -984,6 +1000,31 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         return 0;
     }
     const int nrt = p.ld / 16;
+    if (const int chd = mega_d2_chains(e)) {      // 128 < d <= 256
+        DZCK(upload_params(e));
+        dz::MegaLaunch ml;
+        ml.tri = p.tri != 0; ml.xlds = false; ml.pb = false; ml.k1 = false; ml.ch = chd; ml.wpc = 1; ml.redo = false;
+        ml.grid = dim3((p.nl + chd - 1) / chd); ml.block = dim3(64 * chd);
+        ml.lds = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, false, chd, false, false, true).total;
+        ml.st = e->stream; ml.ka = nullptr; ml.kb = nullptr;
+        ml.pp = (const dz::Params*)e->d_params; ml.g = g; ml.n = n; ml.M = (uint32_t)visible_rows(e); ml.slot0 = slot0; ml.zappend = append_last ? e->M : (int64_t)-1; ml.publish = &pub;
+        if (e->prof) { ml.ka = prof_event(e); ml.kb = prof_event(e); e->ev[PR_GENERATIONS].emplace_back(ml.ka, ml.kb); }
+        const char* name = nullptr;
+        switch (nrt) {
+            case 9: name = dz::mega_launch_nrt9(ml); break; case 10: name = dz::mega_launch_nrt10(ml); break;
+            case 11: name = dz::mega_launch_nrt11(ml); break; case 12: name = dz::mega_launch_nrt12(ml); break;
+            case 13: name = dz::mega_launch_nrt13(ml); break; case 14: name = dz::mega_launch_nrt14(ml); break;
+            case 15: name = dz::mega_launch_nrt15(ml); break; case 16: name = dz::mega_launch_nrt16(ml); break;
+            default: return fail("k_generations_d2: ld out of range");
+        }
+        char buf[96]; snprintf(buf, sizeof buf, name, chd, 1);
+        e->last_variant = buf;
+        DZCK(launch_check("k_generations_d2"));
+        launched();
+        DZCK(after_launch());
+        if (slot0 >= 0) e->ntrace += n;
+        return 0;
+    }
     const int ch = mega_chains(e);
     // waves per chain: 4 when a block holds only 4 chains (fewer than 8 chains per CU) -- the tries of a phase then run side by
     // side (1024 chains: 238 -> 249 M proposals/s, 512: 120 -> 131); at 8 chains per block two waves per chain lose (405 -> 368).
@@ -1088,6 +1129,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     if (const char* kv = getenv("DZ_MEGA_MIX_PB")) e->mega_mix_pb = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_SPLIT")) e->mega_split = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_W4")) e->mega_w4 = atoi(kv) != 0;
+    if (const char* kv = getenv("DZ_MEGA_D2")) e->mega_d2 = atoi(kv) != 0;
     static_assert(dz::DZ_MAX_REDRAWS_DEV == DZ_MAX_REDRAWS && dz::DZ_REDRAW_KEY_STEP_DEV == DZ_REDRAW_KEY_STEP, "redraw constants");
     if (const char* kv = getenv("DZ_QFIN")) e->q_defer = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_FUSE_STREAM")) e->fuse_stream = atoi(kv) != 0;
@@ -1353,12 +1395,12 @@ int dz_set_likelihood_mvn(dz_engine* e, const double* mu, const double* M, int32
     e->p.Mtp = nullptr; e->p.mtp_len = 0;
     e->p.mu_zero = 1;
     for (int j = 0; j < d; ++j) if (!(mu[j] == 0.0) || std::signbit(mu[j])) e->p.mu_zero = 0;
-    if (kind != 0 && ld <= 128) {   // packed triangle for k_logp_mvn_lds (dz_kernels.h tri_row_offset)
+    if (kind != 0 && ld <= 256) {   // packed triangle for k_logp_mvn_lds and the persistent kernels (dz_kernels.h tri_row_offset); 128 < ld <= 256: k_generations_d2 reads it from L2
         const int rows = 4 * ((d + 3) / 4);
         std::vector<double> pk((size_t)dz::tri_row_offset(rows), 0.0);
         for (int r = 0; r < rows; ++r)
             for (int c = 0; c < 16 * (r / 16 + 1); ++c) pk[(size_t)dz::tri_row_offset(r) + c] = mt[(size_t)r * ld + c];
-        if (!e->d_Mtp) DZCK(ealloc(e, &e->d_Mtp, (size_t)dz::tri_row_offset(128)));
+        if (!e->d_Mtp) DZCK(ealloc(e, &e->d_Mtp, (size_t)dz::tri_row_offset(256)));
         HIPCK(hipMemcpy(e->d_Mtp, pk.data(), sizeof(double) * pk.size(), hipMemcpyHostToDevice));
         e->p.Mtp = e->d_Mtp; e->p.mtp_len = (int)pk.size();
     }

@@ -23,6 +23,7 @@ struct MegaLaunch {
 // returns a static string naming the instantiation that was launched ("k_generations<7,tri,xlds,16,1,lean>")
 #define DZ_MEGA_DECL(N_) const char* mega_launch_nrt##N_(const MegaLaunch& a);
 DZ_MEGA_DECL(1) DZ_MEGA_DECL(2) DZ_MEGA_DECL(3) DZ_MEGA_DECL(4) DZ_MEGA_DECL(5) DZ_MEGA_DECL(6) DZ_MEGA_DECL(7) DZ_MEGA_DECL(8)
+DZ_MEGA_DECL(9) DZ_MEGA_DECL(10) DZ_MEGA_DECL(11) DZ_MEGA_DECL(12) DZ_MEGA_DECL(13) DZ_MEGA_DECL(14) DZ_MEGA_DECL(15) DZ_MEGA_DECL(16)      // (k_generations_d2)
 #undef DZ_MEGA_DECL
 
 }  // namespace dz

@@ -2,11 +2,12 @@
 #define DZ_TEMPLATES_ONLY
 #include "dz_megakernel.h"
 #include "dz_megakernel_w4.h"
+#include "dz_megakernel_d2.h"
 #include "dz_mega_launch.h"
 #include <hip/hip_ext.h>
 
 #ifndef DZ_TU_NRT
-#error "compile with -DDZ_TU_NRT=<1..8>"
+#error "compile with -DDZ_TU_NRT=<1..16>"
 #endif
 
 namespace dz {
@@ -16,6 +17,20 @@ namespace dz {
 #define DZ_STR_(x) #x
 #define DZ_STR(x) DZ_STR_(x)
 
+#if DZ_TU_NRT > 8
+// 128 < ld <= 256: k_generations_d2 (dz_megakernel_d2.h) -- the matrix read from L2, two 128-dimension chunks per lane
+const char* DZ_CAT(mega_launch_nrt, DZ_TU_NRT)(const MegaLaunch& a)
+{
+#define DZ_D2(TRI_, CH_)                                                                                                                   \
+    do {                                                                                                                                   \
+        hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, TRI_, CH_>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, \
+                              a.slot0, a.zappend, *a.publish);                                                                             \
+        return TRI_ ? "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,lean>" : "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",dense,xhbm,%d,%d,lean>"; \
+    } while (0)
+    DZ_D2(true, 16);          // (the host only sends the triangular factor at 16 chains per block here: mega_d2_chains)
+#undef DZ_D2
+}
+#else
 template <bool TRI, bool X, int CH, int WPC, bool PB, bool K1>
 static const char* launch_one(const MegaLaunch& a)
 {
@@ -71,5 +86,6 @@ const char* DZ_CAT(mega_launch_nrt, DZ_TU_NRT)(const MegaLaunch& a)
     if (a.tri) return a.xlds ? launch_ch<true, true, false>(a) : launch_ch<true, false, false>(a);
     return a.xlds ? launch_ch<false, true, false>(a) : launch_ch<false, false, false>(a);
 }
+#endif      // DZ_TU_NRT <= 8
 
 }  // namespace dz

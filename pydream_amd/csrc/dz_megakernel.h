@@ -43,13 +43,14 @@ __host__ __device__ inline int mega_rows(int k, int ch)
 // pb: room for the per-dimension prior / boundary constants of the full-code instantiations (PBConsts: five double arrays and one int
 // array of pcn = 16 nrt entries)
 // xo: room for the chains' states as they were at the start of the launch (crossover burn-in: the block's adaptation sums need the jumps)
-__host__ __device__ inline MegaLayout mega_layout(int d, int k, int nrt, int ncr, int ngamma, bool tri, bool xlds, int ch = MEGA_CHAINS, bool pb = false, bool xo = false)
+// nomat: the matrix is NOT staged (k_generations_d2, 128 < d <= 256: it does not fit next to the point tiles and is read from L2)
+__host__ __device__ inline MegaLayout mega_layout(int d, int k, int nrt, int ncr, int ngamma, bool tri, bool xlds, int ch = MEGA_CHAINS, bool pb = false, bool xo = false, bool nomat = false)
 {
     MegaLayout L;
     const int ks4 = 4 * ((d + 3) / 4);
     L.LDM = d + 2;                    // dense matrix row (k index c): d entries + pad; rows d..ks4-1 are zero
     L.LDP = ks4 + 1;                  // point row: zero padded to the k-steps; odd stride keeps the A-layout reads (16 rows x 4 cols) off one bank
-    L.off_P = tri ? tri_row_offset(ks4) : ks4 * L.LDM + 16;       // (+16: the last row tile's column reads run past the last row's end)
+    L.off_P = nomat ? 0 : (tri ? tri_row_offset(ks4) : ks4 * L.LDM + 16);       // (+16: the last row tile's column reads run past the last row's end)
     L.rows = mega_rows(k, ch);
     L.off_q = L.off_P + L.rows * L.LDP;
     L.off_sP = L.off_q + L.rows * nrt;

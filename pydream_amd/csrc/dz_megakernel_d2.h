@@ -1,0 +1,275 @@
+// dz_megakernel_d2.h -- k_generations_d2: the persistent generation kernel for 128 < d <= 256 (round 5; the reference example's own d = 200,
+// pydream/examples/ndim_gaussian/dream_ex_ndim_gaussian.py:29).
+//
+// Same scheme as k_generations (dz_megakernel.h): a block owns its chains through a whole thin-cycle, proposal points live only in LDS as
+// MFMA point tiles, four block barriers per generation.  What differs at these dimensions:
+//   * a lane owns four dimensions (two 128-dimension chunks, NCH = 2): the tries are the multi-kernel path's propose_set<2> -- the same
+//     arithmetic, the same per-lane summation order, hence the same bits -- writing LDS rows instead of HBM rows;
+//   * the matrix does NOT fit LDS next to the point tiles (packed triangle at d = 200: 186 KB; the tiles of 16 chains x 5 tries: 129 KB): the
+//     likelihood units read their A operand (16 matrix rows x 4 k per MFMA, 128-byte segments) from L2 -- the matrix is a few hundred KB,
+//     resident in every XCD's 4 MB -- while the B operand (the points) comes from LDS as before; the four waves of a SIMD hide each other's
+//     L2 round trips;
+//   * the chain states stay in HBM (one row read and, when a move is accepted, written per generation).
+// One wave per chain; 16 chains per block while the point tiles fit (d <= ~218 at 5 tries), else 8.  Eligibility (host, mega_d2_eligible):
+// MVN likelihood, 128 < ld <= 256, multitry 3..15, flat priors, no boundaries, one DE pair; everything else at these dimensions keeps the
+// multi-kernel path.  Inside the crossover burn-in a launch covers one generation and publishes the positions; the adaptation sums come
+// from k_adapt_partials.
+#pragma once
+#include "dz_megakernel.h"
+
+namespace dz {
+
+// The likelihood units of k_generations_d2 (triangular factor; cf. mfma_units, dz_megakernel.h): a unit is a ROW tile and a PAIR of point
+// tiles, so that every A operand fetched from L2 (16 matrix rows x 4 k) feeds two MFMAs -- half the L2 reads and half the load
+// instructions of one unit per point tile; an odd last tile runs alone.  Each accumulator is still ONE chain over k in ascending order
+// (the contract), so the row-tile sums are the bits mfma_units makes.  Units are dealt heaviest first (row tile 0 walks
+// all of k) in snake order over the waves.
+template <int NRT, bool MZ, int NPT>
+DZ_DEV void d2_unit(const double* __restrict__ ap, const double* __restrict__ bp0, const double* __restrict__ bp1, const double* __restrict__ mp,
+                    int t, int KS, int KB, int kq, dz_double4& acc0, dz_double4& acc1)
+{
+#pragma unroll 1
+    for (int b16 = t; b16 < KB; ++b16) {                           // (not unrolled: b16 is wave-uniform, the offsets are scalar arithmetic; unrolled, the compiler
+        double a[4], b0[4], b1[4];                                 //  hoisted the L2 loads of many batches and spilled ninety registers)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                              // the batch's operand reads are issued together, then its MFMAs (ascending k)
+            const int c = 16 * b16 + 4 * q;
+            a[q] = ap[128 * b16 * (b16 + 1) + (4 * q + kq) * 16 * (b16 + 1)];
+            b0[q] = MZ ? bp0[c] : bp0[c] - mp[c];
+            if (NPT == 2) b1[q] = MZ ? bp1[c] : bp1[c] - mp[c];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b0[q], acc0, 0, 0, 0);
+            if (NPT == 2) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b1[q], acc1, 0, 0, 0);
+        }
+    }
+    for (int ks = 4 * KB; ks < KS; ++ks) {                         // the last, partial block: every row tile takes part
+        const int c = 4 * ks;
+        const double av = ap[128 * KB * (KB + 1) + (c - 16 * KB + kq) * 16 * (KB + 1)];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, MZ ? bp0[c] : bp0[c] - mp[c], acc0, 0, 0, 0);
+        if (NPT == 2) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, MZ ? bp1[c] : bp1[c] - mp[c], acc1, 0, 0, 0);
+    }
+}
+template <int NRT, bool MZ>
+DZ_DEV void mfma_units_d2(const Params& p, const double* __restrict__ Mg, const double* __restrict__ Pt, const double* __restrict__ mus,
+                          double* __restrict__ qb, int row0, int ntl, int wv, int tw, int l, int LDP)
+{
+    const int d = p.d, KS = (d + 3) >> 2, KB = KS >> 2;
+    const int pi = l & 15, kq = l >> 4;
+    const int npr = (ntl + 1) >> 1, nun = npr * NRT;
+    const int rcp = ((1 << 20) + npr - 1) / npr;                  // u / npr == (u * rcp) >> 20 for every u < 2^10
+    for (int j = 0; tw * j < nun; ++j) {
+        const int u = mega_unit(j, wv, tw);
+        if (u >= nun) continue;
+        const int t = (u * rcp) >> 20, pr = u - t * npr, trow = row0 + 32 * pr;
+        const bool two = 2 * pr + 1 < ntl;                        // (wave-uniform)
+        const double* bp0 = Pt + (size_t)(trow + pi) * LDP + kq;
+        const double* bp1 = bp0 + (size_t)16 * LDP;
+        const double* mp = mus + kq;
+        const double* ap = Mg + 16 * t + pi;
+        dz_double4 acc0 = dz_double4{0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+        if (two) d2_unit<NRT, MZ, 2>(ap, bp0, bp1, mp, t, KS, KB, kq, acc0, acc1);
+        else d2_unit<NRT, MZ, 1>(ap, bp0, bp1, mp, t, KS, KB, kq, acc0, acc1);
+        const double q0 = tile_q_tri(acc0);
+        if (kq == 0) qb[(trow + pi) * NRT + t] = q0;
+        if (two) {
+            const double q1 = tile_q_tri(acc1);
+            if (kq == 0) qb[(trow + 16 + pi) * NRT + t] = q1;
+        }
+    }
+}
+
+template <int NRT, bool TRI, int CH>
+__global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int64_t zappend, Publish pub)
+{
+    constexpr int NCH = 2, NT = 64 * CH;
+    double* const publish = pub.to;
+    const Params& p = *pp;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int d = p.d, k = p.k, ld = p.ld;
+    const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, false, CH, false, false, true);
+    double* Pt = smem + L.off_P;
+    double* qb = smem + L.off_q;
+    double* sP = smem + L.off_sP; double* sS = smem + L.off_sS; double* sL = smem + L.off_sL;
+    double* rP = smem + L.off_rP; double* rS = smem + L.off_rS;
+    double* mus = smem + L.off_mu;
+    double* probs = smem + L.off_pr;
+    double* st = smem + L.off_st;
+    double* dec = smem + L.off_dec;
+    double* gts = smem + L.off_gt;
+    const double* Mg = TRI ? p.Mtp : p.Mt;           // the matrix, in global memory (L2): packed triangle / transposed square [ld][ld]
+    const int LDMg = ld;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int cl = wv;
+    const int cg = pub.c0 + blockIdx.x * CH + cl;
+    const bool active = cg < pub.c1;
+    const int c = min(cg, pub.c1 - 1);
+    const uint32_t gc = (uint32_t)(p.off + c);
+    const int tstride = CH * L.LDP;                                      // try i of chain cl: Pt + (CH i + cl) LDP
+    double* region = Pt + (size_t)cl * L.LDP;
+
+    for (int i = threadIdx.x; i < L.rows * L.LDP; i += NT) Pt[i] = 0.0;
+    for (int i = threadIdx.x; i < 4 * ((d + 3) / 4) + 4; i += NT) mus[i] = i < d ? p.mu[i] : 0.0;
+    if (pub.TOT) {
+        if (wv == 0) adapt_apply_wave<NCH>(p, pub.TOT, pub.CNT, pub.sh, probs, blockIdx.x == 0 ? pub.sh_out : nullptr, lane);
+    } else {
+        if ((int)threadIdx.x < p.ncr) probs[threadIdx.x] = pub.sh[threadIdx.x];
+        if ((int)threadIdx.x < p.ngamma) probs[p.ncr + threadIdx.x] = pub.sh[3 * p.ncr + threadIdx.x];
+    }
+    for (int i = threadIdx.x; i < p.ngamma * d; i += NT) gts[i] = p.gtab[(size_t)(i / d) * p.depairs * d + (i % d)];
+    if (lane == 0) { st[4 * cl] = p.lprior[c]; st[4 * cl + 1] = p.llike[c]; st[4 * cl + 2] = 0.0; dec[8 * cl + 7] = chain_T(p, c); }
+    __syncthreads();
+
+    auto generation_draws = [&](uint32_t g_) {          // lane s holds slot s of the chain's wave-uniform draws of generation g_
+        DrawSrc q; q.have = true; q.mine = make_uint4(0, 0, 0, 0);
+        if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g_); q.mine = make_uint4(w.x, w.y, w.z, w.w); }
+        return q;
+    };
+    // Q = q_0 + q_1 + ... of point row `pt` in ascending row tile (the MVN contract): the reads in batches of eight, then the ordered adds
+    auto q_sum = [&](int pt) {
+        double Q = 0.0;
+#pragma unroll
+        for (int t0 = 0; t0 < NRT; t0 += 8) {
+            double qt[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qt[j] = t0 + j < NRT ? qb[pt * NRT + t0 + j] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (t0 + j < NRT) Q = Q + qt[j];
+        }
+        return Q;
+    };
+    DrawSrc dsn = generation_draws(g0);
+
+    for (int gi = 0; gi < ngen; ++gi) {
+        const uint32_t g = g0 + (uint32_t)gi;
+        const bool last = gi == ngen - 1;
+        const DrawSrc ds = dsn;
+        for (int phase = 0; phase < 2; ++phase) {
+            // ---- phase 0: k proposals around the chain's state (generate_proposal_points :258-264) into the chain's rows of tiles 0..k-1;
+            //      phase 1: the selected proposal moves to tile 0 and k-1 reference points around it (:295-299) take tiles 1..k-1
+            StepFlags f;
+            double base[NCH][2];
+            if (phase == 0) {
+                Ctrl u;
+                const u32x4 w0 = uniform_draw(p, ds, 0, gc, g), w1 = uniform_draw(p, ds, 1, gc, g), w2 = uniform_draw(p, ds, 2, gc, g);
+                u.u_snk = u53(w0.x, w0.y); u.u_cr = u53(w0.z, w0.w); u.u_de = u53(w1.x, w1.y); u.u_glev = u53(w1.z, w1.w);
+                u.u_sel = u53(w2.x, w2.y); u.u_acc = u53(w2.z, w2.w);
+                f = step_flags_from(p, u, probs, probs + p.ncr);                     // Dream.py:246-256
+                if (lane == 0) {
+                    double* dc = dec + 8 * cl;
+                    dc[0] = u.u_sel; dc[1] = u.u_acc; dc[2] = f.snk ? 1.0 : 0.0; dc[3] = (double)f.cr_idx; dc[4] = (double)f.glev;
+                }
+                load_row<NCH>(p.X + (size_t)c * ld, ld, lane, base);
+            } else {
+                const double* dc = dec + 8 * cl;
+                f.snk = dc[2] != 0.0; f.cr_idx = (int)dc[3]; f.delta = 1; f.glev = (int)dc[4];
+                const double u_sel = dc[0];
+                double lp = -__builtin_huge_val();
+                if (lane < k) {                                                      // likelihoods of the chain's k points, mt_choose_proposal_pt (:291)
+                    const double lk = nan_to_ninf(p.logF - 0.5 * q_sum(lane * CH + cl));
+                    sL[cl * k + lane] = lk;
+                    lp = sP[cl * k + lane] + dec[8 * cl + 7] * lk;
+                }
+                bool fin;
+                const int sel = mt_select_vals(k, lp, u_sel, lane, &fin);
+                if (lane == 0) st[4 * cl + 2] = (double)(sel | (fin ? 256 : 0));
+                const double* row = region + (size_t)sel * tstride;
+#pragma unroll
+                for (int it = 0; it < NCH; ++it) {
+                    const int jj = 128 * it + 2 * lane;
+                    base[it][0] = jj < d ? row[jj] : 0.0; base[it][1] = jj + 1 < d ? row[jj + 1] : 0.0;
+                }
+#pragma unroll
+                for (int it = 0; it < NCH; ++it) {                                   // the selected proposal now sits in tile 0 (each lane moves its own values)
+                    const int jj = 128 * it + 2 * lane;
+                    if (jj < d) region[jj] = base[it][0];
+                    if (jj + 1 < d) region[jj + 1] = base[it][1];
+                }
+            }
+            const bool snk_s = __builtin_amdgcn_readfirstlane((int)f.snk) != 0;
+            const double* grow = gts + (size_t)(__builtin_amdgcn_readfirstlane(f.glev) - 1) * d;
+            const int n = k - phase;
+            double* slp = phase ? rS + cl * (k - 1) : sS + cl * k;
+            double* prp = phase ? rP + cl * (k - 1) : sP + cl * k;
+            if (snk_s) __builtin_amdgcn_s_setprio(3);      // a snooker set is the longest path to the block's barrier
+            propose_set<NCH, false, false, 1>(p, phase, g, M, c, gc, 0, n, n, lane, base, grow, snk_s, f.cr_idx, 1, f.glev, ds,
+                                              region + (size_t)phase * tstride, tstride, slp, nullptr, prp, nullptr);
+            if (snk_s) __builtin_amdgcn_s_setprio(0);
+            if (phase == 1 && !last) dsn = generation_draws(g + 1u);
+            __syncthreads();                                                         // points visible
+            {   // mt_evaluate_logps :278, :302 -- the (point tile, row tile) units, A operand from L2
+                const int row0 = phase ? CH : 0, ntl = (n * CH + 15) / 16;
+                if (TRI) {
+                    if (p.mu_zero) mfma_units_d2<NRT, true>(p, Mg, Pt, mus, qb, row0, ntl, wv, CH, lane, L.LDP);
+                    else mfma_units_d2<NRT, false>(p, Mg, Pt, mus, qb, row0, ntl, wv, CH, lane, L.LDP);
+                } else {
+                    if (p.mu_zero) mfma_units<NRT, TRI, true>(p, Mg, Pt, mus, qb, row0, ntl, wv, CH, lane, LDMg, L.LDP);
+                    else mfma_units<NRT, TRI, false>(p, Mg, Pt, mus, qb, row0, ntl, wv, CH, lane, LDMg, L.LDP);
+                }
+            }
+            __syncthreads();                                                         // q visible
+        }
+        // ---- Metropolis step (:305-347), trace (core.py:114-116), record_history (:919-938)
+        {
+            const double* dc = dec + 8 * cl;
+            const double u_acc = dc[1];
+            const bool snk = dc[2] != 0.0;
+            const int cr_idx = (int)dc[3];
+            const double lpri = st[4 * cl], llik = st[4 * cl + 1], Tch = dc[7];
+            const int sf = (int)st[4 * cl + 2]; const int sel = sf & 255; const bool fin = (sf & 256) != 0;
+            double val = -__builtin_huge_val();
+            if (lane < k) {
+                val = sP[cl * k + lane] + Tch * sL[cl * k + lane];                                       // :279
+                if (snk) val = val + sS[cl * k + lane];                                                  // :307
+            } else if (lane >= 16 && lane < 16 + k) {
+                const int i = lane - 16;
+                if (i < k - 1) val = Tch * nan_to_ninf(p.logF - 0.5 * q_sum((1 + i) * CH + cl)) + rP[cl * (k - 1) + i];     // :303
+                else val = Tch * llik + lpri;                                                            // :877-879
+                if (snk) { const double sr = i < k - 1 ? rS[cl * (k - 1) + i] : 0.0; val = (val + sr) + sS[cl * k + i]; }   // :312-313
+            }
+            double lu;
+            double ratio = mt_log_ratio(k, val, u_acc, lane, &lu);
+            if (!fin) ratio = -__builtin_huge_val();                                 // DESIGN.md deviation D1
+            const bool accept = is_finite(ratio) && (lu < ratio);                    // :993
+            bool diff = false;
+            double2 xn[NCH];
+#pragma unroll
+            for (int it = 0; it < NCH; ++it) {
+                const int jj = 128 * it + 2 * lane;
+                double2 xo = {0.0, 0.0};
+                if (jj < ld) xo = *reinterpret_cast<const double2*>(p.X + (size_t)c * ld + jj);
+                xn[it] = xo;
+                if (accept) { xn[it].x = jj < d ? region[jj] : 0.0; xn[it].y = jj + 1 < d ? region[jj + 1] : 0.0; }      // the selected proposal
+                diff = diff || (xn[it].x != xo.x) || (xn[it].y != xo.y);
+            }
+            const bool moved = __any(diff);                                          // core.py:120
+            const double npri = accept ? sP[cl * k + sel] : lpri, nlik = accept ? sL[cl * k + sel] : llik;   // :345-347
+            if (active) {
+#pragma unroll
+                for (int it = 0; it < NCH; ++it) {
+                    const int jj = 128 * it + 2 * lane;
+                    if (jj < ld) {
+                        if (accept) gstore2(p.X + (size_t)c * ld + jj, xn[it]);
+                        if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn[it]);
+                        if (last && zappend >= 0) gstore2(p.Z + ((size_t)zappend + gc) * ld + jj, xn[it]);      // record_history :933-936
+                        if (publish) gstore2(publish + (size_t)gc * ld + jj, xn[it]);                          // set_current_position_arr :447-449
+                    }
+                }
+                if (lane == 0) {
+                    if (trace_slot0 >= 0) {
+                        const size_t o = (size_t)(trace_slot0 + gi) * p.nl + c;
+                        p.tlogp[o] = Tch * nlik + npri;                              // core.py:115 / :178
+                        p.tmoved[o] = moved ? 1 : 0; p.ttry[o] = sel; p.tcr[o] = cr_idx; p.tsnk[o] = snk ? 1 : 0;
+                    }
+                    if (last) { p.lprior[c] = npri; p.llike[c] = nlik; }
+                }
+            }
+            if (lane == 0) { st[4 * cl] = npri; st[4 * cl + 1] = nlik; }
+        }
+        // (one wave per chain: no barrier here -- the next generation's first phase only touches each wave's own chain's rows and scalars;
+        //  the state row in HBM was written by this wave and is read by this wave)
+    }
+}
+
+}  // namespace dz

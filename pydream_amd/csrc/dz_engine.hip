@@ -179,7 +179,7 @@ struct dz_engine {
     bool mega_redo_on = true;       // redraw rounds (Dream.py:281-289) inside the persistent kernel; DZ_MEGA_REDO=0: such configurations take the multi-kernel path
     unsigned long long* d_redraw_count = nullptr;
     bool mega_mix_pb = true;        // the mixture kernel's full-code instantiation (priors, boundaries, several pairs); DZ_MEGA_MIX_PB=0: multi-kernel path there
-    bool mega_d2 = true;            // 128 < d <= 256: k_generations_d2 (DZ_MEGA_D2=0: the multi-kernel path there)
+    int mega_d2 = 1;                // 128 < d <= 256: k_generations_d2 from 1025 chains on (DZ_MEGA_D2=0: the multi-kernel path there; 2: at any chain count)
     bool mega_w4 = true;            // small populations (4 chains x 4 waves per block), lean, multitry 3..6: k_generations_w4 (DZ_MEGA_W4=0: k_generations<.., 4, 4, lean>)
     bool mega_split = true;         // a remainder of chains beyond whole rounds of 16-chain blocks goes in a second launch of smaller blocks; DZ_MEGA_SPLIT=0: off
     bool mega_burnin = true;        // ... the generations of the crossover burn-in too, one per launch (positions published by the kernel); DZ_MEGA_BURNIN=0: multi-kernel path there
@@ -894,6 +894,7 @@ int mega_d2_chains(const dz_engine* e)
 {
     const dz::Params& p = e->p;
     if (!e->mega || !e->mega_d2 || e->lk != LK_MVN || p.ld <= 128 || p.ld > 256) return 0;
+    if (e->mega_d2 == 1 && p.nl <= 1024) return 0;      // (64 blocks or fewer leave three CUs in four idle: 57 against 52 us per generation at 1024 x 200-D; DZ_MEGA_D2=2 forces it)
     if (p.hard || p.have_prior || p.depairs > 1 || redo_possible(e)) return 0;
     if (p.k < 3 || p.nslots > 64) return 0;
     if (!p.tri || !p.Mtp) return 0;
@@ -1129,7 +1130,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     if (const char* kv = getenv("DZ_MEGA_MIX_PB")) e->mega_mix_pb = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_SPLIT")) e->mega_split = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_W4")) e->mega_w4 = atoi(kv) != 0;
-    if (const char* kv = getenv("DZ_MEGA_D2")) e->mega_d2 = atoi(kv) != 0;
+    if (const char* kv = getenv("DZ_MEGA_D2")) e->mega_d2 = atoi(kv);
     static_assert(dz::DZ_MAX_REDRAWS_DEV == DZ_MAX_REDRAWS && dz::DZ_REDRAW_KEY_STEP_DEV == DZ_REDRAW_KEY_STEP, "redraw constants");
     if (const char* kv = getenv("DZ_QFIN")) e->q_defer = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_FUSE_STREAM")) e->fuse_stream = atoi(kv) != 0;

@@ -192,7 +192,7 @@ def test_d1000_stress_shape_against_oracle(G, O):
                                                              (4096, 100, 1, 1, 0, True, None), (1000, 100, 1, 0, 0, True, None), (96, 10, 1, 1, 0, True, "uniform"),
                                                              (256, 100, 1, 1, 12, True, None), (64, 128, 1, 0, 0, True, "normal"), (4096, 20, 1, 1, 0, True, "uniform"),
                                                              # 128 < d <= 256 (round 5): k_generations_d2 -- the matrix from L2, two 128-dimension chunks per lane
-                                                             (300, 160, 5, 1, 0, True, None), (1000, 200, 5, 1, 0, True, None), (100, 200, 3, 0, 0, False, None),
+                                                             (300, 160, 5, 1, 0, True, None), (1100, 200, 5, 1, 0, True, None), (100, 200, 3, 0, 0, False, None),
                                                              (250, 224, 5, 1, 12, True, None), (64, 140, 4, 1, 12, True, None), (48, 129, 15, 1, 0, False, None), (48, 129, 8, 1, 0, True, None),
                                                              (250, 256, 5, 1, 0, False, None),
                                                              (64, 200, 1, 1, 0, False, None), (64, 200, 5, 1, 0, False, "normal"), (32, 300, 5, 1, 0, False, None)])
@@ -214,9 +214,10 @@ def test_persistent_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, k, tr
 
     def run(Cls, mega):
         monkeypatch.setenv("DZ_MEGA", "1" if mega else "0")
+        monkeypatch.setenv("DZ_MEGA_D2", "2" if N < 1100 else "1")           # (k_generations_d2 is the default from 1025 chains on; the small cases force it)
         e = Cls(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
                 adapt_crossover=1 if burnin else 0, crossover_burnin=burnin)
-        mu = np.linspace(-1.0, 1.0, d) if d in (10, 64) else np.zeros(d)      # (a zero mean takes a shorter code path)
+        mu = np.linspace(-1.0, 1.0, d) if d in (10, 64, 140) else np.zeros(d)      # (a zero mean takes a shorter code path)
         if prior == "uniform":                                                # scipy uniform(loc=-6, scale=22): support [-6, 16]
             e.set_prior(np.full(d, 2, np.int32), np.full(d, -6.0), np.full(d, 22.0))
             e.set_bounds(np.full(d, -6.0), np.full(d, 16.0))

@@ -277,6 +277,8 @@ def workload_label(args, n_local, world):
         return "BASELINE configs[2] as written"
     if args.target == "mvn" and args.dim == 100 and n_local == 4096:
         return "BASELINE north_star target / configs[3] per-GPU shard"
+    if args.target == "mvn" and args.dim == 200:
+        return "the reference example's own dimension (dream_ex_ndim_gaussian.py:29), not a BASELINE configuration"
     return "variant of the BASELINE workloads"
 
 
@@ -317,19 +319,22 @@ def main():
 
 
 def baseline_configs(args):
-    """The other single-GPU BASELINE.json configurations, each measured in this same run the way the headline is (convergence run with
+    """The other single-GPU BASELINE.json configurations (and the reference example's own d = 200), each measured in this same run the way the headline is (convergence run with
     the reference's R-hat rule, warm-up, blocks of exactly K generations, an event-timed pass for the roofline) -- without the dense /
     lag-0 / CPU legs.  -> {"configs[1]": {...}, "configs[2]": {...}, "configs[4] shard": {...}}"""
     import copy
     res = {}
     for key, over in (("configs[1]", dict(chains_per_gpu=1024)),
                       ("configs[2]", dict(target="mix3", adapt=True, burnin_generations=800)),
-                      ("configs[4] shard", dict(chains_per_gpu=512, dim=1000))):
+                      ("configs[4] shard", dict(chains_per_gpu=512, dim=1000)),
+                      # not a BASELINE configuration: the reference example's own dimension (dream_ex_ndim_gaussian.py:29), 4096 chains
+                      ("example d=200", dict(dim=200, rhat_cap=4000))):
         a = copy.copy(args)
+        cap = over.pop("rhat_cap", None)
         for k_, v_ in over.items():
             setattr(a, k_, v_)
         if not args.rhat_max_given:
-            a.rhat_max_generations = max(10000, 16 * a.dim)
+            a.rhat_max_generations = max(10000, 16 * a.dim) if cap is None else cap      # (d = 200: the device trace of the convergence run is 6.8 MB per generation)
         a.burnin_generations = min(a.burnin_generations, max(60, a.rhat_max_generations // 4))
         t0 = time.perf_counter()
         try:

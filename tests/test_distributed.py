@@ -552,7 +552,8 @@ def test_bench_default_line_carries_every_single_gpu_baseline_config(tmp_path):
     d = json.loads([l for l in res.stdout.splitlines() if l.startswith('{"metric"')][0])
     assert "configs[3] per-GPU shard" in d["config"]["workload"]
     c = d["configs"]
-    assert set(c) == {"configs[1]", "configs[2]", "configs[4] shard"}
+    assert set(c) == {"configs[1]", "configs[2]", "configs[4] shard", "example d=200"}
+    assert c["example d=200"]["kernel_variant"] == "k_generations_d2<13,tri,xhbm,16,1,lean>" and c["example d=200"]["value"] > 0
     for key, variant, label in (("configs[1]", "k_generations_w4<7,tri,xlds,4,4,lean,ahead>", "BASELINE configs[1]"),
                                 ("configs[2]", "k_generations_mix", "BASELINE configs[2] as written"),
                                 ("configs[4] shard", "multi-kernel path", "BASELINE configs[4] per-GPU shard")):

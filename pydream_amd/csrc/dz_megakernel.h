@@ -287,8 +287,16 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
         pcs.inside = smem + L.off_pr + p.ncr + p.ngamma;
     }
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;       // (scalar: everything derived from the wave number stays on the scalar unit)
-    const int cl = WPC == 1 ? wv : wv % CH;                              // chain inside the block
-    const int sub = WPC == 1 ? 0 : wv / CH;                              // this wave's number among the chain's waves
+    // chain inside the block; this wave's number among the chain's waves.  Four waves per chain (CH = 4): wave w runs on SIMD w % 4, and a
+    // chain's waves sit on FOUR SIMDs with the numbers rotated per chain (round 5, as in k_generations_w4: when the block waits for one
+    // chain's snooker set, that set has the CU's SIMDs to itself instead of a quarter of one)
+#ifdef DZ_ONE_SIMD_PER_CHAIN
+    const int cl = WPC == 1 ? wv : wv % CH;
+    const int sub = WPC == 1 ? 0 : wv / CH;
+#else
+    const int cl = WPC == 1 ? wv : wv / WPC;
+    const int sub = WPC == 1 ? 0 : ((wv % WPC) + cl) % WPC;
+#endif
     const int cg = pub.c0 + blockIdx.x * CH + cl;
     const bool active = cg < pub.c1;
     const int c = min(cg, pub.c1 - 1);

@@ -21,13 +21,14 @@ namespace dz {
 // 128 < ld <= 256: k_generations_d2 (dz_megakernel_d2.h) -- the matrix read from L2, two 128-dimension chunks per lane
 const char* DZ_CAT(mega_launch_nrt, DZ_TU_NRT)(const MegaLaunch& a)
 {
-#define DZ_D2(TRI_, CH_)                                                                                                                   \
+#define DZ_D2(K1_, NAME_)                                                                                                                 \
     do {                                                                                                                                   \
-        hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, TRI_, CH_>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, \
+        hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 16, K1_>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, \
                               a.slot0, a.zappend, *a.publish);                                                                             \
-        return TRI_ ? "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,lean>" : "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",dense,xhbm,%d,%d,lean>"; \
+        return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d," NAME_ ">";                                                         \
     } while (0)
-    DZ_D2(true, 16);          // (the host only sends the triangular factor at 16 chains per block here: mega_d2_chains)
+    if (a.k1) DZ_D2(true, "lean,k1");          // (the host only sends the triangular factor at 16 chains per block here: mega_d2_chains)
+    DZ_D2(false, "lean");
 #undef DZ_D2
 }
 #else

@@ -80,15 +80,18 @@ DZ_DEV void mfma_units_d2(const Params& p, const double* __restrict__ Mg, const 
     }
 }
 
-template <int NRT, bool TRI, int CH>
+// K1: multitry off (the reference's default, Dream.py:271-275 and :326-334) -- one proposal per generation, no reference set, the single-try
+// snooker formula and the current point's term log |x - z|^(d-1).
+template <int NRT, bool TRI, int CH, bool K1 = false>
 __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int64_t zappend, Publish pub)
 {
     constexpr int NCH = 2, NT = 64 * CH;
     double* const publish = pub.to;
     const Params& p = *pp;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int d = p.d, k = p.k, ld = p.ld;
+    const int d = p.d, k = K1 ? 1 : p.k, ld = p.ld;
     const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, false, CH, false, false, true);
+    constexpr int nph = K1 ? 1 : 2;
     double* Pt = smem + L.off_P;
     double* qb = smem + L.off_q;
     double* sP = smem + L.off_sP; double* sS = smem + L.off_sS; double* sL = smem + L.off_sL;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __rest
         const uint32_t g = g0 + (uint32_t)gi;
         const bool last = gi == ngen - 1;
         const DrawSrc ds = dsn;
-        for (int phase = 0; phase < 2; ++phase) {
+        for (int phase = 0; phase < nph; ++phase) {
             // ---- phase 0: k proposals around the chain's state (generate_proposal_points :258-264) into the chain's rows of tiles 0..k-1;
             //      phase 1: the selected proposal moves to tile 0 and k-1 reference points around it (:295-299) take tiles 1..k-1
             StepFlags f;
@@ -193,10 +196,10 @@ __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __rest
             double* slp = phase ? rS + cl * (k - 1) : sS + cl * k;
             double* prp = phase ? rP + cl * (k - 1) : sP + cl * k;
             if (snk_s) __builtin_amdgcn_s_setprio(3);      // a snooker set is the longest path to the block's barrier
-            propose_set<NCH, false, false, 1>(p, phase, g, M, c, gc, 0, n, n, lane, base, grow, snk_s, f.cr_idx, 1, f.glev, ds,
-                                              region + (size_t)phase * tstride, tstride, slp, nullptr, prp, nullptr);
+            propose_set<NCH, false, false, K1 ? 2 : 1>(p, phase, g, M, c, gc, 0, n, n, lane, base, grow, snk_s, f.cr_idx, 1, f.glev, ds,
+                                                       region + (size_t)phase * tstride, tstride, slp, K1 ? st + 4 * cl + 3 : nullptr, prp, nullptr);   // (k = 1: log |x - z|^(d-1) of the current point, :328-329)
             if (snk_s) __builtin_amdgcn_s_setprio(0);
-            if (phase == 1 && !last) dsn = generation_draws(g + 1u);
+            if (phase == nph - 1 && !last) dsn = generation_draws(g + 1u);
             __syncthreads();                                                         // points visible
             {   // mt_evaluate_logps :278, :302 -- the (point tile, row tile) units, A operand from L2
                 const int row0 = phase ? CH : 0, ntl = (n * CH + 15) / 16;
@@ -219,7 +222,10 @@ __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __rest
             const double lpri = st[4 * cl], llik = st[4 * cl + 1], Tch = dc[7];
             const int sf = (int)st[4 * cl + 2]; const int sel = sf & 255; const bool fin = (sf & 256) != 0;
             double val = -__builtin_huge_val();
-            if (lane < k) {
+            if (K1) {                                                           // single try: the proposal's density straight from the q sums (:271-275)
+                val = nan_to_ninf(p.logF - 0.5 * q_sum(cl));                         // (every lane: the same sums)
+                sL[cl] = val;
+            } else if (lane < k) {
                 val = sP[cl * k + lane] + Tch * sL[cl * k + lane];                                       // :279
                 if (snk) val = val + sS[cl * k + lane];                                                  // :307
             } else if (lane >= 16 && lane < 16 + k) {
@@ -228,9 +234,16 @@ __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __rest
                 else val = Tch * llik + lpri;                                                            // :877-879
                 if (snk) { const double sr = i < k - 1 ? rS[cl * (k - 1) + i] : 0.0; val = (val + sr) + sS[cl * k + i]; }   // :312-313
             }
-            double lu;
-            double ratio = mt_log_ratio(k, val, u_acc, lane, &lu);
-            if (!fin) ratio = -__builtin_huge_val();                                 // DESIGN.md deviation D1
+            double lu, ratio;
+            if (K1) {
+                const double q_logp = Tch * val + sP[cl], last_logp = Tch * llik + lpri;                 // :274, :243
+                if (snk) ratio = nan_to_num((q_logp + sS[cl]) - (last_logp + st[4 * cl + 3]));           // :326-332
+                else ratio = nan_to_num(q_logp) - nan_to_num(last_logp);                                 // :334
+                lu = dlog(u_acc);
+            } else {
+                ratio = mt_log_ratio(k, val, u_acc, lane, &lu);
+                if (!fin) ratio = -__builtin_huge_val();                             // DESIGN.md deviation D1
+            }
             const bool accept = is_finite(ratio) && (lu < ratio);                    // :993
             bool diff = false;
             double2 xn[NCH];

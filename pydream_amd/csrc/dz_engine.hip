@@ -886,7 +886,7 @@ bool mega_mix_eligible(const dz_engine* e)
 }
 // redraw rounds inside the persistent kernel: the instantiations with the full proposal code, multi-try, device MVN likelihood
 bool mega_redo(const dz_engine* e) { return redo_possible(e) && e->lk == LK_MVN && e->p.k > 1 && e->mega_redo_on; }
-// 128 < d <= 256 (the reference example's d = 200): k_generations_d2 -- lean configurations with the triangular factor (what
+// 128 < d <= 256 (the reference example's d = 200): k_generations_d2 -- configurations with the triangular factor (what
 // MVNormalLogLike builds) whose point tiles of 16 chains fit LDS without the matrix (it is read from L2): d <= ~230 at 5 tries.  Measured and
 // left on the multi-kernel path: 8 chains per block (d = 256: 131 against 123 us per generation) and the dense matrix (its 16-chain
 // instantiation spills a hundred registers; at 8 chains per block 156 against 148 us at d = 200).
@@ -895,7 +895,7 @@ int mega_d2_chains(const dz_engine* e)
     const dz::Params& p = e->p;
     if (!e->mega || !e->mega_d2 || e->lk != LK_MVN || p.ld <= 128 || p.ld > 256) return 0;
     if (e->mega_d2 == 1 && p.nl <= 1024) return 0;      // (64 blocks or fewer leave three CUs in four idle: 57 against 52 us per generation at 1024 x 200-D; DZ_MEGA_D2=2 forces it)
-    if (p.hard || p.have_prior || p.depairs > 1 || redo_possible(e)) return 0;
+    if (redo_possible(e)) return 0;      // (whole proposal sets that can be impossible: the multi-kernel path's redraw rounds)
     if ((p.k != 1 && p.k < 3) || p.nslots > 64) return 0;
     if (!p.tri || !p.Mtp) return 0;
     const size_t lds = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, false, 16, false, false, true).total;
@@ -1004,7 +1004,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
     if (const int chd = mega_d2_chains(e)) {      // 128 < d <= 256
         DZCK(upload_params(e));
         dz::MegaLaunch ml;
-        ml.tri = p.tri != 0; ml.xlds = false; ml.pb = false; ml.k1 = p.k == 1; ml.ch = chd; ml.wpc = 1; ml.redo = false;
+        ml.tri = p.tri != 0; ml.xlds = false; ml.pb = p.hard || p.have_prior || p.depairs > 1; ml.k1 = p.k == 1; ml.ch = chd; ml.wpc = 1; ml.redo = false;
         ml.grid = dim3((p.nl + chd - 1) / chd); ml.block = dim3(64 * chd);
         ml.lds = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, false, chd, false, false, true).total;
         ml.st = e->stream; ml.ka = nullptr; ml.kb = nullptr;

@@ -23,12 +23,17 @@ const char* DZ_CAT(mega_launch_nrt, DZ_TU_NRT)(const MegaLaunch& a)
 {
 #define DZ_D2(K1_, NAME_)                                                                                                                 \
     do {                                                                                                                                   \
+        if (a.pb) {                                                                                                                        \
+            hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 16, K1_, true>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, \
+                                  a.slot0, a.zappend, *a.publish);                                                                         \
+            return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,full" NAME_ ">";                                                 \
+        }                                                                                                                                  \
         hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 16, K1_>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, \
                               a.slot0, a.zappend, *a.publish);                                                                             \
-        return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d," NAME_ ">";                                                         \
+        return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,lean" NAME_ ">";                                                     \
     } while (0)
-    if (a.k1) DZ_D2(true, "lean,k1");          // (the host only sends the triangular factor at 16 chains per block here: mega_d2_chains)
-    DZ_D2(false, "lean");
+    if (a.k1) DZ_D2(true, ",k1");          // (the host only sends the triangular factor at 16 chains per block here: mega_d2_chains)
+    DZ_D2(false, "");
 #undef DZ_D2
 }
 #else

@@ -82,7 +82,9 @@ DZ_DEV void mfma_units_d2(const Params& p, const double* __restrict__ Mg, const 
 
 // K1: multitry off (the reference's default, Dream.py:271-275 and :326-334) -- one proposal per generation, no reference set, the single-try
 // snooker formula and the current point's term log |x - z|^(d-1).
-template <int NRT, bool TRI, int CH, bool K1 = false>
+// PB: per-dimension priors (SampledParam norm / uniform, parameters.py:37-47), hard boundaries (Dream.py:733-791), several DE pairs
+// (set_DEpair :571-583) -- the multi-kernel path's full proposal code and prior evaluation, constants from global memory.
+template <int NRT, bool TRI, int CH, bool K1 = false, bool PB = false>
 __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int64_t zappend, Publish pub)
 {
     constexpr int NCH = 2, NT = 64 * CH;
@@ -162,11 +164,12 @@ __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __rest
                 if (lane == 0) {
                     double* dc = dec + 8 * cl;
                     dc[0] = u.u_sel; dc[1] = u.u_acc; dc[2] = f.snk ? 1.0 : 0.0; dc[3] = (double)f.cr_idx; dc[4] = (double)f.glev;
+                    if (PB) dc[5] = (double)f.delta;
                 }
                 load_row<NCH>(p.X + (size_t)c * ld, ld, lane, base);
             } else {
                 const double* dc = dec + 8 * cl;
-                f.snk = dc[2] != 0.0; f.cr_idx = (int)dc[3]; f.delta = 1; f.glev = (int)dc[4];
+                f.snk = dc[2] != 0.0; f.cr_idx = (int)dc[3]; f.delta = PB ? (int)dc[5] : 1; f.glev = (int)dc[4];
                 const double u_sel = dc[0];
                 double lp = -__builtin_huge_val();
                 if (lane < k) {                                                      // likelihoods of the chain's k points, mt_choose_proposal_pt (:291)
@@ -191,11 +194,14 @@ __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __rest
                 }
             }
             const bool snk_s = __builtin_amdgcn_readfirstlane((int)f.snk) != 0;
-            const double* grow = gts + (size_t)(__builtin_amdgcn_readfirstlane(f.glev) - 1) * d;
+            const double* grow = PB ? gamma_row(p, f.glev, f.delta) : gts + (size_t)(__builtin_amdgcn_readfirstlane(f.glev) - 1) * d;
             const int n = k - phase;
             double* slp = phase ? rS + cl * (k - 1) : sS + cl * k;
             double* prp = phase ? rP + cl * (k - 1) : sP + cl * k;
             if (snk_s) __builtin_amdgcn_s_setprio(3);      // a snooker set is the longest path to the block's barrier
+            if (PB) propose_set<NCH, false, true, 0>(p, phase, g, M, c, gc, 0, n, n, lane, base, grow, snk_s, f.cr_idx, f.delta, f.glev, ds,
+                                                     region + (size_t)phase * tstride, tstride, slp, K1 ? st + 4 * cl + 3 : nullptr, prp, nullptr);
+            else
             propose_set<NCH, false, false, K1 ? 2 : 1>(p, phase, g, M, c, gc, 0, n, n, lane, base, grow, snk_s, f.cr_idx, 1, f.glev, ds,
                                                        region + (size_t)phase * tstride, tstride, slp, K1 ? st + 4 * cl + 3 : nullptr, prp, nullptr);   // (k = 1: log |x - z|^(d-1) of the current point, :328-329)
             if (snk_s) __builtin_amdgcn_s_setprio(0);

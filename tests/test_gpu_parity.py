@@ -195,7 +195,7 @@ def test_d1000_stress_shape_against_oracle(G, O):
                                                              (300, 160, 5, 1, 0, True, None), (1100, 200, 5, 1, 0, True, None), (100, 200, 3, 0, 0, False, None),
                                                              (250, 224, 5, 1, 12, True, None), (64, 140, 4, 1, 12, True, None), (48, 129, 15, 1, 0, False, None), (48, 129, 8, 1, 0, True, None),
                                                              (250, 256, 5, 1, 0, False, None),
-                                                             (64, 200, 1, 1, 0, True, None), (300, 160, 1, 1, 12, True, None), (64, 200, 5, 1, 0, False, "normal"), (64, 200, 1, 0, 0, False, None), (32, 300, 5, 1, 0, False, None)])
+                                                             (64, 200, 1, 1, 0, True, None), (300, 160, 1, 1, 12, True, None), (64, 200, 5, 1, 0, True, "normal"), (100, 160, 4, 1, 12, True, "uniform"), (64, 200, 1, 1, 0, True, "uniform"), (64, 200, 1, 0, 0, False, None), (32, 300, 5, 1, 0, False, None)])
 def test_persistent_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, k, tri, burnin, eligible, prior, monkeypatch):
     """k_generations (whole thin-cycles in one launch, the default wherever it is eligible) against the
     multi-kernel path (DZ_MEGA=0) and the oracle: 35 generations across three history appends, chain counts that do
@@ -275,7 +275,7 @@ def test_the_instantiations_the_bench_times_equal_the_oracle(G, O, N, tri, targe
 
 
 @pytest.mark.parametrize("N,d,k,depairs,ngamma,prior", [(1000, 100, 5, 3, 2, None), (96, 10, 3, 2, 1, "uniform"), (256, 100, 1, 2, 3, None),
-                                                        (64, 128, 4, 3, 1, None)])
+                                                        (64, 128, 4, 3, 1, None), (80, 200, 5, 3, 2, None), (64, 160, 1, 2, 3, "uniform")])       # (the last two: k_generations_d2's full-code instantiations)
 def test_persistent_kernel_with_several_pairs_and_gamma_levels(G, O, N, d, k, depairs, ngamma, prior, monkeypatch):
     """DEpairs > 1 and several gamma levels (set_DEpair Dream.py:571-583, set_gamma_level :585-599, the gamma table :692) inside
     k_generations -- the instantiations with the full proposal code -- against the multi-kernel path and the oracle, bit for bit."""
@@ -288,6 +288,7 @@ def test_persistent_kernel_with_several_pairs_and_gamma_levels(G, O, N, d, k, de
 
     def run(Cls, mega):
         monkeypatch.setenv("DZ_MEGA", "1" if mega else "0")
+        monkeypatch.setenv("DZ_MEGA_D2", "2")
         e = Cls(nchains=N, ndim=d, multitry=k, depairs=depairs, ngamma=ngamma, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed)
         e.set_gamma_table(table); e.set_gamma_probs(gp)
         if prior == "uniform":

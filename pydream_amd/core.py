@@ -89,6 +89,9 @@ def run_dream(parameters, likelihood, nchains=5, niterations=50000, start=None, 
     return sampled_params, log_ps
 
 
+last_kernel_variant = None      # which kernel instantiation carried the generations of the last run_dream call (dz_last_kernel_variant), for the curious
+
+
 # ---- the engine kept alive between run_dream calls (the one of the last run that saved its history under a model name) ----
 _parked = {}
 
@@ -277,6 +280,8 @@ def _sample_dream_batched(eng, step, niterations, verbose, nverbose):
     if chunk >= niterations >= 2 and eng.nl == eng.N and hasattr(eng, "get_rhat"):
         # the whole run is still in the device trace: the reference's diagnostic (convergence.py:3-20) over all chains, made there
         sampled.gelman_rubin = eng.get_rhat()
+    global last_kernel_variant
+    last_kernel_variant = eng.last_kernel_variant() if hasattr(eng, "last_kernel_variant") else None
     if step.save_history:
         _save_history_to_disc(eng, step, appended_from=getattr(eng, "continued_from_file_rows", None))
     return sampled, log_ps

@@ -588,3 +588,29 @@ def test_run_dream_with_a_user_device_kernel_and_a_wave_per_point(tmp_path):
     np.testing.assert_array_equal(e.eval_logp(X)[1], np.array([twin(x) for x in X]))
     with pytest.raises(G.DreamZSError, match="hipModuleGetFunction"):
         e.set_likelihood_module(like.code_object(), "no_such_kernel")
+
+
+@pytest.mark.parametrize("multitry", [5, False])
+def test_run_dream_at_the_reference_examples_dimension(tmp_path, monkeypatch, multitry):
+    """The shipped n-dimensional Gaussian example's own d = 200 (dream_ex_ndim_gaussian.py:29, multitry = 5 at :65; and the reference's
+    default, multitry off) through run_dream with the device likelihood: the generations run k_generations_d2 (the matrix from L2, two
+    128-dimension chunks per lane; forced here at 48 chains, the default from 1025 on) and the samples equal run_dream's own sequence on
+    the ORACLE, bit for bit, with crossover adaptation on (the reference's default)."""
+    from scipy.stats import norm
+    monkeypatch.setenv("DZ_MEGA_D2", "2")
+    d, N, n = 200, 48, 40
+    P = H.mvn_precision(d)
+    hist = str(tmp_path / "seed.npy")
+    Z0 = H.seed_history(2000, d, 21)
+    np.save(hist, Z0)
+    pri = [SampledParam(norm, loc=np.zeros(d), scale=np.full(d, 40.0))]
+    kw = dict(history_file=hist, multitry=multitry, save_history=False, crossover_burnin=15)
+    like = MVNormalLogLike(P)
+    sampled, log_ps = run_dream(pri, like, nchains=N, niterations=n, start=[Z0[c] for c in range(N)], verbose=False, seed=4, **kw)
+    from pydream_amd import core
+    assert core.last_kernel_variant == ("k_generations_d2<13,tri,xhbm,16,1,full>" if multitry else "k_generations_d2<13,tri,xhbm,16,1,full,k1>")
+    s_o, l_o = _oracle_run_dream(pri, like, N, n, [Z0[c] for c in range(N)], 4, **kw)
+    np.testing.assert_array_equal(np.array(sampled), np.array(s_o))
+    np.testing.assert_array_equal(np.array(log_ps), np.array(l_o))
+    acc = np.mean([np.any(np.diff(np.asarray(s), axis=0) != 0, axis=1).mean() for s in sampled])
+    assert 0.01 < acc < 0.95

@@ -893,7 +893,13 @@ bool mega_redo(const dz_engine* e) { return redo_possible(e) && e->lk == LK_MVN 
 int mega_d2_chains(const dz_engine* e)
 {
     const dz::Params& p = e->p;
-    if (!e->mega || !e->mega_d2 || e->lk != LK_MVN || p.ld <= 128 || p.ld > 256) return 0;
+    if (!e->mega || !e->mega_d2 || e->lk != LK_MVN || p.ld < 80 || p.ld > 256) return 0;
+    if (p.ld <= 128) {      // d <= 128: only where the classic kernel's 16-chain layout (matrix in LDS) does not fit -- it then runs 8 chains per block (113..128
+                            // dimensions at 5 tries, 100 dimensions at 8 or more)
+        const bool pbx = p.hard || p.have_prior || p.depairs > 1;
+        const size_t classic = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, pbx, 16, pbx && p.pb_lds != 0).total;
+        if (classic <= (size_t)160 * 1024 || p.k == 1) return 0;
+    }
     if (e->mega_d2 == 1 && p.nl <= 1024) return 0;      // (64 blocks or fewer leave three CUs in four idle: 57 against 52 us per generation at 1024 x 200-D; DZ_MEGA_D2=2 forces it)
     if (redo_possible(e)) return 0;      // (whole proposal sets that can be impossible: the multi-kernel path's redraw rounds)
     if ((p.k != 1 && p.k < 3) || p.nslots > 64) return 0;
@@ -1012,6 +1018,8 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         if (e->prof) { ml.ka = prof_event(e); ml.kb = prof_event(e); e->ev[PR_GENERATIONS].emplace_back(ml.ka, ml.kb); }
         const char* name = nullptr;
         switch (nrt) {
+            case 5: name = dz::mega_launch_d2_nrt5(ml); break; case 6: name = dz::mega_launch_d2_nrt6(ml); break;
+            case 7: name = dz::mega_launch_d2_nrt7(ml); break; case 8: name = dz::mega_launch_d2_nrt8(ml); break;
             case 9: name = dz::mega_launch_nrt9(ml); break; case 10: name = dz::mega_launch_nrt10(ml); break;
             case 11: name = dz::mega_launch_nrt11(ml); break; case 12: name = dz::mega_launch_nrt12(ml); break;
             case 13: name = dz::mega_launch_nrt13(ml); break; case 14: name = dz::mega_launch_nrt14(ml); break;

@@ -92,6 +92,24 @@ const char* DZ_CAT(mega_launch_nrt, DZ_TU_NRT)(const MegaLaunch& a)
     if (a.tri) return a.xlds ? launch_ch<true, true, false>(a) : launch_ch<true, false, false>(a);
     return a.xlds ? launch_ch<false, true, false>(a) : launch_ch<false, false, false>(a);
 }
+#if DZ_TU_NRT >= 5
+// d <= 128 with the point tiles of 16 chains NOT fitting next to the matrix in LDS (113..128 dimensions at 5 tries, 100 dimensions at 8 or more): k_generations_d2
+// with one chunk per lane
+const char* DZ_CAT(mega_launch_d2_nrt, DZ_TU_NRT)(const MegaLaunch& a)
+{
+#define DZ_D2(K1_, NAME_)                                                                                                                 \
+    do {                                                                                                                                   \
+        if (a.pb) {                                                                                                                        \
+            hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 16, K1_, true>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, a.slot0, a.zappend, *a.publish); \
+            return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,full" NAME_ ">";                                                 \
+        }                                                                                                                                  \
+        hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 16, K1_>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, a.slot0, a.zappend, *a.publish); \
+        return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,lean" NAME_ ">";                                                     \
+    } while (0)
+    DZ_D2(false, "");          // (multitry on only: the multitry-off kernels' 16-chain layout always fits)
+#undef DZ_D2
+}
+#endif
 #endif      // DZ_TU_NRT <= 8
 
 }  // namespace dz

@@ -87,7 +87,8 @@ DZ_DEV void mfma_units_d2(const Params& p, const double* __restrict__ Mg, const 
 template <int NRT, bool TRI, int CH, bool K1 = false, bool PB = false>
 __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int64_t zappend, Publish pub)
 {
-    constexpr int NCH = 2, NT = 64 * CH;
+    constexpr int NCH = NRT > 8 ? 2 : 1, NT = 64 * CH;          // (NRT = 8, ld = 128: one chunk -- the kernel also serves 113..128 dimensions, where the
+                                                                //  matrix in LDS leaves room for the point tiles of 8 chains only)
     double* const publish = pub.to;
     const Params& p = *pp;
     extern __shared__ __attribute__((aligned(16))) double smem[];

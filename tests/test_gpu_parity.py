@@ -195,7 +195,9 @@ def test_d1000_stress_shape_against_oracle(G, O):
                                                              (300, 160, 5, 1, 0, True, None), (1100, 200, 5, 1, 0, True, None), (100, 200, 3, 0, 0, False, None),
                                                              (250, 224, 5, 1, 12, True, None), (64, 140, 4, 1, 12, True, None), (48, 129, 15, 1, 0, False, None), (48, 129, 8, 1, 0, True, None),
                                                              (250, 256, 5, 1, 0, False, None),
-                                                             (64, 200, 1, 1, 0, True, None), (300, 160, 1, 1, 12, True, None), (64, 200, 5, 1, 0, True, "normal"), (100, 160, 4, 1, 12, True, "uniform"), (64, 200, 1, 1, 0, True, "uniform"), (64, 200, 1, 0, 0, False, None), (32, 300, 5, 1, 0, False, None)])
+                                                             (64, 200, 1, 1, 0, True, None), (300, 160, 1, 1, 12, True, None), (64, 200, 5, 1, 0, True, "normal"), (100, 160, 4, 1, 12, True, "uniform"), (64, 200, 1, 1, 0, True, "uniform"), (64, 200, 1, 0, 0, False, None),
+                                                             (80, 128, 5, 1, 12, True, None), (80, 127, 6, 1, 0, True, "normal"), (48, 100, 12, 1, 0, True, None),      # (d <= 128 where 16 chains do not fit next to the matrix: k_generations_d2<8 / 7,..>)
+                                                             (32, 300, 5, 1, 0, False, None)])
 def test_persistent_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, k, tri, burnin, eligible, prior, monkeypatch):
     """k_generations (whole thin-cycles in one launch, the default wherever it is eligible) against the
     multi-kernel path (DZ_MEGA=0) and the oracle: 35 generations across three history appends, chain counts that do

@@ -139,6 +139,67 @@ DZ_DEV void mfma_units(const Params& p, const double* __restrict__ Ms, const dou
     }
 }
 
+// The likelihood units of k_generations_d2 (triangular factor; cf. mfma_units, dz_megakernel.h): a unit is a ROW tile and a PAIR of point
+// tiles, so that every A operand fetched from L2 (16 matrix rows x 4 k) feeds two MFMAs -- half the L2 reads and half the load
+// instructions of one unit per point tile; an odd last tile runs alone.  Each accumulator is still ONE chain over k in ascending order
+// (the contract), so the row-tile sums are the bits mfma_units makes.  Units are dealt heaviest first (row tile 0 walks
+// all of k) in snake order over the waves.
+template <int NRT, bool MZ, int NPT>
+DZ_DEV void d2_unit(const double* __restrict__ ap, const double* __restrict__ bp0, const double* __restrict__ bp1, const double* __restrict__ mp,
+                    int t, int KS, int KB, int kq, dz_double4& acc0, dz_double4& acc1)
+{
+#pragma unroll 1
+    for (int b16 = t; b16 < KB; ++b16) {                           // (not unrolled: b16 is wave-uniform, the offsets are scalar arithmetic; unrolled, the compiler
+        double a[4], b0[4], b1[4];                                 //  hoisted the L2 loads of many batches and spilled ninety registers)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                              // the batch's operand reads are issued together, then its MFMAs (ascending k)
+            const int c = 16 * b16 + 4 * q;
+            a[q] = ap[128 * b16 * (b16 + 1) + (4 * q + kq) * 16 * (b16 + 1)];
+            b0[q] = MZ ? bp0[c] : bp0[c] - mp[c];
+            if (NPT == 2) b1[q] = MZ ? bp1[c] : bp1[c] - mp[c];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b0[q], acc0, 0, 0, 0);
+            if (NPT == 2) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b1[q], acc1, 0, 0, 0);
+        }
+    }
+    for (int ks = 4 * KB; ks < KS; ++ks) {                         // the last, partial block: every row tile takes part
+        const int c = 4 * ks;
+        const double av = ap[128 * KB * (KB + 1) + (c - 16 * KB + kq) * 16 * (KB + 1)];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, MZ ? bp0[c] : bp0[c] - mp[c], acc0, 0, 0, 0);
+        if (NPT == 2) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, MZ ? bp1[c] : bp1[c] - mp[c], acc1, 0, 0, 0);
+    }
+}
+template <int NRT, bool MZ>
+DZ_DEV void mfma_units_d2(const Params& p, const double* __restrict__ Mg, const double* __restrict__ Pt, const double* __restrict__ mus,
+                          double* __restrict__ qb, int row0, int ntl, int wv, int tw, int l, int LDP)
+{
+    const int d = p.d, KS = (d + 3) >> 2, KB = KS >> 2;
+    const int pi = l & 15, kq = l >> 4;
+    const int npr = (ntl + 1) >> 1, nun = npr * NRT;
+    const int rcp = ((1 << 20) + npr - 1) / npr;                  // u / npr == (u * rcp) >> 20 for every u < 2^10
+    for (int j = 0; tw * j < nun; ++j) {
+        const int u = mega_unit(j, wv, tw);
+        if (u >= nun) continue;
+        const int t = (u * rcp) >> 20, pr = u - t * npr, trow = row0 + 32 * pr;
+        const bool two = 2 * pr + 1 < ntl;                        // (wave-uniform)
+        const double* bp0 = Pt + (size_t)(trow + pi) * LDP + kq;
+        const double* bp1 = bp0 + (size_t)16 * LDP;
+        const double* mp = mus + kq;
+        const double* ap = Mg + 16 * t + pi;
+        dz_double4 acc0 = dz_double4{0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+        if (two) d2_unit<NRT, MZ, 2>(ap, bp0, bp1, mp, t, KS, KB, kq, acc0, acc1);
+        else d2_unit<NRT, MZ, 1>(ap, bp0, bp1, mp, t, KS, KB, kq, acc0, acc1);
+        const double q0 = tile_q_tri(acc0);
+        if (kq == 0) qb[(trow + pi) * NRT + t] = q0;
+        if (two) {
+            const double q1 = tile_q_tri(acc1);
+            if (kq == 0) qb[(trow + 16 + pi) * NRT + t] = q1;
+        }
+    }
+}
+
 // ---- archive-row prefetch of the persistent kernels.  Measured with cycle stamps (tools/stamps.py): with the rows of try i + 1
 // requested at the start of try i, a try of ~2.8 k cycles still waited 1-2 k cycles for them -- the gathers are latency-bound (two
 // 1-KB requests in flight per wave), not bandwidth-bound.  So three row buffers rotate (the rows of tries i + 1 and i + 2 are in
@@ -498,6 +559,8 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 // mt_evaluate_logps :278, :302 (x - 0.0 == x bit for bit, so a zero mean skips the subtraction and its LDS read)
                 {
                     const int row0 = phase ? CH : 0, ntl = ((k - phase) * CH + 15) / 16;
+                    // (the pair-of-tiles units of k_generations_d2 in here, the matrix still in LDS: 714 against 725 M proposals/s at the headline size -- coarser
+                    //  units balance worse over the 16 waves and the rolled batch loop costs address arithmetic; not kept)
                     if (p.mu_zero) mfma_units<NRT, TRI, true>(p, Ms, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, L.LDM, L.LDP);
                     else mfma_units<NRT, TRI, false>(p, Ms, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, L.LDM, L.LDP);
                 }

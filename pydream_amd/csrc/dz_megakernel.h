@@ -78,6 +78,46 @@ __host__ __device__ inline MegaLayout mega_layout(int d, int k, int nrt, int ncr
 // Wave w of tw takes the units w, 2tw-1-w, 2tw+w, ... (snake), which evens out the k-steps per wave and per SIMD.
 DZ_DEV int mega_unit(int j, int wv, int tw) { return (j & 1) ? tw * j + (tw - 1 - wv) : tw * j + wv; }
 
+// One accumulator's chain over the whole batches of a unit that starts at batch T0 (the packed triangle: row tile t joins at k = 16 t),
+// as a software pipeline over half batches (two k-steps): the operands of half batch h + 1 are requested before the MFMAs of h are
+// issued, so that a wave that is alone on its SIMD does not wait an LDS round trip in front of every pair of MFMAs.  The start is a
+// template parameter (one straight-line body per starting batch: the LDS offsets stay immediates and the waitcnt counts exact); KB is
+// NRT - 1 or NRT (d mod 16 in 1..12 or not), so only the last batch is conditional.  Same MFMAs in the same ascending k order.
+template <int NRT, bool TRI, bool MZ, int T0>
+DZ_DEV void unit_batches(const double* __restrict__ ap, const double* __restrict__ bp, const double* __restrict__ mp, int kq, bool lastb, int LDM,
+                         dz_double4& acc)
+{
+    constexpr int H0 = 2 * T0, HN = 2 * NRT;
+    double A[2][2], B[2][2];
+    auto ldh = [&](int h, double (&a2)[2], double (&b2)[2]) {
+        const int b16 = h >> 1, q0 = 2 * (h & 1);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = 16 * b16 + 4 * (q0 + q);
+            b2[q] = MZ ? bp[c] : bp[c] - mp[c];
+            a2[q] = TRI ? ap[128 * b16 * (b16 + 1) + (4 * (q0 + q) + kq) * 16 * (b16 + 1)] : ap[(size_t)(c + kq) * LDM];
+        }
+    };
+#pragma unroll
+    for (int h = H0; h < HN; ++h) {                                // (constant trip count, no early exit: it has to unroll)
+        if (h < HN - 2 || lastb) {
+            if (h == H0) ldh(h, A[h & 1], B[h & 1]);
+            if (h + 1 < HN && (h + 1 < HN - 2 || lastb)) ldh(h + 1, A[(h + 1) & 1], B[(h + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[h & 1][0], B[h & 1][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[h & 1][1], B[h & 1][1], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+template <int NRT, bool TRI, bool MZ, int T>
+DZ_DEV void unit_dispatch(int t, const double* __restrict__ ap, const double* __restrict__ bp, const double* __restrict__ mp, int kq, bool lastb, int LDM,
+                          dz_double4& acc)
+{
+    if (t == T) unit_batches<NRT, TRI, MZ, T>(ap, bp, mp, kq, lastb, LDM, acc);
+    else if constexpr (T + 1 < NRT) unit_dispatch<NRT, TRI, MZ, T + 1>(t, ap, bp, mp, kq, lastb, LDM, acc);
+}
+
 // The (point tile, row tile) units of Y^T = M V^T for the ntl point tiles of 16 rows starting at row row0 of the LDS point area; writes
 // q[point][t], the row-tile sum of the MVN contract (dz_kernels.h tile_q_*).  Transposed tile: the matrix is the MFMA's A operand
 // (lane l: row 16 t + l%16, k = 4 ks + l/16), the points are its B operand (lane l: point l%16, same k), so a lane ends up with four
@@ -106,6 +146,10 @@ DZ_DEV void mfma_units(const Params& p, const double* __restrict__ Ms, const dou
         // No predicates: point rows and mu are zero padded to the k-steps and the matrix rows c >= d are zero, so out-of-range k
         // terms add exact zeros; output rows r >= d of the packed triangle are exact zeros, those of the dense square read whatever
         // sits there, stay inside their own accumulator rows and are dropped by tile_q.
+#ifdef DZ_X_PIPE
+        if (TRI) unit_dispatch<NRT, TRI, MZ, 0>(t, ap, bp, mp, kq, KB == NRT, LDM, acc);
+        else unit_batches<NRT, TRI, MZ, 0>(ap, bp, mp, kq, KB == NRT, LDM, acc);
+#else
 #pragma unroll
         for (int b16 = 0; b16 < NRT; ++b16) {
             if ((TRI && b16 < t) || b16 >= KB) continue;
@@ -119,6 +163,7 @@ DZ_DEV void mfma_units(const Params& p, const double* __restrict__ Ms, const dou
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
         }
+#endif
         for (int ks = 4 * KB; ks < KS; ++ks) {                     // the last, partial block: every row tile takes part (ks >= 4 (NRT - 1) >= 4 t)
             const int c = 4 * ks;
             const double av = TRI ? ap[128 * KB * (KB + 1) + (c - 16 * KB + kq) * 16 * (KB + 1)] : ap[(size_t)(c + kq) * LDM];

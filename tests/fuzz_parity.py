@@ -21,10 +21,10 @@ DIMS = [2, 3, 5, 10, 16, 17, 31, 32, 33, 48, 64, 65, 100, 100, 100, 112, 127, 12
 CHAINS = [3, 4, 5, 15, 16, 17, 48, 63, 64, 65, 100, 250, 256, 1000, 1024, 1100, 2048]
 
 
-def draw_config(rng, long=False):
-    d = int(rng.choice(DIMS))
-    N = int(rng.choice(CHAINS + ([3000, 4096, 4096] if long else [])))
-    if d > 128:
+def draw_config(rng, long=False, dims=None, chains=None):
+    d = int(rng.choice(dims or DIMS))
+    N = int(rng.choice(chains or (CHAINS + ([3000, 4096, 4096] if long else []))))
+    if d > 128 and not chains:                                # (oracle time; --chains lifts it: the k_generations_d2 regime is 128 < d <= 228)
         N = min(N, 256)
     if rng.random() < 0.04:
         d, N = 1000, int(rng.choice([16, 130]))
@@ -200,13 +200,17 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=0.0, help="stop after this long (0: run all --n)")
     ap.add_argument("--long", action="store_true", help="three times the generations, populations up to 4096 chains")
+    ap.add_argument("--dims", default="", help="comma-separated dimensions to draw from instead of the built-in list")
+    ap.add_argument("--chains", default="", help="comma-separated chain counts to draw from (also lifts the 256-chain cap of d > 128)")
     args = ap.parse_args()
+    dims = [int(x) for x in args.dims.split(",") if x] or None
+    chains = [int(x) for x in args.chains.split(",") if x] or None
     from pydream_amd import _capi as G
     from oracle import oracle as O
     rng = np.random.default_rng(args.seed)
     t0 = time.time(); bad = 0; done = 0
     for i in range(args.n):
-        c = draw_config(rng, args.long)
+        c = draw_config(rng, args.long, dims, chains)
         try:
             r = run_one(G, O, c)
         except Exception as ex:                                 # an engine refusing a configuration must refuse it on both sides: report

@@ -146,24 +146,9 @@ DZ_DEV void mfma_units(const Params& p, const double* __restrict__ Ms, const dou
         // No predicates: point rows and mu are zero padded to the k-steps and the matrix rows c >= d are zero, so out-of-range k
         // terms add exact zeros; output rows r >= d of the packed triangle are exact zeros, those of the dense square read whatever
         // sits there, stay inside their own accumulator rows and are dropped by tile_q.
-#ifdef DZ_X_PIPE
+        // the whole batches b16 = (TRI ? t : 0) .. KB - 1, operand reads one half batch ahead of the MFMAs (unit_batches)
         if (TRI) unit_dispatch<NRT, TRI, MZ, 0>(t, ap, bp, mp, kq, KB == NRT, LDM, acc);
         else unit_batches<NRT, TRI, MZ, 0>(ap, bp, mp, kq, KB == NRT, LDM, acc);
-#else
-#pragma unroll
-        for (int b16 = 0; b16 < NRT; ++b16) {
-            if ((TRI && b16 < t) || b16 >= KB) continue;
-            double a[4], b[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {                          // the batch's LDS reads are issued together, then its four MFMAs (ascending k)
-                const int c = 16 * b16 + 4 * q;
-                b[q] = MZ ? bp[c] : bp[c] - mp[c];
-                a[q] = TRI ? ap[128 * b16 * (b16 + 1) + (4 * q + kq) * 16 * (b16 + 1)] : ap[(size_t)(c + kq) * LDM];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
-        }
-#endif
         for (int ks = 4 * KB; ks < KS; ++ks) {                     // the last, partial block: every row tile takes part (ks >= 4 (NRT - 1) >= 4 t)
             const int c = 4 * ks;
             const double av = TRI ? ap[128 * KB * (KB + 1) + (c - 16 * KB + kq) * 16 * (KB + 1)] : ap[(size_t)(c + kq) * LDM];

@@ -234,6 +234,7 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
         for (int phase = 0; phase < 2; ++phase) {
             if (phase) {
                 if (sub == 0) {
+                    __builtin_amdgcn_s_setprio(2);                             // the deciding wave is the block's critical path: it outranks the try waves of its SIMD
                     const double u_sel = dec[8 * cl];
                     double lp = -__builtin_huge_val();
                     if (lane < k) {
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
                     const double b0 = 2 * lane < d ? row[2 * lane] : 0.0, b1 = 2 * lane + 1 < d ? row[2 * lane + 1] : 0.0;
                     if (2 * lane < d) region[2 * lane] = b0;                // (each lane reads its own two values before it writes them: no hazard inside the wave)
                     if (2 * lane + 1 < d) region[2 * lane + 1] = b1;
+                    __builtin_amdgcn_s_setprio(0);
                 } else if (!snk_s) { make_pretries(ds, 1, g, f); DZ_WSTAMP(11); }
                 DZ_W0STAMP(13); DZ_WSTAMP(13);
                 __syncthreads();                                           // the selected proposal sits in tile 0
@@ -304,6 +306,7 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
         // ---- the chain's first wave: Metropolis step (:305-347), trace (core.py:114-116), record_history (:919-938); the others: the
         //      pre-tries of the next generation's proposal set
         if (sub == 0) {
+            __builtin_amdgcn_s_setprio(2);
             const double* dc = dec + 8 * cl;
             const double u_acc = dc[1];
             const bool snk = dc[2] != 0.0;
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
                 }
             }
             if (lane == 0) { st[4 * cl] = npri; st[4 * cl + 1] = nlik; }
+            __builtin_amdgcn_s_setprio(0);
         } else if (!last) {
             have_pre = !fn.snk;                                                // (wave-uniform)
             if (have_pre) make_pretries(dsn, 0, g + 1u, fn);

@@ -84,7 +84,11 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
     // itself instead of one), and the roles are rotated so that every SIMD hosts one deciding wave and three try waves.
     // (measured, 1024 chains, steady state: all of a chain's waves on one SIMD 352.6 M proposals/s, spread 375.1; DE-only generations 12.35
     //  against 13.2 us, but one block in three holds a snooker chain and a launch ends with its unluckiest block)
+#ifdef DZ_ONE_SIMD_PER_CHAIN                                             // (experiment switch: a chain's four waves on ONE SIMD; measured slower, EXPERIMENTS.md)
+    const int cl = wv & 3, sub = wv >> 2;
+#else
     const int cl = wv >> 2, sub = ((wv & 3) + cl) & 3;
+#endif
     const int cg = pub.c0 + blockIdx.x * CH + cl;
     const bool active = cg < pub.c1;
     const int c = min(cg, pub.c1 - 1);

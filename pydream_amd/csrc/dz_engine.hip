@@ -184,6 +184,7 @@ struct dz_engine {
     bool mega_split = true;         // a remainder of chains beyond whole rounds of 16-chain blocks goes in a second launch of smaller blocks; DZ_MEGA_SPLIT=0: off
     bool mega_burnin = true;        // ... the generations of the crossover burn-in too, one per launch (positions published by the kernel); DZ_MEGA_BURNIN=0: multi-kernel path there
     int mega_max_gen = 1 << 20;     // DZ_MEGA_MAXGEN: generations per launch cap (measurement)
+    int mega_segs = 1 << 20;        // DZ_MEGA_SEGS: history appends per launch cap (1: a launch ends with its append, as without a lag)
     int mega_ch = 0;                // DZ_MEGA_CHAINS: force 16 / 8 / 4 chains per block (0: by chain count)
     bool tempering = false; double* d_Tc = nullptr; int32_t* d_tswap = nullptr;    // parallel tempering (dz_set_temperatures)
     // Dream.py:281-289: a proposal set whose tries are all impossible is drawn again (redo_possible / one_generation)
@@ -941,19 +942,31 @@ int mega_segment(const dz_engine* e, uint32_t g, int64_t remaining)
     // crossover burn-in: the positions are published and the probabilities adapted after every generation -- one generation per launch
     if (publishing(e, g)) return (e->mega_burnin && remaining > 0) ? 1 : 0;
     if (e->tempering) return remaining > 0 ? 1 : 0;       // parallel tempering: a temperature swap follows every generation (core.py:185-221)
-    int n = 0;
+    // A launch ends with a history append -- unless the rows it writes are not sampleable yet anyway (history_lag >= 1, every lagged append
+    // already made): on one GPU, where no exchange has to follow an append, the kernel then makes the append itself and runs on, up to
+    // lag + 1 appends per launch (the generations behind the j-th one sample j * N more rows: all of them written before the launch).
+    const int lag = e->c.history_lag;
+    const int segs = (e->world == 1 && lag >= 1 && e->napp >= lag) ? std::min(lag + 1, e->mega_segs) : 1;
+    int n = 0, apps = 0;
     for (uint32_t gg = g; n < remaining && n < e->mega_max_gen; ++gg) {
         if (publishing(e, gg)) break;
         ++n;
-        if (gg % (uint32_t)e->p.thin == 0) break;
+        if (gg % (uint32_t)e->p.thin == 0 && ++apps >= segs) break;
     }
     return n;
 }
 int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
 {
     dz::Params& p = e->p;
-    const bool append_last = ((g + (uint32_t)n - 1) % (uint32_t)p.thin) == 0;
-    if (append_last && e->M + p.N > e->c.history_capacity) return fail("history capacity exceeded");
+    // the history appends of generations g .. g + n - 1 (one at the end, or -- mega_segment -- up to history_lag + 1, the last one at the end)
+    int napps = 0, seg0 = 0;
+    for (int i = 0; i < n; ++i) if ((g + (uint32_t)i) % (uint32_t)p.thin == 0) { if (!napps) seg0 = i + 1; ++napps; }
+    const bool append_last = napps > 0;
+    {   // no generation of the launch may sample rows the launch itself writes: at most history_lag appends in front of any generation
+        const bool ends_with_one = ((g + (uint32_t)n - 1) % (uint32_t)p.thin) == 0;
+        if (napps > 1 && (e->world != 1 || e->napp < e->c.history_lag || napps > e->c.history_lag + (ends_with_one ? 1 : 0))) return fail("internal: too many history appends in one launch");
+    }
+    if (append_last && e->M + (int64_t)napps * p.N > e->c.history_capacity) return fail("history capacity exceeded");
     DZCK(join_all(e));
     DZCK(ensure_visible(e));
     const bool publish = publishing(e, g);            // (then n == 1: mega_segment)
@@ -977,7 +990,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
             if (!e->adapt_groups) DZCK(exchange_rows(e, XK_POS, p.cp_new, 0));      // (ranks that own whole groups exchange their groups' sums instead: adapt_generation)
             DZCK(adapt_generation(e, g, 0, p.N, fused, mega_follows));
         }
-        if (append_last) { DZCK(exchange_rows(e, XK_Z, p.Z, (size_t)e->M)); e->M += p.N; e->napp += 1; }
+        for (int a = 0; a < napps; ++a) { DZCK(exchange_rows(e, XK_Z, p.Z, (size_t)e->M)); e->M += p.N; e->napp += 1; }
         if (e->tempering) {          // (then n == 1) the temperature swap: after every chain's step and the updates above, as on the multi-kernel path
             NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_pt_swap<NCH>, dim3(1), dim3(64), 0, e->stream, p, g, slot0, publish ? 1 : 0));
             DZCK(launch_check("k_pt_swap"));
@@ -997,8 +1010,8 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         const dim3 gridm((p.nl + mw - 1) / mw), blockm(64 * mw);
         const size_t ldsm = sizeof(double) * (size_t)mw * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs + (fused ? lds_xo : 0);
         const bool pbm = p.hard || p.have_prior || p.depairs > 1;
-        if (pbm) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, dz::k_generations_mix<true>, gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, pub);
-        else DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, dz::k_generations_mix<false>, gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, pub);
+        if (pbm) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, dz::k_generations_mix<true>, gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, seg0, pub);
+        else DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, dz::k_generations_mix<false>, gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, seg0, pub);
         DZCK(launch_check("k_generations_mix"));
         launched();
         e->last_variant = pbm ? "k_generations_mix<full>" : "k_generations_mix";
@@ -1014,7 +1027,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         ml.grid = dim3((p.nl + chd - 1) / chd); ml.block = dim3(64 * chd);
         ml.lds = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, false, chd, false, false, true).total;
         ml.st = e->stream; ml.ka = nullptr; ml.kb = nullptr;
-        ml.pp = (const dz::Params*)e->d_params; ml.g = g; ml.n = n; ml.M = (uint32_t)visible_rows(e); ml.slot0 = slot0; ml.zappend = append_last ? e->M : (int64_t)-1; ml.publish = &pub;
+        ml.pp = (const dz::Params*)e->d_params; ml.g = g; ml.n = n; ml.M = (uint32_t)visible_rows(e); ml.slot0 = slot0; ml.zappend = append_last ? e->M : (int64_t)-1; ml.seg0 = seg0; ml.publish = &pub;
         if (e->prof) { ml.ka = prof_event(e); ml.kb = prof_event(e); e->ev[PR_GENERATIONS].emplace_back(ml.ka, ml.kb); }
         const char* name = nullptr;
         switch (nrt) {
@@ -1069,7 +1082,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         ml.tri = p.tri != 0; ml.xlds = pb ? true : xlds; ml.pb = pb; ml.k1 = k1; ml.ch = chp; ml.wpc = wpcp; ml.redo = mega_redo(e);
         ml.ahead = e->mega_w4 && chp == 4 && wpcp == 4 && !pb && xlds && !k1 && p.k >= 3 && p.k <= 6;
         ml.grid = dim3((c1 - c0 + chp - 1) / chp); ml.block = dim3(64 * chp * wpcp); ml.lds = ldsp; ml.st = e->stream; ml.ka = nullptr; ml.kb = nullptr;
-        ml.pp = (const dz::Params*)e->d_params; ml.g = g; ml.n = n; ml.M = (uint32_t)visible_rows(e); ml.slot0 = slot0; ml.zappend = append_last ? e->M : (int64_t)-1; ml.publish = &pp;
+        ml.pp = (const dz::Params*)e->d_params; ml.g = g; ml.n = n; ml.M = (uint32_t)visible_rows(e); ml.slot0 = slot0; ml.zappend = append_last ? e->M : (int64_t)-1; ml.seg0 = seg0; ml.publish = &pp;
         if (e->prof) { ml.ka = prof_event(e); ml.kb = prof_event(e); e->ev[PR_GENERATIONS].emplace_back(ml.ka, ml.kb); }
         const char* name = nullptr;
         switch (nrt) {
@@ -1132,6 +1145,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     if (const char* kv = getenv("DZ_STREAM")) e->stream_propose = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA")) e->mega = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_MAXGEN")) e->mega_max_gen = std::max(1, atoi(kv));
+    if (const char* kv = getenv("DZ_MEGA_SEGS")) e->mega_segs = std::max(1, atoi(kv));
     if (const char* kv = getenv("DZ_MEGA_BURNIN")) e->mega_burnin = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_REDO")) e->mega_redo_on = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_ADAPT_FUSED")) e->adapt_fused = atoi(kv) != 0;

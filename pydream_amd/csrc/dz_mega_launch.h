@@ -17,7 +17,7 @@ struct MegaLaunch {
     int ch, wpc;                // chains per block (16, 8, 4), waves per chain (1; 4 at 4 chains per block with multitry on)
     dim3 grid, block; size_t lds; hipStream_t st;
     hipEvent_t ka, kb;          // the launch's own start / stop events (profiling pass) or null
-    const Params* pp; uint32_t g; int n; uint32_t M; int64_t slot0; int64_t zappend; const Publish* publish;
+    const Params* pp; uint32_t g; int n; uint32_t M; int64_t slot0; int64_t zappend; int seg0 = 0; const Publish* publish;      // seg0: generations up to and including the launch's first history append
 };
 
 // returns a static string naming the instantiation that was launched ("k_generations<7,tri,xlds,16,1,lean>")

@@ -25,11 +25,11 @@ const char* DZ_CAT(mega_launch_nrt, DZ_TU_NRT)(const MegaLaunch& a)
     do {                                                                                                                                   \
         if (a.pb) {                                                                                                                        \
             hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 16, K1_, true>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, \
-                                  a.slot0, a.zappend, *a.publish);                                                                         \
+                                  a.slot0, a.zappend, a.seg0, *a.publish);                                                                         \
             return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,full" NAME_ ">";                                                 \
         }                                                                                                                                  \
         hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 16, K1_>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, \
-                              a.slot0, a.zappend, *a.publish);                                                                             \
+                              a.slot0, a.zappend, a.seg0, *a.publish);                                                                             \
         return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,lean" NAME_ ">";                                                     \
     } while (0)
     if (a.k1) DZ_D2(true, ",k1");          // (the host only sends the triangular factor at 16 chains per block here: mega_d2_chains)
@@ -43,12 +43,12 @@ static const char* launch_one(const MegaLaunch& a)
     if constexpr (PB && !K1) {
         if (a.redo) {
             hipExtLaunchKernelGGL((k_generations<DZ_TU_NRT, TRI, X, CH, WPC, PB, K1, true>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0,
-                                  a.pp, a.g, a.n, a.M, a.slot0, a.zappend, *a.publish);
+                                  a.pp, a.g, a.n, a.M, a.slot0, a.zappend, a.seg0, *a.publish);
             return TRI ? "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,full,redo>" : "k_generations<" DZ_STR(DZ_TU_NRT) ",dense,xlds,%d,%d,full,redo>";
         }
     }
     hipExtLaunchKernelGGL((k_generations<DZ_TU_NRT, TRI, X, CH, WPC, PB, K1>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0,
-                          a.pp, a.g, a.n, a.M, a.slot0, a.zappend, *a.publish);
+                          a.pp, a.g, a.n, a.M, a.slot0, a.zappend, a.seg0, *a.publish);
     // (NRT, matrix, chain states, chains per block, waves per chain, proposal code)
     return TRI ? (X ? (PB ? (K1 ? "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,full,k1>" : "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,full>")
                           : (K1 ? "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,lean,k1>" : "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,lean>"))
@@ -63,7 +63,7 @@ static const char* launch_ch(const MegaLaunch& a)
 {
     if constexpr (!PB && X) {
         if (a.ahead && a.ch == 4 && !a.k1) {      // small populations: four waves per chain, the tries' base-independent halves made ahead (dz_megakernel_w4.h)
-            hipExtLaunchKernelGGL((k_generations_w4<DZ_TU_NRT, TRI>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, a.slot0, a.zappend, *a.publish);
+            hipExtLaunchKernelGGL((k_generations_w4<DZ_TU_NRT, TRI>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, a.slot0, a.zappend, a.seg0, *a.publish);
             return TRI ? "k_generations_w4<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,lean,ahead>" : "k_generations_w4<" DZ_STR(DZ_TU_NRT) ",dense,xlds,%d,%d,lean,ahead>";
         }
     }
@@ -100,10 +100,10 @@ const char* DZ_CAT(mega_launch_d2_nrt, DZ_TU_NRT)(const MegaLaunch& a)
 #define DZ_D2(K1_, NAME_)                                                                                                                 \
     do {                                                                                                                                   \
         if (a.pb) {                                                                                                                        \
-            hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 16, K1_, true>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, a.slot0, a.zappend, *a.publish); \
+            hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 16, K1_, true>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, a.slot0, a.zappend, a.seg0, *a.publish); \
             return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,full" NAME_ ">";                                                 \
         }                                                                                                                                  \
-        hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 16, K1_>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, a.slot0, a.zappend, *a.publish); \
+        hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 16, K1_>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, a.slot0, a.zappend, a.seg0, *a.publish); \
         return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,lean" NAME_ ">";                                                     \
     } while (0)
     DZ_D2(false, "");          // (multitry on only: the multitry-off kernels' 16-chain layout always fits)

@@ -334,8 +334,9 @@ DZ_DEV void propose_de_pf(const Params& p, int phase, uint32_t g, uint32_t M, in
 // propose_point with its prior evaluation; the flat, unbounded case keeps the lean code (2.4 % faster at the headline size).
 // K1: multitry off (the reference's default, Dream.py:271-275 and :326-334) -- one proposal per generation, no reference set, the
 // snooker move's current-point term; a template flag so that the multi-try kernels carry none of it (it cost them a register spill).
-// M: archive rows the generations of this launch sample from; zappend: first row of the append its last generation makes (the rows go
-// to zappend + global chain), or -1 -- with dz_config.history_lag the two differ (rows written earlier are not sampleable yet).
+// M0: archive rows the first generation of this launch samples from; zappend: first row of the first history append made inside the launch
+// (the rows go to zappend + global chain), by its generation index seg0 - 1, or -1: none -- with dz_config.history_lag the two differ (rows
+// written earlier are not sampleable yet), and a launch may hold up to lag + 1 appends, thin generations apart (see the loop).
 // publish: during the crossover burn-in (one generation per launch) the new states also go to the published positions
 // (set_current_position_arr, Dream.py:364-366, :447-449: [N][ld], row = global chain); null otherwise.
 // REDO (with PB, multi-try): a proposal set whose tries are ALL impossible is generated again, with the same decisions, from the key of the
@@ -343,7 +344,7 @@ DZ_DEV void propose_de_pf(const Params& p, int phase, uint32_t g, uint32_t M, in
 // the chains that need it propose again, every wave takes part in the barriers and the likelihood units (the other chains' points have not
 // changed: their sums come out the same), and the block leaves the loop when none of its chains needs another round (DZ_MAX_REDRAWS caps it).
 template <int NRT, bool TRI, bool XLDS, int CH, int WPC, bool PB, bool K1 = false, bool REDO = false>
-__global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int64_t zappend, Publish pub)
+__global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0, int64_t zappend, int seg0, Publish pub)
 {
     double* const publish = pub.to;
     const Params& p = *pp;       // read through the scalar cache on demand: keeps the ~70 fields out of the SGPR file
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     //  and 320 -> 301 M/s at 1024 chains)
     // (not in the full-code instantiations: measured there at -2.5 % -- the pass's registers -- with three row buffers, +-0 with two)
     constexpr bool XF = !PB && !K1 && WPC == 1;
-    auto generation_draws = [&](uint32_t g_) {
+    auto generation_draws = [&](uint32_t g_, uint32_t M) {
         DrawSrc q; q.have = true; q.mine = make_uint4(0, 0, 0, 0);
         if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g_); q.mine = make_uint4(w.x, w.y, w.z, w.w); }
         if (XF && !multipair) {
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     };
     RowPair RA, RB, RC;
     RA.a = double2{0.0, 0.0}; RA.b = RA.a; RB = RA; RC = RA;
-    auto prefetch_first = [&](const DrawSrc& q, int phase_, uint32_t g_) {          // rows of this wave's first two tries of (g_, phase_)
+    auto prefetch_first = [&](const DrawSrc& q, int phase_, uint32_t g_, uint32_t M) {          // rows of this wave's first two tries of (g_, phase_)
         const int n_ = k - phase_;
         const int a0 = WPC == 1 ? 0 : (sub * n_) / WPC, a1 = WPC == 1 ? n_ : ((sub + 1) * n_) / WPC;
         if (a0 < a1) request_pair<XF>(p, q, pt_slot(p, phase_, a0, 1), gc, g_, M, lane, RA, p.Z, 8u * (uint32_t)p.ld);
@@ -481,12 +482,20 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     // the barriers -- and two row buffers rotate instead of three (propose_de_pf).  Measured together: uniform priors + hard boundaries
     // 508 -> 612 M proposals/s, normal priors 522 -> 572 (spilled registers are reloaded on the generation's critical path).
     constexpr bool PF_AHEAD = !PB;
-    DrawSrc dsn = generation_draws(g0);
-    if (PF_AHEAD && !multipair && !draws_say_snooker(dsn, g0)) prefetch_first(dsn, 0, g0);
+    DrawSrc dsn = generation_draws(g0, M0);
+    if (PF_AHEAD && !multipair && !draws_say_snooker(dsn, g0)) prefetch_first(dsn, 0, g0, M0);
+    // History appends inside the launch (history_lag >= 1 on one GPU: the rows an append writes are not sampled before `lag` more appends
+    // have been made, so a launch may run on past it): generation index next_app makes the next one, into rows zrow + global chain; the
+    // generations behind it sample p.N more rows (M: this generation's count, Mn: the next one's).
+    uint32_t M = M0;
+    int next_app = zappend >= 0 ? seg0 - 1 : -1;
+    int64_t zrow = zappend;
 
     for (int gi = 0; gi < ngen; ++gi) {
         const uint32_t g = g0 + (uint32_t)gi;
         const bool last = gi == ngen - 1;
+        const bool app = gi == next_app;
+        const uint32_t Mn = app ? M + (uint32_t)p.N : M;
         DZ_MSTAMP(0);
         const DrawSrc ds = dsn;
         constexpr int nph = K1 ? 1 : 2;                                              // multitry off: no reference set
@@ -575,13 +584,13 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
             };
             for (;;) {
                 if (mine) {
-                    if (((REDO && round > 0) || !PF_AHEAD) && !snk_s && !multipair) prefetch_first(dcur, phase, g);      // (round 0's first rows were requested a phase ahead)
+                    if (((REDO && round > 0) || !PF_AHEAD) && !snk_s && !multipair) prefetch_first(dcur, phase, g, M);      // (round 0's first rows were requested a phase ahead)
                     propose_range(i0, i1, RA, RB, RC);
-                    if (PF_AHEAD && phase == 0 && round == 0 && !snk_s && !multipair) prefetch_first(ds, 1, g);  // the reference set's first rows, ahead of the likelihood pass
+                    if (PF_AHEAD && phase == 0 && round == 0 && !snk_s && !multipair) prefetch_first(ds, 1, g, M);  // the reference set's first rows, ahead of the likelihood pass
                 }
                 if (round == 0 && phase == nph - 1 && !last) {                       // the next generation's draws and first rows
-                    dsn = generation_draws(g + 1u);
-                    if (PF_AHEAD && !multipair && !draws_say_snooker(dsn, g + 1u)) prefetch_first(dsn, 0, g + 1u);
+                    dsn = generation_draws(g + 1u, Mn);
+                    if (PF_AHEAD && !multipair && !draws_say_snooker(dsn, g + 1u)) prefetch_first(dsn, 0, g + 1u, Mn);
                 }
                 DZ_MSTAMP(1 + 4 * phase);
                 __syncthreads();                                                     // points visible
@@ -619,7 +628,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                     if (XF && !multipair) finish_draws(p, dcur, snk_s, M, lane);
                 }
             }
-            if (PF_AHEAD && REDO && phase == 0 && redrew && !snk_s && !multipair) prefetch_first(ds, 1, g);      // (the redraw rounds used the row buffers)
+            if (PF_AHEAD && REDO && phase == 0 && redrew && !snk_s && !multipair) prefetch_first(ds, 1, g, M);      // (the redraw rounds used the row buffers)
             DZ_MSTAMP(4 + 4 * phase);
         }
         // ---- Metropolis step (:305-347), trace (core.py:114-116), record_history (:919-938)
@@ -683,7 +692,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 if (jj < ld) {
                     if (XLDS ? last : accept) gstore2(p.X + (size_t)c * ld + jj, xn);
                     if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn);
-                    if (last && zappend >= 0) gstore2(p.Z + ((size_t)zappend + gc) * ld + jj, xn);      // record_history :933-936
+                    if (app) gstore2(p.Z + ((size_t)zrow + gc) * ld + jj, xn);                         // record_history :933-936
                     if (publish) gstore2(publish + (size_t)gc * ld + jj, xn);                          // set_current_position_arr :447-449
                 }
                 if (lane == 0) {
@@ -701,6 +710,8 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
         // one wave per chain: no barrier here -- the next generation's first phase only touches each wave's own chain's rows
         // and scalars, and the shared q buffer is not written again before the next barrier
         if (WPC > 1) __syncthreads();                                                // the chain's other waves read the new state
+        if (app) { next_app += p.thin; zrow += p.N; }
+        M = Mn;
     }
     // Crossover burn-in (one generation per launch), a block of 16 chains = one unit of the adaptation's column sums (contract v3): the
     // chains' new states sit in LDS, so do the ones they started the launch with (off_Xo); every wave makes its chain's
@@ -731,7 +742,7 @@ __host__ __device__ inline int mega_mix_wave_doubles(int d, int k, int J) { cons
 // PB (round 4): per-dimension priors, hard boundaries, several DE pairs -- the full proposal code and the prior evaluation (constants from
 // global memory: this kernel has no block-wide staging); the flat, unbounded, one-pair case keeps the lean instantiation.
 template <bool PB>
-__global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int64_t zappend, Publish pub)
+__global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0, int64_t zappend, int seg0, Publish pub)
 {
     double* const publish = pub.to;
     const Params& p = *pp;
@@ -777,9 +788,13 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
         acc = wave_bfly(acc);
         if (lane == 0) rP[k - 1] = acc;
     }
+    uint32_t M = M0;                                                        // (appends inside the launch: k_generations)
+    int next_app = zappend >= 0 ? seg0 - 1 : -1;
+    int64_t zrow = zappend;
     for (int gi = 0; gi < ngen; ++gi) {
         const uint32_t g = g0 + (uint32_t)gi;
         const bool last = gi == ngen - 1;
+        const bool app = gi == next_app;
         int sel = 0; bool fin = true;
         DrawSrc ds; ds.have = true; ds.mine = make_uint4(0, 0, 0, 0);      // the generation's wave-uniform draws, both phases read them
         if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g); ds.mine = make_uint4(w.x, w.y, w.z, w.w); }
@@ -889,7 +904,7 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
                 if (jj < ld) {
                     if (last) *reinterpret_cast<double2*>(p.X + (size_t)c * ld + jj) = xn;
                     if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn);
-                    if (last && zappend >= 0) gstore2(p.Z + ((size_t)zappend + gc) * ld + jj, xn);      // record_history :933-936
+                    if (app) gstore2(p.Z + ((size_t)zrow + gc) * ld + jj, xn);                         // record_history :933-936
                     if (publish) gstore2(publish + (size_t)gc * ld + jj, xn);                          // set_current_position_arr :447-449
                 }
                 if (lane == 0) {
@@ -903,6 +918,7 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
             }
             lpri = npri; llik = nlik;
         }
+        if (app) { next_app += p.thin; zrow += p.N; M += (uint32_t)p.N; }
     }
     if (pub.PR) {   // crossover burn-in, blocks of 16 chains (one adaptation unit), k >= 3: the new state into the chain's (dead) row 1, its bins into that row's pad
         int bc, bg;

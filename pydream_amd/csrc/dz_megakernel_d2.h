@@ -24,7 +24,7 @@ namespace dz {
 // PB: per-dimension priors (SampledParam norm / uniform, parameters.py:37-47), hard boundaries (Dream.py:733-791), several DE pairs
 // (set_DEpair :571-583) -- the multi-kernel path's full proposal code and prior evaluation, constants from global memory.
 template <int NRT, bool TRI, int CH, bool K1 = false, bool PB = false>
-__global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int64_t zappend, Publish pub)
+__global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0, int64_t zappend, int seg0, Publish pub)
 {
     constexpr int NCH = NRT > 8 ? 2 : 1, NT = 64 * CH;          // (NRT = 8, ld = 128: one chunk -- the kernel also serves 113..128 dimensions, where the
                                                                 //  matrix in LDS leaves room for the point tiles of 8 chains only)
@@ -85,10 +85,14 @@ __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __rest
         return Q;
     };
     DrawSrc dsn = generation_draws(g0);
+    uint32_t M = M0;                                                        // (appends inside the launch: k_generations)
+    int next_app = zappend >= 0 ? seg0 - 1 : -1;
+    int64_t zrow = zappend;
 
     for (int gi = 0; gi < ngen; ++gi) {
         const uint32_t g = g0 + (uint32_t)gi;
         const bool last = gi == ngen - 1;
+        const bool app = gi == next_app;
         const DrawSrc ds = dsn;
         for (int phase = 0; phase < nph; ++phase) {
             // ---- phase 0: k proposals around the chain's state (generate_proposal_points :258-264) into the chain's rows of tiles 0..k-1;
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __rest
                     if (jj < ld) {
                         if (accept) gstore2(p.X + (size_t)c * ld + jj, xn[it]);
                         if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn[it]);
-                        if (last && zappend >= 0) gstore2(p.Z + ((size_t)zappend + gc) * ld + jj, xn[it]);      // record_history :933-936
+                        if (app) gstore2(p.Z + ((size_t)zrow + gc) * ld + jj, xn[it]);                         // record_history :933-936
                         if (publish) gstore2(publish + (size_t)gc * ld + jj, xn[it]);                          // set_current_position_arr :447-449
                     }
                 }
@@ -228,6 +232,7 @@ __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __rest
         }
         // (one wave per chain: no barrier here -- the next generation's first phase only touches each wave's own chain's rows and scalars;
         //  the state row in HBM was written by this wave and is read by this wave)
+        if (app) { next_app += p.thin; zrow += p.N; M += (uint32_t)p.N; }
     }
 }
 

@@ -59,7 +59,7 @@ DZ_DEV void de_finish(const PreTry& o, double zeta, double x0, double x1, double
 }
 
 template <int NRT, bool TRI>
-__global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M, int64_t trace_slot0, int64_t zappend, Publish pub)
+__global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0, int64_t zappend, int seg0, Publish pub)
 {
     constexpr int CH = 4, WPC = 4, NT = 64 * CH * WPC, NCH = 1;
     double* const publish = pub.to;
@@ -122,6 +122,12 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
         for (int j = lane; j < L.LDP; j += 64) Xs[cl * L.LDP + j] = j < d ? p.X[(size_t)c * ld + j] : 0.0;
     __syncthreads();
 
+    // History appends inside the launch (k_generations): generation index next_app makes the next one into rows zrow + global chain; Mc is the
+    // row count generation gcur samples from, Mn the next generation's (rows and pre-tries are requested a generation ahead).
+    uint32_t gcur = g0, Mc = M0, Mn = M0;
+    int next_app = zappend >= 0 ? seg0 - 1 : -1;
+    int64_t zrow = zappend;
+    auto Mof = [&](uint32_t g_) { return g_ == gcur ? Mc : Mn; };
     auto generation_draws = [&](uint32_t g_) {          // lane s holds slot s of the chain's wave-uniform draws of generation g_
         DrawSrc q; q.have = true; q.mine = make_uint4(0, 0, 0, 0);
         if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g_); q.mine = make_uint4(w.x, w.y, w.z, w.w); }
@@ -146,8 +152,8 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
     // likelihood pass in between
     auto request_rows = [&](const DrawSrc& q, int phase_, uint32_t g_) {
         int a, b; de_range(k - phase_, a, b);
-        if (a < b) request_pair<false>(p, q, pt_slot(p, phase_, a, 1), gc, g_, M, lane, RA, p.Z, ldb);
-        if (a + 1 < b) request_pair<false>(p, q, pt_slot(p, phase_, a + 1, 1), gc, g_, M, lane, RB, p.Z, ldb);
+        if (a < b) request_pair<false>(p, q, pt_slot(p, phase_, a, 1), gc, g_, Mof(g_), lane, RA, p.Z, ldb);
+        if (a + 1 < b) request_pair<false>(p, q, pt_slot(p, phase_, a + 1, 1), gc, g_, Mof(g_), lane, RB, p.Z, ldb);
     };
     // ... and of a snooker set: the three rows (z and the projected pair, :808-810) of this wave's FIRST try -- the row numbers do not depend on
     // the base point either -- into RA.a, RA.b, RB.a.  Not prefetched they are a full archive-gather latency in front of every snooker set,
@@ -156,6 +162,7 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
         int a, b; snk_range(k - phase_, a, b);
         if (a >= b) return;
         const u32x4 w = uniform_draw(p, q, pt_slot(p, phase_, a, 1), gc, g_);
+        const uint32_t M = Mof(g_);
         const uint32_t iz = mulhi_idx(w.x, M), i1x = mulhi_idx(w.y, M), i2x = mulhi_idx(w.z, M);
         const uint32_t jb = (uint32_t)min(16 * lane, (int)ldb - 16);
         const char* Zb = reinterpret_cast<const char*>(p.Z);
@@ -183,12 +190,12 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
         if (a + 1 < b) {        // two tries (at most: k <= 6 over four waves), straight-line: two independent dependency chains for the scheduler to interleave
             RowTerms<NCH> rt1;
             rt1.a[0][0] = RB.b.x; rt1.a[0][1] = RB.b.y; rt1.b[0][0] = RC.a.x - RC.b.x; rt1.b[0][1] = RC.a.y - RC.b.y;
-            const double sq0 = propose_point<NCH, false, 1>(p, phase_, g_, M, c, a, n_, lane, base, grow_, rt0, out + (size_t)a * tstride, nullptr, true, f_.cr_idx, 1, f_.glev, q);
-            const double sq1 = propose_point<NCH, false, 1>(p, phase_, g_, M, c, a + 1, n_, lane, base, grow_, rt1, out + (size_t)(a + 1) * tstride, nullptr, true, f_.cr_idx, 1, f_.glev, q);
+            const double sq0 = propose_point<NCH, false, 1>(p, phase_, g_, Mof(g_), c, a, n_, lane, base, grow_, rt0, out + (size_t)a * tstride, nullptr, true, f_.cr_idx, 1, f_.glev, q);
+            const double sq1 = propose_point<NCH, false, 1>(p, phase_, g_, Mof(g_), c, a + 1, n_, lane, base, grow_, rt1, out + (size_t)(a + 1) * tstride, nullptr, true, f_.cr_idx, 1, f_.glev, q);
             if (lane == 0) { prp[a] = 0.0; prp[a + 1] = 0.0; }
             sqv = lane == 0 ? sq0 : (lane == 1 ? sq1 : sqv);
         } else {
-            const double sq0 = propose_point<NCH, false, 1>(p, phase_, g_, M, c, a, n_, lane, base, grow_, rt0, out + (size_t)a * tstride, nullptr, true, f_.cr_idx, 1, f_.glev, q);
+            const double sq0 = propose_point<NCH, false, 1>(p, phase_, g_, Mof(g_), c, a, n_, lane, base, grow_, rt0, out + (size_t)a * tstride, nullptr, true, f_.cr_idx, 1, f_.glev, q);
             if (lane == 0) prp[a] = 0.0;
             sqv = lane == 0 ? sq0 : sqv;
         }
@@ -221,6 +228,8 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
     for (int gi = 0; gi < ngen; ++gi) {
         const uint32_t g = g0 + (uint32_t)gi;
         const bool last = gi == ngen - 1;
+        const bool app = gi == next_app;
+        gcur = g; Mn = app ? Mc + (uint32_t)p.N : Mc;
         DZ_W0STAMP(0); DZ_WSTAMP(0);
         const DrawSrc ds = dsn;
         const StepFlags f = fn;
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
                 if (jj < ld) {
                     if (last) gstore2(p.X + (size_t)c * ld + jj, xn);
                     if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn);
-                    if (last && zappend >= 0) gstore2(p.Z + ((size_t)zappend + gc) * ld + jj, xn);      // record_history :933-936
+                    if (app) gstore2(p.Z + ((size_t)zrow + gc) * ld + jj, xn);                         // record_history :933-936
                     if (publish) gstore2(publish + (size_t)gc * ld + jj, xn);                          // set_current_position_arr :447-449
                 }
                 if (lane == 0) {
@@ -376,6 +385,8 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
         }
         DZ_W0STAMP(9); DZ_WSTAMP(9);
         __syncthreads();                                                   // the chain's other waves read the new state
+        if (app) { next_app += p.thin; zrow += p.N; }
+        Mc = Mn;
     }
 }
 

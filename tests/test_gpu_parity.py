@@ -276,6 +276,45 @@ def test_the_instantiations_the_bench_times_equal_the_oracle(G, O, N, tri, targe
     assert 0.05 < out[0][0]["moved"].mean() < 0.9
 
 
+@pytest.mark.parametrize("N,d,k,target,lag,thin", [(4096, 100, 5, "mvn", 1, 10), (1024, 100, 5, "mvn", 1, 10), (1024, 100, 5, "mvn", 3, 2), (2048, 48, 3, "mvn", 2, 5),
+                                                   (1040, 200, 5, "mvn", 1, 10), (1040, 160, 1, "mvn", 2, 3), (4096, 100, 5, "mix3", 1, 10), (512, 10, 1, "mix3", 3, 1)])
+def test_launches_that_hold_several_history_appends(G, O, N, d, k, target, lag, thin, monkeypatch):
+    """With history_lag L >= 1 on one GPU the rows an append writes are not sampled before L more appends, so a launch of the persistent
+    kernels runs on past its appends (up to L + 1 of them, dz_engine.hip mega_segment): every generation must still sample exactly the rows
+    the lag schedule shows it (record_history Dream.py:919-938, sample_from_history :646-668).  All four kernels (k_generations,
+    k_generations_w4, k_generations_d2, k_generations_mix), stepped in uneven pieces so that launches start and end inside a thinning cycle,
+    against the same engine with one append per launch (DZ_MEGA_SEGS=1) and against the oracle, bit for bit -- and with fewer launches."""
+    import argparse
+    import bench
+    pieces = (13, 2 * thin * (lag + 1) + 1, 3 * thin + 2, 7)
+    n = sum(pieces)
+    args = argparse.Namespace(dim=d, multitry=k, seed=424242, thin=thin, snooker=0.1, target=target, mvn_kind="tri", steps=n, warmup=0, history_lag=lag)
+
+    def run(Cls, segs):
+        if segs is None:
+            monkeypatch.delenv("DZ_MEGA_SEGS", raising=False)
+        else:
+            monkeypatch.setenv("DZ_MEGA_SEGS", str(segs))
+        e = bench.setup_engine(Cls, args, N, N, 0, n, trace_capacity=n, **({"schedule": 2} if Cls is O.Engine else {}))
+        assert int(e.cfg.history_lag) == lag
+        launches = None
+        if Cls is G.Engine:
+            e.profile_enable(True); e.profile_reset()
+        for m in pieces:
+            e.step(m)
+        if Cls is G.Engine:
+            launches = e.profile_get("generations")[1]
+            e.profile_enable(False)
+            assert e.last_kernel_variant().startswith("k_generations")
+        return e.get_trace(0, n), e.get_history(), launches
+
+    a, b, o = run(G.Engine, None), run(G.Engine, 1), run(O.Engine, None)
+    assert 0 < a[2] < b[2], (a[2], b[2])                                    # the same generations in fewer launches
+    for other in (b, o):
+        assert_traces_identical(a[0], other[0])
+        np.testing.assert_array_equal(a[1], other[1])
+
+
 @pytest.mark.parametrize("N,d,k,depairs,ngamma,prior", [(1000, 100, 5, 3, 2, None), (96, 10, 3, 2, 1, "uniform"), (256, 100, 1, 2, 3, None),
                                                         (64, 128, 4, 3, 1, None), (80, 200, 5, 3, 2, None), (64, 160, 1, 2, 3, "uniform")])       # (the last two: k_generations_d2's full-code instantiations)
 def test_persistent_kernel_with_several_pairs_and_gamma_levels(G, O, N, d, k, depairs, ngamma, prior, monkeypatch):

@@ -235,8 +235,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-matrix (reference formula) pass")
     ap.add_argument("--no-events", action="store_true", help="do not time individual kernels with HIP events")
-    ap.add_argument("--event-generations", type=int, default=200,
-                    help="generations of the event-timed pass (at least --steps): 200 generations are 20 launches of the persistent kernel")
+    ap.add_argument("--event-generations", type=int, default=400,
+                    help="generations of the event-timed pass (at least --steps): 400 generations are 20 launches of the persistent kernel (20 generations each at history_lag 1)")
     ap.add_argument("--history-lag", type=int, default=None,
                     help="dz_config.history_lag: appended rows become sampleable this many appends late.  Default 1 at every N (on several "
                          "GPUs the row exchange then hides behind a thin-cycle; one GPU runs the same schedule so that the scaling curve is "

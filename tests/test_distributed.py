@@ -525,7 +525,7 @@ def test_bench_line_has_the_contracted_fields(tmp_path):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
     assert r["launch_us"] * (20 / r["generations_per_launch"]) <= d["timing"]["block_ms_median"] * 1e3 * (1 + 1e-9)      # a kernel cannot outlast the block around it
-    assert r["launches_timed"] >= 10 and r["generations_per_launch"] == 20 and r["kernel_variant"] == d["kernel_variant"] and d["kernel_variant"] == "k_generations_w4<7,tri,xlds,4,4,lean,ahead>"
+    assert r["launches_timed"] >= 20 and r["generations_per_launch"] == 20 and r["kernel_variant"] == d["kernel_variant"] and d["kernel_variant"] == "k_generations_w4<7,tri,xlds,4,4,lean,ahead>"
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "proposals/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     assert "workload" in d["config"] and "model" not in d["config"]

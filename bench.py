@@ -174,10 +174,19 @@ def measured_pmc(args, n_local):
     out = {"source": "profiles/%s_pmc_summary.json" % PROFILE_TAG}
     # units (checked against the instruction counts): SQ_WAVE_CYCLES and SQ_ACTIVE_INST_VALU count quad-cycles summed over waves,
     # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 SIMDs
+    # generations per dispatch of the profiled run (its average: a launch holds thin generations, or 2 thin at history_lag 1, and the
+    # convergence chunks end ragged): from the traffic file made of the same run (tools/traffic_from_pmc.py), else one thin-cycle
+    gpd = float(args.thin)
+    tpath = os.path.join(ROOT, "profiles", PROFILE_TAG + "_traffic.json")
+    if os.path.exists(tpath):
+        t = json.load(open(tpath))
+        if t.get("dispatches") and t.get("generations_in_run"):
+            gpd = t["generations_in_run"] / float(t["dispatches"])
     if v.get("SQ_WAVES") and v.get("SQ_INSTS_VALU") is not None:
-        out["valu_insts_per_wave_generation"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"] / args.thin
+        out["valu_insts_per_wave_generation"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"] / gpd
         if v.get("SQ_INSTS_MFMA") is not None:
-            out["mfma_insts_per_wave_generation"] = v["SQ_INSTS_MFMA"] / v["SQ_WAVES"] / args.thin
+            out["mfma_insts_per_wave_generation"] = v["SQ_INSTS_MFMA"] / v["SQ_WAVES"] / gpd
+        out["generations_per_profiled_dispatch"] = gpd
     if v.get("SQ_WAVE_CYCLES") and v.get("SQ_WAVES"):
         nsimd = 1024.0
         waves_per_simd = v["SQ_WAVES"] / nsimd

@@ -47,7 +47,9 @@ typedef struct dz_config {
                                * generations between two appends sample from the archive as it was L appends ago -- which lets the
                                * exchange of appended rows between GPUs run behind the next thin-cycle's generations instead of
                                * between two launches (the reference's own chains see each other's appends with
-                               * an arbitrary, scheduler-dependent delay, Dream.py:646-668 under core.py:80) */
+                               * an arbitrary, scheduler-dependent delay, Dream.py:646-668 under core.py:80), and on ONE GPU lets a
+                               * launch of the persistent kernels run on past its appends: (L + 1) history_thin generations per
+                               * launch instead of history_thin */
     int64_t history_capacity; /* rows the Z archive can hold (core.py:260-268)                 */
     int64_t trace_capacity;   /* generations the device trace buffer holds (0 = no trace)      */
     uint64_t seed;            /* key of the counter-based random contract                      */

@@ -946,7 +946,8 @@ int mega_segment(const dz_engine* e, uint32_t g, int64_t remaining)
     // already made): on one GPU, where no exchange has to follow an append, the kernel then makes the append itself and runs on, up to
     // lag + 1 appends per launch (the generations behind the j-th one sample j * N more rows: all of them written before the launch).
     const int lag = e->c.history_lag;
-    const int segs = (e->world == 1 && lag >= 1 && e->napp >= lag) ? std::min(lag + 1, e->mega_segs) : 1;
+    int segs = (e->world == 1 && lag >= 1 && e->napp >= lag) ? std::min(lag + 1, e->mega_segs) : 1;
+    segs = (int)std::max<int64_t>(1, std::min<int64_t>(segs, (e->c.history_capacity - e->M) / std::max(1, e->p.N)));      // (an archive sized to the last append: no launch asks for more rows than one append at a time would)
     int n = 0, apps = 0;
     for (uint32_t gg = g; n < remaining && n < e->mega_max_gen; ++gg) {
         if (publishing(e, gg)) break;

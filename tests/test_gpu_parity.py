@@ -315,6 +315,29 @@ def test_launches_that_hold_several_history_appends(G, O, N, d, k, target, lag, 
         np.testing.assert_array_equal(a[1], other[1])
 
 
+def test_an_archive_sized_to_the_last_append_is_enough_for_launches_with_several_appends(G, O):
+    """history_capacity = seed rows + exactly the appends the run makes (core.py:260-268 sizes the reference's archive the same way): a launch
+    that would make two appends must not ask for rows a one-append launch would not have needed -- the run goes through, equals the oracle,
+    and the append after the last one that fits fails loudly instead of writing past the archive."""
+    N, d, k, thin, lag, n = 256, 16, 3, 5, 1, 40                            # appends after generations 0, 5, .., 40 would be nine; the archive holds eight
+    Z0 = H.seed_history(2 * N, d, 5)
+    P = H.mvn_precision(d)
+    U = np.linalg.cholesky((P + P.T) / 2).T
+    out = []
+    for Cls in (G.Engine, O.Engine):
+        e = Cls(nchains=N, ndim=d, multitry=k, history_thin=thin, history_lag=lag, history_capacity=len(Z0) + N * (n // thin), trace_capacity=n + 1, seed=77)
+        e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), U, 1, 0.0)
+        e.step(n)
+        out.append((e.get_trace(0, n), e.get_history()))
+        if Cls is G.Engine:
+            assert e.last_kernel_variant().startswith("k_generations")
+            with pytest.raises(RuntimeError, match="history capacity exceeded"):
+                e.step(1); e.sync()
+    assert_traces_identical(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    assert len(out[0][1]) == len(Z0) + N * (n // thin)
+
+
 @pytest.mark.parametrize("N,d,k,depairs,ngamma,prior", [(1000, 100, 5, 3, 2, None), (96, 10, 3, 2, 1, "uniform"), (256, 100, 1, 2, 3, None),
                                                         (64, 128, 4, 3, 1, None), (80, 200, 5, 3, 2, None), (64, 160, 1, 2, 3, "uniform")])       # (the last two: k_generations_d2's full-code instantiations)
 def test_persistent_kernel_with_several_pairs_and_gamma_levels(G, O, N, d, k, depairs, ngamma, prior, monkeypatch):

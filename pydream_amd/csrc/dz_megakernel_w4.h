@@ -82,8 +82,9 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
     // chain inside the block; this wave's role among the chain's four (0: selection and Metropolis step; 1..3: tries).  Wave w runs on SIMD
     // w % 4: a chain's four waves sit on FOUR SIMDs (when the block waits for one chain's snooker set, that set has the CU's SIMDs to
     // itself instead of one), and the roles are rotated so that every SIMD hosts one deciding wave and three try waves.
-    // (measured, 1024 chains, steady state: all of a chain's waves on one SIMD 352.6 M proposals/s, spread 375.1; DE-only generations 12.35
-    //  against 13.2 us, but one block in three holds a snooker chain and a launch ends with its unluckiest block)
+    // (measured, 1024 chains, steady state: all of a chain's waves on one SIMD 352.6 M proposals/s, spread 375.1 -- one block in three holds a
+    //  snooker chain and a launch ends with its unluckiest block; with the deciding wave's issue priority, below, 347 against 382, and the
+    //  DE-only generations, 12.35 against 13.2 us before it, no longer differ: 12.65 / 12.60)
 #ifdef DZ_ONE_SIMD_PER_CHAIN                                             // (experiment switch: a chain's four waves on ONE SIMD; measured slower, EXPERIMENTS.md)
     const int cl = wv & 3, sub = wv >> 2;
 #else

@@ -485,11 +485,10 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     DrawSrc dsn = generation_draws(g0, M0);
     if (PF_AHEAD && !multipair && !draws_say_snooker(dsn, g0)) prefetch_first(dsn, 0, g0, M0);
     // History appends inside the launch (history_lag >= 1 on one GPU: the rows an append writes are not sampled before `lag` more appends
-    // have been made, so a launch may run on past it): generation index next_app makes the next one, into rows zrow + global chain; the
+    // have been made, so a launch may run on past it): generation index next_app makes the next one, into rows zappend + (M - M0) + global chain; the
     // generations behind it sample p.N more rows (M: this generation's count, Mn: the next one's).
     uint32_t M = M0;
     int next_app = zappend >= 0 ? seg0 - 1 : -1;
-    int64_t zrow = zappend;
 
     for (int gi = 0; gi < ngen; ++gi) {
         const uint32_t g = g0 + (uint32_t)gi;
@@ -692,7 +691,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 if (jj < ld) {
                     if (XLDS ? last : accept) gstore2(p.X + (size_t)c * ld + jj, xn);
                     if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn);
-                    if (app) gstore2(p.Z + ((size_t)zrow + gc) * ld + jj, xn);                         // record_history :933-936
+                    if (app) gstore2(p.Z + ((size_t)zappend + (M - M0) + gc) * ld + jj, xn);                         // record_history :933-936
                     if (publish) gstore2(publish + (size_t)gc * ld + jj, xn);                          // set_current_position_arr :447-449
                 }
                 if (lane == 0) {
@@ -710,7 +709,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
         // one wave per chain: no barrier here -- the next generation's first phase only touches each wave's own chain's rows
         // and scalars, and the shared q buffer is not written again before the next barrier
         if (WPC > 1) __syncthreads();                                                // the chain's other waves read the new state
-        if (app) { next_app += p.thin; zrow += p.N; }
+        if (app) next_app += p.thin;
         M = Mn;
     }
     // Crossover burn-in (one generation per launch), a block of 16 chains = one unit of the adaptation's column sums (contract v3): the
@@ -790,7 +789,6 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
     }
     uint32_t M = M0;                                                        // (appends inside the launch: k_generations)
     int next_app = zappend >= 0 ? seg0 - 1 : -1;
-    int64_t zrow = zappend;
     for (int gi = 0; gi < ngen; ++gi) {
         const uint32_t g = g0 + (uint32_t)gi;
         const bool last = gi == ngen - 1;
@@ -904,7 +902,7 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
                 if (jj < ld) {
                     if (last) *reinterpret_cast<double2*>(p.X + (size_t)c * ld + jj) = xn;
                     if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn);
-                    if (app) gstore2(p.Z + ((size_t)zrow + gc) * ld + jj, xn);                         // record_history :933-936
+                    if (app) gstore2(p.Z + ((size_t)zappend + (M - M0) + gc) * ld + jj, xn);                         // record_history :933-936
                     if (publish) gstore2(publish + (size_t)gc * ld + jj, xn);                          // set_current_position_arr :447-449
                 }
                 if (lane == 0) {
@@ -918,7 +916,7 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
             }
             lpri = npri; llik = nlik;
         }
-        if (app) { next_app += p.thin; zrow += p.N; M += (uint32_t)p.N; }
+        if (app) { next_app += p.thin; M += (uint32_t)p.N; }
     }
     if (pub.PR) {   // crossover burn-in, blocks of 16 chains (one adaptation unit), k >= 3: the new state into the chain's (dead) row 1, its bins into that row's pad
         int bc, bg;

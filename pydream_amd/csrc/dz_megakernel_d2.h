@@ -87,7 +87,6 @@ __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __rest
     DrawSrc dsn = generation_draws(g0);
     uint32_t M = M0;                                                        // (appends inside the launch: k_generations)
     int next_app = zappend >= 0 ? seg0 - 1 : -1;
-    int64_t zrow = zappend;
 
     for (int gi = 0; gi < ngen; ++gi) {
         const uint32_t g = g0 + (uint32_t)gi;
@@ -215,7 +214,7 @@ __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __rest
                     if (jj < ld) {
                         if (accept) gstore2(p.X + (size_t)c * ld + jj, xn[it]);
                         if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn[it]);
-                        if (app) gstore2(p.Z + ((size_t)zrow + gc) * ld + jj, xn[it]);                         // record_history :933-936
+                        if (app) gstore2(p.Z + ((size_t)zappend + (M - M0) + gc) * ld + jj, xn[it]);                         // record_history :933-936
                         if (publish) gstore2(publish + (size_t)gc * ld + jj, xn[it]);                          // set_current_position_arr :447-449
                     }
                 }
@@ -232,7 +231,7 @@ __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __rest
         }
         // (one wave per chain: no barrier here -- the next generation's first phase only touches each wave's own chain's rows and scalars;
         //  the state row in HBM was written by this wave and is read by this wave)
-        if (app) { next_app += p.thin; zrow += p.N; M += (uint32_t)p.N; }
+        if (app) { next_app += p.thin; M += (uint32_t)p.N; }
     }
 }
 

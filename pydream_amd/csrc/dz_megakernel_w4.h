@@ -123,11 +123,10 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
         for (int j = lane; j < L.LDP; j += 64) Xs[cl * L.LDP + j] = j < d ? p.X[(size_t)c * ld + j] : 0.0;
     __syncthreads();
 
-    // History appends inside the launch (k_generations): generation index next_app makes the next one into rows zrow + global chain; Mc is the
+    // History appends inside the launch (k_generations): generation index next_app makes the next one into rows zappend + (Mc - M0) + global chain; Mc is the
     // row count generation gcur samples from, Mn the next generation's (rows and pre-tries are requested a generation ahead).
     uint32_t gcur = g0, Mc = M0, Mn = M0;
     int next_app = zappend >= 0 ? seg0 - 1 : -1;
-    int64_t zrow = zappend;
     auto Mof = [&](uint32_t g_) { return g_ == gcur ? Mc : Mn; };
     auto generation_draws = [&](uint32_t g_) {          // lane s holds slot s of the chain's wave-uniform draws of generation g_
         DrawSrc q; q.have = true; q.mine = make_uint4(0, 0, 0, 0);
@@ -365,7 +364,7 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
                 if (jj < ld) {
                     if (last) gstore2(p.X + (size_t)c * ld + jj, xn);
                     if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn);
-                    if (app) gstore2(p.Z + ((size_t)zrow + gc) * ld + jj, xn);                         // record_history :933-936
+                    if (app) gstore2(p.Z + ((size_t)zappend + (Mc - M0) + gc) * ld + jj, xn);                         // record_history :933-936
                     if (publish) gstore2(publish + (size_t)gc * ld + jj, xn);                          // set_current_position_arr :447-449
                 }
                 if (lane == 0) {
@@ -386,7 +385,7 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
         }
         DZ_W0STAMP(9); DZ_WSTAMP(9);
         __syncthreads();                                                   // the chain's other waves read the new state
-        if (app) { next_app += p.thin; zrow += p.N; }
+        if (app) next_app += p.thin;
         Mc = Mn;
     }
 }

@@ -12,7 +12,7 @@ i = np.arange(1, d + 1.0)
 P = np.linalg.inv((.5 * np.eye(d) + .5) * np.sqrt(np.outer(i, i)))
 U = np.linalg.cholesky((P + P.T) / 2).T
 Z0 = np.random.default_rng(3).uniform(-5, 15, (max(1000, 2 * N), d))
-e = G.Engine(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * ((3 * gens + 4000) // 10 + 30), trace_capacity=0, seed=5, snooker=snooker)
+e = G.Engine(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * ((3 * gens + 4000) // 10 + 30), trace_capacity=0, seed=5, history_lag=int(os.environ.get('DZ_SCAN_LAG', '1')), snooker=snooker)
 e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), U, 1, 0.0)
 e.step(4000); e.sync()
 best = 0

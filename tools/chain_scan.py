@@ -11,7 +11,7 @@ U = np.linalg.cholesky((P + P.T) / 2).T
 for N in (256, 512, 1024, 2048, 3072, 4096, 5000, 8192, 16384, 32768):
     Z0 = np.random.default_rng(3).uniform(-5, 15, (max(1000, 2 * N), d))
     gens = 400
-    e = G.Engine(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (gens // 10 + 30), trace_capacity=0, seed=5)
+    e = G.Engine(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (gens // 10 + 30), trace_capacity=0, seed=5, history_lag=int(os.environ.get('DZ_SCAN_LAG', '1')))
     e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), U, 1, 0.0)
     e.step(100); e.sync()
     t0 = time.perf_counter(); e.step(gens); e.sync(); dt = time.perf_counter() - t0

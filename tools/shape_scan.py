@@ -16,7 +16,7 @@ for d in DIMS:
     Z0 = np.random.default_rng(3).uniform(-5, 15, (2 * N, d))
     for k in (KS or ((1, 3, 5, 8, 12, 16) if d <= 128 else (1, 5))):
         gens = 600 if d <= 256 else 200
-        e = G.Engine(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (gens // 10 + 40), trace_capacity=0, seed=5)
+        e = G.Engine(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (gens // 10 + 40), trace_capacity=0, seed=5, history_lag=int(os.environ.get('DZ_SCAN_LAG', '1')))
         e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), U, 1, 0.0)
         e.step(100); e.sync()
         reps = []

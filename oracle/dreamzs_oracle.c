@@ -322,6 +322,12 @@ struct orc_engine {
     double *tX, *tlogp; uint8_t *tmoved, *tsnk; int32_t *ttry, *tcr;
     /* parallel tempering (core.py:131-236): per-chain temperatures, one swap attempt per generation */
     double* Tc; int tempering; int32_t* tswap;     /* tswap [trace_capacity][3]: chain a, chain b, accepted */
+    /* adapt_lag (schedule S2): the totals of burn-in generations whose update has not been applied yet, oldest first:
+     * pend_tot [adapt_lag + 1][nq d], pend_cnt [adapt_lag + 1][ncr + ngamma], generations pend_g0 .. pend_g0 + npend - 1; x0ring
+     * [2 (adapt_lag + 1)][d]: global chain 0's published position after generation h at slot h mod 2 (adapt_lag + 1) (x0start: before
+     * generation 0) -- the shift of the column sums of generation h + 1 + adapt_lag */
+    double *pend_tot, *pend_cnt; int npend; int64_t pend_g0;
+    double *x0ring, *x0start;
     /* scratch */
     double *pts, *refs, *work;
 };
@@ -337,6 +343,7 @@ int orc_create(const orc_config* cfg, orc_engine** out)
     if (cfg->ncr < 1 || cfg->ngamma < 1) return fail("bad nCR/gamma_levels");
     if (cfg->schedule != 1 && cfg->schedule != 2) return fail("schedule must be 1 or 2");
     if (cfg->history_lag < 0 || (cfg->history_lag && cfg->schedule != 2)) return fail("history_lag needs schedule 2 and must be >= 0");
+    if (cfg->adapt_lag < 0 || cfg->adapt_lag > 4096 || (cfg->adapt_lag && cfg->schedule != 2)) return fail("adapt_lag needs schedule 2 and must be 0..4096");
     if (cfg->chain_offset < 0 || cfg->chain_offset + cfg->nchains_local > cfg->nchains) return fail("bad shard");
     orc_engine* e = zalloc(sizeof *e);
     e->c = *cfg; e->d = cfg->ndim; e->nl = cfg->nchains_local; e->N = cfg->nchains; e->k = cfg->multitry;
@@ -359,6 +366,11 @@ int orc_create(const orc_config* cfg, orc_engine** out)
     e->tmoved = zalloc(tc * nl); e->tsnk = zalloc(tc * nl);
     e->ttry = zalloc(sizeof(int32_t) * tc * nl); e->tcr = zalloc(sizeof(int32_t) * tc * nl);
     e->pts = zalloc(sizeof(double) * k * d); e->refs = zalloc(sizeof(double) * k * d); e->work = zalloc(sizeof(double) * 8 * d);
+    {
+        const size_t L1 = (size_t)cfg->adapt_lag + 1, nq = 2 + (size_t)cfg->ncr + cfg->ngamma;
+        e->pend_tot = zalloc(sizeof(double) * L1 * nq * d); e->pend_cnt = zalloc(sizeof(double) * L1 * (cfg->ncr + cfg->ngamma));
+        e->x0ring = zalloc(sizeof(double) * 2 * L1 * d); e->x0start = zalloc(sizeof(double) * d);
+    }
     *out = e;
     return 0;
 }
@@ -372,6 +384,7 @@ int orc_destroy(orc_engine* e)
     free(e->pkind); free(e->pa); free(e->pb); free(e->mu); free(e->Mx); free(e->mixF);
     free(e->tX); free(e->tlogp); free(e->tmoved); free(e->tsnk); free(e->ttry); free(e->tcr);
     free(e->Tc); free(e->tswap);
+    free(e->pend_tot); free(e->pend_cnt); free(e->x0ring); free(e->x0start);
     free(e->pts); free(e->refs); free(e->work); free(e);
     return 0;
 }
@@ -441,6 +454,7 @@ int orc_set_temperatures(orc_engine* e, const double* T /* [N] */, int32_t swaps
     if (e->c.schedule != 2 && swaps) return fail("temperature swaps need schedule S2");
     if (!e->Tc) e->Tc = zalloc(sizeof(double) * e->N);
     memcpy(e->Tc, T, sizeof(double) * e->N);
+    if (swaps && e->c.adapt_lag) return fail("adapt_lag is not available with temperature swaps");
     e->tempering = swaps != 0;
     if (e->tempering && !e->tswap) e->tswap = zalloc(sizeof(int32_t) * 3 * (size_t)(e->c.trace_capacity ? e->c.trace_capacity : 1));
     return 0;
@@ -824,11 +838,17 @@ static int adapt_gamma_now(const orc_engine* e, uint32_t g, int gamma_unity, int
  *   w_j = 1 / (sd_j sd_j);  delta_m[m] += nan_to_num(sum_j Dc[m][j] w_j)  (lane/butterfly order, fma), ncr_updates[m] += the bin's count.
  * Differences from the chain-by-chain form: rounding (1e-15 relative), and nan_to_num applied once per bin instead of once per chain
  * -- visible only when a coordinate has population sd exactly 0 in the gamma statistic or a jump overflows. */
-static void adapt_lockstep(orc_engine* e, const int* binc, const int* bing)
+/* adapt_lag (schedule S2): the update a generation makes is the one above, from that generation's own positions,
+ * jumps and bins, accumulated in generation order; what the lag changes is WHEN the chains see it -- generation g <= crossover_burnin
+ * decides with the probabilities as they were after the updates of generations <= g - 1 - adapt_lag, and from the hand-over on
+ * (g > crossover_burnin: the barrier of Dream.py:385-415, where every chain adopts the shared vector) with all of them.  So the
+ * statistic is split: adapt_totals makes a generation's column totals and bin counts (nothing of the shared state is read),
+ * adapt_apply adds them to delta_m / ncr_updates and renormalises (:481-499, :527-538).  The shift of generation g's column sums is
+ * global chain 0's published position after generation g - 1 - adapt_lag (its start position before there is one): with lag 0 the
+ * previous published position, as before. */
+static void adapt_totals(orc_engine* e, const int* binc, const int* bing, const double* shift, double* tot /* [nq d] */, double* cnt /* [ncr + ngamma] */)
 {
     const int N = e->N, d = e->d, ncr = e->c.ncr, ng = e->c.ngamma, nq = 2 + ncr + ng;
-    double* tot = zalloc(sizeof(double) * (size_t)nq * d); double* cnt = zalloc(sizeof(double) * (size_t)(ncr + ng));
-    const double* shift = e->cp_prev;                                   /* row of global chain 0 */
     for (int q = 0; q < nq; ++q)
         for (int j = 0; j < d; ++j) {
             double t = 0.0;
@@ -851,7 +871,12 @@ static void adapt_lockstep(orc_engine* e, const int* binc, const int* bing)
             }
             tot[(size_t)q * d + j] = t;
         }
+    for (int b = 0; b < ncr + ng; ++b) cnt[b] = 0.0;
     for (int c = 0; c < N; ++c) { if (binc[c] >= 0) cnt[binc[c]] += 1.0; if (bing[c] >= 0) cnt[ncr + bing[c]] += 1.0; }
+}
+static void adapt_apply(orc_engine* e, const double* tot, const double* cnt)
+{
+    const int N = e->N, d = e->d, ncr = e->c.ncr, ng = e->c.ngamma;
     double* wc = zalloc(sizeof(double) * d); double* wg = zalloc(sizeof(double) * d);
     for (int j = 0; j < d; ++j) {
         const double a = tot[j] / (double)N;
@@ -869,7 +894,32 @@ static void adapt_lockstep(orc_engine* e, const int* binc, const int* bing)
     }
     if (anyc) renorm_probs(e->cr_probs, e->cr_delta, e->cr_n, ncr, N);
     if (anyg) renorm_probs(e->g_probs, e->g_delta, e->g_n, ng, N);
-    free(tot); free(cnt); free(wc); free(wg);
+    free(wc); free(wg);
+}
+/* end of generation g: its totals join the pending ones; those of generations <= g - adapt_lag (all of them at the hand-over,
+ * g == crossover_burnin) are applied, oldest first -- the state generation g + 1 decides with */
+static void adapt_lockstep(orc_engine* e, uint32_t g, const int* binc, const int* bing)
+{
+    const int d = e->d, L = e->c.adapt_lag, nb = e->c.ncr + e->c.ngamma, nq = 2 + nb, R = 2 * (L + 1);
+    const int64_t hs = (int64_t)g - 1 - L;
+    /* (lag 0: the previous published positions' row 0 itself -- after a temperature swap that row holds the swapped-in state, core.py:204-215) */
+    const double* shift = L == 0 ? e->cp_prev : (hs < 0 ? e->x0start : e->x0ring + (size_t)(hs % R) * d);
+    if (e->npend == 0) e->pend_g0 = (int64_t)g;
+    const int slot = (int)(((int64_t)g - e->pend_g0));                   /* (npend <= L + 1: the oldest ones were applied below) */
+    adapt_totals(e, binc, bing, shift, e->pend_tot + (size_t)slot * nq * d, e->pend_cnt + (size_t)slot * nb);
+    e->npend = slot + 1;
+    memcpy(e->x0ring + (size_t)(g % R) * d, e->cp_new, sizeof(double) * d);      /* global chain 0's position after generation g */
+    const int64_t through = (int64_t)g == (int64_t)e->c.crossover_burnin ? (int64_t)g : (int64_t)g - L;
+    int napply = 0;
+    while (napply < e->npend && e->pend_g0 + napply <= through) {
+        adapt_apply(e, e->pend_tot + (size_t)napply * nq * d, e->pend_cnt + (size_t)napply * nb);
+        ++napply;
+    }
+    if (napply) {
+        memmove(e->pend_tot, e->pend_tot + (size_t)napply * nq * d, sizeof(double) * (size_t)(e->npend - napply) * nq * d);
+        memmove(e->pend_cnt, e->pend_cnt + (size_t)napply * nb, sizeof(double) * (size_t)(e->npend - napply) * nb);
+        e->npend -= napply; e->pend_g0 += napply;
+    }
 }
 
 /* chain flags of ANY global chain at generation g, recomputed from the random
@@ -924,7 +974,10 @@ static int generation_s2(orc_engine* e)
     const int d = e->d, nl = e->nl, N = e->N; const uint32_t g = (uint32_t)e->gen;
     double* Xn = zalloc(sizeof(double) * nl * d); step_res* R = zalloc(sizeof(step_res) * nl);
     int rc = 0;
-    if (g == 0 && (e->c.adapt_crossover || e->c.adapt_gamma)) rc = exchange(e, e->X, e->cp_new, d);
+    if (g == 0 && (e->c.adapt_crossover || e->c.adapt_gamma)) {
+        rc = exchange(e, e->X, e->cp_new, d);
+        memcpy(e->x0start, e->cp_new, sizeof(double) * d); e->npend = 0;      /* global chain 0's start position */
+    }
     /* history_lag: the rows of the last `lag` appends exist (their place in Z is fixed by the append order) but are not sampled yet */
     const int64_t lagged = e->napp < (int64_t)e->c.history_lag ? e->napp : (int64_t)e->c.history_lag;
     const int64_t Mvis = e->M - (int64_t)N * lagged;
@@ -970,7 +1023,7 @@ static int generation_s2(orc_engine* e)
             binc[gcn] = adapt_cr_now(e, g, gu) ? (snk ? e->c.ncr - 1 : cr) : -1;     /* :374-378 */
             bing[gcn] = adapt_gamma_now(e, g, gu, snk) ? gl - 1 : -1;
         }
-        adapt_lockstep(e, binc, bing);
+        adapt_lockstep(e, g, binc, bing);
         free(binc); free(bing);
     }
     /* record_history :360-362, :919-938 */

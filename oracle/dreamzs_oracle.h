@@ -46,6 +46,10 @@ typedef struct orc_config {
     int32_t schedule;         /* 1 = S1 sequential round-robin, 2 = S2 lockstep */
     int32_t device;           /* unused by the oracle                           */
     int32_t history_lag;      /* schedule S2 only: appended rows become sampleable `history_lag` appends late (0 = at once) */
+    int32_t adapt_lag;        /* schedule S2 only: generation g <= crossover_burnin decides with the crossover / gamma-level probabilities
+                               * as they were after the updates of generations <= g - 1 - adapt_lag (0 = after every earlier one); from
+                               * the hand-over on (g > crossover_burnin, Dream.py:385-415) with all of them */
+    int32_t reserved0;        /* keeps the 64-bit fields aligned; must be 0 */
     int64_t history_capacity; /* rows Z can hold                                */
     int64_t trace_capacity;   /* generations the trace buffer can hold          */
     uint64_t seed;

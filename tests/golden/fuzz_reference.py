@@ -66,8 +66,17 @@ def draw_case(rng):
     elif rng.random() < 0.2:
         kw["hardboundaries"] = False if prior in ("flat", "normal") else True
     lag = int(rng.choice([0, 0, 1, 2])) if schedule == 2 else 0
-    return dict(d=d, N=N, G=G, k=k, schedule=schedule, seed=int(rng.integers(1, 2 ** 31 - 1)), target=target, dream_kwargs=kw, prior=prior,
-                rng_seed=int(rng.integers(0, 2 ** 31 - 1)), history_lag=lag)
+    c = dict(d=d, N=N, G=G, k=k, schedule=schedule, seed=int(rng.integers(1, 2 ** 31 - 1)), target=target, dream_kwargs=kw, prior=prior,
+             rng_seed=int(rng.integers(0, 2 ** 31 - 1)), history_lag=lag)
+    if schedule == 2 and (adapt_cr or adapt_g) and (adapt_lag_arm or rng.random() < 0.5):
+        # adapt_lag (round 6): the updates reach the chains' decisions L generations late; burn-ins whose adaptation window (generations
+        # 11 .. burn-in - 1, Dream.py:371) lies inside the run, ends inside it (the hand-over flushes what is held) or beyond it
+        c["adapt_lag"] = int(rng.choice([1, 2, 3, 9, 19]))
+        kw["crossover_burnin"] = int(rng.choice([10, 14, max(12, G - 6), G + 5]))
+    return c
+
+
+adapt_lag_arm = False
 
 
 def draw_tri_case(rng):
@@ -119,7 +128,13 @@ def run_case(c):
         return -1
     e = H.engine_from_trace_fixture(O.Engine, fx)
     G = int(fx["cfg_G"])
-    e.step(G)
+    if int(fx["cfg_schedule"]) == 2 and (int(fx["cfg_adapt_crossover"]) or int(fx["cfg_adapt_gamma"])):
+        for g in range(G):     # the shared probabilities as the reference's chains adopted them after EVERY generation (what an adapt_lag shifts)
+            e.step(1)
+            np.testing.assert_allclose(e.get_cr_state()[0], fx["cross_probs"][g], rtol=1e-11, atol=0, err_msg="cross_probs after generation %d" % g)
+            np.testing.assert_allclose(e.get_gamma_state()[0], fx["gamma_probs"][g], rtol=1e-11, atol=0, err_msg="gamma_probs after generation %d" % g)
+    else:
+        e.step(G)
     tr = e.get_trace(0, G)
     gp = e.get_gamma_state()[0] if int(fx["cfg_adapt_gamma"]) else None
     H.compare_with_reference(tr, fx, e.get_history(), e.get_cr_state()[0], gp)
@@ -146,9 +161,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--adapt-lag", action="store_true", help="the adapt_lag arm: every lockstep case with an adaptation gets a lag (else: half of them)")
     ap.add_argument("--tri", action="store_true", help="the triangular arm: MVN cases up to 100-D, each also run with the triangular factor")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
+    global adapt_lag_arm
+    adapt_lag_arm = args.adapt_lag
     bad = 0; redrawn = 0; skipped = 0; t0 = time.time()
     devnull = open(os.devnull, "w")
     for i in range(args.n):

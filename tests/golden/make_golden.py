@@ -284,8 +284,17 @@ BASE = {"hist": RD.Dream.record_history, "pos": RD.Dream.set_current_position_ar
         "cr": RD.Dream.estimate_crossover_probabilities, "gam": RD.Dream.estimate_gamma_level_probs}
 
 
-def run_reference(params, likelihood, Z0, starts, N, G, seed, schedule, dream_kwargs, workdir, history_lag=0):
+def run_reference(params, likelihood, Z0, starts, N, G, seed, schedule, dream_kwargs, workdir, history_lag=0, adapt_lag=0):
     """Drive the reference's astep for G generations; return everything it produced.
+
+    adapt_lag (schedule S2 only): the deferred estimate_crossover_probabilities / estimate_gamma_level_probs calls of generation g are
+    replayed `adapt_lag` generations late, i.e. after generation g + adapt_lag (all that are still held at the hand-over, generation
+    crossover_burnin: the barrier of Dream.py:385-415) -- through the base-class methods, oldest generation first, with the shared
+    current_positions array holding, for the duration of the replay, what it held when generation g ended (the positions the
+    reference's np.std of Dream.py:476 / :520 is taken over).  The chains adopt the shared probabilities after every generation as
+    before, so generation g decides with the probabilities as they were after the updates of generations <= g - 1 - adapt_lag: the
+    schedule under which a kernel launch can hold adapt_lag + 1 burn-in generations (include/dreamzs.h dz_config.adapt_lag).  The
+    reference's own chains see each other's updates with a scheduler-dependent delay (Dream.py:371-378 under core.py:80).
 
     history_lag (schedule S2 only): the deferred record_history calls of an appending generation are replayed `history_lag` appends
     late -- the reference's own record_history / sample_from_history then see the archive grow with that delay (its `count` lags),
@@ -319,6 +328,7 @@ def run_reference(params, likelihood, Z0, starts, N, G, seed, schedule, dream_kw
                    cross_probs=np.zeros((G, step.nCR)), gamma_probs=np.zeros((G, step.ngamma)),
                    hist_rows=np.zeros(G, np.int64))
         held = []                                         # appends not replayed yet (history_lag), oldest first
+        pend = []                                         # adaptation updates not replayed yet (adapt_lag), oldest first: (g, positions, calls)
         for g in range(G):
             for ci, c in enumerate(chains):
                 rnd.begin_step(ci, g, step.p_gamma_unity)
@@ -336,13 +346,25 @@ def run_reference(params, likelihood, Z0, starts, N, G, seed, schedule, dream_kw
                 out["redraws"][g, ci] = rnd.log.get("redraws", 0)
                 x[ci] = xn
             if schedule == 2:
-                for kind in ("pos", "cr", "gam"):
-                    for c in chains:
-                        for (kk, a, kw) in c.queue:
-                            if kk == kind:
-                                c.iter -= 1           # astep already advanced iter (Dream.py:417); the
-                                BASE[kind](c, *a, **kw)   # base methods must see this generation's value (:446)
-                                c.iter += 1
+                for c in chains:
+                    for (kk, a, kw) in c.queue:
+                        if kk == "pos":
+                            c.iter -= 1           # astep already advanced iter (Dream.py:417); the
+                            BASE["pos"](c, *a, **kw)   # base methods must see this generation's value (:446)
+                            c.iter += 1
+                calls = [(kind, c, a, kw) for kind in ("cr", "gam") for c in chains for (kk, a, kw) in c.queue if kk == kind]
+                if calls:
+                    pend.append((g, np.frombuffer(SV.current_positions.get_obj()).copy(), calls))
+                while pend and pend[0][0] <= (g if g == burnin else g - adapt_lag):
+                    _, snap, calls = pend.pop(0)
+                    cp = np.frombuffer(SV.current_positions.get_obj())
+                    now = cp.copy()
+                    cp[:] = snap                      # what current_positions held when that generation ended
+                    for (kind, c, a, kw) in calls:
+                        c.iter -= 1
+                        BASE[kind](c, *a, **kw)
+                        c.iter += 1
+                    cp[:] = now
                 this_append = [(c, a, kw) for c in chains for (kk, a, kw) in c.queue if kk == "hist"]       # chain order
                 if this_append:
                     held.append(this_append)
@@ -557,7 +579,7 @@ def save(name, **arrs):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
-def trace_case(name, *, d, N, G, k, schedule, seed, target, dream_kwargs=None, prior="flat", rng_seed=0, nseed=None, restart_from=None, history_lag=0):
+def trace_case(name, *, d, N, G, k, schedule, seed, target, dream_kwargs=None, prior="flat", rng_seed=0, nseed=None, restart_from=None, history_lag=0, adapt_lag=0):
     """restart_from: name of an earlier trace fixture -- this run then restarts it the way run_dream(restart=True) does
     (core.py:46-62, 255-263; Dream.py:128-141): seed history = everything that run left in its history file (seed rows + appended
     rows), crossover probabilities loaded from its crossover file through Dream's `crossover_file`, starts = its last states."""
@@ -568,6 +590,8 @@ def trace_case(name, *, d, N, G, k, schedule, seed, target, dream_kwargs=None, p
     extra = {}
     if history_lag:
         cfg["history_lag"] = history_lag
+    if adapt_lag:
+        cfg["adapt_lag"] = adapt_lag
     nseed = nseed or max(10 * d, 2 * N * dream_kwargs.get("DEpairs", 1))
     if prior == "flat":
         params = [FlatParam(test_value=np.zeros(d))]
@@ -614,7 +638,7 @@ def trace_case(name, *, d, N, G, k, schedule, seed, target, dream_kwargs=None, p
                 np.save(os.path.join(wd, "prev_crossoverprob.npy"), prev["cross_probs"][-1])      # Dream.py:961-964
                 dream_kwargs["crossover_file"] = os.path.join(wd, "prev_crossoverprob.npy")
                 extra.update(restart_cr_probs=prev["cross_probs"][-1])
-            out = run_reference(params, like, Z0, starts, N, G, seed, schedule, dict(multitry=mt, **dream_kwargs), wd, history_lag=history_lag)
+            out = run_reference(params, like, Z0, starts, N, G, seed, schedule, dict(multitry=mt, **dream_kwargs), wd, history_lag=history_lag, adapt_lag=adapt_lag)
             dream_kwargs.pop("crossover_file", None)
         finally:
             os.chdir(cwd)
@@ -731,6 +755,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "lag":
         lag_cases()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "adaptlag":
+        adapt_lag_cases()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "s1gamma":
         s1_gamma_case()
         return
@@ -778,7 +805,21 @@ def main():
     trace_case("trace_s2_restart", d=10, N=4, G=60, k=5, schedule=2, seed=12, target=("mvn",), restart_from="trace_s2_adapt",
                dream_kwargs=dict(adapt_crossover=True, crossover_burnin=30))
     lag_cases()
+    adapt_lag_cases()
     s1_gamma_case()
+
+
+def adapt_lag_cases():
+    # T10 (round 6): adapt_lag -- lockstep S2 whose crossover / gamma-level updates reach the chains' decisions L generations late (the
+    # reference's own estimate_* methods, replayed late on the positions of their own generation), the burn-in ending inside the run:
+    # L = 1; L = 9 with history_lag = 1 on the 3-component mixture (the schedule bench.py times configs[2] under: whole thin-cycles
+    # per launch inside the burn-in); L = 3 with gamma-level adaptation, DEpairs = 2 and a normal prior
+    trace_case("trace_s2_adaptlag1", d=10, N=8, G=130, k=5, schedule=2, seed=51, target=("mvn",), adapt_lag=1,
+               dream_kwargs=dict(adapt_crossover=True, crossover_burnin=80))
+    trace_case("trace_s2_adaptlag9_mix", d=20, N=8, G=100, k=5, schedule=2, seed=53, target=("mix", (-5, 0, 5), (1 / 6., 1 / 3., 1 / 2.)),
+               adapt_lag=9, history_lag=1, dream_kwargs=dict(adapt_crossover=True, crossover_burnin=55))
+    trace_case("trace_s2_adaptlag3_gamma", d=6, N=6, G=110, k=5, schedule=2, seed=57, target=("mvn",), prior="normal", adapt_lag=3,
+               dream_kwargs=dict(adapt_crossover=True, adapt_gamma=True, gamma_levels=3, DEpairs=2, crossover_burnin=50))
 
 
 def s1_gamma_case():

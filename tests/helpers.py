@@ -37,6 +37,8 @@ def engine_from_trace_fixture(EngineCls, fx, schedule=None, trace=True, mvn_kind
               p_gamma_unity=float(fx["cfg_p_gamma_unity"]))
     if "cfg_history_lag" in fx:
         kw["history_lag"] = int(fx["cfg_history_lag"])
+    if "cfg_adapt_lag" in fx:
+        kw["adapt_lag"] = int(fx["cfg_adapt_lag"])
     kw.update(over)
     e = EngineCls(**kw)
     if "mins" in fx:

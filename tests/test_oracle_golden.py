@@ -8,7 +8,8 @@ from tests import helpers as H
 
 TRACES = ["trace_s1_c1", "trace_s1_adapt", "trace_s1_adapt_gamma", "trace_s2_adapt", "trace_s2_k1_bounds", "trace_s2_k3_bounds",
           "trace_s2_k3_redraw", "trace_s2_k5_redraw_mvn",
-          "trace_s2_depairs_gamma", "trace_s2_mvn100", "trace_s2_mix3", "trace_s2_restart", "trace_s2_lag1", "trace_s2_lag2_k1"]
+          "trace_s2_depairs_gamma", "trace_s2_mvn100", "trace_s2_mix3", "trace_s2_restart", "trace_s2_lag1", "trace_s2_lag2_k1",
+          "trace_s2_adaptlag1", "trace_s2_adaptlag9_mix", "trace_s2_adaptlag3_gamma"]
 
 
 @pytest.mark.parametrize("name", TRACES)
@@ -19,7 +20,16 @@ def test_astep_traces_match_reference(name):
         assert (fx["redraws"] > 0).mean() > 0.3 and fx["redraws"].max() < 64
     e = H.engine_from_trace_fixture(O.Engine, fx)
     G = int(fx["cfg_G"])
-    e.step(G)
+    if int(fx["cfg_schedule"]) == 2 and int(fx["cfg_adapt_crossover"]):
+        # generation by generation: the shared crossover probabilities as the reference's chains adopted them after every generation
+        # (what pins adapt_lag: with a lag they are those of `adapt_lag` generations earlier)
+        for g in range(G):
+            e.step(1)
+            np.testing.assert_allclose(e.get_cr_state()[0], fx["cross_probs"][g], rtol=1e-11, atol=0, err_msg="generation %d" % g)
+            if int(fx["cfg_adapt_gamma"]):
+                np.testing.assert_allclose(e.get_gamma_state()[0], fx["gamma_probs"][g], rtol=1e-11, atol=0, err_msg="generation %d" % g)
+    else:
+        e.step(G)
     tr = e.get_trace(0, G)
     gp = e.get_gamma_state()[0] if int(fx["cfg_adapt_gamma"]) else None
     H.compare_with_reference(tr, fx, e.get_history(), e.get_cr_state()[0], gp)
@@ -31,6 +41,21 @@ def test_astep_traces_match_reference(name):
         _, dm, nu = e.get_gamma_state()
         np.testing.assert_allclose(dm, fx["delta_m_gamma"], rtol=1e-11)
         np.testing.assert_array_equal(nu, fx["ngamma_updates"])
+
+
+@pytest.mark.parametrize("name,wrong", [("trace_s2_adaptlag1", 0), ("trace_s2_adaptlag1", 2), ("trace_s2_adaptlag9_mix", 8), ("trace_s2_adaptlag3_gamma", 0),
+                                        ("trace_s2_adapt", 1)])
+def test_adapt_lag_fixtures_pin_their_own_lag(name, wrong):
+    """The reference-made adapt_lag fixtures (tests/golden/make_golden.py adapt_lag_cases: the reference's own estimate_* methods replayed
+    L generations late) are reproduced at their own L only: with any other lag the crossover decisions inside the burn-in differ."""
+    fx = H.load(name)
+    e = H.engine_from_trace_fixture(O.Engine, fx, adapt_lag=wrong)
+    G = int(fx["cfg_G"])
+    e.step(G)
+    tr = e.get_trace(0, G)
+    b = int(fx["burnin"])
+    assert not np.array_equal(tr["cr_idx"][:b + 1], fx["cr_idx"][:b + 1])
+    assert np.array_equal(tr["cr_idx"][:12], fx["cr_idx"][:12])          # (no update before generation 11: Dream.py:371)
 
 
 MVN_TRACES = [n for n in TRACES if str(H.load(n)["lk_kind"]) == "mvn"]

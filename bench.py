@@ -80,7 +80,7 @@ def setup_engine(Cls, args, n_global, n_local, offset, steps_total, device=0, **
     if getattr(args, "history_lag", 0):
         kw["history_lag"] = int(args.history_lag)
     if getattr(args, "adapt", False):        # BASELINE configs[2]: crossover adaptation on (the reference's default), burn-in = a tenth of the run (core.py:299-300)
-        kw.update(adapt_crossover=1, crossover_burnin=int(args.burnin_generations))
+        kw.update(adapt_crossover=1, crossover_burnin=int(args.burnin_generations), adapt_lag=int(getattr(args, "adapt_lag", 0) or 0))
     kw.update(extra)
     e = Cls(**kw)
     e.set_history(Z0)
@@ -255,6 +255,10 @@ def parse_args(argv=None):
                     help="crossover adaptation on (BASELINE configs[2]; the reference's default): the first --burnin-generations generations "
                          "publish positions and adapt the crossover probabilities; timed on their own as `burnin_value`")
     ap.add_argument("--burnin-generations", type=int, default=800, help="crossover_burnin with --adapt (the reference: niterations / 10)")
+    ap.add_argument("--adapt-lag", type=int, default=None,
+                    help="dz_config.adapt_lag with --adapt: generation g of the burn-in decides with the crossover probabilities as they were after "
+                         "the updates of generations <= g - 1 - L, so a launch holds L + 1 burn-in generations.  Default thin - 1 (a whole "
+                         "thin-cycle per launch); the lockstep adaptation (L = 0, one generation per launch) is timed beside it: burnin_value_adapt_lag0")
     ap.add_argument("--control", choices=["socket", "torch"], default=os.environ.get("DZ_BENCH_CONTROL", "socket"),
                     help="rendezvous of a multi-GPU run: plain TCP (default) or torch.distributed/gloo")
     ap.add_argument("--transport", choices=["peer", "rccl", "host"], default=None,
@@ -273,6 +277,8 @@ def parse_args(argv=None):
         args.rhat_max_generations = max(args.spinup, min(args.rhat_max_generations, 4 * args.spinup))
     if args.history_lag is None:
         args.history_lag = 1
+    if args.adapt_lag is None:
+        args.adapt_lag = max(0, args.thin - 1)
     return args
 
 
@@ -362,7 +368,10 @@ def baseline_configs(args):
              "seconds": None}
         if "burnin_value" in o:
             c["burnin_value"] = o["burnin_value"]
-            c["burnin"] = {k_: o["burnin"][k_] for k_ in ("burnin_generations", "ms_per_step", "kernel_variant", "cr_probs_after_burnin")}
+            c["burnin"] = {k_: o["burnin"][k_] for k_ in ("burnin_generations", "adapt_lag", "ms_per_step", "kernel_variant", "cr_probs_after_burnin")}
+            if "burnin_value_adapt_lag0" in o:
+                c["burnin_value_adapt_lag0"] = o["burnin_value_adapt_lag0"]
+                c["burnin"]["adapt_lag0"] = o["burnin"]["adapt_lag0"]
         c["seconds"] = time.perf_counter() - t0
         res[key] = c
     return res
@@ -498,31 +507,40 @@ def measure(args, dist, world, rank, sub=False):
         while time.perf_counter() - t_w < 0.4:
             ew.trace_reset(); ew.step(500); ew.sync()
         ew.close()
-        e.trace_reset(); e.step(20); e.sync()
-        bt = []
-        Kb = max(1, min(K, (args.burnin_generations - 30) // 4))
-        while e.generation + Kb < args.burnin_generations - 1 and (1e3 * sum(bt) < args.min_timed_ms or len(bt) < 3) and len(bt) < 400:
-            e.trace_reset()
-            e.sync()
-            if dist is not None:
-                dist.barrier()
-            t0 = time.perf_counter()
-            e.step(Kb)
-            e.sync()
-            dt = time.perf_counter() - t0
-            if dist is not None:
-                dt = dist.all_reduce_max([dt])[0]
-            bt.append(dt)
-        bvar = e.last_kernel_variant()
-        rest = args.burnin_generations + 1 - e.generation
-        if rest > 0:
-            done_b = 0
-            while done_b < rest:
-                n = min(rest - done_b, trace_cap); e.trace_reset(); e.step(n); done_b += n
-        mb = float(np.median(bt)) if bt else None
-        burn = {"burnin_generations": args.burnin_generations, "block_generations": Kb, "timed_blocks": len(bt),
-                "ms_per_step": (1e3 * mb / Kb) if mb else None, "value": (n_global * args.multitry * Kb / mb) if mb else None,
-                "kernel_variant": bvar, "cr_probs_after_burnin": [float(x) for x in e.get_cr_state()[0]]}
+
+        def time_burnin(eb, finish):
+            eb.trace_reset(); eb.step(20); eb.sync()
+            bt = []
+            Kb = max(1, min(K, (args.burnin_generations - 30) // 4))
+            while eb.generation + Kb < args.burnin_generations - 1 and (1e3 * sum(bt) < args.min_timed_ms or len(bt) < 3) and len(bt) < 400:
+                eb.trace_reset()
+                eb.sync()
+                if dist is not None:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                eb.step(Kb)
+                eb.sync()
+                dt = time.perf_counter() - t0
+                if dist is not None:
+                    dt = dist.all_reduce_max([dt])[0]
+                bt.append(dt)
+            bvar = eb.last_kernel_variant()
+            rest = args.burnin_generations + 1 - eb.generation
+            if finish and rest > 0:
+                done_b = 0
+                while done_b < rest:
+                    n = min(rest - done_b, trace_cap); eb.trace_reset(); eb.step(n); done_b += n
+            mb = float(np.median(bt)) if bt else None
+            return {"burnin_generations": args.burnin_generations, "adapt_lag": int(eb.cfg.adapt_lag), "block_generations": Kb, "timed_blocks": len(bt),
+                    "ms_per_step": (1e3 * mb / Kb) if mb else None, "value": (n_global * args.multitry * Kb / mb) if mb else None,
+                    "kernel_variant": bvar, "cr_probs_after_burnin": [float(x) for x in eb.get_cr_state()[0]] if finish else None}
+        burn = time_burnin(e, True)
+        if world == 1 and args.adapt_lag > 0:      # beside it: the lockstep adaptation (adapt_lag 0: one burn-in generation per launch), the same blocks
+            a0 = copy.copy(args); a0.adapt_lag = 0
+            e0 = setup_engine(_capi.Engine, a0, n_global, n_local, 0, args.burnin_generations + 40, device=device, trace_capacity=max(K, 20))
+            b0 = time_burnin(e0, False)
+            e0.close()
+            burn["adapt_lag0"] = {k_: b0[k_] for k_ in ("value", "ms_per_step", "kernel_variant", "timed_blocks")}
     t_enq0 = time.perf_counter()
     times, conv, acc = converge_and_time(e, True)
     med = float(np.median(times))
@@ -615,7 +633,11 @@ def measure(args, dist, world, rank, sub=False):
         if burn is not None:
             out["burnin_value"] = burn["value"]
             out["burnin"] = burn
-            out["config"]["workload"] += "; crossover adaptation ON, crossover_burnin %d: `burnin_value` is the rate inside the burn-in, `value` after it" % args.burnin_generations
+            out["config"]["workload"] += "; crossover adaptation ON, crossover_burnin %d, adapt_lag %d (%s): `burnin_value` is the rate inside the burn-in, `value` after it" % (
+                args.burnin_generations, burn["adapt_lag"], "the updates reach the chains' decisions that many generations late: up to adapt_lag + 1 burn-in generations per launch" if burn["adapt_lag"] else "lockstep adaptation: one burn-in generation per launch")
+            out["config"]["adapt_lag"] = burn["adapt_lag"]
+            if "adapt_lag0" in burn:
+                out["burnin_value_adapt_lag0"] = burn["adapt_lag0"]["value"]
         out["kernel_variant"] = kernel_variant
         out["history_lag"] = args.history_lag
         if replicas is not None:

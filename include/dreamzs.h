@@ -50,6 +50,15 @@ typedef struct dz_config {
                                * an arbitrary, scheduler-dependent delay, Dream.py:646-668 under core.py:80), and on ONE GPU lets a
                                * launch of the persistent kernels run on past its appends: (L + 1) history_thin generations per
                                * launch instead of history_thin */
+    int32_t adapt_lag;        /* 0: generation g of the crossover burn-in decides with the crossover / gamma-level probabilities as every
+                               * earlier generation's update left them (estimate_crossover_probabilities, Dream.py:451-499, in lockstep).
+                               * L >= 1: with the probabilities as they were after the updates of generations <= g - 1 - L; the update a
+                               * generation makes is unchanged (its own positions, jumps and bins, accumulated in generation order), and
+                               * from the hand-over on (g > crossover_burnin: the barrier of Dream.py:385-415, where every chain adopts
+                               * the shared vector) every update is in.  The reference's own chains see each other's updates with a
+                               * scheduler-dependent delay (Dream.py:371-378 under core.py:80); a fixed L lets one launch of the
+                               * persistent kernels hold L + 1 burn-in generations instead of one */
+    int32_t reserved0;        /* must be 0 (keeps the 64-bit fields aligned)                   */
     int64_t history_capacity; /* rows the Z archive can hold (core.py:260-268)                 */
     int64_t trace_capacity;   /* generations the device trace buffer holds (0 = no trace)      */
     uint64_t seed;            /* key of the counter-based random contract                      */

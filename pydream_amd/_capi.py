@@ -23,7 +23,7 @@ class Config(C.Structure):
         ("multitry", C.c_int32), ("depairs", C.c_int32), ("ncr", C.c_int32), ("ngamma", C.c_int32),
         ("history_thin", C.c_int32), ("crossover_burnin", C.c_int32), ("adapt_crossover", C.c_int32),
         ("adapt_gamma", C.c_int32), ("hardboundaries", C.c_int32), ("schedule", C.c_int32), ("device", C.c_int32),
-        ("history_lag", C.c_int32), ("history_capacity", C.c_int64), ("trace_capacity", C.c_int64),
+        ("history_lag", C.c_int32), ("adapt_lag", C.c_int32), ("reserved0", C.c_int32), ("history_capacity", C.c_int64), ("trace_capacity", C.c_int64),
         ("seed", C.c_uint64), ("lamb", C.c_double), ("zeta", C.c_double), ("snooker", C.c_double),
         ("p_gamma_unity", C.c_double), ("temperature", C.c_double),
     ]
@@ -176,7 +176,7 @@ class Engine:
         cfg = Config()
         defaults = dict(nchains_local=kw.get("nchains"), chain_offset=0, multitry=1, depairs=1, ncr=3, ngamma=1,
                         history_thin=10, crossover_burnin=0, adapt_crossover=0, adapt_gamma=0, hardboundaries=1,
-                        schedule=2, device=0, history_lag=0, trace_capacity=0, seed=0, lamb=0.05, zeta=1e-12,
+                        schedule=2, device=0, history_lag=0, adapt_lag=0, reserved0=0, trace_capacity=0, seed=0, lamb=0.05, zeta=1e-12,
                         snooker=0.1, p_gamma_unity=0.2, temperature=1.0)
         defaults.update(kw)
         for k, v in defaults.items():

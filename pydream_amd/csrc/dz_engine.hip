@@ -156,6 +156,12 @@ struct dz_engine {
     // lockstep adaptation, contract v3 (dz_kernels.h adapt_unit_sums): the units' sums [units][nq][ld] and counts [units][ncr + ngamma], their totals
     double *d_PR = nullptr, *d_PC = nullptr, *d_TOT = nullptr, *d_CNT = nullptr;
     bool adapt_fused = true;        // the persistent kernels make their block's unit sums themselves (DZ_ADAPT_FUSED=0: k_adapt_partials does)
+    // dz_config.adapt_lag = L >= 1 (round 6): d_TOT / d_CNT are rings of L + 1 slots (slot = generation mod (L + 1); d_CNT rows of ad_nbp), d_DOT
+    // [L + 1][ad_nbp] the bins' dot products (k_adapt_dots), d_PR / d_PC rings as well when launches hold several burn-in generations (ad_multi).
+    // Updates of generations (ad_applied, ad_made] are pending: made, not yet added to the shared state.  d_x0ring [2 (L + 1)][ld]: global chain
+    // 0's published position after generation h at slot h mod 2 (L + 1); d_x0start: before generation 0.
+    int ad_R1 = 1, ad_nbp = 0; bool ad_multi = false; int64_t ad_applied = -1, ad_made = -1; size_t ad_tot_stride = 0, ad_pr_stride = 0, ad_pc_stride = 0;
+    double *d_DOT = nullptr, *d_x0ring = nullptr, *d_x0start = nullptr;
     // sharded crossover burn-in (round 5): a rank that owns whole groups of 256 chains exchanges its groups' sums (dz_kernels.h k_adapt_groups /
     // k_group_totals) instead of its positions.  d_GS[parity of the generation]: [world][gs_rec] records (two buffers: a peer may be one
     // generation ahead); d_shift[parity]: global chain 0's position after that generation (the shift of the next one's column sums)
@@ -545,30 +551,64 @@ void point_shared(dz_engine* e)
     p.cr_probs = e->d_shared + (size_t)e->sh_cur * 3 * (ncr + ng); p.cr_delta = p.cr_probs + ncr; p.cr_n = p.cr_delta + ncr;
     p.g_probs = p.cr_n + ncr; p.g_delta = p.g_probs + ng; p.g_n = p.g_delta + ng;
 }
+// adapt_lag >= 1: the last generation whose update generation g decides with -- g - 1 - lag inside the burn-in, everything that was made from the
+// hand-over on (g > crossover_burnin: Dream.py:385-415)
+int64_t adapt_due(const dz_engine* e, int64_t g)
+{
+    return g > (int64_t)e->p.burnin ? e->ad_made : std::min<int64_t>(e->ad_made, g - 1 - (int64_t)e->c.adapt_lag);
+}
+// ... and the pending updates up to there added to the shared state, on their own (k_adapt_apply_pending: in place)
+int adapt_apply_due(dz_engine* e, int64_t g)
+{
+    const int64_t due = adapt_due(e, g);
+    if (due <= e->ad_applied) return 0;
+    hipLaunchKernelGGL(dz::k_adapt_apply_pending, dim3(1), dim3(64), 0, e->stream, e->p, (const double*)e->d_DOT, (const double*)e->d_CNT, e->ad_nbp, e->ad_R1,
+                       (long long)(e->ad_applied + 1), (long long)(e->ad_made + 1), (long long)g, e->c.adapt_lag);
+    e->ad_applied = due;
+    return launch_check("k_adapt_apply_pending");
+}
 // totals left by the last generation's adaptation that no launch has applied yet: the update on its own
 int adapt_flush(dz_engine* e)
 {
+    if (e->c.adapt_lag > 0) return adapt_apply_due(e, e->gen);
     if (!e->adapt_pending) return 0;
     NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_adapt_apply<NCH>, dim3(1), dim3(64), 0, e->stream, e->p, (const double*)e->d_TOT, (const double*)e->d_CNT));
     e->adapt_pending = false;
     return launch_check("k_adapt_apply");
 }
-// the totals of the units' sums (k_adapt_totals); the update itself (adapt_apply_wave) is left to the next persistent launch's prologue
-// when `defer` says one follows, else made at once (k_adapt_apply)
-int adapt_finish(dz_engine* e, bool defer)
+// adapt_lag >= 1: behind the totals of generations g .. g + n - 1 (ring slots), their bins' dot products; the updates are then "made"
+int adapt_dots(dz_engine* e, uint32_t g, int n)
+{
+    NCH_DISPATCH(e, hipLaunchKernelGGL(dz::k_adapt_dots<NCH>, dim3(n), dim3(64), 0, e->stream, e->p, (const double*)e->d_TOT, (const double*)e->d_CNT, e->d_DOT,
+                                       (long long)g, e->ad_R1, (long long)e->ad_tot_stride, e->ad_nbp));
+    e->ad_made = (int64_t)g + n - 1;
+    return launch_check("k_adapt_dots");
+}
+// the totals of the units' sums (k_adapt_totals) of generations g .. g + n - 1 (pr_ring: a launch that can hold several burn-in generations, adapt_lag
+// >= 1, has left their units' sums in ring slots; else d_PR / d_PC hold one generation's); adapt_lag 0: the update itself (adapt_apply_wave) is left to the next persistent launch's prologue
+// when `defer` says one follows, else made at once (k_adapt_apply); adapt_lag >= 1: the dot products follow, the update waits until it is due
+int adapt_finish(dz_engine* e, bool defer, uint32_t g = 0, int n = 1, bool pr_ring = false)
 {
     const dz::Params& p = e->p;
-    const int nq = 2 + p.ncr + p.ngamma, units = (p.N + 15) / 16;
-    hipLaunchKernelGGL(dz::k_adapt_totals, dim3((nq * p.d + 15) / 16 + 1), dim3(256), 0, e->stream, (const double*)e->d_PR, (const double*)e->d_PC, units, nq, p.d, p.ld, p.ncr + p.ngamma, e->d_TOT, e->d_CNT);
+    const int nq = 2 + p.ncr + p.ngamma, units = (p.N + 15) / 16, nb = p.ncr + p.ngamma;
+    const bool ring = e->c.adapt_lag > 0;
+    hipLaunchKernelGGL(dz::k_adapt_totals, dim3((nq * p.d + 15) / 16 + 1, n), dim3(256), 0, e->stream, (const double*)e->d_PR, (const double*)e->d_PC, units, nq, p.d, p.ld, nb, e->d_TOT, e->d_CNT,
+                       (long long)g, ring ? e->ad_R1 : 1, (long long)(pr_ring ? e->ad_pr_stride : 0), (long long)(pr_ring ? e->ad_pc_stride : 0), (long long)e->ad_tot_stride, ring ? e->ad_nbp : 0);
     DZCK(launch_check("k_adapt_totals"));
+    if (ring) return adapt_dots(e, g, n);
     e->adapt_pending = true;
     return defer ? 0 : adapt_flush(e);
 }
 
 // the row the column sums of generation g are taken around: global chain 0's previous published position (contract v3).  Ranks that exchange
-// group sums instead of positions get it with the records of generation g - 1 (k_group_totals), generation 0's from the start positions
+// group sums instead of positions get it with the records of generation g - 1 (k_group_totals), generation 0's from the start positions.
+// adapt_lag = L >= 1: global chain 0's position after generation g - 1 - L (its start position before there is one)
 const double* adapt_shift(const dz_engine* e, uint32_t g)
 {
+    if (e->c.adapt_lag > 0) {
+        const int64_t hs = (int64_t)g - 1 - e->c.adapt_lag;
+        return hs < 0 ? e->d_x0start : e->d_x0ring + (size_t)(hs % (2 * e->ad_R1)) * e->p.ld;
+    }
     return (e->adapt_groups && g > 0) ? e->d_shift[(g - 1u) & 1u] : e->p.cp_prev;
 }
 // fused = the generation's persistent launch has already left its units' sums in d_PR / d_PC (adapt_unit_sums in its epilogue)
@@ -580,11 +620,14 @@ int adapt_generation(dz_engine* e, uint32_t g, int gc0, int ngc, bool fused = fa
     // sums the standard deviations need AND the per-bin column sums of squared jumps; their totals; the update.
     // A single chain's update (Dream.astep, schedule S1): the reference's own chain-by-chain form, all rows in row order (numpy's).
     const bool single = ngc != p.N;
+    const bool ring = e->c.adapt_lag > 0;
+    const int slot = ring ? (int)(g % (uint32_t)e->ad_R1) : 0;
+    double* x0_out = ring ? e->d_x0ring + (size_t)(g % (uint32_t)(2 * e->ad_R1)) * p.ld : nullptr;      // global chain 0's position after this generation
     if (!single && e->adapt_groups) {
         // sharded, whole groups per rank: own units' sums -> own groups' sums -> every rank's record everywhere -> the totals (the same
         // additions in the same order as k_adapt_totals makes them from all units: dz_kernels.h)
         const int units_l = p.nl / 16, gl = p.nl / 256, nq = 2 + p.ncr + p.ngamma, nb = p.ncr + p.ngamma, nbp = e->gs_nbp, par = (int)(g & 1u);
-        if (g > 0 && e->gs_last_gen != (int64_t)g - 1) return fail("sharded adaptation: the previous burn-in generation left no shift row");
+        if (!ring && g > 0 && e->gs_last_gen != (int64_t)g - 1) return fail("sharded adaptation: the previous burn-in generation left no shift row");
         if (!fused) {
             hipLaunchKernelGGL(dz::k_adapt_partials, dim3(units_l), dim3(1024), 0, e->stream, p, g, e->d_PR, e->d_PC, p.off / 16, adapt_shift(e, g));
             DZCK(launch_check("k_adapt_partials"));
@@ -594,18 +637,20 @@ int adapt_generation(dz_engine* e, uint32_t g, int gc0, int ngc, bool fused = fa
         DZCK(launch_check("k_adapt_groups"));
         DZCK(exchange_rows(e, XK_SUMS, e->d_GS[par], 0, par));
         hipLaunchKernelGGL(dz::k_group_totals, dim3((nq * p.d + nb + p.ld + 255) / 256), dim3(256), 0, e->stream, (const double*)e->d_GS[par], e->world, e->gs_rec, gl, nq, p.d, p.ld, nb, nbp,
-                           e->d_TOT, e->d_CNT, e->d_shift[par]);
+                           e->d_TOT + (size_t)slot * e->ad_tot_stride, e->d_CNT + (size_t)slot * e->ad_nbp, ring ? x0_out : e->d_shift[par]);
         DZCK(launch_check("k_group_totals"));
         e->gs_last_gen = (int64_t)g;
+        if (ring) return adapt_dots(e, g, 1);
         e->adapt_pending = true;
         return defer ? 0 : adapt_flush(e);
     }
     if (!single) {
+        if (ring) HIPCK(hipMemcpyAsync(x0_out, p.cp_new, sizeof(double) * p.ld, hipMemcpyDeviceToDevice, e->stream));
         if (!fused) {
-            hipLaunchKernelGGL(dz::k_adapt_partials, dim3((p.N + 15) / 16), dim3(1024), 0, e->stream, p, g, e->d_PR, e->d_PC, 0, (const double*)nullptr);
+            hipLaunchKernelGGL(dz::k_adapt_partials, dim3((p.N + 15) / 16), dim3(1024), 0, e->stream, p, g, e->d_PR, e->d_PC, 0, ring ? adapt_shift(e, g) : (const double*)nullptr);
             DZCK(launch_check("k_adapt_partials"));
         }
-        return adapt_finish(e, defer);
+        return adapt_finish(e, defer, g, 1);
     }
     const int strip = p.N, nstrips = 1;
     const dim3 b(128), gcol((p.d + 127) / 128, nstrips);
@@ -703,6 +748,7 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
     const bool full = (c0 == 0 && nc == p.nl);
     if (!full && e->world > 1) return fail("single-chain stepping is not available on a sharded engine");
     if (!full && e->c.history_lag) return fail("single-chain stepping (Dream.astep) appends with immediate effect: history_lag must be 0");
+    if (!full && e->c.adapt_lag) return fail("single-chain stepping (Dream.astep) updates the crossover probabilities with immediate effect: adapt_lag must be 0");
     DZCK(adapt_flush(e));               // (these kernels read the shared probabilities in place)
     DZCK(ensure_visible(e));
     const uint32_t Mv = (uint32_t)visible_rows(e);
@@ -726,6 +772,7 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
         const size_t n = (size_t)p.nl * p.ld;
         hipLaunchKernelGGL(dz::k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, p.X, p.cp_new + (size_t)p.off * p.ld, n);
         DZCK(exchange_rows(e, XK_POS, p.cp_new, 0));
+        if (e->c.adapt_lag > 0) HIPCK(hipMemcpyAsync(e->d_x0start, p.cp_new, sizeof(double) * p.ld, hipMemcpyDeviceToDevice, e->stream));      // global chain 0's start position
         DZCK(join_all(e));
     }
     p.draws = e->d_draws[g & 1]; p.draws_next = e->d_draws[(g + 1) & 1];
@@ -937,11 +984,29 @@ int upload_params(dz_engine* e)
     return 0;
 }
 bool publishing(const dz_engine* e, uint32_t g) { return e->adapt && (int64_t)g < (int64_t)e->p.burnin + 1; }      // Dream.py:364
+// adapt_lag >= 1: can a launch hold several burn-in generations?  One GPU, and a kernel instantiation that makes its block's unit sums
+// generation by generation (blocks of 16 chains = one unit): the mixture kernel's MG instantiations
+size_t mix_multi_lds(const dz_engine* e)
+{
+    const dz::Params& p = e->p;
+    const size_t LDP = (size_t)4 * ((p.d + 3) / 4) + 1;
+    return sizeof(double) * ((size_t)16 * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + (size_t)e->ad_R1 * e->ad_nbp + 64 * LDP + 32);
+}
+bool burnin_multi(const dz_engine* e)
+{
+    if (!e->ad_multi || !e->adapt_fused || !e->mega_burnin || e->tempering) return false;
+    if (e->lk == LK_MIX) return mega_mix_eligible(e) && e->p.k >= 3 && mix_multi_lds(e) <= (size_t)160 * 1024;
+    return false;
+}
 int mega_segment(const dz_engine* e, uint32_t g, int64_t remaining)
 {
-    // crossover burn-in: the positions are published and the probabilities adapted after every generation -- one generation per launch
-    if (publishing(e, g)) return (e->mega_burnin && remaining > 0) ? 1 : 0;
+    // crossover burn-in: the positions are published and the probabilities adapted after every generation -- one generation per launch, or
+    // (adapt_lag = L >= 1, one GPU, a kernel that makes its units' sums generation by generation: burnin_multi) up to L + 1 of them
+    const bool pub0 = publishing(e, g);
     if (e->tempering) return remaining > 0 ? 1 : 0;       // parallel tempering: a temperature swap follows every generation (core.py:185-221)
+    if (pub0 && !burnin_multi(e)) return (e->mega_burnin && remaining > 0) ? 1 : 0;
+    if (pub0 && !e->mega_burnin) return 0;
+    const int maxg = pub0 ? std::min(e->c.adapt_lag + 1, e->mega_max_gen) : e->mega_max_gen;
     // A launch ends with a history append -- unless the rows it writes are not sampleable yet anyway (history_lag >= 1, every lagged append
     // already made): on one GPU, where no exchange has to follow an append, the kernel then makes the append itself and runs on, up to
     // lag + 1 appends per launch (the generations behind the j-th one sample j * N more rows: all of them written before the launch).
@@ -949,8 +1014,8 @@ int mega_segment(const dz_engine* e, uint32_t g, int64_t remaining)
     int segs = (e->world == 1 && lag >= 1 && e->napp >= lag) ? std::min(lag + 1, e->mega_segs) : 1;
     segs = (int)std::max<int64_t>(1, std::min<int64_t>(segs, (e->c.history_capacity - e->M) / std::max(1, e->p.N)));      // (an archive sized to the last append: no launch asks for more rows than one append at a time would)
     int n = 0, apps = 0;
-    for (uint32_t gg = g; n < remaining && n < e->mega_max_gen; ++gg) {
-        if (publishing(e, gg)) break;
+    for (uint32_t gg = g; n < remaining && n < maxg; ++gg) {
+        if (publishing(e, gg) != pub0) break;
         ++n;
         if (gg % (uint32_t)e->p.thin == 0 && ++apps >= segs) break;
     }
@@ -970,11 +1035,16 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
     if (append_last && e->M + (int64_t)napps * p.N > e->c.history_capacity) return fail("history capacity exceeded");
     DZCK(join_all(e));
     DZCK(ensure_visible(e));
-    const bool publish = publishing(e, g);            // (then n == 1: mega_segment)
+    const bool publish = publishing(e, g);            // (then n == 1: mega_segment -- or, adapt_lag >= 1 and burnin_multi, up to adapt_lag + 1)
+    const bool ring = e->c.adapt_lag > 0;
+    const bool multi = publish && ring && burnin_multi(e);      // the launch applies the pending updates itself and makes its units' sums generation by generation
+    if (ring && !multi) DZCK(adapt_apply_due(e, (int64_t)g));   // (every generation of such a launch decides with the same state: one burn-in generation, or none)
+    if (publish && n > 1 && !multi) return fail("internal: several burn-in generations in a launch that cannot hold them");
     if (g == 0 && e->adapt) {   // publish the start positions (Dream_shared_vars.current_positions)
         const size_t nn = (size_t)p.nl * p.ld;
         hipLaunchKernelGGL(dz::k_copy_rows, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, e->stream, p.X, p.cp_new + (size_t)p.off * p.ld, nn);
         DZCK(exchange_rows(e, XK_POS, p.cp_new, 0));
+        if (e->c.adapt_lag > 0) HIPCK(hipMemcpyAsync(e->d_x0start, p.cp_new, sizeof(double) * p.ld, hipMemcpyDeviceToDevice, e->stream));      // global chain 0's start position
     }
     if (publish) { e->cp_idx = (e->cp_idx + 1) % 3; p.cp_prev = p.cp_new; p.cp_new = e->d_cp[e->cp_idx]; }
     const int64_t slot0 = e->c.trace_capacity ? e->ntrace : -1;
@@ -982,12 +1052,22 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
     pub.sh = p.cr_probs; pub.sh_out = nullptr; pub.TOT = nullptr; pub.CNT = nullptr; pub.c0 = 0; pub.c1 = p.nl;
     const bool applies = e->adapt_pending;      // the previous generation's adaptation totals: applied by this launch's prologue, new state into the other copy
     if (applies) { pub.TOT = e->d_TOT; pub.CNT = e->d_CNT; pub.sh_out = e->d_shared + (size_t)(e->sh_cur ^ 1) * 3 * (p.ncr + p.ngamma); }
-    auto launched = [&]() { if (applies) { e->sh_cur ^= 1; point_shared(e); e->adapt_pending = false; } };
+    if (multi) {      // adapt_lag >= 1: the pending updates, the rings, the table of probabilities per generation (Publish, dz_kernels.h)
+        pub.multi = 1; pub.lag = e->c.adapt_lag; pub.burnin = p.burnin; pub.nbp = e->ad_nbp; pub.pend0 = e->ad_applied + 1; pub.pend1 = e->ad_made + 1;
+        pub.DOT = e->d_DOT; pub.CNTR = e->d_CNT; pub.x0ring = e->d_x0ring; pub.x0start = e->d_x0start; pub.pr_stride = (long long)e->ad_pr_stride; pub.pc_stride = (long long)e->ad_pc_stride;
+        pub.PR = e->d_PR; pub.PC = e->d_PC;
+        pub.sh_out = e->d_shared + (size_t)(e->sh_cur ^ 1) * 3 * (p.ncr + p.ngamma);
+    }
+    auto launched = [&]() {
+        if (applies) { e->sh_cur ^= 1; point_shared(e); e->adapt_pending = false; }
+        if (multi) { e->sh_cur ^= 1; point_shared(e); e->ad_applied = std::max(e->ad_applied, adapt_due(e, (int64_t)g + n - 1)); }
+    };
     // crossover burn-in on one GPU: a block of 16 chains is one unit of the adaptation's column sums (contract v3) and makes them itself
     bool fused = false;
     auto fuse_adapt = [&]() { fused = true; pub.shift = adapt_shift(e, g); pub.PR = e->d_PR; pub.PC = e->d_PC; };
     auto after_launch = [&]() -> int {      // end of the generation(s): positions -> adaptation -> history append (schedule S2)
-        if (publish) {
+        if (multi) { ProfScope ps(e, PR_ADAPT); DZCK(adapt_finish(e, false, g, n, true)); }      // the totals and dot products of the launch's n generations (one GPU: nothing to exchange)
+        else if (publish) {
             if (!e->adapt_groups) DZCK(exchange_rows(e, XK_POS, p.cp_new, 0));      // (ranks that own whole groups exchange their groups' sums instead: adapt_generation)
             DZCK(adapt_generation(e, g, 0, p.N, fused, mega_follows));
         }
@@ -1007,15 +1087,20 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         int mw = dz::MIXW;
         const size_t lds_probs = sizeof(double) * (size_t)((p.ncr + p.ngamma + 1) & ~1);
         const size_t lds_xo = sizeof(double) * (size_t)16 * (4 * ((p.d + 3) / 4) + 1);
-        if (publish && e->adapt_fused && (e->world == 1 || e->adapt_groups) && p.k >= 3 && sizeof(double) * (size_t)16 * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs + lds_xo <= (size_t)160 * 1024) { mw = 16; fuse_adapt(); }
+        if (multi) mw = 16;
+        else if (publish && !ring && e->adapt_fused && (e->world == 1 || e->adapt_groups) && p.k >= 3 && sizeof(double) * (size_t)16 * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs + lds_xo <= (size_t)160 * 1024) { mw = 16; fuse_adapt(); }
         const dim3 gridm((p.nl + mw - 1) / mw), blockm(64 * mw);
-        const size_t ldsm = sizeof(double) * (size_t)mw * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs + (fused ? lds_xo : 0);
+        const size_t ldsm = multi ? mix_multi_lds(e) : sizeof(double) * (size_t)mw * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs + (fused ? lds_xo : 0);
         const bool pbm = p.hard || p.have_prior || p.depairs > 1;
+        if (multi) {
+            if (pbm) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations_mix<true, true>), gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, seg0, pub);
+            else DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations_mix<false, true>), gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, seg0, pub);
+        } else
         if (pbm) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, dz::k_generations_mix<true>, gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, seg0, pub);
         else DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, dz::k_generations_mix<false>, gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, seg0, pub);
         DZCK(launch_check("k_generations_mix"));
         launched();
-        e->last_variant = pbm ? "k_generations_mix<full>" : "k_generations_mix";
+        e->last_variant = multi ? (pbm ? "k_generations_mix<full,multi>" : "k_generations_mix<multi>") : (pbm ? "k_generations_mix<full>" : "k_generations_mix");
         DZCK(after_launch());
         if (slot0 >= 0) e->ntrace += n;
         return 0;
@@ -1074,7 +1159,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         size_t ldsp = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, pb ? true : xlds, chp, p.pb_lds != 0).total;
         dz::Publish pp = pub; pp.c0 = c0; pp.c1 = c1;
         if (split_c != p.nl) { pp.PR = nullptr; pp.PC = nullptr; pp.shift = nullptr; }      // (a split generation's unit sums come from k_adapt_partials)
-        else if (publish && e->adapt_fused && (e->world == 1 || e->adapt_groups) && chp == 16 && wpcp == 1 && !k1 && p.k >= 3 && (pb || xlds)) {      // (the new and old states are read from LDS)
+        else if (publish && !ring && e->adapt_fused && (e->world == 1 || e->adapt_groups) && chp == 16 && wpcp == 1 && !k1 && p.k >= 3 && (pb || xlds)) {      // (the new and old states are read from LDS)
             const size_t with_xo = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, true, chp, p.pb_lds != 0, true).total;
             if (with_xo <= (size_t)160 * 1024) { fuse_adapt(); pp.shift = pub.shift; pp.PR = pub.PR; pp.PC = pub.PC; ldsp = with_xo; }
         }
@@ -1135,6 +1220,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     if (cfg->nchains % cfg->nchains_local) return fail("nchains must be a multiple of nchains_local");
     if (cfg->history_thin < 1) return fail("history_thin must be >= 1");
     if (cfg->history_lag < 0 || cfg->history_lag > 64) return fail("history_lag must be 0..64");
+    if (cfg->adapt_lag < 0 || cfg->adapt_lag > 1023 || cfg->reserved0 != 0) return fail("adapt_lag must be 0..1023 (and dz_config.reserved0 zero)");
     int ndev = 0;
     hipError_t derr = hipGetDeviceCount(&ndev);
     if (derr != hipSuccess || ndev < 1) return fail("no HIP device available: libdreamzs has no CPU fallback");
@@ -1227,8 +1313,18 @@ int dz_create(const dz_config* cfg, dz_engine** out)
         rc |= ealloc(e, &e->d_dl, N); rc |= ealloc(e, &e->d_dlg, N); rc |= ealloc(e, &e->d_binc, N); rc |= ealloc(e, &e->d_bing, N);
         rc |= ealloc(e, &e->d_binsum, (size_t)2 * ((N + 63) / 64) * (cfg->ncr + cfg->ngamma));
         const size_t nq = 2 + (size_t)cfg->ncr + cfg->ngamma, units = (N + 15) / 16;
-        rc |= ealloc(e, &e->d_PR, units * nq * ld); rc |= ealloc(e, &e->d_PC, units * (size_t)(cfg->ncr + cfg->ngamma));
-        rc |= ealloc(e, &e->d_TOT, nq * ld); rc |= ealloc(e, &e->d_CNT, (size_t)(cfg->ncr + cfg->ngamma));
+        // adapt_lag = L >= 1: rings of L + 1 generations (engine fields ad_*); several burn-in generations per launch on one GPU (ad_multi)
+        e->ad_R1 = cfg->adapt_lag + 1; e->ad_nbp = (cfg->ncr + cfg->ngamma + 1) & ~1;
+        e->ad_multi = cfg->adapt_lag > 0 && e->world == 1 && !(getenv("DZ_ADAPT_MULTI") && atoi(getenv("DZ_ADAPT_MULTI")) == 0);
+        e->ad_tot_stride = cfg->adapt_lag > 0 ? nq * ld : 0;
+        e->ad_pr_stride = units * nq * ld; e->ad_pc_stride = units * (size_t)(cfg->ncr + cfg->ngamma);
+        const size_t prs = e->ad_multi ? (size_t)e->ad_R1 : 1;
+        rc |= ealloc(e, &e->d_PR, prs * e->ad_pr_stride); rc |= ealloc(e, &e->d_PC, prs * e->ad_pc_stride);
+        rc |= ealloc(e, &e->d_TOT, (size_t)e->ad_R1 * nq * ld); rc |= ealloc(e, &e->d_CNT, (size_t)e->ad_R1 * e->ad_nbp);
+        if (cfg->adapt_lag > 0) {
+            rc |= ealloc(e, &e->d_DOT, (size_t)e->ad_R1 * e->ad_nbp);
+            rc |= ealloc(e, &e->d_x0ring, (size_t)2 * e->ad_R1 * ld); rc |= ealloc(e, &e->d_x0start, ld);
+        }
         // sharded, and this rank owns whole groups of 256 chains (then every rank does: equal shards): the burn-in exchanges group sums
         const bool groups_on = !(getenv("DZ_ADAPT_GROUPS") && atoi(getenv("DZ_ADAPT_GROUPS")) == 0);
         if (e->world > 1 && groups_on && p.off % 256 == 0 && p.nl % 256 == 0) {
@@ -1672,6 +1768,7 @@ int dz_set_temperatures(dz_engine* e, const double* T, int32_t swaps)
 {   // core.py:133-136 (the ladder is the host's), :185-221 (swaps != 0: one swap attempt per generation)
     HIPCK(hipSetDevice(e->c.device));
     if (swaps && e->world > 1) return fail("temperature swaps need all chains on one GPU");
+    if (swaps && e->c.adapt_lag > 0) return fail("temperature swaps are not available with adapt_lag > 0");
     DZCK(sync_all(e));
     if (!e->d_Tc) DZCK(ealloc(e, &e->d_Tc, (size_t)e->p.N));
     HIPCK(hipMemcpy(e->d_Tc, T, sizeof(double) * e->p.N, hipMemcpyHostToDevice));
@@ -1751,6 +1848,7 @@ int dz_continue_run(dz_engine* e, int64_t history_capacity, int64_t trace_capaci
     e->gen = 0; std::fill(e->gen_c.begin(), e->gen_c.end(), (int64_t)0);
     e->napp = 0; e->ntrace = 0; e->draws_gen = -1; e->pending_accept = false; e->pending_slot = -1; e->stream_prop_gen = -1;
     e->have_logp = false; e->need_join = true; e->redraw_rounds = 0;
+    e->ad_applied = -1; e->ad_made = -1;
     std::fill(e->own_init.begin(), e->own_init.end(), 0);
     if (e->adapt) { p.cp_prev = e->d_cp[0]; p.cp_new = e->d_cp[1]; e->cp_idx = 1; }
     e->params_uploaded = false;

@@ -79,7 +79,20 @@ struct Params {
 // block decides with the same bits) and block 0 leaves the new state in sh_out (another buffer than sh: blocks start at different times).
 // c0: the first local chain of this launch (a generation may be two launches: whole rounds of 16-chain blocks, then the remainder in smaller
 // blocks -- run_mega_segment); the launch's chains end at the engine's nl or, for the first part, at c1.
-struct Publish { double* to; const double* shift; double* PR; double* PC; const double* sh; double* sh_out; const double* TOT; const double* CNT; int c0, c1; };
+// adapt_lag >= 1 (round 6; dz_config.adapt_lag): generation g of the burn-in decides with the probabilities as they were after the updates
+// of generations <= g - 1 - lag, so a launch holds up to lag + 1 burn-in generations (`multi`).  Then: the totals of every generation are kept
+// in rings of lag + 1 slots (slot = generation mod (lag + 1)): the units' sums go to PR / PC + slot * pr_stride / pc_stride; DOT / CNTR
+// [slot][nbp] are the bins' dot products and counts of the generations whose update is still pending -- pend0 .. pend1 - 1, all of them made
+// by earlier launches -- which the launch's prologue applies in order (adapt_pending_apply), leaving the probabilities of its i-th generation
+// in an LDS table; x0ring [2 (lag + 1)][ld]: global chain 0's position after generation h at slot h mod 2 (lag + 1), x0start: before
+// generation 0 -- the shift of generation g's column sums is that of generation g - 1 - lag.  `to` then receives the positions of the
+// launch's LAST generation only (what a later launch that is not fused measures its jumps from).
+struct Publish {
+    double* to; const double* shift; double* PR; double* PC; const double* sh; double* sh_out; const double* TOT; const double* CNT; int c0, c1;
+    int multi = 0, lag = 0, burnin = 0, nbp = 0; long long pend0 = 0, pend1 = 0;
+    const double* DOT = nullptr; const double* CNTR = nullptr; double* x0ring = nullptr; const double* x0start = nullptr;
+    long long pr_stride = 0, pc_stride = 0;
+};
 
 // per-phase cycle stamps: defined by dz_experiments.h in instrumented builds only (tools/variants.sh), no-ops in the product
 #ifdef DZ_EXPERIMENTS
@@ -2080,12 +2093,16 @@ DZ_DEV void adapt_unit_sums(const Params& p, const double* xn, int ldx, const do
 }
 
 // sd, the weights 1 / sd^2, the bins' dot products and the new probabilities (:476-493, :522-536) from the totals, by ONE wave: lane b keeps
-// bin b's accumulators (crossover bins first, then the gamma-level bins).  sh_in: the state before (cr_probs|cr_delta|cr_n|g_probs|g_delta|
-// g_n); probs_out: [ncr + ngamma] the new probabilities (LDS of a persistent kernel) or null; sh_out: the whole new state or null (may be sh_in).
+// bin b's accumulators (crossover bins first, then the gamma-level bins).  Two halves (round 6: with an adapt_lag the first is made right behind
+// the generation, the second when the update is due):
+//   adapt_dots_wave: sd and the weights from the column totals, then per bin b with a count the dot product sum_j D[b][j] w_j (the lane's
+//   dimensions by fma in ascending j, the 64 partial sums by the xor butterfly), nan_to_num -- lane b returns bin b's, others 0;
+//   adapt_scalar_step: delta_m[b] += dot, ncr_updates[b] += count, and the renormalisation of a kind whose bins got anything once every one
+//   of its bins has a non-zero delta (:487-493 / :531-536) -- lane b's (delta, n, probability) in registers.
 template <int NCH>
-DZ_DEV void adapt_apply_wave(const Params& p, const double* __restrict__ TOT, const double* __restrict__ CNT, const double* sh_in, double* probs_out, double* sh_out, int lane)
+DZ_DEV double adapt_dots_wave(const Params& p, const double* __restrict__ TOT, double my_cnt, int lane)
 {
-    const int d = p.d, ld = p.ld, ncr = p.ncr, ng = p.ngamma, nb = ncr + ng;
+    const int d = p.d, ld = p.ld, ncr = p.ncr, nb = ncr + p.ngamma;
     const double Nd = (double)p.N;
     double wc[NCH][2], wg[NCH][2];
 #pragma unroll
@@ -2102,11 +2119,7 @@ DZ_DEV void adapt_apply_wave(const Params& p, const double* __restrict__ TOT, co
                 wc[it][s] = 1.0 / (sdc * sdc); wg[it][s] = 1.0 / (sd * sd);
             }
         }
-    const bool mine = lane < nb, isg_l = lane >= ncr;
-    const int m_l = isg_l ? lane - ncr : lane;
-    const int o_probs = isg_l ? 3 * ncr + m_l : m_l, o_delta = isg_l ? 3 * ncr + ng + m_l : ncr + m_l, o_n = isg_l ? 3 * ncr + 2 * ng + m_l : 2 * ncr + m_l;
-    double my_delta = mine ? sh_in[o_delta] : 1.0, my_n = mine ? sh_in[o_n] : 1.0;
-    const double my_old = mine ? sh_in[o_probs] : 0.0, my_cnt = mine ? CNT[lane] : 0.0;
+    double mine = 0.0;
     for (int b = 0; b < nb; ++b) {
         const double cnt = readlane_f64(my_cnt, b);
         if (!(cnt > 0.0)) continue;                                           // (wave-uniform)
@@ -2121,9 +2134,17 @@ DZ_DEV void adapt_apply_wave(const Params& p, const double* __restrict__ TOT, co
                 if (j < d) acc = fma(D[j], isg ? wg[it][s] : wc[it][s], acc);
             }
         const double tot = nan_to_num(wave_bfly(acc));
-        if (lane == b) { my_delta = my_delta + tot; my_n += cnt; }
+        if (lane == b) mine = tot;
     }
-    // :487-493 / :531-536: a kind whose bins got anything is renormalised once every one of its bins has a non-zero delta
+    return mine;
+}
+// lane b < nb: bin b's dot product and count (0 where the bin got nothing) into its accumulators; the new probability
+DZ_DEV void adapt_scalar_step(const Params& p, double my_dot, double my_cnt, double& my_delta, double& my_n, double& my_prob, int lane)
+{
+    const int ncr = p.ncr, nb = ncr + p.ngamma;
+    const double Nd = (double)p.N;
+    const bool mine = lane < nb, isg_l = lane >= ncr;
+    if (mine && my_cnt > 0.0) { my_delta = my_delta + my_dot; my_n += my_cnt; }
     const bool anyc = __any(lane < ncr && my_cnt > 0.0), anyg = __any(mine && isg_l && my_cnt > 0.0);
     const bool allc = !__any(lane < ncr && my_delta == 0.0), allg = !__any(mine && isg_l && my_delta == 0.0);
     const double pm = (my_delta / my_n) * Nd;
@@ -2131,11 +2152,60 @@ DZ_DEV void adapt_apply_wave(const Params& p, const double* __restrict__ TOT, co
     for (int m = 0; m < ncr; ++m) Sc = Sc + readlane_f64(pm, m);
     for (int m = ncr; m < nb; ++m) Sg = Sg + readlane_f64(pm, m);
     const bool renorm = isg_l ? (anyg && allg) : (anyc && allc);
-    const double newp = renorm ? pm / (isg_l ? Sg : Sc) : my_old;
+    if (renorm) my_prob = pm / (isg_l ? Sg : Sc);
+}
+// offsets of bin b's probability / delta / count in the shared state cr_probs|cr_delta|cr_n|g_probs|g_delta|g_n
+DZ_DEV void adapt_state_offsets(int ncr, int ng, int lane, int& o_probs, int& o_delta, int& o_n)
+{
+    const bool isg_l = lane >= ncr; const int m_l = isg_l ? lane - ncr : lane;
+    o_probs = isg_l ? 3 * ncr + m_l : m_l; o_delta = isg_l ? 3 * ncr + ng + m_l : ncr + m_l; o_n = isg_l ? 3 * ncr + 2 * ng + m_l : 2 * ncr + m_l;
+}
+// Both halves at once (adapt_lag 0: the previous generation's totals, applied by the next launch's prologue or by k_adapt_apply).  sh_in: the
+// state before (cr_probs|cr_delta|cr_n|g_probs|g_delta|g_n); probs_out: [ncr + ngamma] the new probabilities (LDS of a persistent kernel) or
+// null; sh_out: the whole new state or null (may be sh_in).
+template <int NCH>
+DZ_DEV void adapt_apply_wave(const Params& p, const double* __restrict__ TOT, const double* __restrict__ CNT, const double* sh_in, double* probs_out, double* sh_out, int lane)
+{
+    const int ncr = p.ncr, ng = p.ngamma, nb = ncr + ng;
+    const bool mine = lane < nb;
+    int o_probs, o_delta, o_n;
+    adapt_state_offsets(ncr, ng, lane, o_probs, o_delta, o_n);
+    double my_delta = mine ? sh_in[o_delta] : 1.0, my_n = mine ? sh_in[o_n] : 1.0;
+    double my_prob = mine ? sh_in[o_probs] : 0.0;
+    const double my_cnt = mine ? CNT[lane] : 0.0;
+    const double my_dot = adapt_dots_wave<NCH>(p, TOT, my_cnt, lane);
+    adapt_scalar_step(p, my_dot, my_cnt, my_delta, my_n, my_prob, lane);
     if (mine) {
-        if (probs_out) probs_out[lane] = newp;
-        if (sh_out) { sh_out[o_probs] = newp; sh_out[o_delta] = my_delta; sh_out[o_n] = my_n; }
+        if (probs_out) probs_out[lane] = my_prob;
+        if (sh_out) { sh_out[o_probs] = my_prob; sh_out[o_delta] = my_delta; sh_out[o_n] = my_n; }
     }
+}
+// adapt_lag >= 1: the pending updates of generations [pend0, pend1) -- dot products and counts in ring slots of `R1` -- applied in order by one
+// wave while it walks the n generations g0 .. g0 + n - 1 the caller is about to run: generation g decides with everything through generation
+// g - 1 - lag (everything there is once g > burnin: the hand-over).  probs_tab: [n][nbp] the probabilities of each of them (LDS) or null;
+// sh_out: the state after the last of them or null (may be sh_in).  Returns nothing; every lane ends with the same walk.
+DZ_DEV void adapt_pending_apply(const Params& p, const double* __restrict__ DOT, const double* __restrict__ CNTR, int nbp, int R1, long long pend0, long long pend1,
+                                long long g0, int n, int lag, int burnin, const double* sh_in, double* probs_tab, double* sh_out, int lane)
+{
+    const int ncr = p.ncr, ng = p.ngamma, nb = ncr + ng;
+    const bool mine = lane < nb;
+    int o_probs, o_delta, o_n;
+    adapt_state_offsets(ncr, ng, lane, o_probs, o_delta, o_n);
+    double my_delta = mine ? sh_in[o_delta] : 1.0, my_n = mine ? sh_in[o_n] : 1.0;
+    double my_prob = mine ? sh_in[o_probs] : 0.0;
+    long long next = pend0;
+    for (int i = 0; i < n; ++i) {
+        const long long g = g0 + i;
+        const long long through = g > (long long)burnin ? pend1 - 1 : g - 1 - lag;
+        while (next < pend1 && next <= through) {
+            const int slot = (int)(next % R1);
+            const double cnt = mine ? CNTR[(size_t)slot * nbp + lane] : 0.0, dot = mine ? DOT[(size_t)slot * nbp + lane] : 0.0;
+            adapt_scalar_step(p, dot, cnt, my_delta, my_n, my_prob, lane);
+            ++next;
+        }
+        if (probs_tab && mine) probs_tab[(size_t)i * nbp + lane] = my_prob;
+    }
+    if (sh_out && mine) { sh_out[o_probs] = my_prob; sh_out[o_delta] = my_delta; sh_out[o_n] = my_n; }
 }
 
 #ifndef DZ_TEMPLATES_ONLY   // plain (non-template) kernels: defined once, in dz_engine.hip's translation unit
@@ -2306,11 +2376,18 @@ __global__ __launch_bounds__(1024) void k_adapt_update(Params p, const double* _
 // Totals of the units' sums.  Block = 16 columns (q, j) of the nq d (one 128-byte segment of every unit's row: 32 blocks pull the
 // 1 MB of 256 units x 500 columns through 32 CUs' paths to L2); thread (i, column) fetches unit i of every group (16 loads in flight),
 // thread (group, column) adds the group's 16 units in order, thread column adds the groups in order.  One more block adds the counts.
+// (round 6, adapt_lag >= 1) blockIdx.y = the i-th generation of a launch: generation g0 + i's sums and totals live in ring slot (g0 + i) mod R1
+// (the strides between slots in doubles; R1 = 1, one row of blocks: the single set of buffers of adapt_lag 0)
 __global__ __launch_bounds__(256) void k_adapt_totals(const double* __restrict__ PR, const double* __restrict__ PC, int nunits, int nq, int d, int ld, int nb,
-                                                      double* __restrict__ TOT /* [nq][ld] */, double* __restrict__ CNT /* [nb] */)
+                                                      double* __restrict__ TOT /* [nq][ld] */, double* __restrict__ CNT /* [nb] */,
+                                                      long long g0, int R1, long long pr_stride, long long pc_stride, long long tot_stride, int cnt_stride)
 {
     __shared__ double s_v[16][16][17];
     __shared__ double s_g[16][17];
+    {
+        const int slot = (int)((g0 + (long long)blockIdx.y) % R1);
+        PR += (size_t)slot * pr_stride; PC += (size_t)slot * pc_stride; TOT += (size_t)slot * tot_stride; CNT += (size_t)slot * cnt_stride;
+    }
     const int tid = threadIdx.x, cl = tid & 15, hi = tid >> 4;
     if (blockIdx.x == gridDim.x - 1) {       // the bins' counts (small integers: exact in any order): wave w = bins w, w + 4, ...
         const int lane = tid & 63, wv = tid >> 6;
@@ -2356,6 +2433,26 @@ template <int NCH>
 __global__ __launch_bounds__(64) void k_adapt_apply(Params p, const double* __restrict__ TOT, const double* __restrict__ CNT)
 {
     adapt_apply_wave<NCH>(p, TOT, CNT, p.cr_probs, nullptr, p.cr_probs, (int)threadIdx.x);
+}
+
+// adapt_lag >= 1: the first half of the update -- the bins' dot products with the weights 1 / sd^2 (adapt_dots_wave) -- right behind the totals
+// of generations g0 .. g0 + gridDim.x - 1 (one wave each; ring slots as in k_adapt_totals), DOT [slot][nbp]; the second half
+// (adapt_pending_apply) runs when the update is due: in the prologue of a persistent launch, or as k_adapt_apply_pending
+template <int NCH>
+__global__ __launch_bounds__(64) void k_adapt_dots(Params p, const double* __restrict__ TOT, const double* __restrict__ CNT, double* __restrict__ DOT,
+                                                   long long g0, int R1, long long tot_stride, int nbp)
+{
+    const int slot = (int)((g0 + (long long)blockIdx.x) % R1), lane = threadIdx.x, nb = p.ncr + p.ngamma;
+    const double my_cnt = lane < nb ? CNT[(size_t)slot * nbp + lane] : 0.0;
+    const double dot = adapt_dots_wave<NCH>(p, TOT + (size_t)slot * tot_stride, my_cnt, lane);
+    if (lane < nbp) DOT[(size_t)slot * nbp + lane] = lane < nb ? dot : 0.0;
+}
+// ... on its own, in place on the engine's current state: everything that is due before generation g (the multi-kernel path, launches that
+// are not fused, the hand-over at the end of the burn-in, the end of dz_step)
+__global__ __launch_bounds__(64) void k_adapt_apply_pending(Params p, const double* __restrict__ DOT, const double* __restrict__ CNTR, int nbp, int R1, long long pend0, long long pend1,
+                                                            long long g, int lag)
+{
+    adapt_pending_apply(p, DOT, CNTR, nbp, R1, pend0, pend1, g, 1, lag, p.burnin, p.cr_probs, nullptr, p.cr_probs, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------

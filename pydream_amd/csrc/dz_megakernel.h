@@ -740,7 +740,12 @@ __host__ __device__ inline int mega_mix_wave_doubles(int d, int k, int J) { cons
 // (blocks of MIXW waves; blocks of 16 -- one adaptation unit -- inside the crossover burn-in, where the block adds its unit's sums)
 // PB (round 4): per-dimension priors, hard boundaries, several DE pairs -- the full proposal code and the prior evaluation (constants from
 // global memory: this kernel has no block-wide staging); the flat, unbounded, one-pair case keeps the lean instantiation.
-template <bool PB>
+// MG (round 6, adapt_lag >= 1): SEVERAL burn-in generations per launch (Publish::multi; blocks of 16).  The prologue applies the pending
+// updates in order and leaves the probabilities of each of the launch's generations in an LDS table; every generation ends with the block's
+// unit sums into that generation's ring slot: the chains' states before and after it and their bins go through a double-buffered LDS stash
+// (one block barrier per generation -- the only one in this kernel: a wave can be at most one generation ahead of the slowest, and the
+// stash it then writes is the other one).  LDS behind the waves' regions: table [lag + 1][nbp] | stash [2]{before, after}[16][LDP] | bins [2][32] (int).
+template <bool PB, bool MG = false>
 __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0, int64_t zappend, int seg0, Publish pub)
 {
     double* const publish = pub.to;
@@ -759,7 +764,10 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
     // the crossover / gamma-level probabilities the launch decides with: behind the waves' regions; made by wave 0 when the previous
     // generation's adaptation totals are still to be applied (Publish::TOT)
     double* probs = smem + (size_t)nwv * mega_mix_wave_doubles(d, k, p.J);
-    if (pub.TOT) { if (wv == 0) adapt_apply_wave<1>(p, pub.TOT, pub.CNT, pub.sh, probs, blockIdx.x == 0 ? pub.sh_out : nullptr, lane); }
+    if (MG) {
+        if (wv == 0) adapt_pending_apply(p, pub.DOT, pub.CNTR, pub.nbp, pub.lag + 1, pub.pend0, pub.pend1, (long long)g0, ngen, pub.lag, pub.burnin, pub.sh, probs,
+                                         blockIdx.x == 0 ? pub.sh_out : nullptr, lane);
+    } else if (pub.TOT) { if (wv == 0) adapt_apply_wave<1>(p, pub.TOT, pub.CNT, pub.sh, probs, blockIdx.x == 0 ? pub.sh_out : nullptr, lane); }
     else {
         if ((int)threadIdx.x < p.ncr) probs[threadIdx.x] = pub.sh[threadIdx.x];
         if ((int)threadIdx.x < p.ngamma) probs[p.ncr + threadIdx.x] = pub.sh[3 * p.ncr + threadIdx.x];
@@ -771,8 +779,8 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
     const uint32_t gc = (uint32_t)(p.off + c);
     double xs[NCH][2];                                                      // the chain's state lives in registers
     load_row<NCH>(p.X + (size_t)c * ld, ld, lane, xs);
-    double* xo_area = probs + ((p.ncr + p.ngamma + 1) & ~1);                // (crossover burn-in, blocks of 16: the states the launch started with, [16][LDP])
-    if (pub.PR) { if (2 * lane < d) xo_area[wv * LDP + 2 * lane] = xs[0][0]; if (2 * lane + 1 < d) xo_area[wv * LDP + 2 * lane + 1] = xs[0][1]; }
+    double* xo_area = probs + (MG ? (pub.lag + 1) * pub.nbp : ((p.ncr + p.ngamma + 1) & ~1));      // (crossover burn-in, blocks of 16: the states the launch started with, [16][LDP]; MG: the stash)
+    if (!MG && pub.PR) { if (2 * lane < d) xo_area[wv * LDP + 2 * lane] = xs[0][0]; if (2 * lane + 1 < d) xo_area[wv * LDP + 2 * lane + 1] = xs[0][1]; }
     double lpri = p.lprior[c], llik = p.llike[c];
     if (lane == 0) dec[6] = chain_T(p, c);                                  // the chain's temperature (Dream.astep's T)
     // (PB) the prior / boundary constants straight from global memory through the PBConsts interface of the block-staged kernels: the prior
@@ -794,6 +802,8 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
         const bool last = gi == ngen - 1;
         const bool app = gi == next_app;
         int sel = 0; bool fin = true;
+        const double* const pr_g = MG ? probs + (size_t)gi * pub.nbp : probs;      // the probabilities this generation decides with
+        const double xb0 = xs[0][0], xb1 = xs[0][1];                          // (MG) the state before the generation
         DrawSrc ds; ds.have = true; ds.mine = make_uint4(0, 0, 0, 0);      // the generation's wave-uniform draws, both phases read them
         if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g); ds.mine = make_uint4(w.x, w.y, w.z, w.w); }
         const int nph = k == 1 ? 1 : 2;                                    // multitry off: one proposal, no reference set
@@ -805,7 +815,7 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
                 const u32x4 w0 = uniform_draw(p, ds, 0, gc, g), w1 = uniform_draw(p, ds, 1, gc, g), w2 = uniform_draw(p, ds, 2, gc, g);
                 u.u_snk = u53(w0.x, w0.y); u.u_cr = u53(w0.z, w0.w); u.u_de = u53(w1.x, w1.y); u.u_glev = u53(w1.z, w1.w);
                 u.u_sel = u53(w2.x, w2.y); u.u_acc = u53(w2.z, w2.w);
-                f = step_flags_from(p, u, probs, probs + p.ncr);                    // Dream.py:246-256
+                f = step_flags_from(p, u, pr_g, pr_g + p.ncr);                      // Dream.py:246-256
                 if (lane == 0) { dec[0] = u.u_sel; dec[1] = u.u_acc; dec[2] = f.snk ? 1.0 : 0.0; dec[3] = (double)f.cr_idx; dec[4] = (double)f.glev; if (PB) dec[7] = (double)f.delta; }
                 base[0][0] = xs[0][0]; base[0][1] = xs[0][1];
             } else {
@@ -903,7 +913,8 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
                     if (last) *reinterpret_cast<double2*>(p.X + (size_t)c * ld + jj) = xn;
                     if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn);
                     if (app) gstore2(p.Z + ((size_t)zappend + (M - M0) + gc) * ld + jj, xn);                         // record_history :933-936
-                    if (publish) gstore2(publish + (size_t)gc * ld + jj, xn);                          // set_current_position_arr :447-449
+                    if (publish && (!MG || last)) gstore2(publish + (size_t)gc * ld + jj, xn);         // set_current_position_arr :447-449
+                    if (MG && gc == 0u) gstore2(pub.x0ring + (size_t)(g % (uint32_t)(2 * (pub.lag + 1))) * ld + jj, xn);      // global chain 0 after generation g: a later generation's shift
                 }
                 if (lane == 0) {
                     if (trace_slot0 >= 0) {
@@ -916,9 +927,26 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
             }
             lpri = npri; llik = nlik;
         }
+        if (MG) {   // the block's unit sums of THIS generation (contract v3) into its ring slot; stash gi & 1
+            const int buf = gi & 1;
+            double* xo_b = xo_area + (size_t)buf * 32 * LDP; double* xn_b = xo_b + (size_t)16 * LDP;
+            int* bins_b = reinterpret_cast<int*>(xo_area + (size_t)64 * LDP) + 32 * buf;
+            int bc, bg;
+            adapt_bins(p, g, (int)gc, lane, bc, bg, pr_g, pr_g + p.ncr);
+            if (2 * lane < d) { xo_b[wv * LDP + 2 * lane] = xb0; xn_b[wv * LDP + 2 * lane] = xs[0][0]; }
+            if (2 * lane + 1 < d) { xo_b[wv * LDP + 2 * lane + 1] = xb1; xn_b[wv * LDP + 2 * lane + 1] = xs[0][1]; }
+            if (lane == 0) { bins_b[2 * wv] = bc; bins_b[2 * wv + 1] = bg; }
+            __syncthreads();
+            const int unit = blockIdx.x, R1 = pub.lag + 1, slot = (int)(g % (uint32_t)R1);
+            const long long hs = (long long)g - 1 - pub.lag;
+            const double* shift = hs < 0 ? pub.x0start : pub.x0ring + (size_t)(hs % (2 * R1)) * ld;
+            adapt_unit_sums(p, xn_b, LDP, xo_b, LDP, min(16, p.nl - 16 * unit), [&](bool isg, int c_) { return bins_b[2 * c_ + (isg ? 1 : 0)]; }, shift,
+                            pub.PR + (size_t)slot * pub.pr_stride + (size_t)unit * adapt_nq(p) * ld, pub.PC + (size_t)slot * pub.pc_stride + (size_t)unit * (p.ncr + p.ngamma),
+                            (int)threadIdx.x, (int)blockDim.x);
+        }
         if (app) { next_app += p.thin; M += (uint32_t)p.N; }
     }
-    if (pub.PR) {   // crossover burn-in, blocks of 16 chains (one adaptation unit), k >= 3: the new state into the chain's (dead) row 1, its bins into that row's pad
+    if (!MG && pub.PR) {   // crossover burn-in, blocks of 16 chains (one adaptation unit), k >= 3: the new state into the chain's (dead) row 1, its bins into that row's pad
         int bc, bg;
         adapt_bins(p, g0, (int)gc, lane, bc, bg, probs, probs + p.ncr);
         double* sn = region + LDP;

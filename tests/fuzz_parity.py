@@ -59,6 +59,11 @@ def draw_config(rng, long=False, dims=None, chains=None):
     cfg["s1"] = int(N <= 17 and rng.random() < 0.5 and not cfg["pt"] and cfg["world"] == 1)
     if cfg["s1"]:
         cfg["lag"] = 0
+    # adapt_lag (round 6): the adaptation's updates reach the chains' decisions L generations late (lockstep generations only)
+    cfg["adapt_lag"] = 0
+    if (adapt_cr or adapt_g) and not cfg["pt"] and not cfg["s1"] and rng.random() < 0.6:
+        cfg["adapt_lag"] = int(rng.choice([1, 2, 4, 9, 19]))
+        cfg["burnin"] = int(rng.choice([6, 15, max(13, n - 8), n + 5]))
     return cfg
 
 
@@ -69,7 +74,7 @@ def build(Cls, c, device_kw):
     Z0 = rng.uniform(-5.0, 15.0, (M0, d))
     kw = dict(nchains=N, ndim=d, multitry=k, depairs=c["depairs"], ncr=c["ncr"], ngamma=c["ngamma"], history_thin=c["thin"],
               crossover_burnin=c["burnin"], adapt_crossover=c["adapt_cr"], adapt_gamma=c["adapt_g"], hardboundaries=0 if c["prior"] == "uniform_open" else 1,
-              history_lag=c["lag"], history_capacity=M0 + N * (n // c["thin"] + 2), trace_capacity=n, seed=c["seed"] & 0x7fffffff,
+              history_lag=c["lag"], adapt_lag=c.get("adapt_lag", 0), history_capacity=M0 + N * (n // c["thin"] + 2), trace_capacity=n, seed=c["seed"] & 0x7fffffff,
               lamb=c["lamb"], zeta=c["zeta"], snooker=c["snooker"], p_gamma_unity=c["pgu"])
     if c.get("s1"):
         kw["schedule"] = 1 if Cls.__module__.startswith("oracle") else 2      # (the device engine is driven chain by chain instead: dz_step_range)

@@ -34,8 +34,9 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_config_struct_layout():
-    # dz_config: 16 int32, 2 int64, 1 uint64, 5 double = 128 bytes, no padding surprises
-    assert ctypes.sizeof(_capi.Config) == 16 * 4 + 3 * 8 + 5 * 8
+    # dz_config: 18 int32 (history_lag, adapt_lag and one reserved word last), 2 int64, 1 uint64, 5 double = 136 bytes, no padding surprises
+    assert ctypes.sizeof(_capi.Config) == 18 * 4 + 3 * 8 + 5 * 8
+    assert _capi.Config.history_capacity.offset == 18 * 4 and _capi.Config.adapt_lag.offset == 16 * 4
 
 
 def test_no_silent_cpu_fallback(lib):

@@ -8,7 +8,8 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 S2_TRACES = ["trace_s2_adapt", "trace_s2_k1_bounds", "trace_s2_k3_bounds", "trace_s2_k3_redraw", "trace_s2_k5_redraw_mvn", "trace_s2_depairs_gamma",
-             "trace_s2_mvn100", "trace_s2_mix3", "trace_s2_restart", "trace_s2_lag1", "trace_s2_lag2_k1"]
+             "trace_s2_mvn100", "trace_s2_mix3", "trace_s2_restart", "trace_s2_lag1", "trace_s2_lag2_k1",
+             "trace_s2_adaptlag1", "trace_s2_adaptlag9_mix", "trace_s2_adaptlag3_gamma"]
 
 
 @pytest.fixture(scope="module")
@@ -724,6 +725,59 @@ def test_crossover_burnin_at_4096_chains_against_oracle(G, O, variant, monkeypat
     np.testing.assert_array_equal(out[0][2], out[1][2])
     assert not np.allclose(out[0][1][0], 1 / 3.) and out[0][3].startswith("k_generations<7,")
     assert ("full" in out[0][3]) == (variant in ("uniform_bounds", "normal"))
+
+
+@pytest.mark.parametrize("target,N,lag,hlag,multi,variant", [
+    ("mix", 4096, 9, 1, "1", "k_generations_mix<multi>"),      # what bench.py times configs[2] under: whole thin-cycles per launch inside the burn-in
+    ("mix", 4096, 9, 0, "1", "k_generations_mix<multi>"),
+    ("mix", 4096, 3, 1, "1", "k_generations_mix<multi>"),      # launches of four generations, history appends in the middle of some
+    ("mix", 4096, 9, 1, "0", "k_generations_mix"),             # the same schedule one generation per launch (DZ_ADAPT_MULTI=0): unit sums by k_adapt_partials
+    ("mix", 1000, 19, 1, "1", "k_generations_mix<multi>"),     # a ragged last block of 8 chains; twenty generations per launch
+    ("mix_pb", 2048, 9, 1, "1", "k_generations_mix<full,multi>"),
+    ("mvn", 4096, 9, 1, "1", "k_generations<7,"),              # the MVN kernels: one burn-in generation per launch, the updates applied when due
+    ("mvn", 300, 2, 0, "1", "k_generations_w4<7,"),
+])
+def test_crossover_burnin_with_an_adapt_lag_against_oracle(G, O, target, N, lag, hlag, multi, variant, monkeypatch):
+    """dz_config.adapt_lag = L (round 6): generation g of the burn-in decides with the probabilities as they were after the updates of
+    generations <= g - 1 - L, so a launch of the mixture kernel holds up to L + 1 burn-in generations (its blocks make their unit sums generation
+    by generation, the pending updates are applied in the prologue).  55 generations, the window of the adaptation (generations 11 .. burn-in - 1,
+    Dream.py:371) and the hand-over (generation 38: everything still held is applied, Dream.py:385-415) inside them, then whole thin-cycles:
+    equal to the oracle bit for bit -- decisions, states, archive, adapted probabilities and accumulators -- and the state handed out
+    after EVERY dz_step of a run stepped in pieces is the oracle's (updates still pending are not in it)."""
+    monkeypatch.setenv("DZ_ADAPT_MULTI", multi)
+    d, n, seed, burn = 100, 55, 77, 38
+    rng = np.random.default_rng(seed)
+    mu = np.array([np.full(d, m) for m in (-5.0, 0.0, 5.0)])
+    logF = np.log(np.array([1 / 6., 1 / 3., 1 / 2.])) - (d / 2.) * np.log(2 * np.pi)
+    Z0 = mu[rng.integers(0, 3, 2 * N + 100)] + 2.0 * rng.standard_normal((2 * N + 100, d)) if target.startswith("mix") else H.seed_history(2 * N + 100, d, 6)
+    pieces = (7, 13, 1, 20, 14)
+    out = []
+    for Cls in (G.Engine, O.Engine):
+        e = Cls(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
+                adapt_crossover=1, crossover_burnin=burn, adapt_lag=lag, history_lag=hlag)
+        if target == "mix_pb":
+            e.set_prior(np.full(d, 1, np.int32), np.linspace(-1.0, 1.0, d), np.linspace(20.0, 40.0, d))
+        e.set_history(Z0); e.set_state(Z0[:N])
+        if target.startswith("mix"):
+            e.set_likelihood_mixture(mu, logF)
+        else:
+            P = H.mvn_precision(d)
+            e.set_likelihood_mvn(np.zeros(d), np.linalg.cholesky((P + P.T) / 2).T, 1, 0.0)
+        states, variants = [], set()
+        for m in pieces:
+            e.step(m)
+            states.append(e.get_cr_state())
+            if Cls is G.Engine:
+                variants.add(e.last_kernel_variant())
+        out.append((e.get_trace(0, n), states, e.get_history(), variants))
+    assert_traces_identical(out[0][0], out[1][0])
+    for sa, sb in zip(out[0][1], out[1][1]):
+        for a, b in zip(sa, sb):
+            np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    assert not np.allclose(out[0][1][-1][0], 1 / 3.)
+    assert any(v.startswith(variant) for v in out[0][3]), out[0][3]
+    assert (("k_generations_mix<multi>" in out[0][3]) or ("k_generations_mix<full,multi>" in out[0][3])) == (multi == "1" and target.startswith("mix"))
 
 
 @pytest.mark.parametrize("adapt", [0, 1])

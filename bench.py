@@ -257,8 +257,8 @@ def parse_args(argv=None):
     ap.add_argument("--burnin-generations", type=int, default=800, help="crossover_burnin with --adapt (the reference: niterations / 10)")
     ap.add_argument("--adapt-lag", type=int, default=None,
                     help="dz_config.adapt_lag with --adapt: generation g of the burn-in decides with the crossover probabilities as they were after "
-                         "the updates of generations <= g - 1 - L, so a launch holds L + 1 burn-in generations.  Default thin - 1 (a whole "
-                         "thin-cycle per launch); the lockstep adaptation (L = 0, one generation per launch) is timed beside it: burnin_value_adapt_lag0")
+                         "the updates of generations <= g - 1 - L, so a launch holds L + 1 burn-in generations.  Default (history_lag + 1) thin - 1 (the "
+                         "launches inside the burn-in hold as many generations as those behind it); the lockstep adaptation (L = 0, one generation per launch) is timed beside it: burnin_value_adapt_lag0")
     ap.add_argument("--control", choices=["socket", "torch"], default=os.environ.get("DZ_BENCH_CONTROL", "socket"),
                     help="rendezvous of a multi-GPU run: plain TCP (default) or torch.distributed/gloo")
     ap.add_argument("--transport", choices=["peer", "rccl", "host"], default=None,
@@ -277,8 +277,8 @@ def parse_args(argv=None):
         args.rhat_max_generations = max(args.spinup, min(args.rhat_max_generations, 4 * args.spinup))
     if args.history_lag is None:
         args.history_lag = 1
-    if args.adapt_lag is None:
-        args.adapt_lag = max(0, args.thin - 1)
+    if args.adapt_lag is None:      # as many burn-in generations per launch as the launches behind the burn-in hold generations
+        args.adapt_lag = max(0, (args.history_lag + 1) * args.thin - 1)
     return args
 
 

@@ -881,29 +881,50 @@ int one_generation(dz_engine* e, int c0, int nc, uint32_t g, bool traced, bool m
 // chain states, gamma table and decisions ride in LDS next to the matrix whenever that fits (the packed triangle at
 // d=100 leaves room; the dense square does not)
 // chains (= waves) per block: 16 once that still gives every CU a block, else 8 or 4 (C2: 1024 chains -> 256 blocks of 4)
-int mega_chains(const dz_engine* e)
+// -> chains per block of the (first) launch; split_c / ch_b: a generation as TWO launches -- whole rounds of ch-chain blocks for the local chains
+// [0, split_c), the remainder in blocks of ch_b chains (split_c == nl: one launch)
+struct MegaPlan { int ch, split_c, ch_b; };
+MegaPlan mega_plan(const dz_engine* e)
 {
-    if (e->mega_ch) return e->mega_ch;
-    // One block per CU is resident (LDS), so a launch takes ceil(blocks / CUs) rounds of a block's time; measured at 100-D
-    // a block of 8 chains needs 0.67 and one of 4 chains (four waves per chain) 0.49 of the time of a block of 16.  The
-    // smallest product wins, the larger block on a tie: 4096 chains -> 16, 3072 -> 16 (192 CUs at full speed beat 384 blocks
-    // of 8 in two rounds: 431 vs 333 M proposals/s), 2048 -> 8, 1024 -> 4.
-    // ... among the block sizes whose LDS layout fits at all (round 4): at 113..128 dimensions the point tiles of 16 chains no longer fit
-    // next to the matrix, those of 8 do -- 4096 chains x 128-D ran the multi-kernel path at 300 M proposals/s for want of that
-    const int ncu = e->num_cu > 0 ? e->num_cu : 1;
-    const double cost[3] = {1.0, 0.67, 0.49};
     const dz::Params& p = e->p;
+    if (e->mega_ch) return MegaPlan{e->mega_ch, p.nl, 0};
+    // One block per CU is resident (LDS), so a launch takes ceil(blocks / CUs) rounds of a block's time; measured at 100-D a block of 12
+    // chains needs 0.82 (round 6), one of 8 chains 0.67 and one of 4 chains (four waves per chain) 0.49 of the time of a block of 16.  The
+    // smallest product wins, the larger block on a tie: 4096 chains -> 16, 3072 -> 12 (round 6: 256 blocks of 12 -- 677 M proposals/s; as
+    // 192 blocks of 16, a quarter of the chip idle, 561), 2048 -> 8, 1024 -> 4 ... among the block sizes whose LDS layout fits at all (round
+    // 4): at 113..128 dimensions the point tiles of 16 chains no longer fit next to the matrix, those of 8 do.
+    // A chain count just above whole rounds -- 5000 chains: 313 blocks of 16 -- pays a whole round for its remainder; the remainder can go in
+    // a SECOND launch of smaller blocks (whole rounds of the large blocks first).  The second launch's blocks start while the first one's
+    // last blocks drain, worth about 0.12 of a 16-chain block's time (5000 chains: 16 + 8 measured 39.8 us per generation, modelled without
+    // the overlap 46.4; 12 + 8: 40.0; 417 blocks of 12 in two rounds: 43.1).
+    const int ncu = e->num_cu > 0 ? e->num_cu : 1;
+    static const double c12 = getenv("DZ_COST12") ? atof(getenv("DZ_COST12")) : 0.82;
+    const int cand[4] = {16, 12, 8, 4};
+    const double cost[4] = {1.0, c12, 0.67, 0.49};
     const bool need_x = p.hard || p.have_prior || p.depairs > 1;          // (the full-code instantiations keep the states in LDS)
-    int best = dz::MEGA_CHAINS; double tb = -1.0;
-    for (int i = 0, ch = dz::MEGA_CHAINS; i < 3; ++i, ch >>= 1) {
-        const size_t lds = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, p.tri != 0, need_x, ch, need_x && p.pb_lds != 0).total;
-        if (lds > (size_t)160 * 1024) continue;
-        const int blocks = (p.nl + ch - 1) / ch, rounds = (blocks + ncu - 1) / ncu;
+    const bool k1 = p.k == 1;
+    bool fits[4];
+    for (int i = 0; i < 4; ++i)
+        fits[i] = !(cand[i] == 12 && k1) &&
+                  sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, p.tri != 0, need_x, cand[i], need_x && p.pb_lds != 0).total <= (size_t)160 * 1024;
+    MegaPlan best{dz::MEGA_CHAINS, p.nl, 0}; double tb = -1.0;
+    for (int i = 0; i < 4; ++i) {
+        if (!fits[i]) continue;
+        const int ch = cand[i], blocks = (p.nl + ch - 1) / ch, rounds = (blocks + ncu - 1) / ncu;
         const double t = rounds * cost[i];
-        if (tb < 0.0 || t < tb - 1e-9) { best = ch; tb = t; }
+        if (tb < 0.0 || t < tb - 1e-9) { best = MegaPlan{ch, p.nl, 0}; tb = t; }
+        if (!e->mega_split || k1 || ch < 12 || blocks <= ncu || blocks % ncu == 0) continue;
+        const int full = (blocks / ncu) * ncu * ch, r = p.nl - full;
+        for (int j = i + 1; j < 4; ++j) {
+            if (!fits[j]) continue;
+            const int rb = ((r + cand[j] - 1) / cand[j] + ncu - 1) / ncu;
+            const double t2 = (blocks / ncu) * cost[i] + rb * cost[j] - 0.12;
+            if (t2 < tb - 1e-9) { best = MegaPlan{ch, full, cand[j]}; tb = t2; }
+        }
     }
     return best;
 }
+int mega_chains(const dz_engine* e) { return mega_plan(e).ch; }
 size_t mega_lds_bytes(const dz_engine* e, bool xlds)
 {
     return sizeof(double) * (size_t)dz::mega_layout(e->p.d, e->p.k, e->p.ld / 16, e->p.ncr, e->p.ngamma, e->p.tri != 0, xlds, mega_chains(e), e->p.pb_lds != 0).total;
@@ -953,7 +974,11 @@ int mega_d2_chains(const dz_engine* e)
     if ((p.k != 1 && p.k < 3) || p.nslots > 64) return 0;
     if (!p.tri || !p.Mtp) return 0;
     const size_t lds = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, false, 16, false, false, true).total;
-    return lds <= (size_t)160 * 1024 ? 16 : 0;
+    if (lds <= (size_t)160 * 1024) return 16;
+    // round 6: 8 chains x 2 waves per block where the point tiles of 16 chains do not fit (128 < d: 229..256 dimensions at 5 tries) -- multi-try only
+    if (p.ld > 128 && p.k >= 3 && !(getenv("DZ_MEGA_D2_W2") && atoi(getenv("DZ_MEGA_D2_W2")) == 0) &&
+        sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, false, 8, false, false, true).total <= (size_t)160 * 1024) return 8;
+    return 0;
 }
 bool mega_eligible(dz_engine* e)
 {
@@ -1109,8 +1134,9 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
     if (const int chd = mega_d2_chains(e)) {      // 128 < d <= 256
         DZCK(upload_params(e));
         dz::MegaLaunch ml;
-        ml.tri = p.tri != 0; ml.xlds = false; ml.pb = p.hard || p.have_prior || p.depairs > 1; ml.k1 = p.k == 1; ml.ch = chd; ml.wpc = 1; ml.redo = false;
-        ml.grid = dim3((p.nl + chd - 1) / chd); ml.block = dim3(64 * chd);
+        const int wpcd = chd == 8 ? 2 : 1;
+        ml.tri = p.tri != 0; ml.xlds = false; ml.pb = p.hard || p.have_prior || p.depairs > 1; ml.k1 = p.k == 1; ml.ch = chd; ml.wpc = wpcd; ml.redo = false;
+        ml.grid = dim3((p.nl + chd - 1) / chd); ml.block = dim3(64 * chd * wpcd);
         ml.lds = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, false, chd, false, false, true).total;
         ml.st = e->stream; ml.ka = nullptr; ml.kb = nullptr;
         ml.pp = (const dz::Params*)e->d_params; ml.g = g; ml.n = n; ml.M = (uint32_t)visible_rows(e); ml.slot0 = slot0; ml.zappend = append_last ? e->M : (int64_t)-1; ml.seg0 = seg0; ml.publish = &pub;
@@ -1125,7 +1151,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
             case 15: name = dz::mega_launch_nrt15(ml); break; case 16: name = dz::mega_launch_nrt16(ml); break;
             default: return fail("k_generations_d2: ld out of range");
         }
-        char buf[96]; snprintf(buf, sizeof buf, name, chd, 1);
+        char buf[96]; snprintf(buf, sizeof buf, name, chd, wpcd);
         e->last_variant = buf;
         DZCK(launch_check("k_generations_d2"));
         launched();
@@ -1141,18 +1167,9 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
     const bool xlds = mega_xlds(e);
     const bool pb = p.hard || p.have_prior || p.depairs > 1 || mega_redo(e);      // the instantiations with the full proposal code
     DZCK(upload_params(e));
-    // A generation is ceil(blocks / CUs) rounds of blocks (one block per CU is resident), so a chain count just above a whole number of
-    // rounds -- 5000 chains: 313 blocks of 16 -- pays a whole round for its remainder.  The remainder then goes in a SECOND launch of
-    // smaller blocks (8 chains: 0.67, 4 chains x 4 waves: 0.49 of a 16-chain block's time) when that is cheaper than one more round.
-    int split_c = p.nl, ch_b = 0;
-    if (ch == 16 && !k1 && e->mega_split) {
-        const int ncu = e->num_cu > 0 ? e->num_cu : 1, blocks = (p.nl + 15) / 16;
-        if (blocks > ncu && blocks % ncu != 0) {
-            const int full = (blocks / ncu) * ncu * 16, r = p.nl - full;
-            const double c8 = (double)(((r + 7) / 8 + ncu - 1) / ncu) * 0.67, c4 = (double)(((r + 3) / 4 + ncu - 1) / ncu) * 0.49;
-            if (std::min(c8, c4) < 1.0 - 1e-9) { split_c = full; ch_b = c4 < c8 ? 4 : 8; }
-        }
-    }
+    // (a chain count just above whole rounds of blocks: the remainder in a second launch of smaller blocks -- mega_plan)
+    const MegaPlan plan = mega_plan(e);
+    const int split_c = plan.split_c, ch_b = plan.split_c != p.nl ? plan.ch_b : 0;
     std::string variant;
     auto launch_part = [&](int c0, int c1, int chp) -> int {
         const int wpcp = (chp == 4 && !k1) ? 4 : 1;
@@ -1244,7 +1261,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     if (const char* kv = getenv("DZ_QFIN")) e->q_defer = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_FUSE_STREAM")) e->fuse_stream = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_LOGP_BM")) e->logp_bm = atoi(kv);          // 64 / 128: points per block of k_logp_mvn_gemm (default: by size)
-    if (const char* kv = getenv("DZ_MEGA_CHAINS")) { const int v = atoi(kv); e->mega_ch = (v == 16 || v == 8 || v == 4) ? v : 0; }
+    if (const char* kv = getenv("DZ_MEGA_CHAINS")) { const int v = atoi(kv); e->mega_ch = (v == 16 || v == 12 || v == 8 || v == 4) ? v : 0; }
     if (const char* kv = getenv("DZ_WPB")) e->waves_per_block = atoi(kv);
     if (const char* kv = getenv("DZ_PROPOSE_SPLIT")) e->propose_split = atoi(kv);
     if (const char* kv = getenv("DZ_MFMA_PT")) e->force_pt = atoi(kv) == 2 ? 2 : atoi(kv) == 1 ? 1 : 0;
@@ -1459,6 +1476,7 @@ int dz_set_cr_probs(dz_engine* e, const double* pr, int32_t n)
 {
     if (n != e->c.ncr) return fail("nCR mismatch");
     HIPCK(hipSetDevice(e->c.device));
+    DZCK(adapt_flush(e));
     DZCK(sync_all(e));
     HIPCK(hipMemcpy(e->p.cr_probs, pr, sizeof(double) * n, hipMemcpyHostToDevice));
     std::fill(e->own_init.begin(), e->own_init.end(), 0);
@@ -1469,6 +1487,7 @@ int dz_set_gamma_probs(dz_engine* e, const double* pr, int32_t n)
 {
     if (n != e->c.ngamma) return fail("ngamma mismatch");
     HIPCK(hipSetDevice(e->c.device));
+    DZCK(adapt_flush(e));
     DZCK(sync_all(e));
     HIPCK(hipMemcpy(e->p.g_probs, pr, sizeof(double) * n, hipMemcpyHostToDevice));
     std::fill(e->own_init.begin(), e->own_init.end(), 0);
@@ -1798,6 +1817,7 @@ int dz_continue_run(dz_engine* e, int64_t history_capacity, int64_t trace_capaci
     HIPCK(hipSetDevice(e->c.device));
     if (e->peer_on || e->comm || e->world > 1) return fail("dz_continue_run: not on a sharded engine");
     if (e->tempering || e->p.Tc) return fail("dz_continue_run: not on a tempering engine");
+    DZCK(adapt_flush(e));           // (the probabilities the new run starts from: everything that was due is in)
     DZCK(sync_all(e));
     if (e->copy_stream) HIPCK(hipStreamSynchronize(e->copy_stream));
     dz::Params& p = e->p;
@@ -1887,7 +1907,9 @@ int dz_step(dz_engine* e, int64_t generations)
             if (e->ra_used[oldest]) HIPCK(hipEventSynchronize(e->ra_ev[oldest]));
         }
     }
-    return adapt_flush(e);          // (adaptation totals are left pending only between two launches of this loop)
+    // (adapt_lag 0: adaptation totals are left pending only between two launches of this loop; adapt_lag >= 1: updates that are due stay pending
+    //  until a launch or a getter needs the state -- adapt_flush in dz_get_cr_state & co. -- instead of a launch of their own behind every dz_step)
+    return e->c.adapt_lag > 0 ? 0 : adapt_flush(e);
 }
 
 int dz_step_range(dz_engine* e, int32_t c0, int32_t nc)
@@ -1930,6 +1952,7 @@ int dz_get_chain_probs(dz_engine* e, int32_t c, double* cr_probs, double* gamma_
 {   // Dream.CR_probabilities / Dream.gamma_probabilities of the instance that drives chain c (Dream.py:375, :383)
     HIPCK(hipSetDevice(e->c.device));
     if (c < 0 || c >= e->p.nl) return fail("bad chain index");
+    DZCK(adapt_flush(e));
     DZCK(sync_all(e));
     const bool own = e->d_own_cr && c < (int)e->own_init.size() && e->own_init[c];
     if (cr_probs) HIPCK(hipMemcpy(cr_probs, own ? e->d_own_cr + (size_t)c * e->p.ncr : e->p.cr_probs, sizeof(double) * e->p.ncr, hipMemcpyDeviceToHost));
@@ -2152,7 +2175,6 @@ int dz_history_checksum(dz_engine* e, uint64_t* sum, int64_t* rows)
 
 static int get_shared(dz_engine* e, const double* probs, const double* delta, const double* n, int nb, double* o_probs, double* o_delta, double* o_n)
 {
-    HIPCK(hipSetDevice(e->c.device));
     DZCK(sync_all(e));
     if (o_probs) HIPCK(hipMemcpy(o_probs, probs, sizeof(double) * nb, hipMemcpyDeviceToHost));
     if (o_delta) HIPCK(hipMemcpy(o_delta, delta, sizeof(double) * nb, hipMemcpyDeviceToHost));
@@ -2161,10 +2183,14 @@ static int get_shared(dz_engine* e, const double* probs, const double* delta, co
 }
 int dz_get_cr_state(dz_engine* e, double* probs, double* delta_m, double* n_updates)
 {
+    HIPCK(hipSetDevice(e->c.device));
+    DZCK(adapt_flush(e));           // (adapt_lag >= 1: the updates the next generation decides with are in; later ones stay pending)
     return get_shared(e, e->p.cr_probs, e->p.cr_delta, e->p.cr_n, e->c.ncr, probs, delta_m, n_updates);
 }
 int dz_get_gamma_state(dz_engine* e, double* probs, double* delta_m, double* n_updates)
 {
+    HIPCK(hipSetDevice(e->c.device));
+    DZCK(adapt_flush(e));
     return get_shared(e, e->p.g_probs, e->p.g_delta, e->p.g_n, e->c.ngamma, probs, delta_m, n_updates);
 }
 

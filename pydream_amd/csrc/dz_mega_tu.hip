@@ -33,6 +33,16 @@ const char* DZ_CAT(mega_launch_nrt, DZ_TU_NRT)(const MegaLaunch& a)
         return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,lean" NAME_ ">";                                                     \
     } while (0)
     if (a.k1) DZ_D2(true, ",k1");          // (the host only sends the triangular factor at 16 chains per block here: mega_d2_chains)
+    if (a.ch == 8) {                       // ... or, where the point tiles of 16 chains do not fit LDS (d > ~228 at 5 tries), at 8 chains x 2 waves (round 6)
+        if (a.pb) {
+            hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 8, false, true, 2>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M,
+                                  a.slot0, a.zappend, a.seg0, *a.publish);
+            return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,full>";
+        }
+        hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 8, false, false, 2>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M,
+                              a.slot0, a.zappend, a.seg0, *a.publish);
+        return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,lean>";
+    }
     DZ_D2(false, "");
 #undef DZ_D2
 }
@@ -80,6 +90,7 @@ static const char* launch_ch(const MegaLaunch& a)
         return launch_one<TRI, X, 4, 1, PB, true>(a);
     }
     if (a.ch == 16) return launch_one<TRI, X, 16, 1, PB, false>(a);
+    if (a.ch == 12) return launch_one<TRI, X, 12, 1, PB, false>(a);      // (round 6: 2049 .. 3072 chains on 256 CUs -- multi-try only)
     if (a.ch == 8) return launch_one<TRI, X, 8, 1, PB, false>(a);
     return launch_one<TRI, X, 4, 4, PB, false>(a);
 #endif

@@ -23,10 +23,14 @@ namespace dz {
 // snooker formula and the current point's term log |x - z|^(d-1).
 // PB: per-dimension priors (SampledParam norm / uniform, parameters.py:37-47), hard boundaries (Dream.py:733-791), several DE pairs
 // (set_DEpair :571-583) -- the multi-kernel path's full proposal code and prior evaluation, constants from global memory.
-template <int NRT, bool TRI, int CH, bool K1 = false, bool PB = false>
-__global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0, int64_t zappend, int seg0, Publish pub)
+// WPC (round 6): waves per chain -- 2 at 8 chains per block, where the point tiles of 16 chains no longer fit LDS (d > ~228 at 5 tries): the
+// tries of a phase are dealt to the chain's two waves, all 16 waves share the likelihood units, the chain's first wave selects and makes
+// the Metropolis step (as in k_generations: two more barriers per generation keep the base point and the new state consistent between them).
+template <int NRT, bool TRI, int CH, bool K1 = false, bool PB = false, int WPC = 1>
+__global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0, int64_t zappend, int seg0, Publish pub)
 {
-    constexpr int NCH = NRT > 8 ? 2 : 1, NT = 64 * CH;          // (NRT = 8, ld = 128: one chunk -- the kernel also serves 113..128 dimensions, where the
+    static_assert(WPC == 1 || !K1, "one try per generation: one wave per chain");
+    constexpr int NCH = NRT > 8 ? 2 : 1, NT = 64 * CH * WPC;    // (NRT = 8, ld = 128: one chunk -- the kernel also serves 113..128 dimensions, where the
                                                                 //  matrix in LDS leaves room for the point tiles of 8 chains only)
     double* const publish = pub.to;
     const Params& p = *pp;
@@ -46,7 +50,8 @@ __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __rest
     const double* Mg = TRI ? p.Mtp : p.Mt;           // the matrix, in global memory (L2): packed triangle / transposed square [ld][ld]
     const int LDMg = ld;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int cl = wv;
+    const int cl = WPC == 1 ? wv : wv / WPC;                            // chain inside the block; this wave's number among the chain's waves (rotated per chain:
+    const int sub = WPC == 1 ? 0 : ((wv % WPC) + cl) % WPC;             //  the first waves of the chains spread over the SIMDs)
     const int cg = pub.c0 + blockIdx.x * CH + cl;
     const bool active = cg < pub.c1;
     const int c = min(cg, pub.c1 - 1);
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __rest
         if ((int)threadIdx.x < p.ngamma) probs[p.ncr + threadIdx.x] = pub.sh[3 * p.ncr + threadIdx.x];
     }
     for (int i = threadIdx.x; i < p.ngamma * d; i += NT) gts[i] = p.gtab[(size_t)(i / d) * p.depairs * d + (i % d)];
-    if (lane == 0) { st[4 * cl] = p.lprior[c]; st[4 * cl + 1] = p.llike[c]; st[4 * cl + 2] = 0.0; dec[8 * cl + 7] = chain_T(p, c); }
+    if (lane == 0 && sub == 0) { st[4 * cl] = p.lprior[c]; st[4 * cl + 1] = p.llike[c]; st[4 * cl + 2] = 0.0; dec[8 * cl + 7] = chain_T(p, c); }
     __syncthreads();
 
     auto generation_draws = [&](uint32_t g_) {          // lane s holds slot s of the chain's wave-uniform draws of generation g_
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __rest
                 u.u_snk = u53(w0.x, w0.y); u.u_cr = u53(w0.z, w0.w); u.u_de = u53(w1.x, w1.y); u.u_glev = u53(w1.z, w1.w);
                 u.u_sel = u53(w2.x, w2.y); u.u_acc = u53(w2.z, w2.w);
                 f = step_flags_from(p, u, probs, probs + p.ncr);                     // Dream.py:246-256
-                if (lane == 0) {
+                if (lane == 0 && sub == 0) {
                     double* dc = dec + 8 * cl;
                     dc[0] = u.u_sel; dc[1] = u.u_acc; dc[2] = f.snk ? 1.0 : 0.0; dc[3] = (double)f.cr_idx; dc[4] = (double)f.glev;
                     if (PB) dc[5] = (double)f.delta;
@@ -117,53 +122,59 @@ __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __rest
                 double lp = -__builtin_huge_val();
                 if (lane < k) {                                                      // likelihoods of the chain's k points, mt_choose_proposal_pt (:291)
                     const double lk = nan_to_ninf(p.logF - 0.5 * q_sum(lane * CH + cl));
-                    sL[cl * k + lane] = lk;
+                    if (sub == 0) sL[cl * k + lane] = lk;
                     lp = sP[cl * k + lane] + dec[8 * cl + 7] * lk;
                 }
                 bool fin;
                 const int sel = mt_select_vals(k, lp, u_sel, lane, &fin);
-                if (lane == 0) st[4 * cl + 2] = (double)(sel | (fin ? 256 : 0));
+                if (lane == 0 && sub == 0) st[4 * cl + 2] = (double)(sel | (fin ? 256 : 0));
                 const double* row = region + (size_t)sel * tstride;
 #pragma unroll
                 for (int it = 0; it < NCH; ++it) {
                     const int jj = 128 * it + 2 * lane;
                     base[it][0] = jj < d ? row[jj] : 0.0; base[it][1] = jj + 1 < d ? row[jj + 1] : 0.0;
                 }
+                if (WPC > 1) __syncthreads();                                        // every wave of the chain holds the base point before any try row is rewritten
+                if (sub == 0) {
 #pragma unroll
-                for (int it = 0; it < NCH; ++it) {                                   // the selected proposal now sits in tile 0 (each lane moves its own values)
-                    const int jj = 128 * it + 2 * lane;
-                    if (jj < d) region[jj] = base[it][0];
-                    if (jj + 1 < d) region[jj + 1] = base[it][1];
+                    for (int it = 0; it < NCH; ++it) {                               // the selected proposal now sits in tile 0 (each lane moves its own values)
+                        const int jj = 128 * it + 2 * lane;
+                        if (jj < d) region[jj] = base[it][0];
+                        if (jj + 1 < d) region[jj + 1] = base[it][1];
+                    }
                 }
             }
             const bool snk_s = __builtin_amdgcn_readfirstlane((int)f.snk) != 0;
             const double* grow = PB ? gamma_row(p, f.glev, f.delta) : gts + (size_t)(__builtin_amdgcn_readfirstlane(f.glev) - 1) * d;
             const int n = k - phase;
+            const int i0 = WPC == 1 ? 0 : (sub * n) / WPC, i1 = WPC == 1 ? n : ((sub + 1) * n) / WPC;     // this wave's tries
             double* slp = phase ? rS + cl * (k - 1) : sS + cl * k;
             double* prp = phase ? rP + cl * (k - 1) : sP + cl * k;
             if (snk_s) __builtin_amdgcn_s_setprio(3);      // a snooker set is the longest path to the block's barrier
-            if (PB) propose_set<NCH, false, true, 0>(p, phase, g, M, c, gc, 0, n, n, lane, base, grow, snk_s, f.cr_idx, f.delta, f.glev, ds,
+            if (i0 < i1) {
+            if (PB) propose_set<NCH, false, true, 0>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, snk_s, f.cr_idx, f.delta, f.glev, ds,
                                                      region + (size_t)phase * tstride, tstride, slp, K1 ? st + 4 * cl + 3 : nullptr, prp, nullptr);
             else
-            propose_set<NCH, false, false, K1 ? 2 : 1>(p, phase, g, M, c, gc, 0, n, n, lane, base, grow, snk_s, f.cr_idx, 1, f.glev, ds,
+            propose_set<NCH, false, false, K1 ? 2 : 1>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, snk_s, f.cr_idx, 1, f.glev, ds,
                                                        region + (size_t)phase * tstride, tstride, slp, K1 ? st + 4 * cl + 3 : nullptr, prp, nullptr);   // (k = 1: log |x - z|^(d-1) of the current point, :328-329)
+            }
             if (snk_s) __builtin_amdgcn_s_setprio(0);
             if (phase == nph - 1 && !last) dsn = generation_draws(g + 1u);
             __syncthreads();                                                         // points visible
             {   // mt_evaluate_logps :278, :302 -- the (point tile, row tile) units, A operand from L2
                 const int row0 = phase ? CH : 0, ntl = (n * CH + 15) / 16;
                 if (TRI) {
-                    if (p.mu_zero) mfma_units_d2<NRT, true>(p, Mg, Pt, mus, qb, row0, ntl, wv, CH, lane, L.LDP);
-                    else mfma_units_d2<NRT, false>(p, Mg, Pt, mus, qb, row0, ntl, wv, CH, lane, L.LDP);
+                    if (p.mu_zero) mfma_units_d2<NRT, true>(p, Mg, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, L.LDP);
+                    else mfma_units_d2<NRT, false>(p, Mg, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, L.LDP);
                 } else {
-                    if (p.mu_zero) mfma_units<NRT, TRI, true>(p, Mg, Pt, mus, qb, row0, ntl, wv, CH, lane, LDMg, L.LDP);
-                    else mfma_units<NRT, TRI, false>(p, Mg, Pt, mus, qb, row0, ntl, wv, CH, lane, LDMg, L.LDP);
+                    if (p.mu_zero) mfma_units<NRT, TRI, true>(p, Mg, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, LDMg, L.LDP);
+                    else mfma_units<NRT, TRI, false>(p, Mg, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, LDMg, L.LDP);
                 }
             }
             __syncthreads();                                                         // q visible
         }
         // ---- Metropolis step (:305-347), trace (core.py:114-116), record_history (:919-938)
-        {
+        if (sub == 0) {
             const double* dc = dec + 8 * cl;
             const double u_acc = dc[1];
             const bool snk = dc[2] != 0.0;
@@ -231,6 +242,7 @@ __global__ __launch_bounds__(64 * CH) void k_generations_d2(const Params* __rest
         }
         // (one wave per chain: no barrier here -- the next generation's first phase only touches each wave's own chain's rows and scalars;
         //  the state row in HBM was written by this wave and is read by this wave)
+        if (WPC > 1) __syncthreads();                                                // the chain's other wave reads the new state (same CU: its stores are drained before the barrier)
         if (app) { next_app += p.thin; M += (uint32_t)p.N; }
     }
 }

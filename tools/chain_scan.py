@@ -8,7 +8,7 @@ d, k = 100, 5
 i = np.arange(1, d + 1.0)
 P = np.linalg.inv((.5 * np.eye(d) + .5) * np.sqrt(np.outer(i, i)))
 U = np.linalg.cholesky((P + P.T) / 2).T
-for N in (256, 512, 1024, 2048, 3072, 4096, 5000, 8192, 16384, 32768):
+for N in ([int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else (256, 512, 1024, 1536, 2048, 2560, 3072, 3584, 4096, 5000, 6144, 8192, 16384, 32768)):
     Z0 = np.random.default_rng(3).uniform(-5, 15, (max(1000, 2 * N), d))
     gens = 400
     e = G.Engine(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (gens // 10 + 30), trace_capacity=0, seed=5, history_lag=int(os.environ.get('DZ_SCAN_LAG', '1')))

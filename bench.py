@@ -31,8 +31,11 @@ handles / the RCCL unique id) -- no torch in the process (its first import on a 
 torch.distributed/gloo instead.  The engine itself is libdreamzs.so (HIP; copy-engine peer pushes or RCCL), through ctypes.
 After the timed blocks of an N>1 run every rank reduces its replica of the archive to a 64-bit checksum on the device
 (dz_history_checksum); the line carries "replicas_identical" and the exit code is 3 if they are not.
-history_lag (appended rows become sampleable L appends late) is 1 at EVERY N, so that the 1 -> 8 curve is one algorithm; at N = 1
-the lockstep schedule (lag 0) is timed beside it: `value_history_lag0`.
+history_lag (appended rows become sampleable L appends late) is 3 at EVERY N and a launch of the persistent kernels holds two history
+appends (20 generations) at EVERY N (round 6; --appends-per-launch), so that the 1 -> 8 curve is one algorithm AND one launch structure:
+with the copy engines pushing a launch's rows while the next launch computes, no generation of that next launch may sample them, which
+two appends per launch meet from lag 3 on (rounds 3-5 ran lag 1: 20 generations per launch on one GPU, 10 on several).  At N = 1 the
+lockstep schedule (lag 0, 10 generations per launch) is timed beside it: `value_history_lag0`.
 
 Prints ONE JSON line on rank 0.
 """
@@ -58,6 +61,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6 # v_mfma_f64_16x16x4_f64: 64 cycles per instruction
                              # equal to the FP64 vector rate -- the guide's table has no FP64 row
 PROFILE_TAG = next((t for t in ("r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", t + "_pmc_summary.json"))), "r04")
                              # profiles/<tag>_traffic.json, profiles/<tag>_pmc_summary.json (tools/collect_profiles.sh)
+STRONG_CHAINS = 32768        # BASELINE configs[3]: "8xMI355X: 32768 chains, 100D MVN ... report 1/2/4/8 scaling"
 ENGINE_CLOCK_HZ = 2.4e9      # MI355X peak engine clock (MI355X_MICROARCH.md); the headline kernel's cycle stamps give 2.35 GHz under load
 
 
@@ -245,11 +249,14 @@ def parse_args(argv=None):
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-matrix (reference formula) pass")
     ap.add_argument("--no-events", action="store_true", help="do not time individual kernels with HIP events")
     ap.add_argument("--event-generations", type=int, default=400,
-                    help="generations of the event-timed pass (at least --steps): 400 generations are 20 launches of the persistent kernel (20 generations each at history_lag 1)")
+                    help="generations of the event-timed pass (at least --steps): 400 generations are 20 launches of the persistent kernel (20 generations each: two history appends per launch)")
     ap.add_argument("--history-lag", type=int, default=None,
-                    help="dz_config.history_lag: appended rows become sampleable this many appends late.  Default 1 at every N (on several "
+                    help="dz_config.history_lag: appended rows become sampleable this many appends late.  Default 3 at every N (on several "
                          "GPUs the row exchange then hides behind a thin-cycle; one GPU runs the same schedule so that the scaling curve is "
                          "one algorithm, and times lag 0 -- the lockstep schedule -- beside it: value_history_lag0)")
+    ap.add_argument("--appends-per-launch", type=int, default=None,
+                    help="history appends one launch of the persistent kernels may hold (DZ_MEGA_SEGS).  Default (history_lag + 1) // 2: what the peer "
+                         "transport allows on several GPUs, applied at every N")
     ap.add_argument("--no-lag0", action="store_true", help="one GPU: skip the extra lag-0 pass")
     ap.add_argument("--adapt", action="store_true",
                     help="crossover adaptation on (BASELINE configs[2]; the reference's default): the first --burnin-generations generations "
@@ -257,7 +264,7 @@ def parse_args(argv=None):
     ap.add_argument("--burnin-generations", type=int, default=800, help="crossover_burnin with --adapt (the reference: niterations / 10)")
     ap.add_argument("--adapt-lag", type=int, default=None,
                     help="dz_config.adapt_lag with --adapt: generation g of the burn-in decides with the crossover probabilities as they were after "
-                         "the updates of generations <= g - 1 - L, so a launch holds L + 1 burn-in generations.  Default (history_lag + 1) thin - 1 (the "
+                         "the updates of generations <= g - 1 - L, so a launch holds L + 1 burn-in generations.  Default appends_per_launch x thin - 1 (the "
                          "launches inside the burn-in hold as many generations as those behind it); the lockstep adaptation (L = 0, one generation per launch) is timed beside it: burnin_value_adapt_lag0")
     ap.add_argument("--control", choices=["socket", "torch"], default=os.environ.get("DZ_BENCH_CONTROL", "socket"),
                     help="rendezvous of a multi-GPU run: plain TCP (default) or torch.distributed/gloo")
@@ -266,6 +273,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-configs", action="store_true",
                     help="one GPU, default workload: skip the `configs` block (BASELINE configs[1], configs[2] as written, the configs[4] shard, each measured "
                          "the same way as the headline in the same run)")
+    ap.add_argument("--no-strong", action="store_true", help="several GPUs: skip the strong-scaling leg (BASELINE configs[3] as written: 32768 chains over the N GPUs)")
     ap.add_argument("--no-rccl-leg", action="store_true", help="several GPUs: skip the second set of timed blocks over the RCCL all-gather (`rccl_value`)")
     ap.add_argument("--rccl-leg", action="store_true", help="one GPU: run the RCCL leg too (a communicator of one rank)")
     args = ap.parse_args(argv)
@@ -276,9 +284,13 @@ def parse_args(argv=None):
         args.rhat_min_generations = args.spinup
         args.rhat_max_generations = max(args.spinup, min(args.rhat_max_generations, 4 * args.spinup))
     if args.history_lag is None:
-        args.history_lag = 1
+        args.history_lag = 3
+    if args.appends_per_launch is None:
+        args.appends_per_launch = max(1, (args.history_lag + 1) // 2)
+    # (the engine's cap on history appends per launch -- one GPU alone could hold history_lag + 1: the same launches at every N)
+    os.environ["DZ_MEGA_SEGS"] = str(args.appends_per_launch)
     if args.adapt_lag is None:      # as many burn-in generations per launch as the launches behind the burn-in hold generations
-        args.adapt_lag = max(0, (args.history_lag + 1) * args.thin - 1)
+        args.adapt_lag = max(0, args.appends_per_launch * args.thin - 1)
     return args
 
 
@@ -292,6 +304,8 @@ def workload_label(args, n_local, world):
         return "BASELINE configs[2] as written"
     if args.target == "mvn" and args.dim == 100 and n_local == 4096:
         return "BASELINE north_star target / configs[3] per-GPU shard"
+    if args.target == "mvn" and args.dim == 100 and n_local * world == 32768:
+        return "BASELINE configs[3] as written (32768 chains) on %d GPU%s: the strong-scaling reading" % (world, "" if world == 1 else "s")
     if args.target == "mvn" and args.dim == 200:
         return "the reference example's own dimension (dream_ex_ndim_gaussian.py:29), not a BASELINE configuration"
     return "variant of the BASELINE workloads"
@@ -341,6 +355,9 @@ def baseline_configs(args):
     res = {}
     for key, over in (("configs[1]", dict(chains_per_gpu=1024)),
                       ("configs[2]", dict(target="mix3", adapt=True, burnin_generations=800)),
+                      # configs[3] as written is 32768 chains over 8 GPUs: its N = 1 point (the strong-scaling anchor; the N > 1 lines carry
+                      # `strong_scaling`: the same 32768 chains over their N GPUs)
+                      ("configs[3] @ 1 GPU", dict(chains_per_gpu=32768, rhat_cap=2000)),
                       ("configs[4] shard", dict(chains_per_gpu=512, dim=1000)),
                       # not a BASELINE configuration: the reference example's own dimension (dream_ex_ndim_gaussian.py:29), 4096 chains
                       ("example d=200", dict(dim=200, rhat_cap=4000))):
@@ -594,6 +611,40 @@ def measure(args, dist, world, rank, sub=False):
                             "position-keyed hash of every element) and the bytes of its crossover probabilities, all-gathered after the run"}
         e.sync()
         dist.barrier()           # every rank is past its last exchange: only now may a rank unmap its buffers
+    strong = None
+    if world > 1 and not sub and not getattr(args, "no_strong", False) and STRONG_CHAINS % world == 0 and args.target == "mvn" and args.dim == 100:
+        # BASELINE configs[3] as written -- 32768 chains, 100-D MVN, "report 1/2/4/8 scaling" -- read as STRONG scaling: the same 32768 chains over
+        # this run's N GPUs (the N = 1 point is `configs["configs[3] @ 1 GPU"]` of the one-GPU line); a second set of engines on the transport
+        # the weak blocks used, a short warm-up from the seed archive, blocks of K generations
+        import copy
+        try:
+            ns_local = STRONG_CHAINS // world
+            a_s = copy.copy(args); a_s.chains_per_gpu = ns_local
+            sblocks = 24
+            e_s = setup_engine(_capi.Engine, a_s, STRONG_CHAINS, ns_local, rank * ns_local, 400 + K * (sblocks + 3) + 4 * args.thin, device=device, trace_capacity=max(K, 200))
+            from pydream_amd.distributed import attach_transport
+            attach_transport(e_s, rank, world, transport=transport, group=dist.group)
+
+            def sbarrier():
+                e_s.sync()
+                dist.barrier()
+                e_s.comm_barrier()
+            e_s.trace_reset(); e_s.step(200); e_s.trace_reset(); e_s.step(190 + (-(390 - 1)) % args.thin)      # (ends a thin-cycle: the blocks are whole launches)
+            sbarrier()
+            st = timed_blocks(e_s, K, min(args.min_timed_ms, 25.0), sbarrier, dist, sblocks)
+            smed = float(np.median(st))
+            hs, rows_s = e_s.history_checksum()
+            got = dist.all_gather_object([hs, rows_s])
+            strong = {"chains_global": STRONG_CHAINS, "chains_per_gpu": ns_local, "n_gpus": world, "value": STRONG_CHAINS * args.multitry * K / smed, "unit": "proposals/s",
+                      "ms_per_step": 1e3 * smed / K, "timed_blocks": len(st), "block_generations": K, "kernel_variant": e_s.last_kernel_variant(), "transport": transport,
+                      "replicas_identical": all(g[0] == got[0][0] and g[1] == got[0][1] for g in got),
+                      "what": "BASELINE configs[3] as written (32768 chains x 100-D MVN) over this run's GPUs: total work fixed as N grows (the top-level "
+                              "`value` is the weak-scaling reading, 4096 chains per GPU); its N = 1 point is configs[\"configs[3] @ 1 GPU\"] of the one-GPU line"}
+            e_s.sync()
+            dist.barrier()
+            e_s.close()
+        except Exception as ex:
+            strong = {"value": None, "note": "strong-scaling leg not run: %s: %s" % (type(ex).__name__, ex)}
     dense = lag0 = rccl = None
     def assemble():
         """the JSON line (rank 0) from what has been measured so far"""
@@ -643,6 +694,8 @@ def measure(args, dist, world, rank, sub=False):
         if replicas is not None:
             out["replicas_identical"] = replicas["identical"]
             out["replica_check"] = replicas
+        if strong is not None:
+            out["strong_scaling"] = strong
         if rccl is not None:
             out["rccl_value"] = rccl.get("value")
             out["rccl_ranks"] = rccl.get("ranks")

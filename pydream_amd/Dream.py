@@ -98,6 +98,15 @@ class Dream():
         self.multitry = 1 if multitry == False else (5 if multitry == True else multitry)      # noqa: E712  (1.0 / 0.0 too, as in the reference)
         if self.multitry == 2:
             raise Exception('multitry=2 fails inside the reference (Dream.py:867-868); use 1 or >= 3.')
+        # What the reference accepts and this engine does not (any integer there: Dream.py:108-122, :148-161, :81-83): said here, when the
+        # sampler is described, with the limit -- not later by dz_create.  The limits are the fixed lane budgets of the GPU kernels: a
+        # generation's multi-try weights, crossover / gamma-level bins and DE pairs are held one per lane of a 64-lane wave, and a
+        # point's dimensions two per lane in at most eight 128-dimension chunks.
+        LIMITS = (('multitry', self.multitry, 32), ('DEpairs', DEpairs, 8), ('nCR', self.nCR, 32), ('gamma_levels', gamma_levels, 32),
+                  ('the total dimension of all variables', d, 1024))
+        for what, value, limit in LIMITS:
+            if value > limit:
+                raise Exception('%s = %d: this GPU engine supports at most %d (the reference, pydream/Dream.py, takes any integer).' % (what, value, limit))
 
         # jump scale 2.38 / sqrt(2 delta d') by (gamma level, number of pairs delta, crossed dimensions d'), halved from one
         # level to the next (Dream.py:172-179)

@@ -29,7 +29,10 @@ def run_dream(parameters, likelihood, nchains=5, niterations=50000, start=None, 
     kwargs: passed to Dream (see Dream).  Extra keys understood here: ``seed`` (int, key of the random
         contract; default drawn from the OS), ``device`` (HIP device ordinal), ``history_lag`` (int, default 0: the rows a
         generation appends to the history are sampled from the next generation on; L >= 1: L appends later -- fewer and
-        longer kernel launches, a few percent faster with a device likelihood; see include/dreamzs.h dz_config.history_lag).
+        longer kernel launches, a few percent faster with a device likelihood; see include/dreamzs.h dz_config.history_lag),
+        ``adapt_lag`` (int, default 0: every generation of the crossover burn-in decides with the probabilities all earlier generations'
+        updates left -- the reference in lockstep; L >= 1: with those of generations <= g - 1 - L, which lets one kernel launch hold
+        L + 1 burn-in generations -- the burn-in then runs nearly as fast as the rest of the run; dz_config.adapt_lag).
 
     Returns
     -------
@@ -66,7 +69,8 @@ def run_dream(parameters, likelihood, nchains=5, niterations=50000, start=None, 
     release_engines()
     try:
         pool = _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=start, mp_context=mp_context,
-                                    seed=kwargs.get('seed'), device=kwargs.get('device', 0), history_lag=kwargs.get('history_lag', 0), live=live)
+                                    seed=kwargs.get('seed'), device=kwargs.get('device', 0), history_lag=kwargs.get('history_lag', 0),
+                                    adapt_lag=kwargs.get('adapt_lag', 0), live=live)
     except BaseException:
         if live is not None:              # (claimed out of the parked table: nobody else would close it -- bad nchains / start shape, an allocation failing in continue_run)
             live.close()
@@ -102,7 +106,7 @@ def _signature(step, kwargs, nchains, likelihood, engine):
     pri = None if dev_prior is None else tuple(np.asarray(a).tobytes() for a in dev_prior)
     return (nchains, step.total_var_dimension, int(step.multitry), len(step.DEpairs), int(step.nCR), int(step.ngamma), int(step.history_thin),
             bool(step.adapt_crossover), bool(step.adapt_gamma), bool(step.boundaries), float(step.lamb), float(step.zeta), float(step.snooker),
-            float(step.p_gamma_unity), int(kwargs.get('device', 0)), int(kwargs.get('history_lag', 0)), bool(getattr(step, 'parallel', False)),
+            float(step.p_gamma_unity), int(kwargs.get('device', 0)), int(kwargs.get('history_lag', 0)), int(kwargs.get('adapt_lag', 0)), bool(getattr(step, 'parallel', False)),
             np.asarray(step.mins).tobytes() if step.boundaries else None, np.asarray(step.maxs).tobytes() if step.boundaries else None,
             np.asarray(step.gamma_arr).tobytes(), pri, id(likelihood))
 
@@ -374,7 +378,7 @@ def _mp_dream_init(engine, nchains):
 
 
 def _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=None, mp_context=None, seed=None, device=0,
-                         chain_offset=0, nchains_local=None, engine_cls=None, history_lag=0, live=None):
+                         chain_offset=0, nchains_local=None, engine_cls=None, history_lag=0, live=None, adapt_lag=0):
     """Validate, size and allocate the shared sampler state (core.py:250-314) -- in HBM.
     `live`: the engine of the run whose files this restart would load (run_dream): continued in place, nothing uploaded."""
     min_njobs = (2 * len(step_instance.DEpairs)) + 1
@@ -421,7 +425,7 @@ def _setup_mp_dream_pool(nchains, niterations, step_instance, start_pt=None, mp_
                        depairs=len(step_instance.DEpairs), ncr=int(step_instance.nCR), ngamma=int(step_instance.ngamma),
                        history_thin=int(thin), crossover_burnin=int(min(step_instance.crossover_burnin, 2 ** 31 - 1)),
                        adapt_crossover=int(bool(step_instance.adapt_crossover)), adapt_gamma=int(bool(step_instance.adapt_gamma)),
-                       hardboundaries=int(bool(step_instance.boundaries)), schedule=2, device=int(device), history_lag=int(history_lag),
+                       hardboundaries=int(bool(step_instance.boundaries)), schedule=2, device=int(device), history_lag=int(history_lag), adapt_lag=int(adapt_lag),
                        history_capacity=len(seed_rows) + nchains * n_appends, trace_capacity=trace_cap, seed=int(seed),
                        lamb=float(step_instance.lamb), zeta=float(step_instance.zeta), snooker=float(step_instance.snooker),
                        p_gamma_unity=float(step_instance.p_gamma_unity))

@@ -498,10 +498,13 @@ int peer_check(dz_engine* e)
     return 0;
 }
 // before generations that sample the archive: the rows of every append that is visible now have arrived from every rank
-int ensure_visible(dz_engine* e)
+// (ahead: history appends the launch makes itself in front of its last generation -- the generations behind the j-th of them sample the rows
+//  of one more append)
+int ensure_visible(dz_engine* e, int ahead = 0)
 {
     if (!e->peer_on) return 0;
-    const int64_t need = e->napp - std::min<int64_t>(e->napp, (int64_t)e->c.history_lag);
+    const int64_t made = e->napp + ahead;
+    const int64_t need = made - std::min<int64_t>(made, (int64_t)e->c.history_lag);
     if (need > e->z_gated) { DZCK(peer_gate(e, XK_Z, (unsigned long long)need)); e->z_gated = need; }
     return 0;
 }
@@ -1009,6 +1012,17 @@ int upload_params(dz_engine* e)
     return 0;
 }
 bool publishing(const dz_engine* e, uint32_t g) { return e->adapt && (int64_t)g < (int64_t)e->p.burnin + 1; }      // Dream.py:364
+// History appends one launch of the persistent kernels may hold (the last one at its end), a: a generation behind i appends samples the rows
+// of the first i - lag of them, and no generation of a launch may sample rows the launch itself writes (blocks do not meet): a <= lag + 1.
+// Several GPUs (round 6): the rows the launch's own chains append travel AFTER the launch -- by an all-gather or through the host at once
+// (then a <= lag + 1 as well: the exchange stays exposed, between two launches), or by the copy engines while the next launch computes: that
+// launch must not sample them either, so 2 a - 1 <= lag (lag 1: one append per launch; lag 3: two, the 20 generations per launch one GPU runs).
+int mega_appends_per_launch(const dz_engine* e)
+{
+    const int lag = e->c.history_lag;
+    const int a = (e->world > 1 && e->peer_on) ? (lag + 1) / 2 : lag + 1;
+    return std::max(1, std::min(a, e->mega_segs));
+}
 // adapt_lag >= 1: can a launch hold several burn-in generations?  One GPU, and a kernel instantiation that makes its block's unit sums
 // generation by generation (blocks of 16 chains = one unit): the mixture kernel's MG instantiations
 size_t mix_multi_lds(const dz_engine* e)
@@ -1033,10 +1047,10 @@ int mega_segment(const dz_engine* e, uint32_t g, int64_t remaining)
     if (pub0 && !e->mega_burnin) return 0;
     const int maxg = pub0 ? std::min(e->c.adapt_lag + 1, e->mega_max_gen) : e->mega_max_gen;
     // A launch ends with a history append -- unless the rows it writes are not sampleable yet anyway (history_lag >= 1, every lagged append
-    // already made): on one GPU, where no exchange has to follow an append, the kernel then makes the append itself and runs on, up to
-    // lag + 1 appends per launch (the generations behind the j-th one sample j * N more rows: all of them written before the launch).
+    // already made): the kernel then makes the append itself and runs on, up to mega_appends_per_launch of them (the generations behind the
+    // j-th one sample j * N more rows: all of them written -- and, sharded, received -- before the launch).
     const int lag = e->c.history_lag;
-    int segs = (e->world == 1 && lag >= 1 && e->napp >= lag) ? std::min(lag + 1, e->mega_segs) : 1;
+    int segs = (lag >= 1 && e->napp >= lag) ? mega_appends_per_launch(e) : 1;
     segs = (int)std::max<int64_t>(1, std::min<int64_t>(segs, (e->c.history_capacity - e->M) / std::max(1, e->p.N)));      // (an archive sized to the last append: no launch asks for more rows than one append at a time would)
     int n = 0, apps = 0;
     for (uint32_t gg = g; n < remaining && n < maxg; ++gg) {
@@ -1055,11 +1069,15 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
     const bool append_last = napps > 0;
     {   // no generation of the launch may sample rows the launch itself writes: at most history_lag appends in front of any generation
         const bool ends_with_one = ((g + (uint32_t)n - 1) % (uint32_t)p.thin) == 0;
-        if (napps > 1 && (e->world != 1 || e->napp < e->c.history_lag || napps > e->c.history_lag + (ends_with_one ? 1 : 0))) return fail("internal: too many history appends in one launch");
+        const int allowed = mega_appends_per_launch(e);
+        if (napps > 1 && (e->napp < e->c.history_lag || napps > allowed - (ends_with_one ? 0 : 1))) return fail("internal: too many history appends in one launch");
     }
     if (append_last && e->M + (int64_t)napps * p.N > e->c.history_capacity) return fail("history capacity exceeded");
     DZCK(join_all(e));
-    DZCK(ensure_visible(e));
+    {   // the rows the launch samples have arrived: its last generation may sit behind all but the last of its own appends
+        const bool ends_with_one = ((g + (uint32_t)n - 1) % (uint32_t)p.thin) == 0;
+        DZCK(ensure_visible(e, std::max(0, napps - (ends_with_one ? 1 : 0))));
+    }
     const bool publish = publishing(e, g);            // (then n == 1: mega_segment -- or, adapt_lag >= 1 and burnin_multi, up to adapt_lag + 1)
     const bool ring = e->c.adapt_lag > 0;
     const bool multi = publish && ring && burnin_multi(e);      // the launch applies the pending updates itself and makes its units' sums generation by generation

@@ -468,7 +468,8 @@ def run_dream_sharded(parameters, likelihood, nchains=8, niterations=1000, start
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
     pool = _setup_mp_dream_pool(nchains, niterations, step, start_pt=start, seed=seed, device=device,
-                                chain_offset=off, nchains_local=nl, engine_cls=engine_cls, history_lag=kwargs.get('history_lag', 0))
+                                chain_offset=off, nchains_local=nl, engine_cls=engine_cls, history_lag=kwargs.get('history_lag', 0),
+                                adapt_lag=kwargs.get('adapt_lag', 0))
     try:
         attach_transport(pool.engine, rank, world, transport, group)
         save = step.save_history

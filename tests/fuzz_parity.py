@@ -43,7 +43,7 @@ def draw_config(rng, long=False, dims=None, chains=None):
     if prior == "uniform_open" and k == 1:
         prior = "uniform"
     cfg = dict(d=d, N=N, k=k, depairs=depairs, ngamma=ngamma, ncr=ncr, adapt_cr=adapt_cr, adapt_g=adapt_g, burnin=burnin, n=n, lk=lk, prior=prior,
-               thin=int(rng.choice([1, 2, 5, 10, 10])), lag=int(rng.choice([0, 0, 0, 1, 2])), snooker=float(rng.choice([0.0, 0.1, 0.1, 0.4])),
+               thin=int(rng.choice([1, 2, 5, 10, 10])), lag=int(rng.choice([0, 0, 0, 1, 2, 3])), snooker=float(rng.choice([0.0, 0.1, 0.1, 0.4])),
                pgu=float(rng.choice([0.0, 0.2, 0.2, 0.6])), lamb=float(rng.choice([0.05, 0.2])), zeta=float(rng.choice([1e-12, 1e-6])),
                zero_mean=int(rng.random() < 0.5), J=int(rng.choice([2, 3])), extra_rows=int(rng.integers(0, 40)), seed=int(rng.integers(1, 2 ** 31 - 1)))
     # parallel tempering (core.py:131-248): the reference's ladder T_i = 0.001^(i/N), one swap attempt per generation (S2 only, no lag)

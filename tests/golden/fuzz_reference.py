@@ -65,7 +65,7 @@ def draw_case(rng):
         kw["hardboundaries"] = False
     elif rng.random() < 0.2:
         kw["hardboundaries"] = False if prior in ("flat", "normal") else True
-    lag = int(rng.choice([0, 0, 1, 2])) if schedule == 2 else 0
+    lag = int(rng.choice([0, 0, 1, 2, 3])) if schedule == 2 else 0
     c = dict(d=d, N=N, G=G, k=k, schedule=schedule, seed=int(rng.integers(1, 2 ** 31 - 1)), target=target, dream_kwargs=kw, prior=prior,
              rng_seed=int(rng.integers(0, 2 ** 31 - 1)), history_lag=lag)
     if schedule == 2 and (adapt_cr or adapt_g) and (adapt_lag_arm or rng.random() < 0.5):

@@ -837,6 +837,10 @@ def lag_cases():
                dream_kwargs=dict(adapt_crossover=True, crossover_burnin=40, history_thin=5, snooker=.2))
     trace_case("trace_s2_lag2_k1", d=6, N=5, G=90, k=1, schedule=2, seed=43, target=("mvn",), history_lag=2,
                dream_kwargs=dict(adapt_crossover=False, crossover_burnin=10 ** 9, history_thin=3))
+    # (round 6) history_lag = 3: what bench.py runs at every N from round 6 on -- two appends per launch of the persistent kernels on several GPUs
+    # too, the copy engines' pushes of a launch's rows hidden behind the whole next launch (include/dreamzs.h dz_config.history_lag)
+    trace_case("trace_s2_lag3", d=10, N=5, G=120, k=5, schedule=2, seed=47, target=("mvn",), history_lag=3,
+               dream_kwargs=dict(adapt_crossover=True, crossover_burnin=30, history_thin=4, snooker=.2))
 
 
 if __name__ == "__main__":

@@ -91,8 +91,12 @@ def main():
     group = socket_group_from_env(timeout=240.0)
     e = build(config, rank, world, G, lag, device=int(os.environ.get("DZ_SHARD_DEVICE", "0")), M=np.load(os.path.join(outdir, "matrix.npy")))
     attach_transport(e, rank, world, transport=transport, group=group)
+    e.profile_enable(True); e.profile_reset()
     e.step(G)
+    launches = e.profile_get("generations")[1]          # launches of the persistent kernels
+    e.profile_enable(False)
     out = results(e, G, with_history=(rank == 0))
+    out["launches"] = np.array([launches])
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
     e.sync()
     group.barrier()                  # a rank's buffers stay mapped until no peer can still be writing into them

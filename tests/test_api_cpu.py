@@ -71,6 +71,55 @@ def test_option_handling():
         Dream(model=m, multitry=2)
 
 
+def test_limits_of_the_engine_are_said_at_construction():
+    """The reference takes any integer for multitry, DEpairs, nCR, gamma_levels and any dimension (Dream.py:81-83, :108-122, :148-161); the
+    GPU kernels have fixed lane budgets.  The user hears it from Dream(...), with the limit, not from dz_create in the middle of run_dream."""
+    p, l = multidmodel()
+    m = Model(l, p)
+    for kw, what in ((dict(multitry=33), "multitry = 33"), (dict(DEpairs=9), "DEpairs = 9"), (dict(gamma_levels=40), "gamma_levels = 40")):
+        with pytest.raises(Exception, match=what + ": this GPU engine supports at most"):
+            Dream(model=m, **kw)
+    assert Dream(model=m, multitry=32, DEpairs=8, gamma_levels=32).multitry == 32
+    big = Model(simple_likelihood, [FlatParam(np.zeros(1025))])
+    with pytest.raises(Exception, match="total dimension of all variables = 1025"):
+        Dream(model=big)
+    assert Dream(model=Model(simple_likelihood, [FlatParam(np.zeros(1024))]), nCR=32).nCR == 32
+    with pytest.raises(Exception, match="nCR = 33"):
+        Dream(model=Model(simple_likelihood, [FlatParam(np.zeros(64))]), nCR=33)
+
+
+def test_adapt_lag_goes_through_run_dreams_own_sequence(tmp_path, monkeypatch):
+    """`adapt_lag` (and `history_lag`) as run_dream keywords reach the engine's configuration: core._setup_mp_dream_pool ->
+    _sample_dream_batched with the oracle as the engine gives the samples of an oracle engine configured by hand, and other samples
+    than adapt_lag = 0."""
+    from oracle import oracle as O
+    from pydream_amd.core import _sample_dream_batched, _setup_mp_dream_pool
+    monkeypatch.chdir(tmp_path)
+    d, N, G = 6, 8, 80
+    P = H.mvn_precision(d)
+    like = MVNormalLogLike(P, factorize=False)
+    Z0 = H.seed_history(40, d, 5)
+    np.save("seed.npy", Z0)
+
+    def run(lag):
+        step = Dream(model=Model(like, [FlatParam(np.zeros(d))]), verbose=False, multitry=5, history_file="seed.npy", save_history=False, crossover_burnin=60)
+        pool = _setup_mp_dream_pool(N, G, step, start_pt=list(Z0[:N]), seed=21, engine_cls=O.Engine, history_lag=1, adapt_lag=lag)
+        try:
+            pool._initializer(*pool._initargs)
+            assert int(pool.engine.cfg.adapt_lag) == lag and int(pool.engine.cfg.history_lag) == 1
+            s, _ = _sample_dream_batched(pool.engine, step, G, False, 10)
+        finally:
+            pool.close(); pool.join()
+        return np.array(s)
+    a, b = run(4), run(0)
+    e = O.Engine(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * (G // 10 + 2), trace_capacity=G, seed=21, adapt_crossover=1, crossover_burnin=60,
+                 adapt_lag=4, history_lag=1)
+    e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mvn(np.zeros(d), P, 0, float(like.log_F) if hasattr(like, "log_F") else 0.0)
+    e.step(G)
+    np.testing.assert_array_equal(a, e.get_trace(0, G)["X"].transpose(1, 0, 2))
+    assert not np.array_equal(a, b)
+
+
 def test_priors_and_model():
     """parameters.py:37-47, 62-63; model.py:17-32"""
     p, l = multidmodel()

@@ -266,7 +266,7 @@ def _launch_ranks(script_args, nranks, env, cwd, timeout):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("config,transport,lag", [("c3", "peer", 1), ("c4", "peer", 1), ("c3", "peer", 0), ("c4", "host", 0)])
+@pytest.mark.parametrize("config,transport,lag", [("c3", "peer", 3), ("c3", "peer", 1), ("c4", "peer", 1), ("c4", "peer", 3), ("c3", "peer", 0), ("c4", "host", 0), ("c3", "host", 1)])
 def test_baseline_multi_gpu_configs_at_full_size_equal_the_unsharded_engine(tmp_path, config, transport, lag):
     """BASELINE configs[3] (8 ranks x 4096 chains x 100-D MVN = 32768 chains) and configs[4] (8 x 512 chains x 1000-D correlated MVN)
     AS WRITTEN, the eight ranks time-sharing the test box's one MI355X: every rank's states, cached log densities and decision
@@ -277,7 +277,9 @@ def test_baseline_multi_gpu_configs_at_full_size_equal_the_unsharded_engine(tmp_
     engine, which runs different block sizes and, at 1000-D, different tile shapes of the likelihood product than the shards do.)"""
     from pydream_amd import _capi
     from tests import shard_rank as SR
-    G, W = 25, 8
+    # (round 6) lag 3 over the peer transport, lag 1 through the host: sharded launches that run on past an append -- two per launch, as on one
+    # GPU (dz_engine.hip mega_appends_per_launch) -- over 45 generations, the rows of the launches' first appends among those sampled
+    G, W = (45 if (lag == 3 or (transport == "host" and lag == 1)) and config == "c3" else 25), 8
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DZ_PEER_TIMEOUT_S="200", DZ_SHARD_DEVICE="0")
     M = SR.matrix(config)
     np.save(tmp_path / "matrix.npy", M)
@@ -287,7 +289,7 @@ def test_baseline_multi_gpu_configs_at_full_size_equal_the_unsharded_engine(tmp_
     ref = SR.results(e, G, with_history=True)
     e.close()
     N, d, _ = SR.CONFIGS[config]
-    assert ref["Z"].shape == (max(10 * d, 2 * N) + 3 * N, d) and ref["moved"].mean() > 0.02
+    assert ref["Z"].shape == (max(10 * d, 2 * N) + ((G - 1) // 10 + 1) * N, d) and ref["moved"].mean() > 0.02
     assert int(ref["checksum"][0]) == _capi.history_checksum_host(ref["Z"])          # the device checksum is the documented sum
     nl = N // W
     for r in range(W):
@@ -298,6 +300,8 @@ def test_baseline_multi_gpu_configs_at_full_size_equal_the_unsharded_engine(tmp_
         for key in ("logp", "moved", "try_idx", "cr_idx", "snooker"):
             np.testing.assert_array_equal(got[key], ref[key][:, sl], err_msg="%s of rank %d" % (key, r))
         assert int(got["rows"][0]) == len(ref["Z"]) and int(got["checksum"][0]) == int(ref["checksum"][0]), "archive replica of rank %d" % r
+        if config == "c3":       # generations 0 | 1-10 | 11-20 | ... one append per launch; with two per launch once `lag` appends are made: 0 | 1-10 | 11-20 | 21-40 | 41-45 (lag 3)
+            assert int(got["launches"][0]) == {(25, 0): 4, (25, 1): 4, (45, 3): 5, (45, 1): 4}[(G, lag)], (int(got["launches"][0]), G, lag)
         if r == 0:
             np.testing.assert_array_equal(got["Z"], ref["Z"])
 
@@ -488,7 +492,8 @@ def test_bench_eight_rank_control_flow_on_one_gpu(tmp_path, transport):
                           "--no-cpu-baseline"], env, str(tmp_path))
     assert d["n_gpus"] == 8 and d["steps"] == 20 and d["scaling"] == "weak"
     assert d["config"]["chains_global"] == 8 * 128 and transport in d["config"]["parallelism"]
-    assert d["history_lag"] == 1 and d["replicas_identical"] is True and len(d["replica_check"]["archive_rows"]) == 8
+    assert d["history_lag"] == 3 and d["replicas_identical"] is True and len(d["replica_check"]["archive_rows"]) == 8
+    assert d["roofline"]["generations_per_launch"] == 20      # (round 6) two history appends per launch on several GPUs as on one
     if transport == "host":
         assert d["transport"] == "host-fallback"          # (a host-staged number is named as such at the top level)
     else:                                                  # eight ranks, each mapping the seven others' archives: seven copy streams per rank
@@ -517,8 +522,8 @@ def test_bench_line_has_the_contracted_fields(tmp_path):
                 "roofline", "cpu_baseline", "kernel_variant", "rhat_max", "convergence"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["unit"] == "proposals/s" and d["dtype"] == "f64" and d["vs_baseline"] is None
-    # one GPU runs the schedule the scaling runs use (history_lag 1) and times the lockstep schedule (lag 0) beside it
-    assert d["history_lag"] == 1 and d["config"]["history_lag"] == 1 and d["value_history_lag0"] > 0 and d["history_lag0"]["kernel_variant"] == d["kernel_variant"]
+    # one GPU runs the schedule the scaling runs use (history_lag 3, two appends per launch) and times the lockstep schedule (lag 0) beside it
+    assert d["history_lag"] == 3 and d["config"]["history_lag"] == 3 and d["value_history_lag0"] > 0 and d["history_lag0"]["kernel_variant"] == d["kernel_variant"]
     assert "replicas_identical" not in d
     assert abs(d["value"] - 512 * 5 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
     r = d["roofline"]
@@ -552,7 +557,12 @@ def test_bench_default_line_carries_every_single_gpu_baseline_config(tmp_path):
     d = json.loads([l for l in res.stdout.splitlines() if l.startswith('{"metric"')][0])
     assert "configs[3] per-GPU shard" in d["config"]["workload"]
     c = d["configs"]
-    assert set(c) == {"configs[1]", "configs[2]", "configs[4] shard", "example d=200"}
+    assert set(c) == {"configs[1]", "configs[2]", "configs[3] @ 1 GPU", "configs[4] shard", "example d=200"}
+    # (round 6) configs[3] as written is 32768 chains: its one-GPU point, the anchor of the strong-scaling reading (`strong_scaling` in the N > 1 lines)
+    x = c["configs[3] @ 1 GPU"]
+    assert "error" not in x, x
+    assert "32768 chains" in x["workload"] and "strong-scaling" in x["workload"] and x["kernel_variant"] == "k_generations<7,tri,xlds,16,1,lean>"
+    assert x["value"] > 0 and 0 < x["roofline"]["frac"] < 1 and np.isfinite(x["rhat_run_so_far"])
     assert c["example d=200"]["kernel_variant"] == "k_generations_d2<13,tri,xhbm,16,1,lean>" and c["example d=200"]["value"] > 0
     for key, variant, label in (("configs[1]", "k_generations_w4<7,tri,xlds,4,4,lean,ahead>", "BASELINE configs[1]"),
                                 ("configs[2]", "k_generations_mix", "BASELINE configs[2] as written"),
@@ -564,6 +574,10 @@ def test_bench_default_line_carries_every_single_gpu_baseline_config(tmp_path):
     assert c["configs[1]"]["roofline"]["bound"] == "hbm" and c["configs[4] shard"]["roofline"]["bound"] == "fp64_mfma"
     assert 0 < c["configs[4] shard"]["roofline"]["whole_generation_frac"] < 1
     assert c["configs[2]"]["burnin_value"] > 0 and c["configs[2]"]["value"] > c["configs[2]"]["burnin_value"]
+    # (round 6) the burn-in runs with an adapt_lag -- named in the workload string --, whole launches of 20 generations inside it; the lockstep adaptation beside it
+    b = c["configs[2]"]["burnin"]
+    assert b["adapt_lag"] == 19 and "adapt_lag 19" in c["configs[2]"]["workload"] and b["kernel_variant"] == "k_generations_mix<multi>"
+    assert 0 < c["configs[2]"]["burnin_value_adapt_lag0"] < c["configs[2]"]["burnin_value"] and b["adapt_lag0"]["kernel_variant"] == "k_generations_mix"
     assert not np.allclose(c["configs[2]"]["burnin"]["cr_probs_after_burnin"], 1 / 3.)
 
 
@@ -601,8 +615,8 @@ def test_bench_with_crossover_adaptation_reports_the_burnin_rate(tmp_path):
                          cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     d = json.loads([l for l in res.stdout.splitlines() if l.startswith('{"metric"')][0])
-    assert d["burnin"]["kernel_variant"] == "k_generations_mix" and d["kernel_variant"] == "k_generations_mix"
-    assert d["burnin_value"] > 0 and d["value"] > d["burnin_value"]
+    assert d["burnin"]["kernel_variant"] == "k_generations_mix<multi>" and d["kernel_variant"] == "k_generations_mix" and d["config"]["adapt_lag"] == 19
+    assert d["burnin_value"] > 0 and d["value"] > d["burnin_value"] > d["burnin_value_adapt_lag0"] > 0
     assert not np.allclose(d["burnin"]["cr_probs_after_burnin"], 1 / 3.)          # the probabilities were adapted
 
 
@@ -624,7 +638,8 @@ def test_bench_gpus_2_as_one_command_starts_its_own_ranks(tmp_path):
     lines = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, res.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["transport"] == "peer" and d["history_lag"] == 1, (d.get("transport"), d.get("transport_note"))
+    assert d["n_gpus"] == 2 and d["transport"] == "peer" and d["history_lag"] == 3, (d.get("transport"), d.get("transport_note"))
+    assert d["roofline"]["generations_per_launch"] == 20      # (round 6) the N = 1 line's launches: two history appends each
     assert d["replicas_identical"] is True and len(set(d["replica_check"]["archive_checksums"])) == 1 and len(d["replica_check"]["archive_rows"]) == 2
     assert d["exchange"]["gates"] > 0 and d["exchange_exposed_us_per_cycle"] is not None and d["exchange_exposed_us_per_cycle"] >= 0.0
     assert d["kernel_variant"] == "k_generations_w4<7,tri,xlds,4,4,lean,ahead>"
@@ -634,6 +649,10 @@ def test_bench_gpus_2_as_one_command_starts_its_own_ranks(tmp_path):
         assert key in d, key
     assert (d["rccl_value"] is None and "RCCL leg not run" in d["rccl"]["note"]) or (d["rccl_value"] > 0 and d["rccl_ranks"] == 2 and d["rccl"]["replicas_identical"])
     assert d["exchange_bytes_to_each_peer"]["history_rows"] > 0 and d["exchange_bytes_to_each_peer"]["positions"] == 0
+    # (round 6) BASELINE configs[3] as written, the strong-scaling reading: 32768 chains over the run's GPUs
+    ss = d["strong_scaling"]
+    assert ss["chains_global"] == 32768 and ss["chains_per_gpu"] == 16384 and ss["value"] > 0 and ss["replicas_identical"] is True and ss["transport"] == "peer"
+    assert ss["kernel_variant"] == "k_generations<7,tri,xlds,16,1,lean>"
     from pydream_amd import _capi
     if _capi.device_count() < 2:                           # the refusal: never fewer ranks than asked for
         env.pop("DZ_BENCH_DEVICE")

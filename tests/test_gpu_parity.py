@@ -8,7 +8,7 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 S2_TRACES = ["trace_s2_adapt", "trace_s2_k1_bounds", "trace_s2_k3_bounds", "trace_s2_k3_redraw", "trace_s2_k5_redraw_mvn", "trace_s2_depairs_gamma",
-             "trace_s2_mvn100", "trace_s2_mix3", "trace_s2_restart", "trace_s2_lag1", "trace_s2_lag2_k1",
+             "trace_s2_mvn100", "trace_s2_mix3", "trace_s2_restart", "trace_s2_lag1", "trace_s2_lag2_k1", "trace_s2_lag3",
              "trace_s2_adaptlag1", "trace_s2_adaptlag9_mix", "trace_s2_adaptlag3_gamma"]
 
 
@@ -245,24 +245,28 @@ def test_persistent_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, k, tr
         np.testing.assert_array_equal(a[2], other[2])
 
 
-@pytest.mark.parametrize("N,tri,target,lag,variant", [(4096, 1, "mvn", 1, "k_generations<7,tri,xlds,16,1,lean>"),    # bench.py's headline `value` (history_lag = 1 at every N)
+@pytest.mark.parametrize("N,tri,target,lag,variant", [(4096, 1, "mvn", 3, "k_generations<7,tri,xlds,16,1,lean>"),    # bench.py's headline `value` (history_lag = 3, two appends per launch at every N: round 6)
                                                       (4096, 1, "mvn", 0, "k_generations<7,tri,xlds,16,1,lean>"),    # ... `value_history_lag0`
-                                                      (4096, 0, "mvn", 1, "k_generations<7,dense,xhbm,16,1,lean>"),  # ... `dense_value`
+                                                      (4096, 1, "mvn", 1, "k_generations<7,tri,xlds,16,1,lean>"),    # (rounds 3-5's headline schedule)
+                                                      (4096, 0, "mvn", 3, "k_generations<7,dense,xhbm,16,1,lean>"),  # ... `dense_value`
                                                       (4096, 0, "mvn", 0, "k_generations<7,dense,xhbm,16,1,lean>"),
-                                                      (1024, 1, "mvn", 1, "k_generations_w4<7,tri,xlds,4,4,lean,ahead>"),     # BASELINE configs[1] (the `configs` block of the line)
+                                                      (1024, 1, "mvn", 3, "k_generations_w4<7,tri,xlds,4,4,lean,ahead>"),     # BASELINE configs[1] (the `configs` block of the line)
                                                       (1024, 1, "mvn", 0, "k_generations_w4<7,tri,xlds,4,4,lean,ahead>"),
-                                                      (1024, 0, "mvn", 1, "k_generations_w4<7,dense,xlds,4,4,lean,ahead>"),
-                                                      (2048, 1, "mvn", 1, "k_generations<7,tri,xlds,8,1,lean>"),
-                                                      (4096, 1, "mix3", 1, "k_generations_mix"),                     # BASELINE configs[2] after the burn-in
+                                                      (1024, 0, "mvn", 3, "k_generations_w4<7,dense,xlds,4,4,lean,ahead>"),
+                                                      (2048, 1, "mvn", 3, "k_generations<7,tri,xlds,8,1,lean>"),
+                                                      (3072, 1, "mvn", 3, "k_generations<7,tri,xlds,12,1,lean>"),    # (round 6: 12 chains per block)
+                                                      (4096, 1, "mix3", 3, "k_generations_mix"),                     # BASELINE configs[2] after the burn-in
                                                       (4096, 1, "mix3", 0, "k_generations_mix")])
-def test_the_instantiations_the_bench_times_equal_the_oracle(G, O, N, tri, target, lag, variant):
-    """Exactly what bench.py times -- 100-D, multitry 5, flat prior, bench.py's own engine set-up INCLUDING its history_lag (1 for the
-    driver's `value`, 0 for `value_history_lag0`) -- against the oracle, bit for bit, over 45 generations (four history appends, so that
-    with lag 1 three appends have become sampleable), with the engine reporting which instantiation ran (dz_last_kernel_variant):
-    16 chains per block with one wave per chain needs >= ~2100 chains, which no other oracle comparison reaches."""
+def test_the_instantiations_the_bench_times_equal_the_oracle(G, O, N, tri, target, lag, variant, monkeypatch):
+    """Exactly what bench.py times -- 100-D, multitry 5, flat prior, bench.py's own engine set-up INCLUDING its history_lag (3 for the
+    driver's `value`, with bench.py's two appends per launch; 0 for `value_history_lag0`) -- against the oracle, bit for bit, over 65
+    generations (seven history appends, so that with lag 3 the rows of three of them have been sampled), with the engine reporting which
+    instantiation ran (dz_last_kernel_variant): 16 chains per block with one wave per chain needs >= ~2100 chains, which no other oracle
+    comparison reaches."""
+    monkeypatch.setenv("DZ_MEGA_SEGS", "2")
     import argparse
     import bench
-    n = 45
+    n = 65 if lag == 3 else 45
     args = argparse.Namespace(dim=100, multitry=5, seed=20260929, thin=10, snooker=0.1, target=target, mvn_kind="tri" if tri else "dense",
                               steps=n, warmup=0, history_lag=lag)
     out = []

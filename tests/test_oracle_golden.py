@@ -8,7 +8,7 @@ from tests import helpers as H
 
 TRACES = ["trace_s1_c1", "trace_s1_adapt", "trace_s1_adapt_gamma", "trace_s2_adapt", "trace_s2_k1_bounds", "trace_s2_k3_bounds",
           "trace_s2_k3_redraw", "trace_s2_k5_redraw_mvn",
-          "trace_s2_depairs_gamma", "trace_s2_mvn100", "trace_s2_mix3", "trace_s2_restart", "trace_s2_lag1", "trace_s2_lag2_k1",
+          "trace_s2_depairs_gamma", "trace_s2_mvn100", "trace_s2_mix3", "trace_s2_restart", "trace_s2_lag1", "trace_s2_lag2_k1", "trace_s2_lag3",
           "trace_s2_adaptlag1", "trace_s2_adaptlag9_mix", "trace_s2_adaptlag3_gamma"]
 
 

@@ -526,7 +526,7 @@ def measure(args, dist, world, rank, sub=False):
         ew.close()
 
         def time_burnin(eb, finish):
-            eb.trace_reset(); eb.step(20); eb.sync()
+            eb.trace_reset(); eb.step(20 + (-(20 - 1)) % args.thin); eb.sync()      # (the blocks start right behind a history append, like the timed blocks after the burn-in: whole launches)
             bt = []
             Kb = max(1, min(K, (args.burnin_generations - 30) // 4))
             while eb.generation + Kb < args.burnin_generations - 1 and (1e3 * sum(bt) < args.min_timed_ms or len(bt) < 3) and len(bt) < 400:
@@ -554,7 +554,7 @@ def measure(args, dist, world, rank, sub=False):
         burn = time_burnin(e, True)
         if world == 1 and args.adapt_lag > 0:      # beside it: the lockstep adaptation (adapt_lag 0: one burn-in generation per launch), the same blocks
             a0 = copy.copy(args); a0.adapt_lag = 0
-            e0 = setup_engine(_capi.Engine, a0, n_global, n_local, 0, args.burnin_generations + 40, device=device, trace_capacity=max(K, 20))
+            e0 = setup_engine(_capi.Engine, a0, n_global, n_local, 0, args.burnin_generations + 40, device=device, trace_capacity=max(K, 20 + args.thin))
             b0 = time_burnin(e0, False)
             e0.close()
             burn["adapt_lag0"] = {k_: b0[k_] for k_ in ("value", "ms_per_step", "kernel_variant", "timed_blocks")}

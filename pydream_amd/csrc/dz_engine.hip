@@ -1303,6 +1303,12 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     e->nch = chunks <= 1 ? 1 : chunks <= 2 ? 2 : chunks <= 4 ? 4 : 8;
     e->adapt = cfg->adapt_crossover || cfg->adapt_gamma;
     e->world = cfg->nchains / cfg->nchains_local; e->rank = cfg->chain_offset / cfg->nchains_local;
+    if (const char* cm = (getenv("DZ_CUMASK") && *getenv("DZ_CUMASK")) ? getenv("DZ_CUMASK") : nullptr) {      // measurement switch: every kernel of the engine on the first DZ_CUMASK compute units of each XCD-interleaved numbering
+        const int ncu = std::max(1, atoi(cm));
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < ncu && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
+        HIPCK(hipExtStreamCreateWithCUMask(&e->stream, 8, mask));
+    } else
     HIPCK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     {
         int nl_req = 1;     // chain groups on separate streams; 2 gains ~3% at 4096 chains but shows occasional 2x-slow passes

@@ -1605,12 +1605,22 @@ int dz_set_likelihood_module(dz_engine* e, const char* code_object_path, const c
     if (err != hipSuccess) { (void)hipGetLastError(); return fail(std::string("hipModuleLoad(") + code_object_path + "): " + hipGetErrorString(err) + " (a gfx950 code object is expected: hipcc --offload-arch=gfx950 --genco)"); }
     err = hipModuleGetFunction(&fn, mod, kernel_name);
     if (err != hipSuccess) { (void)hipGetLastError(); (void)hipModuleUnload(mod); return fail(std::string("hipModuleGetFunction(") + kernel_name + "): " + hipGetErrorString(err) + " (the kernel must be extern \"C\")"); }
-    if (e->lk_module) (void)hipModuleUnload(e->lk_module);
-    if (e->d_lk_data) { (void)hipFree(e->d_lk_data); e->d_lk_data = nullptr; }
+    // the new data block first, into a temporary: the engine's module, function and data change together, and only once every step has
+    // succeeded -- a failure leaves the engine as it was (advisor, round 5)
+    void* d_new = nullptr;
     if (data_bytes > 0) {
-        HIPCK(hipMalloc(&e->d_lk_data, (size_t)data_bytes));
-        HIPCK(hipMemcpy(e->d_lk_data, data, (size_t)data_bytes, hipMemcpyHostToDevice));
+        hipError_t me = hipMalloc(&d_new, (size_t)data_bytes);
+        if (me == hipSuccess) me = hipMemcpy(d_new, data, (size_t)data_bytes, hipMemcpyHostToDevice);
+        if (me != hipSuccess) {
+            (void)hipGetLastError();
+            if (d_new) (void)hipFree(d_new);
+            (void)hipModuleUnload(mod);
+            return fail(std::string("dz_set_likelihood_module: data block: ") + hipGetErrorString(me));
+        }
     }
+    if (e->lk_module) { (void)hipModuleUnload(e->lk_module); e->lk_module = nullptr; e->lk_fn = nullptr; }
+    if (e->d_lk_data) { (void)hipFree(e->d_lk_data); e->d_lk_data = nullptr; }
+    e->d_lk_data = d_new;
     e->lk_module = mod; e->lk_fn = fn; e->lk_lanes = lanes_per_point; e->lk_finite = (flags & DZ_LIKE_ALWAYS_FINITE) != 0;
     e->lk = LK_MODULE; e->have_logp = false;
     return 0;

@@ -18,6 +18,7 @@ The control plane (rendezvous, handle / unique-id exchange, the host transport) 
 process group, or None for the default one -- or the built-in ``SocketGroup`` below (plain TCP on one node, no torch in the process:
 what bench.py and the GPU tests use; importing torch costs minutes on a freshly started box).
 """
+import os
 import socket
 import struct
 import time
@@ -407,7 +408,18 @@ def attach_transport(engine, rank, world, transport="rccl", group=None):
         boot = engine.peer_export() if transport == "peer" else (_capi.comm_unique_id() if transport == "rccl" and rank == 0 else None)
     except Exception as ex:
         err = "%s" % ex
-    boots = _gather_objects(boot if not err else None, group)
+    # ... and (advisor, round 5) what decides WHAT the ranks exchange must be the same everywhere: the sampler's configuration, and the
+    # environment switches the engine read at dz_create (whether the burn-in exchanges group sums or positions, how many appends a launch
+    # holds) -- ranks that disagree would issue all-gathers of different sizes and kinds, which hangs or corrupts silently
+    cfg = getattr(engine, "cfg", None)
+    sig = tuple(int(getattr(cfg, f)) for f in ("nchains", "nchains_local", "ndim", "multitry", "depairs", "ncr", "ngamma", "history_thin", "crossover_burnin",
+                                                "adapt_crossover", "adapt_gamma", "history_lag", "adapt_lag", "seed") if cfg is not None and hasattr(cfg, f)) + \
+        tuple(os.environ.get(v, "") for v in ("DZ_ADAPT_GROUPS", "DZ_ADAPT_FUSED", "DZ_MEGA", "DZ_MEGA_BURNIN"))
+    got = _gather_objects((boot if not err else None, sig), group)
+    boots = [g[0] for g in got]
+    if not err and any(g[1] != sig for g in got):
+        err = "the ranks' engines were configured differently (sampler options or DZ_* environment switches): %r on rank %d, %r here" % (
+            next(g[1] for g in got if g[1] != sig), next(i for i, g in enumerate(got) if g[1] != sig), sig)
     if not err:
         try:
             if transport == "peer":
@@ -446,7 +458,8 @@ def run_dream_sharded(parameters, likelihood, nchains=8, niterations=1000, start
     ranks (pass it, or leave it None to have rank 0 draw and broadcast one).
     restart=True continues an earlier run the way run_dream does (pydream/core.py:46-62): every rank loads the history and the adapted
     crossover / gamma-level probabilities from the three files `model_name` names (written by rank 0 of the run before: the archive is
-    replicated) and takes its own slice of `start` -- a list of nchains vectors, the last states of ALL chains."""
+    replicated) and takes its own slice of `start` -- a list of nchains vectors, the last states of ALL chains.  The files are read by
+    EVERY rank: they must lie on a filesystem all ranks see (one node: any directory; several nodes: a shared one)."""
     import os
     rank, world = _rank_world(group)
     if restart:
@@ -474,9 +487,20 @@ def run_dream_sharded(parameters, likelihood, nchains=8, niterations=1000, start
         attach_transport(pool.engine, rank, world, transport, group)
         save = step.save_history
         step.save_history = save and rank == 0          # the archive is replicated: one writer is enough
-        out = _sample_dream_batched(pool.engine, step, niterations, verbose and rank == 0, nverbose)
-        if save and world > 1:
-            _barrier(group)                             # the files are complete before any rank returns (a restart reads them on every rank)
+        # (advisor, round 5) a rank that fails -- rank 0 writing the files to a full disk, a likelihood raising on one shard -- must not
+        # leave the others waiting in a barrier: every rank reports its outcome (the gather is the barrier) and every rank raises if any failed
+        failure, out = "", None
+        try:
+            out = _sample_dream_batched(pool.engine, step, niterations, verbose and rank == 0, nverbose)
+        except Exception as ex:
+            if world == 1:
+                raise
+            failure = "%s: %s" % (type(ex).__name__, ex)
+        if world > 1:
+            outcomes = _gather_objects(failure, group)   # also: the files are complete before any rank returns (a restart reads them on every rank)
+            if any(outcomes):
+                r = next(i for i, x in enumerate(outcomes) if x)
+                raise Exception("run_dream_sharded: rank %d failed: %s" % (r, outcomes[r]))
         if transport == "peer" and world > 1:
             pool.engine.sync()
             _barrier(group)                             # a rank's buffers stay mapped until no peer can still be writing into them

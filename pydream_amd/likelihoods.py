@@ -59,26 +59,50 @@ class GaussianMixtureLogLike:
 KERNEL_SIGNATURE = 'extern "C" __global__ void NAME(const double* X, long long n, int d, int ld, double* like, const void* data)'
 
 
-def compile_device_kernel(source, out_path=None, extra_flags=()):
-    """HIP source text -> a gfx950 code object (.hsaco) for DeviceKernelLogLike: `hipcc --offload-arch=gfx950 --genco`.
+def compile_device_kernel(source, out_path=None, extra_flags=(), arch="gfx950"):
+    """HIP source text -> a code object (.hsaco) for DeviceKernelLogLike: `hipcc --offload-arch=<arch> --genco` (arch: the engine is built
+    for gfx950, the MI355X; the argument is there so that an error names what was asked for).
     -ffp-contract=off is on by default so that a density written with + and * rounds like the same expression in numpy (a host
     likelihood and its device twin then make the same accept / reject decisions bit for bit); pass extra_flags=("-ffp-contract=fast",)
-    to let the compiler fuse.  Returns the path (a file next to nothing in particular: a private temporary directory unless given)."""
+    to let the compiler fuse.  Without out_path the code object is CACHED under a key of (source, flags, arch) in
+    $DREAMZS_KERNEL_CACHE (default ~/.cache/dreamzs_kernels, else the temporary directory): the same source is compiled once, by
+    whichever process or unpickled copy asks first (advisor, round 5: a fresh temporary directory and a fresh hipcc run per call).
+    Returns the path."""
+    import hashlib
     import os
     import subprocess
     import tempfile
-    if out_path is None:
-        out_path = os.path.join(tempfile.mkdtemp(prefix="dreamzs_kernel_"), "likelihood.hsaco")
-    src = out_path + ".hip"
+    text = source if "hip_runtime.h" in source else "#include <hip/hip_runtime.h>\n" + source
+    flags = ["--offload-arch=%s" % arch, "--genco", "--no-gpu-bundle-output", "-O3", "-std=c++17", "-ffp-contract=off"] + list(extra_flags)
+    cached = out_path is None
+    if cached:
+        key = hashlib.sha256(("\0".join(flags) + "\0" + text).encode()).hexdigest()[:32]
+        cdir = os.environ.get("DREAMZS_KERNEL_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "dreamzs_kernels")
+        try:
+            os.makedirs(cdir, exist_ok=True)
+            if not os.access(cdir, os.W_OK):
+                raise OSError("not writable")
+        except OSError:
+            cdir = os.path.join(tempfile.gettempdir(), "dreamzs_kernels_%d" % os.getuid())
+            os.makedirs(cdir, exist_ok=True)
+        out_path = os.path.join(cdir, key + ".hsaco")
+        if os.path.exists(out_path) and os.path.getsize(out_path) > 0:
+            return out_path
+    tmp = "%s.%d.tmp" % (out_path, os.getpid())          # (built beside the target, renamed into place: concurrent builders never see half a file)
+    src = tmp + ".hip"
     with open(src, "w") as f:
-        if "hip_runtime.h" not in source:
-            f.write("#include <hip/hip_runtime.h>\n")
-        f.write(source)
+        f.write(text)
     hipcc = next((c for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc") if c and os.path.exists(c)), "hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "--genco", "--no-gpu-bundle-output", "-O3", "-std=c++17", "-ffp-contract=off"] + list(extra_flags) + ["-o", out_path, src]
-    res = subprocess.run(cmd, capture_output=True, text=True)
+    res = subprocess.run([hipcc] + flags + ["-o", tmp, src], capture_output=True, text=True)
+    try:
+        os.remove(src) if cached else os.replace(src, out_path + ".hip")
+    except OSError:
+        pass
     if res.returncode != 0:
-        raise Exception("hipcc failed for the device likelihood:\n%s" % res.stderr[-4000:])
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        raise Exception("hipcc failed for the device likelihood (--offload-arch=%s):\n%s" % (arch, res.stderr[-4000:]))
+    os.replace(tmp, out_path)
     return out_path
 
 

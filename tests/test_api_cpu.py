@@ -1,6 +1,8 @@
 """Host-side mirror of the reference's Python API (no GPU needed): priors, Model, Gelman_Rubin, the
 Dream constructor's option handling and run_dream's validation errors -- written after the
 reference's own tests (pydream/tests/test_dream.py)."""
+import os
+
 import numpy as np
 import pytest
 from scipy.stats import norm, uniform, gamma as gamma_dist
@@ -246,7 +248,7 @@ def test_gelman_rubin_on_run_dream_shaped_results_copies_nothing():
     assert r.shape == (20,) and np.all(r > 1.0)
 
 
-def test_a_user_kernel_compiles_to_a_gfx950_code_object_that_exports_it(tmp_path):
+def test_a_user_kernel_compiles_to_a_gfx950_code_object_that_exports_it(tmp_path, monkeypatch):
     """pydream_amd.likelihoods.compile_device_kernel (hipcc cross-compiles without a GPU): the example's HIP twin of a Python likelihood
     becomes an ELF code object exporting the extern "C" kernel dz_set_likelihood_module looks up; the host twin is the reference-style
     callable f(x[d]) -> float (pydream/model.py:31)."""
@@ -264,3 +266,10 @@ def test_a_user_kernel_compiles_to_a_gfx950_code_object_that_exports_it(tmp_path
         DeviceKernelLogLike("f", 3)                                                  # neither source nor path
     with pytest.raises(Exception, match="hipcc failed"):
         compile_device_kernel("this is not HIP", str(tmp_path / "bad.hsaco"))
+    # without an output path the code object is cached by (source, flags, architecture): the second request compiles nothing
+    monkeypatch.setenv("DREAMZS_KERNEL_CACHE", str(tmp_path / "cache"))
+    import time
+    t0 = time.perf_counter(); a = compile_device_kernel(B.SOURCE); t1 = time.perf_counter(); b = compile_device_kernel(B.SOURCE); t2 = time.perf_counter()
+    assert a == b and os.path.dirname(a) == str(tmp_path / "cache") and (t2 - t1) < 0.2 * (t1 - t0)
+    assert compile_device_kernel(B.SOURCE, extra_flags=("-ffp-contract=fast",)) != a
+    assert sorted(f for f in os.listdir(tmp_path / "cache")) == sorted(os.path.basename(x) for x in (a, compile_device_kernel(B.SOURCE, extra_flags=("-ffp-contract=fast",))))

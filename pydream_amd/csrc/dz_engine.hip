@@ -1031,10 +1031,23 @@ size_t mix_multi_lds(const dz_engine* e)
     const size_t LDP = (size_t)4 * ((p.d + 3) / 4) + 1;
     return sizeof(double) * ((size_t)16 * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + (size_t)e->ad_R1 * e->ad_nbp + 64 * LDP + 32);
 }
+size_t mvn_multi_lds(const dz_engine* e)
+{
+    const dz::Params& p = e->p;
+    return sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, p.tri != 0, true, 16, p.pb_lds != 0, true, false, e->ad_R1).total;
+}
 bool burnin_multi(const dz_engine* e)
 {
     if (!e->ad_multi || !e->adapt_fused || !e->mega_burnin || e->tempering) return false;
     if (e->lk == LK_MIX) return mega_mix_eligible(e) && e->p.k >= 3 && mix_multi_lds(e) <= (size_t)160 * 1024;
+    if (e->lk == LK_MVN) {      // k_generations<.., 16, 1, .., multi>: 16 chains per block in ONE launch, one wave each, multi-try, the chains' states in LDS, no redraw rounds
+        const dz::Params& p = e->p;
+        if (!e->mega || mega_d2_chains(e) > 0 || p.ld > 128 || p.k < 3 || p.k > dz::MAXK || p.nslots > 64 || redo_possible(e) || (p.tri && !p.Mtp)) return false;
+        const MegaPlan plan = mega_plan(e);
+        if (plan.ch != 16 || plan.split_c != p.nl) return false;
+        const bool pb = p.hard || p.have_prior || p.depairs > 1;
+        return (pb || mega_xlds(e)) && mvn_multi_lds(e) <= (size_t)160 * 1024;
+    }
     return false;
 }
 int mega_segment(const dz_engine* e, uint32_t g, int64_t remaining)
@@ -1193,6 +1206,8 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         const int wpcp = (chp == 4 && !k1) ? 4 : 1;
         size_t ldsp = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, pb ? true : xlds, chp, p.pb_lds != 0).total;
         dz::Publish pp = pub; pp.c0 = c0; pp.c1 = c1;
+        if (multi) ldsp = mvn_multi_lds(e);      // (burnin_multi: one launch of 16-chain blocks, the states in LDS; + the states before the generation, + the table of probabilities)
+        else
         if (split_c != p.nl) { pp.PR = nullptr; pp.PC = nullptr; pp.shift = nullptr; }      // (a split generation's unit sums come from k_adapt_partials)
         else if (publish && !ring && e->adapt_fused && (e->world == 1 || e->adapt_groups) && chp == 16 && wpcp == 1 && !k1 && p.k >= 3 && (pb || xlds)) {      // (the new and old states are read from LDS)
             const size_t with_xo = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, true, chp, p.pb_lds != 0, true).total;
@@ -1202,6 +1217,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         dz::MegaLaunch ml;
         ml.tri = p.tri != 0; ml.xlds = pb ? true : xlds; ml.pb = pb; ml.k1 = k1; ml.ch = chp; ml.wpc = wpcp; ml.redo = mega_redo(e);
         ml.ahead = e->mega_w4 && chp == 4 && wpcp == 4 && !pb && xlds && !k1 && p.k >= 3 && p.k <= 6;
+        ml.multi = multi;
         ml.grid = dim3((c1 - c0 + chp - 1) / chp); ml.block = dim3(64 * chp * wpcp); ml.lds = ldsp; ml.st = e->stream; ml.ka = nullptr; ml.kb = nullptr;
         ml.pp = (const dz::Params*)e->d_params; ml.g = g; ml.n = n; ml.M = (uint32_t)visible_rows(e); ml.slot0 = slot0; ml.zappend = append_last ? e->M : (int64_t)-1; ml.seg0 = seg0; ml.publish = &pp;
         if (e->prof) { ml.ka = prof_event(e); ml.kb = prof_event(e); e->ev[PR_GENERATIONS].emplace_back(ml.ka, ml.kb); }

@@ -57,6 +57,14 @@ static const char* launch_one(const MegaLaunch& a)
             return TRI ? "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,full,redo>" : "k_generations<" DZ_STR(DZ_TU_NRT) ",dense,xlds,%d,%d,full,redo>";
         }
     }
+    if constexpr (X && CH == 16 && WPC == 1 && !K1) {
+        if (a.multi) {      // adapt_lag >= 1: several burn-in generations per launch
+            hipExtLaunchKernelGGL((k_generations<DZ_TU_NRT, TRI, X, CH, WPC, PB, K1, false, true>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0,
+                                  a.pp, a.g, a.n, a.M, a.slot0, a.zappend, a.seg0, *a.publish);
+            return TRI ? (PB ? "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,full,multi>" : "k_generations<" DZ_STR(DZ_TU_NRT) ",tri,xlds,%d,%d,lean,multi>")
+                       : (PB ? "k_generations<" DZ_STR(DZ_TU_NRT) ",dense,xlds,%d,%d,full,multi>" : "k_generations<" DZ_STR(DZ_TU_NRT) ",dense,xlds,%d,%d,lean,multi>");
+        }
+    }
     hipExtLaunchKernelGGL((k_generations<DZ_TU_NRT, TRI, X, CH, WPC, PB, K1>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0,
                           a.pp, a.g, a.n, a.M, a.slot0, a.zappend, a.seg0, *a.publish);
     // (NRT, matrix, chain states, chains per block, waves per chain, proposal code)

@@ -31,7 +31,7 @@ constexpr int DZ_MAX_REDRAWS_DEV = 64;                                  // == DZ
 constexpr unsigned long long DZ_REDRAW_KEY_STEP_DEV = 0x9E3779B97F4A7C15ull;   // == DZ_REDRAW_KEY_STEP
 constexpr int MEGA_CHAINS = 16;      // chains (= waves) per block at full size; 8 or 4 when there are too few chains to give every CU a block
 
-struct MegaLayout { int LDM, LDP, rows, off_P, off_q, off_sP, off_sS, off_sL, off_rP, off_rS, off_mu, off_pr, off_st, off_dec, off_gt, off_X, off_pc, pcn, off_Xo, total; };
+struct MegaLayout { int LDM, LDP, rows, off_P, off_q, off_sP, off_sS, off_sL, off_rP, off_rS, off_mu, off_pr, off_st, off_dec, off_gt, off_X, off_pc, pcn, off_Xo, off_tab, total; };
 
 // point rows of a block: try i of chain c at row i*ch + c; tiles are 16 consecutive rows, from row 0 (k tries) or from
 // row ch (the k-1 reference tries); rows past the last point stay zero
@@ -44,7 +44,9 @@ __host__ __device__ inline int mega_rows(int k, int ch)
 // array of pcn = 16 nrt entries)
 // xo: room for the chains' states as they were at the start of the launch (crossover burn-in: the block's adaptation sums need the jumps)
 // nomat: the matrix is NOT staged (k_generations_d2, 128 < d <= 256: it does not fit next to the point tiles and is read from L2)
-__host__ __device__ inline MegaLayout mega_layout(int d, int k, int nrt, int ncr, int ngamma, bool tri, bool xlds, int ch = MEGA_CHAINS, bool pb = false, bool xo = false, bool nomat = false)
+// ntab: rows of the table of crossover / gamma-level probabilities per generation of the launch (adapt_lag >= 1: several burn-in generations per
+// launch, the MG instantiations; rows of (ncr + ngamma + 1) & ~1 doubles)
+__host__ __device__ inline MegaLayout mega_layout(int d, int k, int nrt, int ncr, int ngamma, bool tri, bool xlds, int ch = MEGA_CHAINS, bool pb = false, bool xo = false, bool nomat = false, int ntab = 0)
 {
     MegaLayout L;
     const int ks4 = 4 * ((d + 3) / 4);
@@ -71,6 +73,8 @@ __host__ __device__ inline MegaLayout mega_layout(int d, int k, int nrt, int ncr
     L.total += L.total & 1;
     L.off_Xo = L.total;
     if (xo) L.total += ch * L.LDP + ((ch * L.LDP) & 1);
+    L.off_tab = L.total;
+    L.total += ntab * ((ncr + ngamma + 1) & ~1);
     return L;
 }
 
@@ -343,7 +347,11 @@ DZ_DEV void propose_de_pf(const Params& p, int phase, uint32_t g, uint32_t M, in
 // next redraw round, and evaluated again (Dream.py:281-289) -- a block-level loop around the proposal and likelihood steps of phase 0: only
 // the chains that need it propose again, every wave takes part in the barriers and the likelihood units (the other chains' points have not
 // changed: their sums come out the same), and the block leaves the loop when none of its chains needs another round (DZ_MAX_REDRAWS caps it).
-template <int NRT, bool TRI, bool XLDS, int CH, int WPC, bool PB, bool K1 = false, bool REDO = false>
+// MG (round 6, adapt_lag >= 1; blocks of 16 chains with one wave each, the states in LDS): SEVERAL burn-in generations per launch
+// (Publish::multi) -- the prologue applies the pending updates in order and leaves the probabilities of each of the launch's generations in an
+// LDS table; every generation ends with the block's unit sums into that generation's ring slot (one more barrier per generation: the chains'
+// states before the generation come from the Metropolis step's registers, the states after it are the LDS rows).
+template <int NRT, bool TRI, bool XLDS, int CH, int WPC, bool PB, bool K1 = false, bool REDO = false, bool MG = false>
 __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0, int64_t zappend, int seg0, Publish pub)
 {
     double* const publish = pub.to;
@@ -358,8 +366,9 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int d = p.d, k = K1 ? 1 : p.k, ld = p.ld;
     const bool pbl = PB && p.pb_lds != 0;
-    const bool fuse_adapt = CH == 16 && WPC == 1 && !K1 && XLDS && pub.PR != nullptr;
-    const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, XLDS, CH, pbl, fuse_adapt);
+    static_assert(!MG || (CH == 16 && WPC == 1 && !K1 && XLDS && !REDO), "several burn-in generations per launch: 16 chains per block, one wave each, states in LDS");
+    const bool fuse_adapt = !MG && CH == 16 && WPC == 1 && !K1 && XLDS && pub.PR != nullptr;
+    const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, XLDS, CH, pbl, MG || fuse_adapt, false, MG ? pub.lag + 1 : 0);
     double* Ms = smem;
     double* Pt = smem + L.off_P;
     double* qb = smem + L.off_q;
@@ -413,7 +422,10 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     }
     for (int i = threadIdx.x; i < L.rows * L.LDP; i += NT) Pt[i] = 0.0;
     if (threadIdx.x < 4 * ((d + 3) / 4) + 4) mus[threadIdx.x] = threadIdx.x < d ? p.mu[threadIdx.x] : 0.0;
-    if (pub.TOT) {      // the previous generation's adaptation totals are still to be applied: every block makes the update for itself (wave 0)
+    if (MG) {           // adapt_lag >= 1: the pending updates, in order; the probabilities of each of the launch's generations into the table
+        if (wv == 0) adapt_pending_apply(p, pub.DOT, pub.CNTR, pub.nbp, pub.lag + 1, pub.pend0, pub.pend1, (long long)g0, ngen, pub.lag, pub.burnin, pub.sh, smem + L.off_tab,
+                                         blockIdx.x == 0 ? pub.sh_out : nullptr, lane);
+    } else if (pub.TOT) {      // the previous generation's adaptation totals are still to be applied: every block makes the update for itself (wave 0)
         if (wv == 0) adapt_apply_wave<1>(p, pub.TOT, pub.CNT, pub.sh, probs, blockIdx.x == 0 ? pub.sh_out : nullptr, lane);
     } else {
         if (threadIdx.x < p.ncr) probs[threadIdx.x] = pub.sh[threadIdx.x];
@@ -495,6 +507,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
         const bool last = gi == ngen - 1;
         const bool app = gi == next_app;
         const uint32_t Mn = app ? M + (uint32_t)p.N : M;
+        const double* const pr_g = MG ? smem + L.off_tab + (size_t)gi * pub.nbp : probs;      // the probabilities this generation decides with
         DZ_MSTAMP(0);
         const DrawSrc ds = dsn;
         constexpr int nph = K1 ? 1 : 2;                                              // multitry off: no reference set
@@ -510,7 +523,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                 const u32x4 w0 = uniform_draw(p, ds, 0, gc, g), w1 = uniform_draw(p, ds, 1, gc, g), w2 = uniform_draw(p, ds, 2, gc, g);
                 u.u_snk = u53(w0.x, w0.y); u.u_cr = u53(w0.z, w0.w); u.u_de = u53(w1.x, w1.y); u.u_glev = u53(w1.z, w1.w);
                 u.u_sel = u53(w2.x, w2.y); u.u_acc = u53(w2.z, w2.w);
-                f = step_flags_from(p, u, probs, probs + p.ncr);                     // Dream.py:246-256
+                f = step_flags_from(p, u, pr_g, pr_g + p.ncr);                       // Dream.py:246-256
                 if (lane == 0 && sub == 0) {
                     double* dc = dec + 8 * cl;
                     dc[0] = u.u_sel; dc[1] = u.u_acc; dc[2] = f.snk ? 1.0 : 0.0; dc[3] = (double)f.cr_idx; dc[4] = (double)f.glev;
@@ -687,12 +700,14 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
             const bool moved = __any((xn.x != xo.x) || (xn.y != xo.y));              // core.py:120
             const double npri = accept ? sP[cl * k + sel] : lpri, nlik = accept ? sL[cl * k + sel] : llik;   // :345-347
             if (XLDS && accept) { double* xr = Xs + cl * L.LDP; if (jj < d) xr[jj] = xn.x; if (jj + 1 < d) xr[jj + 1] = xn.y; }
+            if (MG) { double* xq = smem + L.off_Xo + cl * L.LDP; if (jj < d) xq[jj] = xo.x; if (jj + 1 < d) xq[jj + 1] = xo.y; }      // the state before this generation (the jump's base)
             if (active) {
                 if (jj < ld) {
                     if (XLDS ? last : accept) gstore2(p.X + (size_t)c * ld + jj, xn);
                     if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn);
                     if (app) gstore2(p.Z + ((size_t)zappend + (M - M0) + gc) * ld + jj, xn);                         // record_history :933-936
-                    if (publish) gstore2(publish + (size_t)gc * ld + jj, xn);                          // set_current_position_arr :447-449
+                    if (publish && (!MG || last)) gstore2(publish + (size_t)gc * ld + jj, xn);         // set_current_position_arr :447-449
+                    if (MG && gc == 0u) gstore2(pub.x0ring + (size_t)(g % (uint32_t)(2 * (pub.lag + 1))) * ld + jj, xn);      // global chain 0 after generation g: a later generation's shift
                 }
                 if (lane == 0) {
                     if (trace_slot0 >= 0) {
@@ -706,6 +721,18 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
             if (lane == 0) { st[4 * cl] = npri; st[4 * cl + 1] = nlik; }
         }
         DZ_MSTAMP(9);
+        if (MG) {   // the block's unit sums of THIS generation (contract v3) into its ring slot: the states before (off_Xo) and after it (the chains' LDS rows)
+            int bc, bg;
+            adapt_bins(p, g, (int)gc, lane, bc, bg, pr_g, pr_g + p.ncr);
+            if (lane == 0) { st[4 * cl + 3] = (double)bc; dec[8 * cl + 6] = (double)bg; }
+            __syncthreads();
+            const int unit = blockIdx.x, R1 = pub.lag + 1, slot = (int)(g % (uint32_t)R1);
+            const long long hs = (long long)g - 1 - pub.lag;
+            const double* shift = hs < 0 ? pub.x0start : pub.x0ring + (size_t)(hs % (2 * R1)) * ld;
+            adapt_unit_sums(p, Xs, L.LDP, smem + L.off_Xo, L.LDP, min(16, p.nl - 16 * unit), [&](bool isg, int c_) { return (int)(isg ? dec[8 * c_ + 6] : st[4 * c_ + 3]); }, shift,
+                            pub.PR + (size_t)slot * pub.pr_stride + (size_t)unit * adapt_nq(p) * ld, pub.PC + (size_t)slot * pub.pc_stride + (size_t)unit * (p.ncr + p.ngamma),
+                            (int)threadIdx.x, NT);
+        }
         // one wave per chain: no barrier here -- the next generation's first phase only touches each wave's own chain's rows
         // and scalars, and the shared q buffer is not written again before the next barrier
         if (WPC > 1) __syncthreads();                                                // the chain's other waves read the new state

@@ -739,8 +739,11 @@ def test_crossover_burnin_at_4096_chains_against_oracle(G, O, variant, monkeypat
     ("mix", 4096, 9, 1, "0", "k_generations_mix"),             # the same schedule one generation per launch (DZ_ADAPT_MULTI=0): unit sums by k_adapt_partials
     ("mix", 1000, 19, 1, "1", "k_generations_mix<multi>"),     # a ragged last block of 8 chains; twenty generations per launch
     ("mix_pb", 2048, 9, 1, "1", "k_generations_mix<full,multi>"),
-    ("mvn", 4096, 9, 1, "1", "k_generations<7,"),              # the MVN kernels: one burn-in generation per launch, the updates applied when due
-    ("mvn", 300, 2, 0, "1", "k_generations_w4<7,"),
+    ("mvn", 4096, 9, 1, "1", "k_generations<7,tri,xlds,16,1,lean,multi>"),      # the MVN kernel's multi instantiation (16 chains per block)
+    ("mvn", 4096, 19, 1, "1", "k_generations<7,tri,xlds,16,1,lean,multi>"),
+    ("mvn_pb", 4000, 9, 0, "1", "k_generations<7,tri,xlds,16,1,full,multi>"),   # ... with normal priors (the full proposal code), a ragged last block
+    ("mvn", 4096, 9, 1, "0", "k_generations<7,tri,xlds,16,1,lean>"),            # the same schedule one generation per launch
+    ("mvn", 300, 2, 0, "1", "k_generations_w4<7,"),                             # small populations: one burn-in generation per launch, the updates applied when due
 ])
 def test_crossover_burnin_with_an_adapt_lag_against_oracle(G, O, target, N, lag, hlag, multi, variant, monkeypatch):
     """dz_config.adapt_lag = L (round 6): generation g of the burn-in decides with the probabilities as they were after the updates of
@@ -760,7 +763,7 @@ def test_crossover_burnin_with_an_adapt_lag_against_oracle(G, O, target, N, lag,
     for Cls in (G.Engine, O.Engine):
         e = Cls(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
                 adapt_crossover=1, crossover_burnin=burn, adapt_lag=lag, history_lag=hlag)
-        if target == "mix_pb":
+        if target in ("mix_pb", "mvn_pb"):
             e.set_prior(np.full(d, 1, np.int32), np.linspace(-1.0, 1.0, d), np.linspace(20.0, 40.0, d))
         e.set_history(Z0); e.set_state(Z0[:N])
         if target.startswith("mix"):
@@ -782,7 +785,7 @@ def test_crossover_burnin_with_an_adapt_lag_against_oracle(G, O, target, N, lag,
     np.testing.assert_array_equal(out[0][2], out[1][2])
     assert not np.allclose(out[0][1][-1][0], 1 / 3.)
     assert any(v.startswith(variant) for v in out[0][3]), out[0][3]
-    assert (("k_generations_mix<multi>" in out[0][3]) or ("k_generations_mix<full,multi>" in out[0][3])) == (multi == "1" and target.startswith("mix"))
+    assert any("multi>" in v for v in out[0][3]) == (multi == "1" and N >= 1000)
 
 
 @pytest.mark.parametrize("adapt", [0, 1])

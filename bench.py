@@ -59,7 +59,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6 # v_mfma_f64_16x16x4_f64: 64 cycles per instruction and SIMD (tools/micro/mfma_f64_rate.hip measured 77.4 TFLOP/s);
                              # equal to the FP64 vector rate -- the guide's table has no FP64 row
-PROFILE_TAG = next((t for t in ("r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", t + "_pmc_summary.json"))), "r04")
+PROFILE_TAG = next((t for t in ("r06", "r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", t + "_pmc_summary.json"))), "r04")
                              # profiles/<tag>_traffic.json, profiles/<tag>_pmc_summary.json (tools/collect_profiles.sh)
 STRONG_CHAINS = 32768        # BASELINE configs[3]: "8xMI355X: 32768 chains, 100D MVN ... report 1/2/4/8 scaling"
 ENGINE_CLOCK_HZ = 2.4e9      # MI355X peak engine clock (MI355X_MICROARCH.md); the headline kernel's cycle stamps give 2.35 GHz under load

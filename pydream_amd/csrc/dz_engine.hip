@@ -965,8 +965,13 @@ bool mega_redo(const dz_engine* e) { return redo_possible(e) && e->lk == LK_MVN 
 int mega_d2_chains(const dz_engine* e)
 {
     const dz::Params& p = e->p;
-    if (!e->mega || !e->mega_d2 || e->lk != LK_MVN || p.ld < 80 || p.ld > 256) return 0;
-    if (p.ld <= 128) {      // d <= 128: only where the classic kernel's 16-chain layout (matrix in LDS) does not fit -- it then runs 8 chains per block (113..128
+    if (!e->mega || !e->mega_d2 || e->lk != LK_MVN || p.ld > 256) return 0;
+    if (p.ld < 80 && p.nslots <= 64) return 0;
+    // (round 6) more than 15 tries: a generation's draw slots exceed a wave's lanes, the classic kernels do not take them; this one keeps one phase's
+    // slots at a time (k npt <= 64: up to 32 tries with one or two DE pairs)
+    const bool bigk = p.nslots > 64;
+    if (bigk && (p.k * p.npt > 64 || p.k > dz::MAXK || (getenv("DZ_MEGA_BIGK") && atoi(getenv("DZ_MEGA_BIGK")) == 0))) return 0;
+    if (p.ld <= 128 && !bigk) {      // d <= 128: only where the classic kernel's 16-chain layout (matrix in LDS) does not fit -- it then runs 8 chains per block (113..128
                             // dimensions at 5 tries, 100 dimensions at 8 or more)
         const bool pbx = p.hard || p.have_prior || p.depairs > 1;
         const size_t classic = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, pbx, 16, pbx && p.pb_lds != 0).total;
@@ -974,12 +979,16 @@ int mega_d2_chains(const dz_engine* e)
     }
     if (e->mega_d2 == 1 && p.nl <= 1024) return 0;      // (64 blocks or fewer leave three CUs in four idle: 57 against 52 us per generation at 1024 x 200-D; DZ_MEGA_D2=2 forces it)
     if (redo_possible(e)) return 0;      // (whole proposal sets that can be impossible: the multi-kernel path's redraw rounds)
-    if ((p.k != 1 && p.k < 3) || p.nslots > 64) return 0;
+    if (p.k != 1 && p.k < 3) return 0;
     if (!p.tri || !p.Mtp) return 0;
     const size_t lds = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, false, 16, false, false, true).total;
     if (lds <= (size_t)160 * 1024) return 16;
     // round 6: 8 chains x 2 waves per block where the point tiles of 16 chains do not fit (128 < d: 229..256 dimensions at 5 tries) -- multi-try only
-    if (p.ld > 128 && p.k >= 3 && !(getenv("DZ_MEGA_D2_W2") && atoi(getenv("DZ_MEGA_D2_W2")) == 0) &&
+    if (p.ld <= 128 && !bigk) {      // (13..15 tries at 100 dimensions: the classic kernel would run 4 chains x 4 waves -- 603 M proposals/s at k = 15 against 693 for 8 x 2 here at k = 16)
+        const bool pbx = p.hard || p.have_prior || p.depairs > 1;
+        if (sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, pbx, 8, pbx && p.pb_lds != 0).total <= (size_t)160 * 1024) return 0;
+    }
+    if (p.k >= 3 && !(getenv("DZ_MEGA_D2_W2") && atoi(getenv("DZ_MEGA_D2_W2")) == 0) &&
         sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, false, 8, false, false, true).total <= (size_t)160 * 1024) return 8;
     return 0;
 }
@@ -1174,6 +1183,8 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         if (e->prof) { ml.ka = prof_event(e); ml.kb = prof_event(e); e->ev[PR_GENERATIONS].emplace_back(ml.ka, ml.kb); }
         const char* name = nullptr;
         switch (nrt) {
+            case 1: name = dz::mega_launch_d2_nrt1(ml); break; case 2: name = dz::mega_launch_d2_nrt2(ml); break;
+            case 3: name = dz::mega_launch_d2_nrt3(ml); break; case 4: name = dz::mega_launch_d2_nrt4(ml); break;
             case 5: name = dz::mega_launch_d2_nrt5(ml); break; case 6: name = dz::mega_launch_d2_nrt6(ml); break;
             case 7: name = dz::mega_launch_d2_nrt7(ml); break; case 8: name = dz::mega_launch_d2_nrt8(ml); break;
             case 9: name = dz::mega_launch_nrt9(ml); break; case 10: name = dz::mega_launch_nrt10(ml); break;

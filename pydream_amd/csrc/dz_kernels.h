@@ -211,7 +211,9 @@ DZ_DEV u32x4 slot_counter_draw(const Params& p, int slot, uint32_t gc, uint32_t 
 // .x/.y/.z = z and the projected pair (:808-810).
 // rekey: a redraw round of the persistent kernel (Dream.py:281-289) -- the point, dimension and boundary streams of the proposal set come
 // from the Philox key (k0, k1) = seed + round * DZ_REDRAW_KEY_STEP instead of the run's (DESIGN.md section 4 "Redraw rounds").
-struct DrawSrc { uint4 mine; bool have; bool xf = false; bool rekey = false; uint32_t k0 = 0, k1 = 0; };
+// base (round 6, k_generations_d2 with more than 15 tries): lane s holds slot base + s -- a generation whose draw slots exceed a wave's 64 lanes
+// keeps one phase's tries at a time (base = the phase's first slot); 0 everywhere else.
+struct DrawSrc { uint4 mine; bool have; bool xf = false; bool rekey = false; uint32_t k0 = 0, k1 = 0; int base = 0; };
 DZ_DEV DrawSrc load_draws(const Params& p, const uint4* dr, int lane)
 {
     DrawSrc d; d.have = (dr != nullptr) && p.nslots <= 64; d.mine = make_uint4(0, 0, 0, 0);
@@ -223,7 +225,7 @@ DZ_DEV DrawSrc load_draws(const Params& p, const uint4* dr, int lane)
 DZ_DEV u32x4 uniform_draw(const Params& p, const DrawSrc& d, int slot, uint32_t gc, uint32_t g)
 {
     if (d.have) {
-        const int sl = __builtin_amdgcn_readfirstlane(slot);
+        const int sl = __builtin_amdgcn_readfirstlane(slot) - d.base;
         return u32x4{(uint32_t)__builtin_amdgcn_readlane((int)d.mine.x, sl), (uint32_t)__builtin_amdgcn_readlane((int)d.mine.y, sl),
                      (uint32_t)__builtin_amdgcn_readlane((int)d.mine.z, sl), (uint32_t)__builtin_amdgcn_readlane((int)d.mine.w, sl)};
     }

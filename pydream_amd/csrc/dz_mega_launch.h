@@ -25,8 +25,10 @@ struct MegaLaunch {
 #define DZ_MEGA_DECL(N_) const char* mega_launch_nrt##N_(const MegaLaunch& a);
 DZ_MEGA_DECL(1) DZ_MEGA_DECL(2) DZ_MEGA_DECL(3) DZ_MEGA_DECL(4) DZ_MEGA_DECL(5) DZ_MEGA_DECL(6) DZ_MEGA_DECL(7) DZ_MEGA_DECL(8)
 DZ_MEGA_DECL(9) DZ_MEGA_DECL(10) DZ_MEGA_DECL(11) DZ_MEGA_DECL(12) DZ_MEGA_DECL(13) DZ_MEGA_DECL(14) DZ_MEGA_DECL(15) DZ_MEGA_DECL(16)      // (k_generations_d2)
-const char* mega_launch_d2_nrt5(const MegaLaunch& a); const char* mega_launch_d2_nrt6(const MegaLaunch& a);      // (k_generations_d2 at ld <= 128: where 16 chains'
-const char* mega_launch_d2_nrt7(const MegaLaunch& a); const char* mega_launch_d2_nrt8(const MegaLaunch& a);      //  point tiles do not fit next to the matrix in LDS)
+const char* mega_launch_d2_nrt1(const MegaLaunch& a); const char* mega_launch_d2_nrt2(const MegaLaunch& a);      // (k_generations_d2 at ld <= 128: where 16 chains'
+const char* mega_launch_d2_nrt3(const MegaLaunch& a); const char* mega_launch_d2_nrt4(const MegaLaunch& a);      //  point tiles do not fit next to the matrix in LDS,
+const char* mega_launch_d2_nrt5(const MegaLaunch& a); const char* mega_launch_d2_nrt6(const MegaLaunch& a);      //  and for more than 15 tries)
+const char* mega_launch_d2_nrt7(const MegaLaunch& a); const char* mega_launch_d2_nrt8(const MegaLaunch& a);
 #undef DZ_MEGA_DECL
 
 }  // namespace dz

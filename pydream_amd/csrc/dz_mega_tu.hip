@@ -111,11 +111,19 @@ const char* DZ_CAT(mega_launch_nrt, DZ_TU_NRT)(const MegaLaunch& a)
     if (a.tri) return a.xlds ? launch_ch<true, true, false>(a) : launch_ch<true, false, false>(a);
     return a.xlds ? launch_ch<false, true, false>(a) : launch_ch<false, false, false>(a);
 }
-#if DZ_TU_NRT >= 5
-// d <= 128 with the point tiles of 16 chains NOT fitting next to the matrix in LDS (113..128 dimensions at 5 tries, 100 dimensions at 8 or more): k_generations_d2
-// with one chunk per lane
+// d <= 128 with the point tiles of 16 chains NOT fitting next to the matrix in LDS (113..128 dimensions at 5 tries, 100 dimensions at 8 or more), and
+// (round 6) more than 15 tries at any d <= 128: k_generations_d2 with one chunk per lane -- 16 chains per block, or 8 chains x 2 waves where the tiles of 16
+// do not fit even without the matrix (100 dimensions at 16..20 tries)
 const char* DZ_CAT(mega_launch_d2_nrt, DZ_TU_NRT)(const MegaLaunch& a)
 {
+    if (a.ch == 8) {
+        if (a.pb) {
+            hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 8, false, true, 2>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, a.slot0, a.zappend, a.seg0, *a.publish);
+            return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,full>";
+        }
+        hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 8, false, false, 2>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, a.slot0, a.zappend, a.seg0, *a.publish);
+        return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,lean>";
+    }
 #define DZ_D2(K1_, NAME_)                                                                                                                 \
     do {                                                                                                                                   \
         if (a.pb) {                                                                                                                        \
@@ -128,7 +136,6 @@ const char* DZ_CAT(mega_launch_d2_nrt, DZ_TU_NRT)(const MegaLaunch& a)
     DZ_D2(false, "");          // (multitry on only: the multitry-off kernels' 16-chain layout always fits)
 #undef DZ_D2
 }
-#endif
 #endif      // DZ_TU_NRT <= 8
 
 }  // namespace dz

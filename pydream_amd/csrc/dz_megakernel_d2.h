@@ -71,9 +71,14 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
     if (lane == 0 && sub == 0) { st[4 * cl] = p.lprior[c]; st[4 * cl + 1] = p.llike[c]; st[4 * cl + 2] = 0.0; dec[8 * cl + 7] = chain_T(p, c); }
     __syncthreads();
 
-    auto generation_draws = [&](uint32_t g_) {          // lane s holds slot s of the chain's wave-uniform draws of generation g_
-        DrawSrc q; q.have = true; q.mine = make_uint4(0, 0, 0, 0);
-        if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g_); q.mine = make_uint4(w.x, w.y, w.z, w.w); }
+    // More than 15 tries (round 6; the reference takes any integer, Dream.py:155-161): a generation's draw slots (3 control + two per try of both
+    // sets) exceed the wave's 64 lanes -- the wave then holds ONE phase's slots at a time (DrawSrc::base: k npt <= 64 of them), the three
+    // control slots are evaluated where they are read; selection and multi-try ratio over 32 + 32 lanes (mt_select_vals<true>, mt_log_ratio<true>).
+    const bool bigk = p.nslots > 64;
+    const int base1 = 3 + k * p.npt;                    // first slot of the reference set's tries
+    auto generation_draws = [&](uint32_t g_, int base_ = 0) {          // lane s holds slot base_ + s of the chain's wave-uniform draws of generation g_
+        DrawSrc q; q.have = true; q.mine = make_uint4(0, 0, 0, 0); q.base = base_;
+        if (lane + base_ < p.nslots) { const u32x4 w = slot_counter_draw(p, lane + base_, gc, g_); q.mine = make_uint4(w.x, w.y, w.z, w.w); }
         return q;
     };
     // Q = q_0 + q_1 + ... of point row `pt` in ascending row tile (the MVN contract): the reads in batches of eight, then the ordered adds
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
         }
         return Q;
     };
-    DrawSrc dsn = generation_draws(g0);
+    DrawSrc dsn = generation_draws(g0, bigk ? 3 : 0);
     uint32_t M = M0;                                                        // (appends inside the launch: k_generations)
     int next_app = zappend >= 0 ? seg0 - 1 : -1;
 
@@ -97,15 +102,17 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
         const uint32_t g = g0 + (uint32_t)gi;
         const bool last = gi == ngen - 1;
         const bool app = gi == next_app;
-        const DrawSrc ds = dsn;
+        DrawSrc ds = dsn;
         for (int phase = 0; phase < nph; ++phase) {
+            if (bigk && phase == 1) ds = generation_draws(g, base1);                  // the reference set's slots take the proposal set's place
             // ---- phase 0: k proposals around the chain's state (generate_proposal_points :258-264) into the chain's rows of tiles 0..k-1;
             //      phase 1: the selected proposal moves to tile 0 and k-1 reference points around it (:295-299) take tiles 1..k-1
             StepFlags f;
             double base[NCH][2];
             if (phase == 0) {
                 Ctrl u;
-                const u32x4 w0 = uniform_draw(p, ds, 0, gc, g), w1 = uniform_draw(p, ds, 1, gc, g), w2 = uniform_draw(p, ds, 2, gc, g);
+                const u32x4 w0 = bigk ? slot_counter_draw(p, 0, gc, g) : uniform_draw(p, ds, 0, gc, g), w1 = bigk ? slot_counter_draw(p, 1, gc, g) : uniform_draw(p, ds, 1, gc, g),
+                            w2 = bigk ? slot_counter_draw(p, 2, gc, g) : uniform_draw(p, ds, 2, gc, g);
                 u.u_snk = u53(w0.x, w0.y); u.u_cr = u53(w0.z, w0.w); u.u_de = u53(w1.x, w1.y); u.u_glev = u53(w1.z, w1.w);
                 u.u_sel = u53(w2.x, w2.y); u.u_acc = u53(w2.z, w2.w);
                 f = step_flags_from(p, u, probs, probs + p.ncr);                     // Dream.py:246-256
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
                     lp = sP[cl * k + lane] + dec[8 * cl + 7] * lk;
                 }
                 bool fin;
-                const int sel = mt_select_vals(k, lp, u_sel, lane, &fin);
+                const int sel = k > 16 ? mt_select_vals<true>(k, lp, u_sel, lane, &fin) : mt_select_vals(k, lp, u_sel, lane, &fin);
                 if (lane == 0 && sub == 0) st[4 * cl + 2] = (double)(sel | (fin ? 256 : 0));
                 const double* row = region + (size_t)sel * tstride;
 #pragma unroll
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
                                                        region + (size_t)phase * tstride, tstride, slp, K1 ? st + 4 * cl + 3 : nullptr, prp, nullptr);   // (k = 1: log |x - z|^(d-1) of the current point, :328-329)
             }
             if (snk_s) __builtin_amdgcn_s_setprio(0);
-            if (phase == nph - 1 && !last) dsn = generation_draws(g + 1u);
+            if (phase == nph - 1 && !last) dsn = generation_draws(g + 1u, bigk ? 3 : 0);
             __syncthreads();                                                         // points visible
             {   // mt_evaluate_logps :278, :302 -- the (point tile, row tile) units, A operand from L2
                 const int row0 = phase ? CH : 0, ntl = (n * CH + 15) / 16;
@@ -188,8 +195,8 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
             } else if (lane < k) {
                 val = sP[cl * k + lane] + Tch * sL[cl * k + lane];                                       // :279
                 if (snk) val = val + sS[cl * k + lane];                                                  // :307
-            } else if (lane >= 16 && lane < 16 + k) {
-                const int i = lane - 16;
+            } else if (lane >= mt_boff(k) && lane < mt_boff(k) + k) {
+                const int i = lane - mt_boff(k);
                 if (i < k - 1) val = Tch * nan_to_ninf(p.logF - 0.5 * q_sum((1 + i) * CH + cl)) + rP[cl * (k - 1) + i];     // :303
                 else val = Tch * llik + lpri;                                                            // :877-879
                 if (snk) { const double sr = i < k - 1 ? rS[cl * (k - 1) + i] : 0.0; val = (val + sr) + sS[cl * k + i]; }   // :312-313
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
                 else ratio = nan_to_num(q_logp) - nan_to_num(last_logp);                                 // :334
                 lu = dlog(u_acc);
             } else {
-                ratio = mt_log_ratio(k, val, u_acc, lane, &lu);
+                ratio = k > 16 ? mt_log_ratio<true>(k, val, u_acc, lane, &lu) : mt_log_ratio(k, val, u_acc, lane, &lu);
                 if (!fin) ratio = -__builtin_huge_val();                             // DESIGN.md deviation D1
             }
             const bool accept = is_finite(ratio) && (lu < ratio);                    // :993

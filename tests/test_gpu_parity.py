@@ -811,10 +811,17 @@ def test_a_chain_count_just_above_whole_rounds_of_blocks_against_oracle(G, O, ad
     assert out[0][3] == "k_generations<7,tri,xlds,16,1,lean> + k_generations_w4<7,tri,xlds,4,4,lean,ahead>", out[0][3]
 
 
-@pytest.mark.parametrize("k,d,N,lk", [(16, 100, 300, "tri"), (17, 10, 64, "dense"), (24, 140, 48, "tri"), (32, 33, 40, "mix"), (32, 300, 16, "tri")])
-def test_more_than_sixteen_tries_against_oracle(G, O, k, d, N, lk):
+@pytest.mark.parametrize("k,d,N,lk,variant", [(16, 100, 300, "tri", "multi-kernel path"), (17, 10, 64, "dense", "multi-kernel path"), (24, 140, 48, "tri", "multi-kernel path"),
+                                              (32, 33, 40, "mix", "multi-kernel path"), (32, 300, 16, "tri", "multi-kernel path"),
+                                              # (round 6) k_generations_d2 keeps one phase's draw slots at a time: 16..32 tries inside a persistent kernel (triangular factor, > 1024 chains)
+                                              (16, 100, 1100, "tri", "k_generations_d2<7,tri,xhbm,8,2,lean>"), (20, 100, 1040, "tri", "k_generations_d2<7,tri,xhbm,8,2,lean>"),
+                                              (32, 10, 1030, "tri", "k_generations_d2<1,tri,xhbm,16,1,lean>"), (17, 48, 1100, "tri", "k_generations_d2<3,tri,xhbm,16,1,lean>"),
+                                              (16, 132, 1040, "tri", "k_generations_d2<9,tri,xhbm,8,2,lean>"), (16, 200, 1040, "tri", "multi-kernel path"), (24, 100, 1040, "tri", "multi-kernel path"),
+                                              (15, 100, 1100, "tri", "k_generations_d2<7,tri,xhbm,8,2,lean>")])
+def test_more_than_sixteen_tries_against_oracle(G, O, k, d, N, lk, variant):
     """The reference takes any integer as `multitry` (Dream.py:155-161).  Up to 15 tries a generation's draw slots fit one wave's lanes and the
-    persistent kernels run; 16..32 tries run the multi-kernel path (selection and multi-try ratio over 32 + 32 lanes): states, decisions,
+    persistent kernels run; 16..32 tries run the multi-kernel path or -- round 6: triangular factor, more than 1024 chains, the point tiles of 16 chains or of
+    8 chains x 2 waves fitting LDS -- k_generations_d2 (selection and multi-try ratio over 32 + 32 lanes either way): states, decisions,
     archive and adapted probabilities equal the oracle's bit for bit, through a crossover burn-in, snooker sets and history appends, for the
     per-chain (d <= 256) and the streamed (d = 300) proposal kernels."""
     n, seed = 24, 7
@@ -831,9 +838,10 @@ def test_more_than_sixteen_tries_against_oracle(G, O, k, d, N, lk):
             P = H.mvn_precision(d)
             e.set_likelihood_mvn(np.zeros(d), H.tri_factor(P) if lk == "tri" else P, 1 if lk == "tri" else 0, 0.0)
         e.step(n)
-        out.append((e.get_trace(0, n), e.get_history(), e.get_cr_state()))
+        out.append((e.get_trace(0, n), e.get_history(), e.get_cr_state(), e.last_kernel_variant() if Cls is G.Engine else ""))
     assert_traces_identical(out[0][0], out[1][0])
     np.testing.assert_array_equal(out[0][1], out[1][1])
     for a, b in zip(out[0][2], out[1][2]):
         np.testing.assert_array_equal(a, b)
     assert out[0][0]["try_idx"].max() >= min(k - 1, 12) and 0.005 < out[0][0]["moved"].mean() < 0.98
+    assert out[0][3] == variant, out[0][3]

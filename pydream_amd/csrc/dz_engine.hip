@@ -962,6 +962,15 @@ bool mega_redo(const dz_engine* e) { return redo_possible(e) && e->lk == LK_MVN 
 // MVNormalLogLike builds) whose point tiles of 16 chains fit LDS without the matrix (it is read from L2): d <= ~230 at 5 tries.  Measured and
 // left on the multi-kernel path: 8 chains per block (d = 256: 131 against 123 us per generation) and the dense matrix (its 16-chain
 // instantiation spills a hundred registers; at 8 chains per block 156 against 148 us at d = 200).
+// (round 6) 16 chains per block whose k tries' point tiles do not fit but k - 1 do (229..256 dimensions at 5 tries): the proposal set in two passes
+// (k_generations_d2<.., SP>); 3..15 tries, 128 < d
+bool mega_d2_two_pass(const dz_engine* e)
+{
+    const dz::Params& p = e->p;
+    if (p.ld <= 128 || p.k < 3 || p.nslots > 64 || (getenv("DZ_MEGA_D2_SP") && atoi(getenv("DZ_MEGA_D2_SP")) == 0)) return false;
+    if (sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, false, 16, false, false, true).total <= (size_t)160 * 1024) return false;
+    return sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, false, 16, false, false, true, 0, true).total <= (size_t)160 * 1024;
+}
 int mega_d2_chains(const dz_engine* e)
 {
     const dz::Params& p = e->p;
@@ -983,6 +992,7 @@ int mega_d2_chains(const dz_engine* e)
     if (!p.tri || !p.Mtp) return 0;
     const size_t lds = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, false, 16, false, false, true).total;
     if (lds <= (size_t)160 * 1024) return 16;
+    if (mega_d2_two_pass(e)) return 16;
     // round 6: 8 chains x 2 waves per block where the point tiles of 16 chains do not fit (128 < d: 229..256 dimensions at 5 tries) -- multi-try only
     if (p.ld <= 128 && !bigk) {      // (13..15 tries at 100 dimensions: the classic kernel would run 4 chains x 4 waves -- 603 M proposals/s at k = 15 against 693 for 8 x 2 here at k = 16)
         const bool pbx = p.hard || p.have_prior || p.depairs > 1;
@@ -1175,9 +1185,10 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         DZCK(upload_params(e));
         dz::MegaLaunch ml;
         const int wpcd = chd == 8 ? 2 : 1;
-        ml.tri = p.tri != 0; ml.xlds = false; ml.pb = p.hard || p.have_prior || p.depairs > 1; ml.k1 = p.k == 1; ml.ch = chd; ml.wpc = wpcd; ml.redo = false;
+        const bool sp = chd == 16 && mega_d2_two_pass(e);
+        ml.tri = p.tri != 0; ml.xlds = false; ml.pb = p.hard || p.have_prior || p.depairs > 1; ml.k1 = p.k == 1; ml.ch = chd; ml.wpc = wpcd; ml.redo = false; ml.sp = sp;
         ml.grid = dim3((p.nl + chd - 1) / chd); ml.block = dim3(64 * chd * wpcd);
-        ml.lds = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, false, chd, false, false, true).total;
+        ml.lds = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, false, chd, false, false, true, 0, sp).total;
         ml.st = e->stream; ml.ka = nullptr; ml.kb = nullptr;
         ml.pp = (const dz::Params*)e->d_params; ml.g = g; ml.n = n; ml.M = (uint32_t)visible_rows(e); ml.slot0 = slot0; ml.zappend = append_last ? e->M : (int64_t)-1; ml.seg0 = seg0; ml.publish = &pub;
         if (e->prof) { ml.ka = prof_event(e); ml.kb = prof_event(e); e->ev[PR_GENERATIONS].emplace_back(ml.ka, ml.kb); }

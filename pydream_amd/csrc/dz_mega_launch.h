@@ -13,6 +13,7 @@ struct Publish;
 struct MegaLaunch {
     bool tri, xlds, pb, k1, redo;     // (redo: redraw rounds inside the kernel, with pb and multitry on)
     bool ahead = false;               // 4 chains x 4 waves, lean, multitry 3..6: k_generations_w4 (the tries' base-independent halves made ahead)
+    bool sp = false;                  // k_generations_d2, 16 chains per block whose proposal set goes through the point tiles in two passes (229..256 dimensions at 5 tries)
     bool multi = false;               // adapt_lag >= 1: several burn-in generations per launch (16 chains per block, one wave each, states in LDS: the MG instantiations)
     // triangular factor / chain states in LDS / full proposal code (priors, bounds, DEpairs > 1) / multitry off
     int ch, wpc;                // chains per block (16, 8, 4), waves per chain (1; 4 at 4 chains per block with multitry on)

@@ -46,14 +46,17 @@ __host__ __device__ inline int mega_rows(int k, int ch)
 // nomat: the matrix is NOT staged (k_generations_d2, 128 < d <= 256: it does not fit next to the point tiles and is read from L2)
 // ntab: rows of the table of crossover / gamma-level probabilities per generation of the launch (adapt_lag >= 1: several burn-in generations per
 // launch, the MG instantiations; rows of (ncr + ngamma + 1) & ~1 doubles)
-__host__ __device__ inline MegaLayout mega_layout(int d, int k, int nrt, int ncr, int ngamma, bool tri, bool xlds, int ch = MEGA_CHAINS, bool pb = false, bool xo = false, bool nomat = false, int ntab = 0)
+// sp (k_generations_d2<.., SP>, round 6): the proposal set goes through the point tiles in two passes (tries 0 .. k-2, then the last one), the selected
+// proposal stays in registers: k - 1 tries' rows instead of k
+__host__ __device__ inline MegaLayout mega_layout(int d, int k, int nrt, int ncr, int ngamma, bool tri, bool xlds, int ch = MEGA_CHAINS, bool pb = false, bool xo = false, bool nomat = false, int ntab = 0,
+                                                  bool sp = false)
 {
     MegaLayout L;
     const int ks4 = 4 * ((d + 3) / 4);
     L.LDM = d + 2;                    // dense matrix row (k index c): d entries + pad; rows d..ks4-1 are zero
     L.LDP = ks4 + 1;                  // point row: zero padded to the k-steps; odd stride keeps the A-layout reads (16 rows x 4 cols) off one bank
     L.off_P = nomat ? 0 : (tri ? tri_row_offset(ks4) : ks4 * L.LDM + 16);       // (+16: the last row tile's column reads run past the last row's end)
-    L.rows = mega_rows(k, ch);
+    L.rows = sp ? 16 * (((k - 1) * ch + 15) / 16) : mega_rows(k, ch);
     L.off_q = L.off_P + L.rows * L.LDP;
     L.off_sP = L.off_q + L.rows * nrt;
     L.off_sS = L.off_sP + ch * k;

@@ -26,17 +26,22 @@ namespace dz {
 // WPC (round 6): waves per chain -- 2 at 8 chains per block, where the point tiles of 16 chains no longer fit LDS (d > ~228 at 5 tries): the
 // tries of a phase are dealt to the chain's two waves, all 16 waves share the likelihood units, the chain's first wave selects and makes
 // the Metropolis step (as in k_generations: two more barriers per generation keep the base point and the new state consistent between them).
-template <int NRT, bool TRI, int CH, bool K1 = false, bool PB = false, int WPC = 1>
+// SP (round 6): where the point tiles of 16 chains x k tries do not fit LDS but those of k - 1 tries do (229..256 dimensions at 5 tries), the
+// proposal set goes through the tiles in TWO passes -- tries 0 .. k-2, their likelihoods, then try k-1 over the rows of try 0 -- and the reference
+// set takes all of them, the selected proposal staying in registers until the Metropolis step.  A selected try whose rows were overwritten
+// (try 0) is generated again from the same counters: the same bits (one extra try for a fifth of the chain-generations at 5 tries).
+template <int NRT, bool TRI, int CH, bool K1 = false, bool PB = false, int WPC = 1, bool SP = false>
 __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0, int64_t zappend, int seg0, Publish pub)
 {
     static_assert(WPC == 1 || !K1, "one try per generation: one wave per chain");
+    static_assert(!SP || (CH == 16 && WPC == 1 && !K1), "the two-pass proposal set: 16 chains per block (a try = one point tile), one wave each, multi-try");
     constexpr int NCH = NRT > 8 ? 2 : 1, NT = 64 * CH * WPC;    // (NRT = 8, ld = 128: one chunk -- the kernel also serves 113..128 dimensions, where the
                                                                 //  matrix in LDS leaves room for the point tiles of 8 chains only)
     double* const publish = pub.to;
     const Params& p = *pp;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int d = p.d, k = K1 ? 1 : p.k, ld = p.ld;
-    const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, false, CH, false, false, true);
+    const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, false, CH, false, false, true, 0, SP);
     constexpr int nph = K1 ? 1 : 2;
     double* Pt = smem + L.off_P;
     double* qb = smem + L.off_q;
@@ -103,6 +108,9 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
         const bool last = gi == ngen - 1;
         const bool app = gi == next_app;
         DrawSrc ds = dsn;
+        double bsel[NCH][2];                                                          // (SP) the selected proposal, from the selection to the Metropolis step
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) { bsel[it][0] = 0.0; bsel[it][1] = 0.0; }
         for (int phase = 0; phase < nph; ++phase) {
             if (bigk && phase == 1) ds = generation_draws(g, base1);                  // the reference set's slots take the proposal set's place
             // ---- phase 0: k proposals around the chain's state (generate_proposal_points :258-264) into the chain's rows of tiles 0..k-1;
@@ -128,20 +136,36 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
                 const double u_sel = dc[0];
                 double lp = -__builtin_huge_val();
                 if (lane < k) {                                                      // likelihoods of the chain's k points, mt_choose_proposal_pt (:291)
-                    const double lk = nan_to_ninf(p.logF - 0.5 * q_sum(lane * CH + cl));
-                    if (sub == 0) sL[cl * k + lane] = lk;
+                    const double lk = SP ? sL[cl * k + lane] : nan_to_ninf(p.logF - 0.5 * q_sum(lane * CH + cl));      // (SP: made pass by pass, below)
+                    if (!SP && sub == 0) sL[cl * k + lane] = lk;
                     lp = sP[cl * k + lane] + dec[8 * cl + 7] * lk;
                 }
                 bool fin;
                 const int sel = k > 16 ? mt_select_vals<true>(k, lp, u_sel, lane, &fin) : mt_select_vals(k, lp, u_sel, lane, &fin);
                 if (lane == 0 && sub == 0) st[4 * cl + 2] = (double)(sel | (fin ? 256 : 0));
-                const double* row = region + (size_t)sel * tstride;
+                int srow = sel;
+                if (SP) {     // where the selected try's point is: the last try sits in row 0; try 0 was overwritten by it and is generated again (same counters, same bits)
+                    if (sel == k - 1) srow = 0;
+                    else if (sel == 0) {
+                        const bool snk0 = __builtin_amdgcn_readfirstlane((int)f.snk) != 0;
+                        const double* grow0 = PB ? gamma_row(p, f.glev, f.delta) : gts + (size_t)(__builtin_amdgcn_readfirstlane(f.glev) - 1) * d;
+                        double xb[NCH][2];
+                        load_row<NCH>(p.X + (size_t)c * ld, ld, lane, xb);
+                        if (PB) propose_set<NCH, false, true, 0>(p, 0, g, M, c, gc, 0, 1, k, lane, xb, grow0, snk0, f.cr_idx, f.delta, f.glev, ds, region, tstride, sS + cl * k, nullptr, sP + cl * k, nullptr);
+                        else propose_set<NCH, false, false, 1>(p, 0, g, M, c, gc, 0, 1, k, lane, xb, grow0, snk0, f.cr_idx, 1, f.glev, ds, region, tstride, sS + cl * k, nullptr, sP + cl * k, nullptr);
+                    }
+                }
+                const double* row = region + (size_t)srow * tstride;
 #pragma unroll
                 for (int it = 0; it < NCH; ++it) {
                     const int jj = 128 * it + 2 * lane;
                     base[it][0] = jj < d ? row[jj] : 0.0; base[it][1] = jj + 1 < d ? row[jj + 1] : 0.0;
                 }
                 if (WPC > 1) __syncthreads();                                        // every wave of the chain holds the base point before any try row is rewritten
+                if (SP) {
+#pragma unroll
+                    for (int it = 0; it < NCH; ++it) { bsel[it][0] = base[it][0]; bsel[it][1] = base[it][1]; }
+                } else
                 if (sub == 0) {
 #pragma unroll
                     for (int it = 0; it < NCH; ++it) {                               // the selected proposal now sits in tile 0 (each lane moves its own values)
@@ -157,19 +181,20 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
             const int i0 = WPC == 1 ? 0 : (sub * n) / WPC, i1 = WPC == 1 ? n : ((sub + 1) * n) / WPC;     // this wave's tries
             double* slp = phase ? rS + cl * (k - 1) : sS + cl * k;
             double* prp = phase ? rP + cl * (k - 1) : sP + cl * k;
-            if (snk_s) __builtin_amdgcn_s_setprio(3);      // a snooker set is the longest path to the block's barrier
-            if (i0 < i1) {
-            if (PB) propose_set<NCH, false, true, 0>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, snk_s, f.cr_idx, f.delta, f.glev, ds,
-                                                     region + (size_t)phase * tstride, tstride, slp, K1 ? st + 4 * cl + 3 : nullptr, prp, nullptr);
-            else
-            propose_set<NCH, false, false, K1 ? 2 : 1>(p, phase, g, M, c, gc, i0, i1, n, lane, base, grow, snk_s, f.cr_idx, 1, f.glev, ds,
-                                                       region + (size_t)phase * tstride, tstride, slp, K1 ? st + 4 * cl + 3 : nullptr, prp, nullptr);   // (k = 1: log |x - z|^(d-1) of the current point, :328-329)
-            }
-            if (snk_s) __builtin_amdgcn_s_setprio(0);
-            if (phase == nph - 1 && !last) dsn = generation_draws(g + 1u, bigk ? 3 : 0);
-            __syncthreads();                                                         // points visible
-            {   // mt_evaluate_logps :278, :302 -- the (point tile, row tile) units, A operand from L2
-                const int row0 = phase ? CH : 0, ntl = (n * CH + 15) / 16;
+            // tries [a, b) of the set into rows (try - r0) of the chain's column of tiles
+            auto propose = [&](int a, int b, int r0) {
+                if (snk_s) __builtin_amdgcn_s_setprio(3);      // a snooker set is the longest path to the block's barrier
+                double* out = region + (size_t)((SP ? 0 : phase) - r0) * tstride;
+                if (a < b) {
+                    if (PB) propose_set<NCH, false, true, 0>(p, phase, g, M, c, gc, a, b, n, lane, base, grow, snk_s, f.cr_idx, f.delta, f.glev, ds,
+                                                             out, tstride, slp, K1 ? st + 4 * cl + 3 : nullptr, prp, nullptr);
+                    else
+                    propose_set<NCH, false, false, K1 ? 2 : 1>(p, phase, g, M, c, gc, a, b, n, lane, base, grow, snk_s, f.cr_idx, 1, f.glev, ds,
+                                                               out, tstride, slp, K1 ? st + 4 * cl + 3 : nullptr, prp, nullptr);   // (k = 1: log |x - z|^(d-1) of the current point, :328-329)
+                }
+                if (snk_s) __builtin_amdgcn_s_setprio(0);
+            };
+            auto units = [&](int row0, int ntl) {   // mt_evaluate_logps :278, :302 -- the (point tile, row tile) units, A operand from L2
                 if (TRI) {
                     if (p.mu_zero) mfma_units_d2<NRT, true>(p, Mg, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, L.LDP);
                     else mfma_units_d2<NRT, false>(p, Mg, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, L.LDP);
@@ -177,6 +202,26 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
                     if (p.mu_zero) mfma_units<NRT, TRI, true>(p, Mg, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, LDMg, L.LDP);
                     else mfma_units<NRT, TRI, false>(p, Mg, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, LDMg, L.LDP);
                 }
+            };
+            if (SP && phase == 0) {      // the proposal set in two passes over k - 1 tiles: tries 0 .. k-2, then try k-1 over try 0's rows
+                propose(0, k - 1, 0);
+                __syncthreads();
+                units(0, k - 1);
+                __syncthreads();
+                if (lane < k - 1) sL[cl * k + lane] = nan_to_ninf(p.logF - 0.5 * q_sum(lane * CH + cl));
+                propose(k - 1, k, k - 1);
+                __syncthreads();
+                units(0, 1);
+                __syncthreads();
+                if (lane == k - 1) sL[cl * k + lane] = nan_to_ninf(p.logF - 0.5 * q_sum(cl));
+                continue;
+            }
+            propose(i0, i1, 0);
+            if (phase == nph - 1 && !last) dsn = generation_draws(g + 1u, bigk ? 3 : 0);
+            __syncthreads();                                                         // points visible
+            {
+                const int row0 = (phase && !SP) ? CH : 0, ntl = (n * CH + 15) / 16;
+                units(row0, ntl);
             }
             __syncthreads();                                                         // q visible
         }
@@ -197,7 +242,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
                 if (snk) val = val + sS[cl * k + lane];                                                  // :307
             } else if (lane >= mt_boff(k) && lane < mt_boff(k) + k) {
                 const int i = lane - mt_boff(k);
-                if (i < k - 1) val = Tch * nan_to_ninf(p.logF - 0.5 * q_sum((1 + i) * CH + cl)) + rP[cl * (k - 1) + i];     // :303
+                if (i < k - 1) val = Tch * nan_to_ninf(p.logF - 0.5 * q_sum(((SP ? 0 : 1) + i) * CH + cl)) + rP[cl * (k - 1) + i];     // :303
                 else val = Tch * llik + lpri;                                                            // :877-879
                 if (snk) { const double sr = i < k - 1 ? rS[cl * (k - 1) + i] : 0.0; val = (val + sr) + sS[cl * k + i]; }   // :312-313
             }
@@ -220,7 +265,10 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
                 double2 xo = {0.0, 0.0};
                 if (jj < ld) xo = *reinterpret_cast<const double2*>(p.X + (size_t)c * ld + jj);
                 xn[it] = xo;
-                if (accept) { xn[it].x = jj < d ? region[jj] : 0.0; xn[it].y = jj + 1 < d ? region[jj + 1] : 0.0; }      // the selected proposal
+                if (accept) {      // the selected proposal
+                    if (SP) { xn[it].x = jj < d ? bsel[it][0] : 0.0; xn[it].y = jj + 1 < d ? bsel[it][1] : 0.0; }
+                    else { xn[it].x = jj < d ? region[jj] : 0.0; xn[it].y = jj + 1 < d ? region[jj + 1] : 0.0; }
+                }
                 diff = diff || (xn[it].x != xo.x) || (xn[it].y != xo.y);
             }
             const bool moved = __any(diff);                                          // core.py:120

@@ -289,8 +289,8 @@ def parse_args(argv=None):
         args.appends_per_launch = max(1, (args.history_lag + 1) // 2)
     # (the engine's cap on history appends per launch -- one GPU alone could hold history_lag + 1: the same launches at every N)
     os.environ["DZ_MEGA_SEGS"] = str(args.appends_per_launch)
-    if args.adapt_lag is None:      # as many burn-in generations per launch as the launches behind the burn-in hold generations
-        args.adapt_lag = max(0, args.appends_per_launch * args.thin - 1)
+    if args.adapt_lag is None:      # as many burn-in generations per launch as the launches behind the burn-in hold generations -- on one GPU: sharded engines
+        args.adapt_lag = max(0, args.appends_per_launch * args.thin - 1) if args.gpus == 1 else 0      # run one burn-in generation per launch at any lag
     return args
 
 

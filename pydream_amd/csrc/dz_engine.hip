@@ -1000,6 +1000,10 @@ int mega_d2_chains(const dz_engine* e)
     }
     if (p.k >= 3 && !(getenv("DZ_MEGA_D2_W2") && atoi(getenv("DZ_MEGA_D2_W2")) == 0) &&
         sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, false, 8, false, false, true).total <= (size_t)160 * 1024) return 8;
+    // ... and 4 chains x 4 waves where not even those fit (24..32 tries at 100 dimensions, 20..32 at 128, 8 at 256): four rounds of 1024 blocks at 4096
+    // chains, still ahead of the multi-kernel path
+    if (p.k >= 4 && !(getenv("DZ_MEGA_D2_W4") && atoi(getenv("DZ_MEGA_D2_W4")) == 0) &&
+        sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, false, 4, false, false, true).total <= (size_t)160 * 1024) return 4;
     return 0;
 }
 bool mega_eligible(dz_engine* e)
@@ -1184,7 +1188,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
     if (const int chd = mega_d2_chains(e)) {      // 128 < d <= 256
         DZCK(upload_params(e));
         dz::MegaLaunch ml;
-        const int wpcd = chd == 8 ? 2 : 1;
+        const int wpcd = chd == 8 ? 2 : (chd == 4 ? 4 : 1);
         const bool sp = chd == 16 && mega_d2_two_pass(e);
         ml.tri = p.tri != 0; ml.xlds = false; ml.pb = p.hard || p.have_prior || p.depairs > 1; ml.k1 = p.k == 1; ml.ch = chd; ml.wpc = wpcd; ml.redo = false; ml.sp = sp;
         ml.grid = dim3((p.nl + chd - 1) / chd); ml.block = dim3(64 * chd * wpcd);

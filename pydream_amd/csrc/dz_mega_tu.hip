@@ -43,6 +43,16 @@ const char* DZ_CAT(mega_launch_nrt, DZ_TU_NRT)(const MegaLaunch& a)
                               a.slot0, a.zappend, a.seg0, *a.publish);
         return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,lean,two-pass>";
     }
+    if (a.ch == 4) {                       // ... 4 chains x 4 waves where not even 8 chains' tiles fit (256 dimensions at 8 tries)
+        if (a.pb) {
+            hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 4, false, true, 4>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M,
+                                  a.slot0, a.zappend, a.seg0, *a.publish);
+            return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,full>";
+        }
+        hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 4, false, false, 4>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M,
+                              a.slot0, a.zappend, a.seg0, *a.publish);
+        return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,lean>";
+    }
     if (a.ch == 8) {                       // ... or, where the point tiles of 16 chains do not fit LDS (d > ~228 at 5 tries), at 8 chains x 2 waves (round 6)
         if (a.pb) {
             hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 8, false, true, 2>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M,
@@ -126,6 +136,14 @@ const char* DZ_CAT(mega_launch_nrt, DZ_TU_NRT)(const MegaLaunch& a)
 // do not fit even without the matrix (100 dimensions at 16..20 tries)
 const char* DZ_CAT(mega_launch_d2_nrt, DZ_TU_NRT)(const MegaLaunch& a)
 {
+    if (a.ch == 4) {                       // 4 chains x 4 waves: 24..32 tries at 100 dimensions, 20..32 at 128
+        if (a.pb) {
+            hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 4, false, true, 4>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, a.slot0, a.zappend, a.seg0, *a.publish);
+            return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,full>";
+        }
+        hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 4, false, false, 4>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, a.slot0, a.zappend, a.seg0, *a.publish);
+        return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,lean>";
+    }
     if (a.ch == 8) {
         if (a.pb) {
             hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 8, false, true, 2>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M, a.slot0, a.zappend, a.seg0, *a.publish);

@@ -816,7 +816,7 @@ def test_a_chain_count_just_above_whole_rounds_of_blocks_against_oracle(G, O, ad
                                               # (round 6) k_generations_d2 keeps one phase's draw slots at a time: 16..32 tries inside a persistent kernel (triangular factor, > 1024 chains)
                                               (16, 100, 1100, "tri", "k_generations_d2<7,tri,xhbm,8,2,lean>"), (20, 100, 1040, "tri", "k_generations_d2<7,tri,xhbm,8,2,lean>"),
                                               (32, 10, 1030, "tri", "k_generations_d2<1,tri,xhbm,16,1,lean>"), (17, 48, 1100, "tri", "k_generations_d2<3,tri,xhbm,16,1,lean>"),
-                                              (16, 132, 1040, "tri", "k_generations_d2<9,tri,xhbm,8,2,lean>"), (16, 200, 1040, "tri", "multi-kernel path"), (24, 100, 1040, "tri", "multi-kernel path"),
+                                              (16, 132, 1040, "tri", "k_generations_d2<9,tri,xhbm,8,2,lean>"), (16, 200, 1040, "tri", "k_generations_d2<13,tri,xhbm,4,4,lean>"), (24, 100, 1040, "tri", "k_generations_d2<7,tri,xhbm,4,4,lean>"), (32, 128, 1030, "tri", "k_generations_d2<8,tri,xhbm,4,4,lean>"),      # (4 chains x 4 waves where 8 x 2 do not fit)
                                               (15, 100, 1100, "tri", "k_generations_d2<7,tri,xhbm,8,2,lean>")])
 def test_more_than_sixteen_tries_against_oracle(G, O, k, d, N, lk, variant):
     """The reference takes any integer as `multitry` (Dream.py:155-161).  Up to 15 tries a generation's draw slots fit one wave's lanes and the

@@ -28,7 +28,7 @@ def draw_config(rng, long=False, dims=None, chains=None):
         N = min(N, 256)
     if rng.random() < 0.04:
         d, N = 1000, int(rng.choice([16, 130]))
-    k = int(rng.choice([1, 1, 3, 4, 5, 5, 5, 6]))
+    k = int(rng.choice([1, 1, 3, 4, 5, 5, 5, 6, 9, 16, 20]))      # (round 6: 16..32 tries run k_generations_d2 above 1024 chains with the triangular factor; below, and otherwise, the multi-kernel path)
     depairs = int(rng.choice([1, 1, 1, 2, 3]))
     ngamma = int(rng.choice([1, 1, 2, 4]))
     ncr = int(min(d, rng.choice([1, 2, 3, 3, 5])))

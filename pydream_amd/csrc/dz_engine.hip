@@ -964,12 +964,12 @@ bool mega_redo(const dz_engine* e) { return redo_possible(e) && e->lk == LK_MVN 
 // instantiation spills a hundred registers; at 8 chains per block 156 against 148 us at d = 200).
 // (round 6) 16 chains per block whose k tries' point tiles do not fit but k - 1 do (229..256 dimensions at 5 tries): the proposal set in two passes
 // (k_generations_d2<.., SP>); 3..15 tries, 128 < d
-bool mega_d2_two_pass(const dz_engine* e)
+bool mega_d2_two_pass(const dz_engine* e, int ch = 16)
 {
     const dz::Params& p = e->p;
     if (p.ld <= 128 || p.k < 3 || p.nslots > 64 || (getenv("DZ_MEGA_D2_SP") && atoi(getenv("DZ_MEGA_D2_SP")) == 0)) return false;
-    if (sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, false, 16, false, false, true).total <= (size_t)160 * 1024) return false;
-    return sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, false, 16, false, false, true, 0, true).total <= (size_t)160 * 1024;
+    if (sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, false, ch, false, false, true).total <= (size_t)160 * 1024) return false;
+    return sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, false, ch, false, false, true, 0, true).total <= (size_t)160 * 1024;
 }
 int mega_d2_chains(const dz_engine* e)
 {
@@ -1000,6 +1000,7 @@ int mega_d2_chains(const dz_engine* e)
     }
     if (p.k >= 3 && !(getenv("DZ_MEGA_D2_W2") && atoi(getenv("DZ_MEGA_D2_W2")) == 0) &&
         sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, true, false, 8, false, false, true).total <= (size_t)160 * 1024) return 8;
+    if (p.k >= 3 && !(getenv("DZ_MEGA_D2_W2") && atoi(getenv("DZ_MEGA_D2_W2")) == 0) && mega_d2_two_pass(e, 8)) return 8;      // 8 x 2 with the two-pass set (256 dimensions at 8 tries)
     // ... and 4 chains x 4 waves where not even those fit (24..32 tries at 100 dimensions, 20..32 at 128, 8 at 256): four rounds of 1024 blocks at 4096
     // chains, still ahead of the multi-kernel path
     if (p.k >= 4 && !(getenv("DZ_MEGA_D2_W4") && atoi(getenv("DZ_MEGA_D2_W4")) == 0) &&
@@ -1189,7 +1190,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         DZCK(upload_params(e));
         dz::MegaLaunch ml;
         const int wpcd = chd == 8 ? 2 : (chd == 4 ? 4 : 1);
-        const bool sp = chd == 16 && mega_d2_two_pass(e);
+        const bool sp = (chd == 16 && mega_d2_two_pass(e)) || (chd == 8 && mega_d2_two_pass(e, 8));
         ml.tri = p.tri != 0; ml.xlds = false; ml.pb = p.hard || p.have_prior || p.depairs > 1; ml.k1 = p.k == 1; ml.ch = chd; ml.wpc = wpcd; ml.redo = false; ml.sp = sp;
         ml.grid = dim3((p.nl + chd - 1) / chd); ml.block = dim3(64 * chd * wpcd);
         ml.lds = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, false, chd, false, false, true, 0, sp).total;

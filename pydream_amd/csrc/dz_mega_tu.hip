@@ -33,7 +33,7 @@ const char* DZ_CAT(mega_launch_nrt, DZ_TU_NRT)(const MegaLaunch& a)
         return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,lean" NAME_ ">";                                                     \
     } while (0)
     if (a.k1) DZ_D2(true, ",k1");          // (the host only sends the triangular factor at 16 chains per block here: mega_d2_chains)
-    if (a.sp) {                            // 16 chains per block, the proposal set in two passes over k - 1 point tiles (round 6)
+    if (a.sp && a.ch == 16) {              // 16 chains per block, the proposal set in two passes over k - 1 point tiles (round 6)
         if (a.pb) {
             hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 16, false, true, 1, true>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M,
                                   a.slot0, a.zappend, a.seg0, *a.publish);
@@ -52,6 +52,16 @@ const char* DZ_CAT(mega_launch_nrt, DZ_TU_NRT)(const MegaLaunch& a)
         hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 4, false, false, 4>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M,
                               a.slot0, a.zappend, a.seg0, *a.publish);
         return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,lean>";
+    }
+    if (a.ch == 8 && a.sp) {               // 8 chains x 2 waves with the two-pass set (256 dimensions at 8 tries)
+        if (a.pb) {
+            hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 8, false, true, 2, true>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M,
+                                  a.slot0, a.zappend, a.seg0, *a.publish);
+            return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,full,two-pass>";
+        }
+        hipExtLaunchKernelGGL((k_generations_d2<DZ_TU_NRT, true, 8, false, false, 2, true>), a.grid, a.block, a.lds, a.st, a.ka, a.kb, 0, a.pp, a.g, a.n, a.M,
+                              a.slot0, a.zappend, a.seg0, *a.publish);
+        return "k_generations_d2<" DZ_STR(DZ_TU_NRT) ",tri,xhbm,%d,%d,lean,two-pass>";
     }
     if (a.ch == 8) {                       // ... or, where the point tiles of 16 chains do not fit LDS (d > ~228 at 5 tries), at 8 chains x 2 waves (round 6)
         if (a.pb) {

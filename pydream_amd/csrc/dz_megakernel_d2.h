@@ -34,7 +34,7 @@ template <int NRT, bool TRI, int CH, bool K1 = false, bool PB = false, int WPC =
 __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0, int64_t zappend, int seg0, Publish pub)
 {
     static_assert(WPC == 1 || !K1, "one try per generation: one wave per chain");
-    static_assert(!SP || (CH == 16 && WPC == 1 && !K1), "the two-pass proposal set: 16 chains per block (a try = one point tile), one wave each, multi-try");
+    static_assert(!SP || (!K1 && ((CH == 16 && WPC == 1) || (CH == 8 && WPC == 2))), "the two-pass proposal set: 16 chains x 1 wave or 8 chains x 2 waves per block, multi-try");
     constexpr int NCH = NRT > 8 ? 2 : 1, NT = 64 * CH * WPC;    // (NRT = 8, ld = 128: one chunk -- the kernel also serves 113..128 dimensions, where the
                                                                 //  matrix in LDS leaves room for the point tiles of 8 chains only)
     double* const publish = pub.to;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
                 int srow = sel;
                 if (SP) {     // where the selected try's point is: the last try sits in row 0; try 0 was overwritten by it and is generated again (same counters, same bits)
                     if (sel == k - 1) srow = 0;
-                    else if (sel == 0) {
+                    else if (sel == 0 && sub == 0) {
                         const bool snk0 = __builtin_amdgcn_readfirstlane((int)f.snk) != 0;
                         const double* grow0 = PB ? gamma_row(p, f.glev, f.delta) : gts + (size_t)(__builtin_amdgcn_readfirstlane(f.glev) - 1) * d;
                         double xb[NCH][2];
@@ -154,6 +154,8 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
                         if (PB) propose_set<NCH, false, true, 0>(p, 0, g, M, c, gc, 0, 1, k, lane, xb, grow0, snk0, f.cr_idx, f.delta, f.glev, ds, region, tstride, sS + cl * k, nullptr, sP + cl * k, nullptr);
                         else propose_set<NCH, false, false, 1>(p, 0, g, M, c, gc, 0, 1, k, lane, xb, grow0, snk0, f.cr_idx, 1, f.glev, ds, region, tstride, sS + cl * k, nullptr, sP + cl * k, nullptr);
                     }
+                    if (sel == 0) srow = 0;
+                    if (WPC > 1) __syncthreads();                                    // (the chain's other wave reads the point its first wave has just made again)
                 }
                 const double* row = region + (size_t)srow * tstride;
 #pragma unroll
@@ -203,17 +205,19 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
                     else mfma_units<NRT, TRI, false>(p, Mg, Pt, mus, qb, row0, ntl, wv, CH * WPC, lane, LDMg, L.LDP);
                 }
             };
-            if (SP && phase == 0) {      // the proposal set in two passes over k - 1 tiles: tries 0 .. k-2, then try k-1 over try 0's rows
-                propose(0, k - 1, 0);
+            if (SP && phase == 0) {      // the proposal set in two passes over the rows of k - 1 tries: tries 0 .. k-2, then try k-1 over try 0's rows
+                const int a0 = WPC == 1 ? 0 : (sub * (k - 1)) / WPC, a1 = WPC == 1 ? k - 1 : ((sub + 1) * (k - 1)) / WPC;
+                propose(a0, a1, 0);
                 __syncthreads();
-                units(0, k - 1);
+                units(0, ((k - 1) * CH + 15) / 16);
                 __syncthreads();
-                if (lane < k - 1) sL[cl * k + lane] = nan_to_ninf(p.logF - 0.5 * q_sum(lane * CH + cl));
-                propose(k - 1, k, k - 1);
+                if (lane < k - 1 && sub == 0) sL[cl * k + lane] = nan_to_ninf(p.logF - 0.5 * q_sum(lane * CH + cl));
+                if (sub == WPC - 1) propose(k - 1, k, k - 1);
                 __syncthreads();
-                units(0, 1);
+                units(0, 1);                                                 // (8 chains per block: the tile's other half holds try 1 -- its sums come out the same again)
                 __syncthreads();
-                if (lane == k - 1) sL[cl * k + lane] = nan_to_ninf(p.logF - 0.5 * q_sum(cl));
+                if (lane == k - 1 && sub == 0) sL[cl * k + lane] = nan_to_ninf(p.logF - 0.5 * q_sum(cl));
+                if (WPC > 1) __syncthreads();                                // (both waves of the chain select from sL)
                 continue;
             }
             propose(i0, i1, 0);

@@ -196,6 +196,7 @@ def test_d1000_stress_shape_against_oracle(G, O):
                                                              (300, 160, 5, 1, 0, True, None), (1100, 200, 5, 1, 0, True, None), (100, 200, 3, 0, 0, False, None),
                                                              (250, 224, 5, 1, 12, True, None), (64, 140, 4, 1, 12, True, None), (48, 129, 15, 1, 0, True, None), (48, 129, 8, 1, 0, True, None),
                                                              (250, 256, 5, 1, 0, True, None), (1100, 240, 5, 1, 0, True, None), (200, 256, 5, 1, 12, True, None), (100, 250, 4, 1, 0, True, "normal"),      # (round 6: 8 chains x 2 waves per block where 16 chains' point tiles do not fit)
+                                                             (1100, 256, 8, 1, 0, True, None), (200, 250, 9, 1, 12, True, "normal"), (120, 256, 12, 1, 0, True, None),      # (8 x 2 with the two-pass set; 4 x 4)
                                                              (3072, 100, 5, 1, 0, True, None), (2500, 100, 5, 1, 12, True, "uniform"), (2300, 64, 3, 0, 0, True, None),      # (round 6: 12 chains per block)
                                                              (64, 200, 1, 1, 0, True, None), (300, 160, 1, 1, 12, True, None), (64, 200, 5, 1, 0, True, "normal"), (100, 160, 4, 1, 12, True, "uniform"), (64, 200, 1, 1, 0, True, "uniform"), (64, 200, 1, 0, 0, False, None),
                                                              (80, 128, 5, 1, 12, True, None), (80, 127, 6, 1, 0, True, "normal"), (48, 100, 12, 1, 0, True, None),      # (d <= 128 where 16 chains do not fit next to the matrix: k_generations_d2<8 / 7,..>)

@@ -162,6 +162,10 @@ struct dz_engine {
     // 0's published position after generation h at slot h mod 2 (L + 1); d_x0start: before generation 0.
     int ad_R1 = 1, ad_nbp = 0; bool ad_multi = false; int64_t ad_applied = -1, ad_made = -1; size_t ad_tot_stride = 0, ad_pr_stride = 0, ad_pc_stride = 0;
     double *d_DOT = nullptr, *d_x0ring = nullptr, *d_x0start = nullptr;
+    // ... and for the kernels that do not make their blocks' unit sums (burnin_multi == 2): d_posring [L + 2][N][ld] the published positions of the last
+    // L + 2 generations (slot = generation mod (L + 2); made on first use), posring_gen the last generation in it; d_PG [L + 1][ad_nbp] the probabilities
+    // the last launch's generations decided with (k_adapt_partials_ring)
+    double *d_posring = nullptr, *d_PG = nullptr; int64_t posring_gen = -2; bool ad_ring = true;
     // sharded crossover burn-in (round 5): a rank that owns whole groups of 256 chains exchanges its groups' sums (dz_kernels.h k_adapt_groups /
     // k_group_totals) instead of its positions.  d_GS[parity of the generation]: [world][gs_rec] records (two buffers: a peer may be one
     // generation ahead); d_shift[parity]: global chain 0's position after that generation (the shift of the next one's column sums)
@@ -1060,19 +1064,38 @@ size_t mvn_multi_lds(const dz_engine* e)
     const dz::Params& p = e->p;
     return sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, p.ld / 16, p.ncr, p.ngamma, p.tri != 0, true, 16, p.pb_lds != 0, true, false, e->ad_R1).total;
 }
-bool burnin_multi(const dz_engine* e)
+// -> 1: the kernel makes its blocks' unit sums generation by generation (the MG instantiations: blocks of 16 chains = one unit);  2: any other persistent
+// kernel (blocks of 12 / 8 / 4 chains, split generations, 128 < d <= 256, multitry off, redraw rounds) -- every generation's positions go to a ring of
+// published positions and ONE k_adapt_partials_ring launch behind it makes the sums of all its generations;  0: one burn-in generation per launch
+int burnin_multi(const dz_engine* e)
 {
-    if (!e->ad_multi || !e->adapt_fused || !e->mega_burnin || e->tempering) return false;
-    if (e->lk == LK_MIX) return mega_mix_eligible(e) && e->p.k >= 3 && mix_multi_lds(e) <= (size_t)160 * 1024;
-    if (e->lk == LK_MVN) {      // k_generations<.., 16, 1, .., multi>: 16 chains per block in ONE launch, one wave each, multi-try, the chains' states in LDS, no redraw rounds
-        const dz::Params& p = e->p;
-        if (!e->mega || mega_d2_chains(e) > 0 || p.ld > 128 || p.k < 3 || p.k > dz::MAXK || p.nslots > 64 || redo_possible(e) || (p.tri && !p.Mtp)) return false;
-        const MegaPlan plan = mega_plan(e);
-        if (plan.ch != 16 || plan.split_c != p.nl) return false;
-        const bool pb = p.hard || p.have_prior || p.depairs > 1;
-        return (pb || mega_xlds(e)) && mvn_multi_lds(e) <= (size_t)160 * 1024;
+    if (!e->ad_multi || !e->mega_burnin || e->tempering) return 0;
+    const dz::Params& p = e->p;
+    const size_t tab = sizeof(double) * (size_t)e->ad_R1 * e->ad_nbp, cap = (size_t)160 * 1024;
+    const bool ring_ok = e->ad_ring && sizeof(double) * (size_t)(e->c.adapt_lag + 2) * p.N * p.ld <= ((size_t)8 << 30);
+    if (e->lk == LK_MIX) {
+        if (!mega_mix_eligible(e)) return 0;
+        if (e->adapt_fused && p.k >= 3 && mix_multi_lds(e) <= cap) return 1;
+        return (ring_ok && sizeof(double) * (size_t)dz::MIXW * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + tab <= cap) ? 2 : 0;
     }
-    return false;
+    if (e->lk != LK_MVN || !e->mega) return 0;
+    const int nrt = p.ld / 16;
+    if (const int chd = mega_d2_chains(e)) {
+        const bool sp = (chd == 16 && mega_d2_two_pass(e)) || (chd == 8 && mega_d2_two_pass(e, 8));
+        return (ring_ok && sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, false, chd, false, false, true, e->ad_R1, sp).total <= cap) ? 2 : 0;
+    }
+    if (p.ld > 128 || (p.k != 1 && p.k < 3) || p.k > dz::MAXK || p.nslots > 64 || (p.tri && !p.Mtp)) return 0;
+    const MegaPlan plan = mega_plan(e);
+    const bool pb = p.hard || p.have_prior || p.depairs > 1 || mega_redo(e);
+    if (e->adapt_fused && p.k >= 3 && !redo_possible(e) && plan.ch == 16 && plan.split_c == p.nl && (pb || mega_xlds(e)) && mvn_multi_lds(e) <= cap) return 1;
+    if (!ring_ok || (redo_possible(e) && !mega_redo(e))) return 0;
+    const bool xl = pb ? true : mega_xlds(e);
+    for (int part = 0; part < 2; ++part) {
+        const int chp = part ? plan.ch_b : plan.ch;
+        if (part && plan.split_c == p.nl) break;
+        if (sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, xl, chp, p.pb_lds != 0, false, false, e->ad_R1).total > cap) return 0;
+    }
+    return 2;
 }
 int mega_segment(const dz_engine* e, uint32_t g, int64_t remaining)
 {
@@ -1117,16 +1140,24 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
     }
     const bool publish = publishing(e, g);            // (then n == 1: mega_segment -- or, adapt_lag >= 1 and burnin_multi, up to adapt_lag + 1)
     const bool ring = e->c.adapt_lag > 0;
-    const bool multi = publish && ring && burnin_multi(e);      // the launch applies the pending updates itself and makes its units' sums generation by generation
-    if (ring && !multi) DZCK(adapt_apply_due(e, (int64_t)g));   // (every generation of such a launch decides with the same state: one burn-in generation, or none)
-    if (publish && n > 1 && !multi) return fail("internal: several burn-in generations in a launch that cannot hold them");
+    const int mmode = (publish && ring) ? burnin_multi(e) : 0;
+    const bool multi = mmode == 1;      // the launch applies the pending updates itself and makes its units' sums generation by generation
+    const bool rmulti = mmode == 2;     // ... or leaves every generation's positions in the ring; the sums follow (k_adapt_partials_ring)
+    if (ring && !mmode) DZCK(adapt_apply_due(e, (int64_t)g));   // (every generation of such a launch decides with the same state: one burn-in generation, or none)
+    if (publish && n > 1 && !mmode) return fail("internal: several burn-in generations in a launch that cannot hold them");
     if (g == 0 && e->adapt) {   // publish the start positions (Dream_shared_vars.current_positions)
         const size_t nn = (size_t)p.nl * p.ld;
         hipLaunchKernelGGL(dz::k_copy_rows, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, e->stream, p.X, p.cp_new + (size_t)p.off * p.ld, nn);
         DZCK(exchange_rows(e, XK_POS, p.cp_new, 0));
         if (e->c.adapt_lag > 0) HIPCK(hipMemcpyAsync(e->d_x0start, p.cp_new, sizeof(double) * p.ld, hipMemcpyDeviceToDevice, e->stream));      // global chain 0's start position
     }
-    if (publish) { e->cp_idx = (e->cp_idx + 1) % 3; p.cp_prev = p.cp_new; p.cp_new = e->d_cp[e->cp_idx]; }
+    if (publish && !rmulti) { e->cp_idx = (e->cp_idx + 1) % 3; p.cp_prev = p.cp_new; p.cp_new = e->d_cp[e->cp_idx]; }
+    const size_t pos_stride = (size_t)p.N * p.ld; const int RP = e->c.adapt_lag + 2;
+    if (rmulti) {      // the ring of published positions; the positions before this launch's first generation are the chains' states now
+        if (!e->d_posring) { DZCK(ealloc(e, &e->d_posring, (size_t)RP * pos_stride)); DZCK(ealloc(e, &e->d_PG, (size_t)e->ad_R1 * e->ad_nbp)); }
+        if (e->posring_gen != (int64_t)g - 1)
+            HIPCK(hipMemcpyAsync(e->d_posring + (size_t)(((int64_t)g - 1 + RP) % RP) * pos_stride, p.X, sizeof(double) * pos_stride, hipMemcpyDeviceToDevice, e->stream));
+    }
     const int64_t slot0 = e->c.trace_capacity ? e->ntrace : -1;
     dz::Publish pub; pub.to = publish ? p.cp_new : nullptr; pub.shift = nullptr; pub.PR = nullptr; pub.PC = nullptr;
     pub.sh = p.cr_probs; pub.sh_out = nullptr; pub.TOT = nullptr; pub.CNT = nullptr; pub.c0 = 0; pub.c1 = p.nl;
@@ -1138,15 +1169,29 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         pub.PR = e->d_PR; pub.PC = e->d_PC;
         pub.sh_out = e->d_shared + (size_t)(e->sh_cur ^ 1) * 3 * (p.ncr + p.ngamma);
     }
+    if (rmulti) {
+        pub.multi = 2; pub.lag = e->c.adapt_lag; pub.burnin = p.burnin; pub.nbp = e->ad_nbp; pub.pend0 = e->ad_applied + 1; pub.pend1 = e->ad_made + 1;
+        pub.DOT = e->d_DOT; pub.CNTR = e->d_CNT; pub.to = e->d_posring; pub.pos_stride = (long long)pos_stride; pub.PG = e->d_PG;
+        pub.sh_out = e->d_shared + (size_t)(e->sh_cur ^ 1) * 3 * (p.ncr + p.ngamma);
+    }
     auto launched = [&]() {
         if (applies) { e->sh_cur ^= 1; point_shared(e); e->adapt_pending = false; }
-        if (multi) { e->sh_cur ^= 1; point_shared(e); e->ad_applied = std::max(e->ad_applied, adapt_due(e, (int64_t)g + n - 1)); }
+        if (multi || rmulti) { e->sh_cur ^= 1; point_shared(e); e->ad_applied = std::max(e->ad_applied, adapt_due(e, (int64_t)g + n - 1)); }
     };
     // crossover burn-in on one GPU: a block of 16 chains is one unit of the adaptation's column sums (contract v3) and makes them itself
     bool fused = false;
     auto fuse_adapt = [&]() { fused = true; pub.shift = adapt_shift(e, g); pub.PR = e->d_PR; pub.PC = e->d_PC; };
     auto after_launch = [&]() -> int {      // end of the generation(s): positions -> adaptation -> history append (schedule S2)
         if (multi) { ProfScope ps(e, PR_ADAPT); DZCK(adapt_finish(e, false, g, n, true)); }      // the totals and dot products of the launch's n generations (one GPU: nothing to exchange)
+        else if (rmulti) {
+            ProfScope ps(e, PR_ADAPT);
+            hipLaunchKernelGGL(dz::k_adapt_partials_ring, dim3((p.N + 15) / 16, n), dim3(1024), 0, e->stream, p, g, e->ad_R1, (const double*)e->d_posring, (long long)pos_stride,
+                               (const double*)e->d_PG, e->ad_nbp, e->d_PR, e->d_PC, (long long)e->ad_pr_stride, (long long)e->ad_pc_stride, e->d_x0ring, (const double*)e->d_x0start);
+            DZCK(launch_check("k_adapt_partials_ring"));
+            DZCK(adapt_finish(e, false, g, n, true));
+            e->posring_gen = (int64_t)g + n - 1;
+            p.cp_new = e->d_posring + (size_t)(e->posring_gen % RP) * pos_stride;      // (what a later launch that is not of this kind measures its jumps from)
+        }
         else if (publish) {
             if (!e->adapt_groups) DZCK(exchange_rows(e, XK_POS, p.cp_new, 0));      // (ranks that own whole groups exchange their groups' sums instead: adapt_generation)
             DZCK(adapt_generation(e, g, 0, p.N, fused, mega_follows));
@@ -1170,7 +1215,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         if (multi) mw = 16;
         else if (publish && !ring && e->adapt_fused && (e->world == 1 || e->adapt_groups) && p.k >= 3 && sizeof(double) * (size_t)16 * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs + lds_xo <= (size_t)160 * 1024) { mw = 16; fuse_adapt(); }
         const dim3 gridm((p.nl + mw - 1) / mw), blockm(64 * mw);
-        const size_t ldsm = multi ? mix_multi_lds(e) : sizeof(double) * (size_t)mw * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs + (fused ? lds_xo : 0);
+        const size_t ldsm = multi ? mix_multi_lds(e) : sizeof(double) * (size_t)mw * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + (rmulti ? sizeof(double) * (size_t)e->ad_R1 * e->ad_nbp : lds_probs) + (fused ? lds_xo : 0);
         const bool pbm = p.hard || p.have_prior || p.depairs > 1;
         if (multi) {
             if (pbm) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations_mix<true, true>), gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, seg0, pub);
@@ -1181,6 +1226,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         DZCK(launch_check("k_generations_mix"));
         launched();
         e->last_variant = multi ? (pbm ? "k_generations_mix<full,multi>" : "k_generations_mix<multi>") : (pbm ? "k_generations_mix<full>" : "k_generations_mix");
+        if (rmulti) e->last_variant += " +ring";
         DZCK(after_launch());
         if (slot0 >= 0) e->ntrace += n;
         return 0;
@@ -1193,7 +1239,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         const bool sp = (chd == 16 && mega_d2_two_pass(e)) || (chd == 8 && mega_d2_two_pass(e, 8));
         ml.tri = p.tri != 0; ml.xlds = false; ml.pb = p.hard || p.have_prior || p.depairs > 1; ml.k1 = p.k == 1; ml.ch = chd; ml.wpc = wpcd; ml.redo = false; ml.sp = sp;
         ml.grid = dim3((p.nl + chd - 1) / chd); ml.block = dim3(64 * chd * wpcd);
-        ml.lds = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, false, chd, false, false, true, 0, sp).total;
+        ml.lds = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, false, chd, false, false, true, rmulti ? e->ad_R1 : 0, sp).total;
         ml.st = e->stream; ml.ka = nullptr; ml.kb = nullptr;
         ml.pp = (const dz::Params*)e->d_params; ml.g = g; ml.n = n; ml.M = (uint32_t)visible_rows(e); ml.slot0 = slot0; ml.zappend = append_last ? e->M : (int64_t)-1; ml.seg0 = seg0; ml.publish = &pub;
         if (e->prof) { ml.ka = prof_event(e); ml.kb = prof_event(e); e->ev[PR_GENERATIONS].emplace_back(ml.ka, ml.kb); }
@@ -1211,6 +1257,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         }
         char buf[96]; snprintf(buf, sizeof buf, name, chd, wpcd);
         e->last_variant = buf;
+        if (rmulti) e->last_variant += " +ring";
         DZCK(launch_check("k_generations_d2"));
         launched();
         DZCK(after_launch());
@@ -1231,9 +1278,10 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
     std::string variant;
     auto launch_part = [&](int c0, int c1, int chp) -> int {
         const int wpcp = (chp == 4 && !k1) ? 4 : 1;
-        size_t ldsp = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, pb ? true : xlds, chp, p.pb_lds != 0).total;
+        size_t ldsp = sizeof(double) * (size_t)dz::mega_layout(p.d, p.k, nrt, p.ncr, p.ngamma, p.tri != 0, pb ? true : xlds, chp, p.pb_lds != 0, false, false, rmulti ? e->ad_R1 : 0).total;
         dz::Publish pp = pub; pp.c0 = c0; pp.c1 = c1;
         if (multi) ldsp = mvn_multi_lds(e);      // (burnin_multi: one launch of 16-chain blocks, the states in LDS; + the states before the generation, + the table of probabilities)
+        else if (rmulti) { }
         else
         if (split_c != p.nl) { pp.PR = nullptr; pp.PC = nullptr; pp.shift = nullptr; }      // (a split generation's unit sums come from k_adapt_partials)
         else if (publish && !ring && e->adapt_fused && (e->world == 1 || e->adapt_groups) && chp == 16 && wpcp == 1 && !k1 && p.k >= 3 && (pb || xlds)) {      // (the new and old states are read from LDS)
@@ -1262,7 +1310,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
     };
     DZCK(launch_part(0, split_c, ch));
     if (ch_b) DZCK(launch_part(split_c, p.nl, ch_b));
-    e->last_variant = variant;
+    e->last_variant = variant + (rmulti ? " +ring" : "");
     DZCK(launch_check("k_generations"));
     launched();
     DZCK(after_launch());
@@ -1316,6 +1364,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     if (const char* kv = getenv("DZ_ADAPT_FUSED")) e->adapt_fused = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_MIX_PB")) e->mega_mix_pb = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_SPLIT")) e->mega_split = atoi(kv) != 0;
+    if (const char* kv = getenv("DZ_ADAPT_RING")) e->ad_ring = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_W4")) e->mega_w4 = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_D2")) e->mega_d2 = atoi(kv);
     static_assert(dz::DZ_MAX_REDRAWS_DEV == DZ_MAX_REDRAWS && dz::DZ_REDRAW_KEY_STEP_DEV == DZ_REDRAW_KEY_STEP, "redraw constants");

@@ -92,6 +92,10 @@ struct Publish {
     int multi = 0, lag = 0, burnin = 0, nbp = 0; long long pend0 = 0, pend1 = 0;
     const double* DOT = nullptr; const double* CNTR = nullptr; double* x0ring = nullptr; const double* x0start = nullptr;
     long long pr_stride = 0, pc_stride = 0;
+    // multi == 2 (any instantiation): several burn-in generations per launch whose unit sums are made BEHIND the launch -- `to` is a ring of
+    // lag + 2 position arrays, pos_stride doubles apart (generation g's at slot g mod (lag + 2)); PG [generations of the launch][nbp]: the
+    // probabilities each of them decided with (block 0 leaves its table there), read by k_adapt_partials_ring
+    double* PG = nullptr; long long pos_stride = 0;
 };
 
 // per-phase cycle stamps: defined by dz_experiments.h in instrumented builds only (tools/variants.sh), no-ops in the product
@@ -2228,6 +2232,38 @@ __global__ __launch_bounds__(1024) void k_adapt_partials(Params p, uint32_t g, d
     const int nc = min(16, p.N - 16 * unit), nq = adapt_nq(p);
     adapt_unit_sums(p, p.cp_new + (size_t)16 * unit * p.ld, p.ld, p.cp_prev + (size_t)16 * unit * p.ld, p.ld, nc, [&](bool isg, int c) { return isg ? s_bg[c] : s_bc[c]; }, shift ? shift : p.cp_prev,
                     PR + (size_t)blockIdx.x * nq * p.ld, PC + (size_t)blockIdx.x * (p.ncr + p.ngamma), threadIdx.x, 1024);
+}
+
+// adapt_lag >= 1, several burn-in generations per launch by a kernel that does not make its blocks' unit sums (Publish::multi == 2: blocks of 12, 8
+// or 4 chains, split generations, 128 < d, multitry off): the sums of the launch's n generations g0 .. g0 + n - 1 from the RING of published
+// positions -- block (unit, i): generation g = g0 + i, new positions = slot g mod (R1 + 1), previous = slot (g - 1) mod (R1 + 1) (generation
+// -1: the start positions, seeded by the host), the bins from the probabilities generation g decided with (PG[i], left by the launch's block
+// 0), the shift = global chain 0's position after generation g - R1 -- into the rings' slot g mod R1.  Unit 0 also leaves chain 0's new
+// position in x0ring (slot g mod 2 R1: no generation of this launch reads a slot this launch writes).
+__global__ __launch_bounds__(1024) void k_adapt_partials_ring(Params p, uint32_t g0, int R1, const double* __restrict__ pos, long long pos_stride, const double* __restrict__ PG, int nbp,
+                                                              double* __restrict__ PR, double* __restrict__ PC, long long pr_stride, long long pc_stride,
+                                                              double* __restrict__ x0ring, const double* __restrict__ x0start)
+{
+    __shared__ int s_bc[16], s_bg[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, unit = blockIdx.x;
+    const uint32_t g = g0 + blockIdx.y;
+    const int R = R1 + 1;
+    const int gcn = 16 * unit + wv;
+    const double* pr_g = PG + (size_t)blockIdx.y * nbp;
+    int bc = -1, bg = -1;
+    if (gcn < p.N) adapt_bins(p, g, gcn, lane, bc, bg, pr_g, pr_g + p.ncr);
+    if (lane == 0) { s_bc[wv] = bc; s_bg[wv] = bg; }
+    __syncthreads();
+    const int nc = min(16, p.N - 16 * unit), nq = adapt_nq(p);
+    const double* xn = pos + (size_t)(g % (uint32_t)R) * pos_stride + (size_t)16 * unit * p.ld;
+    const double* xp = pos + (size_t)((g + (uint32_t)R - 1u) % (uint32_t)R) * pos_stride + (size_t)16 * unit * p.ld;
+    const long long hs = (long long)g - (long long)R1;
+    const double* shift = hs < 0 ? x0start : x0ring + (size_t)(hs % (2 * R1)) * p.ld;
+    const int slot = (int)(g % (uint32_t)R1);
+    adapt_unit_sums(p, xn, p.ld, xp, p.ld, nc, [&](bool isg, int c) { return isg ? s_bg[c] : s_bc[c]; }, shift,
+                    PR + (size_t)slot * pr_stride + (size_t)unit * nq * p.ld, PC + (size_t)slot * pc_stride + (size_t)unit * (p.ncr + p.ngamma), threadIdx.x, 1024);
+    if (unit == 0)
+        for (int j = threadIdx.x; j < p.ld; j += 1024) x0ring[(size_t)(g % (uint32_t)(2 * R1)) * p.ld + j] = xn[j];
 }
 
 // ---- sharded crossover burn-in (round 5): the ranks exchange their GROUPS' sums, not their positions.  Contract v3 adds the units' sums

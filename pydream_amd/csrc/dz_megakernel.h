@@ -370,8 +370,11 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     const int d = p.d, k = K1 ? 1 : p.k, ld = p.ld;
     const bool pbl = PB && p.pb_lds != 0;
     static_assert(!MG || (CH == 16 && WPC == 1 && !K1 && XLDS && !REDO), "several burn-in generations per launch: 16 chains per block, one wave each, states in LDS");
-    const bool fuse_adapt = !MG && CH == 16 && WPC == 1 && !K1 && XLDS && pub.PR != nullptr;
-    const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, XLDS, CH, pbl, MG || fuse_adapt, false, MG ? pub.lag + 1 : 0);
+    // (any instantiation; Publish::multi == 2) several burn-in generations per launch WITHOUT the block's own unit sums: the positions of every generation go to
+    // the ring of published positions and k_adapt_partials_ring makes the sums behind the launch; the prologue and the table as with MG
+    const bool RG = !MG && pub.multi == 2;
+    const bool fuse_adapt = !MG && !RG && CH == 16 && WPC == 1 && !K1 && XLDS && pub.PR != nullptr;
+    const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, XLDS, CH, pbl, MG || fuse_adapt, false, (MG || RG) ? pub.lag + 1 : 0);
     double* Ms = smem;
     double* Pt = smem + L.off_P;
     double* qb = smem + L.off_q;
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
     }
     for (int i = threadIdx.x; i < L.rows * L.LDP; i += NT) Pt[i] = 0.0;
     if (threadIdx.x < 4 * ((d + 3) / 4) + 4) mus[threadIdx.x] = threadIdx.x < d ? p.mu[threadIdx.x] : 0.0;
-    if (MG) {           // adapt_lag >= 1: the pending updates, in order; the probabilities of each of the launch's generations into the table
+    if (MG || RG) {     // adapt_lag >= 1: the pending updates, in order; the probabilities of each of the launch's generations into the table
         if (wv == 0) adapt_pending_apply(p, pub.DOT, pub.CNTR, pub.nbp, pub.lag + 1, pub.pend0, pub.pend1, (long long)g0, ngen, pub.lag, pub.burnin, pub.sh, smem + L.off_tab,
                                          blockIdx.x == 0 ? pub.sh_out : nullptr, lane);
     } else if (pub.TOT) {      // the previous generation's adaptation totals are still to be applied: every block makes the update for itself (wave 0)
@@ -452,6 +455,8 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
         }
     }
     __syncthreads();
+    if (RG && blockIdx.x == 0 && pub.c0 == 0)      // the table for k_adapt_partials_ring (the bins of every generation come from ITS probabilities)
+        for (int i = threadIdx.x; i < ngen * pub.nbp; i += NT) pub.PG[i] = smem[L.off_tab + i];
     if (PB && pbl && p.have_prior && p.prior_nonormal) {      // the log prior of a point inside every uniform support: the sum every such try would make
         if (wv == 0) {
             double acc = 0.0;
@@ -510,7 +515,8 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
         const bool last = gi == ngen - 1;
         const bool app = gi == next_app;
         const uint32_t Mn = app ? M + (uint32_t)p.N : M;
-        const double* const pr_g = MG ? smem + L.off_tab + (size_t)gi * pub.nbp : probs;      // the probabilities this generation decides with
+        const double* const pr_g = (MG || RG) ? smem + L.off_tab + (size_t)gi * pub.nbp : probs;      // the probabilities this generation decides with
+        double* const publish_g = RG ? publish + (size_t)(g % (uint32_t)(pub.lag + 2)) * pub.pos_stride : publish;      // (the ring of published positions: lag + 2 slots)
         DZ_MSTAMP(0);
         const DrawSrc ds = dsn;
         constexpr int nph = K1 ? 1 : 2;                                              // multitry off: no reference set
@@ -709,7 +715,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations(const Params* __r
                     if (XLDS ? last : accept) gstore2(p.X + (size_t)c * ld + jj, xn);
                     if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn);
                     if (app) gstore2(p.Z + ((size_t)zappend + (M - M0) + gc) * ld + jj, xn);                         // record_history :933-936
-                    if (publish && (!MG || last)) gstore2(publish + (size_t)gc * ld + jj, xn);         // set_current_position_arr :447-449
+                    if (publish && (!MG || last)) gstore2(publish_g + (size_t)gc * ld + jj, xn);         // set_current_position_arr :447-449
                     if (MG && gc == 0u) gstore2(pub.x0ring + (size_t)(g % (uint32_t)(2 * (pub.lag + 1))) * ld + jj, xn);      // global chain 0 after generation g: a later generation's shift
                 }
                 if (lane == 0) {
@@ -794,7 +800,8 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
     // the crossover / gamma-level probabilities the launch decides with: behind the waves' regions; made by wave 0 when the previous
     // generation's adaptation totals are still to be applied (Publish::TOT)
     double* probs = smem + (size_t)nwv * mega_mix_wave_doubles(d, k, p.J);
-    if (MG) {
+    const bool RG = !MG && pub.multi == 2;      // (k_generations: the positions of every generation into the ring, the sums behind the launch)
+    if (MG || RG) {
         if (wv == 0) adapt_pending_apply(p, pub.DOT, pub.CNTR, pub.nbp, pub.lag + 1, pub.pend0, pub.pend1, (long long)g0, ngen, pub.lag, pub.burnin, pub.sh, probs,
                                          blockIdx.x == 0 ? pub.sh_out : nullptr, lane);
     } else if (pub.TOT) { if (wv == 0) adapt_apply_wave<1>(p, pub.TOT, pub.CNT, pub.sh, probs, blockIdx.x == 0 ? pub.sh_out : nullptr, lane); }
@@ -803,6 +810,8 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
         if ((int)threadIdx.x < p.ngamma) probs[p.ncr + threadIdx.x] = pub.sh[3 * p.ncr + threadIdx.x];
     }
     __syncthreads();
+    if (RG && blockIdx.x == 0 && pub.c0 == 0)
+        for (int i = threadIdx.x; i < ngen * pub.nbp; i += (int)blockDim.x) pub.PG[i] = probs[i];
     const int cg = pub.c0 + blockIdx.x * nwv + wv;
     const bool active = cg < pub.c1;
     const int c = min(cg, pub.c1 - 1);
@@ -832,7 +841,8 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
         const bool last = gi == ngen - 1;
         const bool app = gi == next_app;
         int sel = 0; bool fin = true;
-        const double* const pr_g = MG ? probs + (size_t)gi * pub.nbp : probs;      // the probabilities this generation decides with
+        const double* const pr_g = (MG || RG) ? probs + (size_t)gi * pub.nbp : probs;      // the probabilities this generation decides with
+        double* const publish_g = RG ? publish + (size_t)(g % (uint32_t)(pub.lag + 2)) * pub.pos_stride : publish;
         const double xb0 = xs[0][0], xb1 = xs[0][1];                          // (MG) the state before the generation
         DrawSrc ds; ds.have = true; ds.mine = make_uint4(0, 0, 0, 0);      // the generation's wave-uniform draws, both phases read them
         if (lane < p.nslots) { const u32x4 w = slot_counter_draw(p, lane, gc, g); ds.mine = make_uint4(w.x, w.y, w.z, w.w); }
@@ -943,7 +953,7 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
                     if (last) *reinterpret_cast<double2*>(p.X + (size_t)c * ld + jj) = xn;
                     if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn);
                     if (app) gstore2(p.Z + ((size_t)zappend + (M - M0) + gc) * ld + jj, xn);                         // record_history :933-936
-                    if (publish && (!MG || last)) gstore2(publish + (size_t)gc * ld + jj, xn);         // set_current_position_arr :447-449
+                    if (publish && (!MG || last)) gstore2(publish_g + (size_t)gc * ld + jj, xn);         // set_current_position_arr :447-449
                     if (MG && gc == 0u) gstore2(pub.x0ring + (size_t)(g % (uint32_t)(2 * (pub.lag + 1))) * ld + jj, xn);      // global chain 0 after generation g: a later generation's shift
                 }
                 if (lane == 0) {

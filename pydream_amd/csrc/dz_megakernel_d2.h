@@ -41,7 +41,8 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
     const Params& p = *pp;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int d = p.d, k = K1 ? 1 : p.k, ld = p.ld;
-    const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, false, CH, false, false, true, 0, SP);
+    const bool RG = pub.multi == 2;      // several burn-in generations per launch, the positions of each into the ring (Publish, dz_kernels.h)
+    const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, false, CH, false, false, true, RG ? pub.lag + 1 : 0, SP);
     constexpr int nph = K1 ? 1 : 2;
     double* Pt = smem + L.off_P;
     double* qb = smem + L.off_q;
@@ -66,7 +67,10 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
 
     for (int i = threadIdx.x; i < L.rows * L.LDP; i += NT) Pt[i] = 0.0;
     for (int i = threadIdx.x; i < 4 * ((d + 3) / 4) + 4; i += NT) mus[i] = i < d ? p.mu[i] : 0.0;
-    if (pub.TOT) {
+    if (RG) {
+        if (wv == 0) adapt_pending_apply(p, pub.DOT, pub.CNTR, pub.nbp, pub.lag + 1, pub.pend0, pub.pend1, (long long)g0, ngen, pub.lag, pub.burnin, pub.sh, smem + L.off_tab,
+                                         blockIdx.x == 0 ? pub.sh_out : nullptr, lane);
+    } else if (pub.TOT) {
         if (wv == 0) adapt_apply_wave<NCH>(p, pub.TOT, pub.CNT, pub.sh, probs, blockIdx.x == 0 ? pub.sh_out : nullptr, lane);
     } else {
         if ((int)threadIdx.x < p.ncr) probs[threadIdx.x] = pub.sh[threadIdx.x];
@@ -75,6 +79,8 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
     for (int i = threadIdx.x; i < p.ngamma * d; i += NT) gts[i] = p.gtab[(size_t)(i / d) * p.depairs * d + (i % d)];
     if (lane == 0 && sub == 0) { st[4 * cl] = p.lprior[c]; st[4 * cl + 1] = p.llike[c]; st[4 * cl + 2] = 0.0; dec[8 * cl + 7] = chain_T(p, c); }
     __syncthreads();
+    if (RG && blockIdx.x == 0 && pub.c0 == 0)
+        for (int i = threadIdx.x; i < ngen * pub.nbp; i += NT) pub.PG[i] = smem[L.off_tab + i];
 
     // More than 15 tries (round 6; the reference takes any integer, Dream.py:155-161): a generation's draw slots (3 control + two per try of both
     // sets) exceed the wave's 64 lanes -- the wave then holds ONE phase's slots at a time (DrawSrc::base: k npt <= 64 of them), the three
@@ -123,7 +129,8 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
                             w2 = bigk ? slot_counter_draw(p, 2, gc, g) : uniform_draw(p, ds, 2, gc, g);
                 u.u_snk = u53(w0.x, w0.y); u.u_cr = u53(w0.z, w0.w); u.u_de = u53(w1.x, w1.y); u.u_glev = u53(w1.z, w1.w);
                 u.u_sel = u53(w2.x, w2.y); u.u_acc = u53(w2.z, w2.w);
-                f = step_flags_from(p, u, probs, probs + p.ncr);                     // Dream.py:246-256
+                const double* const pr_g = RG ? smem + L.off_tab + (size_t)gi * pub.nbp : probs;      // the probabilities this generation decides with
+                f = step_flags_from(p, u, pr_g, pr_g + p.ncr);                       // Dream.py:246-256
                 if (lane == 0 && sub == 0) {
                     double* dc = dec + 8 * cl;
                     dc[0] = u.u_sel; dc[1] = u.u_acc; dc[2] = f.snk ? 1.0 : 0.0; dc[3] = (double)f.cr_idx; dc[4] = (double)f.glev;
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(64 * CH * WPC) void k_generations_d2(const Params* 
                         if (accept) gstore2(p.X + (size_t)c * ld + jj, xn[it]);
                         if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn[it]);
                         if (app) gstore2(p.Z + ((size_t)zappend + (M - M0) + gc) * ld + jj, xn[it]);                         // record_history :933-936
-                        if (publish) gstore2(publish + (size_t)gc * ld + jj, xn[it]);                          // set_current_position_arr :447-449
+                        if (publish) gstore2(publish + (RG ? (size_t)(g % (uint32_t)(pub.lag + 2)) * pub.pos_stride : (size_t)0) + (size_t)gc * ld + jj, xn[it]);                          // set_current_position_arr :447-449
                     }
                 }
                 if (lane == 0) {

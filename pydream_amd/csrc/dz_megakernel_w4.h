@@ -66,7 +66,8 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
     const Params& p = *pp;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int d = p.d, k = p.k, ld = p.ld;
-    const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, true, CH, false, false);
+    const bool RG = pub.multi == 2;      // several burn-in generations per launch, the positions of each into the ring (Publish, dz_kernels.h)
+    const MegaLayout L = mega_layout(d, k, NRT, p.ncr, p.ngamma, TRI, true, CH, false, false, false, RG ? pub.lag + 1 : 0);
     double* Ms = smem;
     double* Pt = smem + L.off_P;
     double* qb = smem + L.off_q;
@@ -111,7 +112,10 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
     }
     for (int i = threadIdx.x; i < L.rows * L.LDP; i += NT) Pt[i] = 0.0;
     if ((int)threadIdx.x < 4 * ((d + 3) / 4) + 4) mus[threadIdx.x] = (int)threadIdx.x < d ? p.mu[threadIdx.x] : 0.0;
-    if (pub.TOT) {
+    if (RG) {
+        if (wv == 0) adapt_pending_apply(p, pub.DOT, pub.CNTR, pub.nbp, pub.lag + 1, pub.pend0, pub.pend1, (long long)g0, ngen, pub.lag, pub.burnin, pub.sh, smem + L.off_tab,
+                                         blockIdx.x == 0 ? pub.sh_out : nullptr, lane);
+    } else if (pub.TOT) {
         if (wv == 0) adapt_apply_wave<1>(p, pub.TOT, pub.CNT, pub.sh, probs, blockIdx.x == 0 ? pub.sh_out : nullptr, lane);
     } else {
         if ((int)threadIdx.x < p.ncr) probs[threadIdx.x] = pub.sh[threadIdx.x];
@@ -122,6 +126,8 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
     if (sub == 0)
         for (int j = lane; j < L.LDP; j += 64) Xs[cl * L.LDP + j] = j < d ? p.X[(size_t)c * ld + j] : 0.0;
     __syncthreads();
+    if (RG && blockIdx.x == 0 && pub.c0 == 0)
+        for (int i = threadIdx.x; i < ngen * pub.nbp; i += NT) pub.PG[i] = smem[L.off_tab + i];
 
     // History appends inside the launch (k_generations): generation index next_app makes the next one into rows zappend + (Mc - M0) + global chain; Mc is the
     // row count generation gcur samples from, Mn the next generation's (rows and pre-tries are requested a generation ahead).
@@ -137,7 +143,8 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
         const u32x4 w0 = uniform_draw(p, q, 0, gc, g_), w1 = uniform_draw(p, q, 1, gc, g_), w2 = uniform_draw(p, q, 2, gc, g_);
         u.u_snk = u53(w0.x, w0.y); u.u_cr = u53(w0.z, w0.w); u.u_de = u53(w1.x, w1.y); u.u_glev = u53(w1.z, w1.w);
         u.u_sel = u53(w2.x, w2.y); u.u_acc = u53(w2.z, w2.w);
-        return step_flags_from(p, u, probs, probs + p.ncr);
+        const double* pr_g = RG ? smem + L.off_tab + (size_t)min((int)(g_ - g0), ngen - 1) * pub.nbp : probs;      // the probabilities generation g_ decides with
+        return step_flags_from(p, u, pr_g, pr_g + p.ncr);
     };
     // the tries of a DE set of n that this wave makes ahead: none for the chain's first wave (it is busy with what the set waits for), the
     // set dealt over the other three (n <= 6: at most two each).  A snooker set, made after its base point, is dealt over all four.
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(1024) void k_generations_w4(const Params* __restric
                     if (last) gstore2(p.X + (size_t)c * ld + jj, xn);
                     if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn);
                     if (app) gstore2(p.Z + ((size_t)zappend + (Mc - M0) + gc) * ld + jj, xn);                         // record_history :933-936
-                    if (publish) gstore2(publish + (size_t)gc * ld + jj, xn);                          // set_current_position_arr :447-449
+                    if (publish) gstore2(publish + (RG ? (size_t)(g % (uint32_t)(pub.lag + 2)) * pub.pos_stride : (size_t)0) + (size_t)gc * ld + jj, xn);                          // set_current_position_arr :447-449
                 }
                 if (lane == 0) {
                     if (trace_slot0 >= 0) {

@@ -21,7 +21,7 @@ DIMS = [2, 3, 5, 10, 16, 17, 31, 32, 33, 48, 64, 65, 100, 100, 100, 112, 127, 12
 CHAINS = [3, 4, 5, 15, 16, 17, 48, 63, 64, 65, 100, 250, 256, 1000, 1024, 1100, 2048]
 
 
-def draw_config(rng, long=False, dims=None, chains=None):
+def draw_config(rng, long=False, dims=None, chains=None, adapt_lag_arm=False):
     d = int(rng.choice(dims or DIMS))
     N = int(rng.choice(chains or (CHAINS + ([3000, 4096, 4096] if long else []))))
     if d > 128 and not chains:                                # (oracle time; --chains lifts it: the k_generations_d2 regime is 128 < d <= 228)
@@ -32,8 +32,10 @@ def draw_config(rng, long=False, dims=None, chains=None):
     depairs = int(rng.choice([1, 1, 1, 2, 3]))
     ngamma = int(rng.choice([1, 1, 2, 4]))
     ncr = int(min(d, rng.choice([1, 2, 3, 3, 5])))
-    adapt_cr = int(rng.random() < 0.35)
+    adapt_cr = int(rng.random() < (0.85 if adapt_lag_arm else 0.35))
     adapt_g = int(ngamma > 1 and rng.random() < 0.5)
+    if adapt_lag_arm and not (adapt_cr or adapt_g):
+        adapt_cr = 1
     n = int(rng.integers(12, 42)) * (3 if long else 1)
     burnin = int(rng.choice([6, 15, n + 5])) if (adapt_cr or adapt_g) else 0
     lk = str(rng.choice(["mvn_dense", "mvn_tri", "mvn_tri", "mix"]))
@@ -47,7 +49,7 @@ def draw_config(rng, long=False, dims=None, chains=None):
                pgu=float(rng.choice([0.0, 0.2, 0.2, 0.6])), lamb=float(rng.choice([0.05, 0.2])), zeta=float(rng.choice([1e-12, 1e-6])),
                zero_mean=int(rng.random() < 0.5), J=int(rng.choice([2, 3])), extra_rows=int(rng.integers(0, 40)), seed=int(rng.integers(1, 2 ** 31 - 1)))
     # parallel tempering (core.py:131-248): the reference's ladder T_i = 0.001^(i/N), one swap attempt per generation (S2 only, no lag)
-    cfg["pt"] = int(rng.random() < 0.08 and cfg["lag"] == 0 and prior != "uniform_open")
+    cfg["pt"] = int(rng.random() < 0.08 and cfg["lag"] == 0 and prior != "uniform_open" and not adapt_lag_arm)
     # chains sharded over W engines (one per rank in production; here W threads of one process, rows exchanged through the host
     # transport): the result must not depend on W
     cfg["world"] = 1
@@ -56,12 +58,12 @@ def draw_config(rng, long=False, dims=None, chains=None):
         if ws:
             cfg["world"] = int(rng.choice(ws))
     # schedule S1 (Dream.astep driven chain by chain, every chain with its own copy of the adapted probabilities): few chains, no lag
-    cfg["s1"] = int(N <= 17 and rng.random() < 0.5 and not cfg["pt"] and cfg["world"] == 1)
+    cfg["s1"] = int(N <= 17 and rng.random() < 0.5 and not cfg["pt"] and cfg["world"] == 1 and not adapt_lag_arm)
     if cfg["s1"]:
         cfg["lag"] = 0
     # adapt_lag (round 6): the adaptation's updates reach the chains' decisions L generations late (lockstep generations only)
     cfg["adapt_lag"] = 0
-    if (adapt_cr or adapt_g) and not cfg["pt"] and not cfg["s1"] and rng.random() < 0.6:
+    if (adapt_cr or adapt_g) and not cfg["pt"] and not cfg["s1"] and (adapt_lag_arm or rng.random() < 0.6):
         cfg["adapt_lag"] = int(rng.choice([1, 2, 4, 9, 19]))
         cfg["burnin"] = int(rng.choice([6, 15, max(13, n - 8), n + 5]))
     return cfg
@@ -161,6 +163,16 @@ def run_sharded(G, c):
     return tr, res[0][1], res[0][2], res[0][3], state
 
 
+KINDS = {}
+
+
+def tally(variant):
+    """which kind of launch ran last (the summary line says how much of each the drawn configurations reached)"""
+    kind = ("ring" if variant.endswith("+ring") else "multi" if "multi>" in variant else "multi-kernel" if variant.startswith("multi-kernel") else
+            variant.split("<")[0] if variant else "none")
+    KINDS[kind] = KINDS.get(kind, 0) + 1
+
+
 def run_one(G, O, c):
     """-> None when the two agree on everything, else a description of the first difference."""
     out = []
@@ -180,7 +192,12 @@ def run_one(G, O, c):
             e.close()
             continue
         half = c["n"] // 2                                      # two step calls: launch segmentation restarts in between
-        e.step(half); e.step(c["n"] - half)
+        e.step(half)
+        if Cls is G.Engine:
+            tally(e.last_kernel_variant())
+        e.step(c["n"] - half)
+        if Cls is G.Engine:
+            tally(e.last_kernel_variant())
         out.append((e.get_trace(0, c["n"]), e.get_history(), e.get_cr_state(), e.get_gamma_state(), e.get_state()) + ((e.get_swaps(0, c["n"]),) if c.get("pt") else ()))
         e.close()
     a, b = out
@@ -205,6 +222,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=0.0, help="stop after this long (0: run all --n)")
     ap.add_argument("--long", action="store_true", help="three times the generations, populations up to 4096 chains")
+    ap.add_argument("--adapt-lag", action="store_true", help="every configuration with an adaptation and an adapt_lag (lockstep, no tempering): the launches that hold several burn-in generations")
     ap.add_argument("--dims", default="", help="comma-separated dimensions to draw from instead of the built-in list")
     ap.add_argument("--chains", default="", help="comma-separated chain counts to draw from (also lifts the 256-chain cap of d > 128)")
     args = ap.parse_args()
@@ -215,7 +233,7 @@ def main():
     rng = np.random.default_rng(args.seed)
     t0 = time.time(); bad = 0; done = 0
     for i in range(args.n):
-        c = draw_config(rng, args.long, dims, chains)
+        c = draw_config(rng, args.long, dims, chains, args.adapt_lag)
         try:
             r = run_one(G, O, c)
         except Exception as ex:                                 # an engine refusing a configuration must refuse it on both sides: report
@@ -227,6 +245,7 @@ def main():
         if args.seconds and time.time() - t0 > args.seconds:
             break
     print("fuzz: %d configurations, %d mismatches, %.0f s (seed %d)" % (done, bad, time.time() - t0, args.seed))
+    print("last launch after each half, by kind: " + ", ".join("%s %d" % kv for kv in sorted(KINDS.items())))
     return 1 if bad else 0
 
 

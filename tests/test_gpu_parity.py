@@ -744,7 +744,18 @@ def test_crossover_burnin_at_4096_chains_against_oracle(G, O, variant, monkeypat
     ("mvn", 4096, 19, 1, "1", "k_generations<7,tri,xlds,16,1,lean,multi>"),
     ("mvn_pb", 4000, 9, 0, "1", "k_generations<7,tri,xlds,16,1,full,multi>"),   # ... with normal priors (the full proposal code), a ragged last block
     ("mvn", 4096, 9, 1, "0", "k_generations<7,tri,xlds,16,1,lean>"),            # the same schedule one generation per launch
-    ("mvn", 300, 2, 0, "1", "k_generations_w4<7,"),                             # small populations: one burn-in generation per launch, the updates applied when due
+    # any other persistent kernel: every generation's positions into the ring of published positions, the unit sums behind the launch (k_adapt_partials_ring)
+    ("mvn", 300, 2, 0, "1", "k_generations_w4<7, +ring"),                       # 4 chains x 4 waves per block, three generations per launch, a ragged last unit
+    ("mvn", 300, 2, 0, "0", "k_generations_w4<7,"),                             # ... and one burn-in generation per launch, the updates applied when due
+    ("mvn", 1024, 19, 3, "1", "k_generations_w4<7, +ring"),                     # BASELINE configs[1]'s population, twenty generations per launch
+    ("mvn", 2048, 9, 1, "1", "k_generations<7,tri,xlds,8,1,lean> +ring"),       # 8 chains per block
+    ("mvn", 3072, 9, 0, "1", "k_generations<7,tri,xlds,12,1,lean> +ring"),      # 12 chains per block
+    ("mvn", 4196, 9, 1, "1", "k_generations<7,tri,xlds,16,1,lean> + k_generations_w4<7, +ring"),      # a generation in two launches
+    ("mvn_pb", 2000, 3, 1, "1", "k_generations<7,tri,xlds,8,1,full> +ring"),    # the full proposal code
+    ("mvn_redo", 2048, 3, 1, "1", "k_generations<7,tri,xlds,8,1,full,redo> +ring"),      # uniform priors without boundaries: the instantiation with the redraw rounds
+    ("mvn_k1", 4096, 9, 1, "1", "k_generations<7,tri,xlds,16,1,lean,k1> +ring"),     # multitry off (the reference's default)
+    ("mvn_d200", 2048, 9, 1, "1", "k_generations_d2<13, +ring"),                # 128 < d <= 256
+    ("mix_k1", 4096, 9, 1, "1", "k_generations_mix +ring"),                     # the mixture kernel without multi-try (blocks of 4 waves)
 ])
 def test_crossover_burnin_with_an_adapt_lag_against_oracle(G, O, target, N, lag, hlag, multi, variant, monkeypatch):
     """dz_config.adapt_lag = L (round 6): generation g of the burn-in decides with the probabilities as they were after the updates of
@@ -754,7 +765,10 @@ def test_crossover_burnin_with_an_adapt_lag_against_oracle(G, O, target, N, lag,
     equal to the oracle bit for bit -- decisions, states, archive, adapted probabilities and accumulators -- and the state handed out
     after EVERY dz_step of a run stepped in pieces is the oracle's (updates still pending are not in it)."""
     monkeypatch.setenv("DZ_ADAPT_MULTI", multi)
-    d, n, seed, burn = 100, 55, 77, 38
+    if "d200" in target:
+        monkeypatch.setenv("DZ_MEGA_D2", "2")
+    d, n, seed, burn = (200 if "d200" in target else 100), 55, 77, 38
+    k = 1 if target.endswith("_k1") else 5
     rng = np.random.default_rng(seed)
     mu = np.array([np.full(d, m) for m in (-5.0, 0.0, 5.0)])
     logF = np.log(np.array([1 / 6., 1 / 3., 1 / 2.])) - (d / 2.) * np.log(2 * np.pi)
@@ -762,10 +776,12 @@ def test_crossover_burnin_with_an_adapt_lag_against_oracle(G, O, target, N, lag,
     pieces = (7, 13, 1, 20, 14)
     out = []
     for Cls in (G.Engine, O.Engine):
-        e = Cls(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
+        e = Cls(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
                 adapt_crossover=1, crossover_burnin=burn, adapt_lag=lag, history_lag=hlag)
         if target in ("mix_pb", "mvn_pb"):
             e.set_prior(np.full(d, 1, np.int32), np.linspace(-1.0, 1.0, d), np.linspace(20.0, 40.0, d))
+        if target == "mvn_redo":
+            e.set_prior(np.full(d, 2, np.int32), np.full(d, -12.0), np.full(d, 40.0))
         e.set_history(Z0); e.set_state(Z0[:N])
         if target.startswith("mix"):
             e.set_likelihood_mixture(mu, logF)
@@ -785,8 +801,11 @@ def test_crossover_burnin_with_an_adapt_lag_against_oracle(G, O, target, N, lag,
             np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(out[0][2], out[1][2])
     assert not np.allclose(out[0][1][-1][0], 1 / 3.)
-    assert any(v.startswith(variant) for v in out[0][3]), out[0][3]
-    assert any("multi>" in v for v in out[0][3]) == (multi == "1" and N >= 1000)
+    ring = variant.endswith(" +ring")
+    prefix = variant[:-len(" +ring")] if ring else variant
+    assert any(v.startswith(prefix) and v.endswith(" +ring") == ring for v in out[0][3]), out[0][3]
+    assert any("multi>" in v for v in out[0][3]) == (multi == "1" and not ring)
+    assert any(v.endswith("+ring") for v in out[0][3]) == ring
 
 
 @pytest.mark.parametrize("adapt", [0, 1])

@@ -132,6 +132,8 @@ struct dz_engine {
     dz_logp_cb cb = nullptr; void* cb_user = nullptr;
     // a user-supplied DEVICE likelihood (dz_set_likelihood_module): a kernel of a code object the user built, launched where k_logp_* run
     hipModule_t lk_module = nullptr; hipFunction_t lk_fn = nullptr; void* d_lk_data = nullptr; int lk_lanes = 1; bool lk_finite = false;
+    // ... and, when the code object has them, the persistent kernels with that density inlined (generations_wave_body<.., UserLike>): [0] lean, [1] full proposal code
+    hipFunction_t lk_gen_fn[2] = {nullptr, nullptr};
     dz_exchange_cb xcb = nullptr; void* xcb_user = nullptr;
     ncclComm_t comm = nullptr; int rank = 0, world = 1;
     // peer transport (dz_peer_export / dz_peer_attach): the other ranks' archives, position buffers and flag words mapped into this
@@ -957,7 +959,7 @@ bool mega_mix_eligible(const dz_engine* e)
 {
     const dz::Params& p = e->p;
     const bool pbm = p.hard || p.have_prior || p.depairs > 1;
-    return e->mega && e->lk == LK_MIX && !redo_possible(e) && (!pbm || e->mega_mix_pb) && p.ld <= 128 && (p.k == 1 || p.k >= 3) && p.k <= dz::MAXK &&
+    return e->mega && (e->lk == LK_MIX || (e->lk == LK_MODULE && e->lk_gen_fn[pbm ? 1 : 0])) && !redo_possible(e) && (!pbm || e->mega_mix_pb) && p.ld <= 128 && (p.k == 1 || p.k >= 3) && p.k <= dz::MAXK &&
            p.nslots <= 64 && p.J <= 32;
 }
 // redraw rounds inside the persistent kernel: the instantiations with the full proposal code, multi-try, device MVN likelihood
@@ -1073,9 +1075,9 @@ int burnin_multi(const dz_engine* e)
     const dz::Params& p = e->p;
     const size_t tab = sizeof(double) * (size_t)e->ad_R1 * e->ad_nbp, cap = (size_t)160 * 1024;
     const bool ring_ok = e->ad_ring && sizeof(double) * (size_t)(e->c.adapt_lag + 2) * p.N * p.ld <= ((size_t)8 << 30);
-    if (e->lk == LK_MIX) {
+    if (e->lk == LK_MIX || e->lk == LK_MODULE) {
         if (!mega_mix_eligible(e)) return 0;
-        if (e->adapt_fused && p.k >= 3 && mix_multi_lds(e) <= cap) return 1;
+        if (e->lk == LK_MIX && e->adapt_fused && p.k >= 3 && mix_multi_lds(e) <= cap) return 1;
         return (ring_ok && sizeof(double) * (size_t)dz::MIXW * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + tab <= cap) ? 2 : 0;
     }
     if (e->lk != LK_MVN || !e->mega) return 0;
@@ -1207,7 +1209,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         for (auto& gcv : e->gen_c) gcv = e->gen;
         return 0;
     };
-    if (e->lk == LK_MIX) {
+    if (e->lk == LK_MIX || e->lk == LK_MODULE) {
         DZCK(upload_params(e));
         int mw = dz::MIXW;
         const size_t lds_probs = sizeof(double) * (size_t)((p.ncr + p.ngamma + 1) & ~1);
@@ -1217,6 +1219,21 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         const dim3 gridm((p.nl + mw - 1) / mw), blockm(64 * mw);
         const size_t ldsm = multi ? mix_multi_lds(e) : sizeof(double) * (size_t)mw * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + (rmulti ? sizeof(double) * (size_t)e->ad_R1 * e->ad_nbp : lds_probs) + (fused ? lds_xo : 0);
         const bool pbm = p.hard || p.have_prior || p.depairs > 1;
+        if (e->lk == LK_MODULE) {      // the user's density inside the same kernel: the code object's own instantiation (dz_set_likelihood_module)
+            const dz::Params* pp_ = (const dz::Params*)e->d_params; uint32_t g_ = g; int n_ = n; uint32_t M_ = (uint32_t)visible_rows(e); int64_t s_ = slot0, z_ = append_last ? e->M : (int64_t)-1; int seg_ = seg0;
+            void* args[] = {&pp_, &g_, &n_, &M_, &s_, &z_, &seg_, &pub};
+            if (e->prof) {
+                hipEvent_t ka = prof_event(e), kb = prof_event(e);
+                e->ev[PR_GENERATIONS].emplace_back(ka, kb);
+                HIPCK(hipExtModuleLaunchKernel(e->lk_gen_fn[pbm ? 1 : 0], gridm.x * blockm.x, 1, 1, blockm.x, 1, 1, ldsm, e->stream, args, nullptr, ka, kb, 0));
+            } else HIPCK(hipModuleLaunchKernel(e->lk_gen_fn[pbm ? 1 : 0], gridm.x, 1, 1, blockm.x, 1, 1, (unsigned)ldsm, e->stream, args, nullptr));
+            DZCK(launch_check("dz_user_generations"));
+            launched();
+            e->last_variant = std::string(pbm ? "k_generations_user<full>" : "k_generations_user") + (rmulti ? " +ring" : "");
+            DZCK(after_launch());
+            if (slot0 >= 0) e->ntrace += n;
+            return 0;
+        }
         if (multi) {
             if (pbm) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations_mix<true, true>), gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, seg0, pub);
             else DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations_mix<false, true>), gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, seg0, pub);
@@ -1697,6 +1714,10 @@ int dz_set_likelihood_module(dz_engine* e, const char* code_object_path, const c
     if (err != hipSuccess) { (void)hipGetLastError(); return fail(std::string("hipModuleLoad(") + code_object_path + "): " + hipGetErrorString(err) + " (a gfx950 code object is expected: hipcc --offload-arch=gfx950 --genco)"); }
     err = hipModuleGetFunction(&fn, mod, kernel_name);
     if (err != hipSuccess) { (void)hipGetLastError(); (void)hipModuleUnload(mod); return fail(std::string("hipModuleGetFunction(") + kernel_name + "): " + hipGetErrorString(err) + " (the kernel must be extern \"C\")"); }
+    hipFunction_t gen[2] = {nullptr, nullptr};      // optional: the persistent kernels around the same density (a code object built by DeviceFunctionLogLike has them)
+    if (hipModuleGetFunction(&gen[0], mod, "dz_user_generations_v" DZ_USER_STR(DZ_USER_ABI)) != hipSuccess) { (void)hipGetLastError(); gen[0] = nullptr; }
+    if (hipModuleGetFunction(&gen[1], mod, "dz_user_generations_full_v" DZ_USER_STR(DZ_USER_ABI)) != hipSuccess) { (void)hipGetLastError(); gen[1] = nullptr; }
+    if (getenv("DZ_MEGA_USER") && atoi(getenv("DZ_MEGA_USER")) == 0) { gen[0] = nullptr; gen[1] = nullptr; }
     // the new data block first, into a temporary: the engine's module, function and data change together, and only once every step has
     // succeeded -- a failure leaves the engine as it was (advisor, round 5)
     void* d_new = nullptr;
@@ -1713,6 +1734,7 @@ int dz_set_likelihood_module(dz_engine* e, const char* code_object_path, const c
     if (e->lk_module) { (void)hipModuleUnload(e->lk_module); e->lk_module = nullptr; e->lk_fn = nullptr; }
     if (e->d_lk_data) { (void)hipFree(e->d_lk_data); e->d_lk_data = nullptr; }
     e->d_lk_data = d_new;
+    e->lk_gen_fn[0] = gen[0]; e->lk_gen_fn[1] = gen[1]; e->p.udata = d_new; e->p.J = 1;      // (J: the wave's scratch row in the persistent kernel's layout)
     e->lk_module = mod; e->lk_fn = fn; e->lk_lanes = lanes_per_point; e->lk_finite = (flags & DZ_LIKE_ALWAYS_FINITE) != 0;
     e->lk = LK_MODULE; e->have_logp = false;
     return 0;

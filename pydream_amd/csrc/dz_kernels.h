@@ -68,7 +68,13 @@ struct Params {
     const double *qfin_p, *qfin_r; int qfin_nrt, qfin_c0, qfin_nc;
     int pb_lds;      // persistent kernel, full-code instantiations: the prior / boundary constants are staged in LDS (PBConsts; set by the host when they fit)
     unsigned long long* dbg;  // cycle-stamp buffer of instrumented builds (-DDZ_EXPERIMENTS, dz_experiments.h); null otherwise
+    const void* udata;        // a user's device likelihood inside the persistent kernel (dz_user_generations.hip.in): its data block
 };
+// The layout generation of Params / Publish as a code object built at run time sees them (the names of the persistent kernels such an object exports
+// carry it: dz_user_generations_v<N> / dz_user_generations_full_v<N>; an object built against other headers simply does not have them)
+#define DZ_USER_ABI 6
+#define DZ_USER_STR2(x) #x
+#define DZ_USER_STR(x) DZ_USER_STR2(x)
 // What a persistent launch inside the crossover burn-in (one generation per launch) leaves behind besides the new states:
 // to: the published positions (set_current_position_arr, Dream.py:364-366, :447-449: [N][ld], row = global chain), or null outside the
 // burn-in; PR / PC / shift: when set, the block also makes the adaptation sums of its unit of 16 chains (adapt_unit_sums; contract v3),

@@ -781,8 +781,57 @@ __host__ __device__ inline int mega_mix_wave_doubles(int d, int k, int J) { cons
 // unit sums into that generation's ring slot: the chains' states before and after it and their bins go through a double-buffered LDS stash
 // (one block barrier per generation -- the only one in this kernel: a wave can be at most one generation ahead of the slowest, and the
 // stash it then writes is the other one).  LDS behind the waves' regions: table [lag + 1][nbp] | stash [2]{before, after}[16][LDP] | bins [2][32] (int).
-template <bool PB, bool MG = false>
-__global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0, int64_t zappend, int seg0, Publish pub)
+// LK: the likelihood of the wave's n points (mt_evaluate_logps :278, :302) -- rows [n][LDP] in the wave's LDS region -> out[0 .. n-1]; lh: the wave's
+// scratch ([k][J] doubles).  MixLike: the built-in mixture.  A user's device function takes its place in a code object built at run time
+// (dz_user_generations.hip.in; pydream_amd.likelihoods.DeviceFunctionLogLike): the same kernel around ANY density a wave can evaluate.
+struct MixLike {
+    DZ_DEV static void eval(const Params& p, const double* rows, int LDP, int n, int lane, double* lh, double* out)
+    {
+        const int d = p.d;
+        // The squared distances to the J means need the whole wave (one butterfly each); the log-sum-exp of a point is scalar work, so lane i
+        // does it for point i and the n points cost one pass of exp / log instead of n (same operations per point as k_logp_mix).
+        // (points in groups of GP: GP independent reductions in flight per component, and each mean is read once per group)
+        constexpr int GP = 4;
+        for (int i0 = 0; i0 < n; i0 += GP) {
+            double x0[GP], x1[GP];
+#pragma unroll
+            for (int u = 0; u < GP; ++u) {
+                const double* row = rows + (size_t)min(i0 + u, n - 1) * LDP;
+                x0[u] = 2 * lane < d ? row[2 * lane] : 0.0; x1[u] = 2 * lane + 1 < d ? row[2 * lane + 1] : 0.0;
+            }
+            for (int j = 0; j < p.J; ++j) {
+                const double* mj = p.mu + (size_t)j * p.ld;
+                const double m0 = 2 * lane < d ? mj[2 * lane] : 0.0, m1 = 2 * lane + 1 < d ? mj[2 * lane + 1] : 0.0;
+                double S[GP];
+#pragma unroll
+                for (int u = 0; u < GP; ++u) {
+                    double acc = 0.0;
+                    if (2 * lane < d) { const double t = x0[u] - m0; acc = fma(t, t, acc); }
+                    if (2 * lane + 1 < d) { const double t = x1[u] - m1; acc = fma(t, t, acc); }
+                    S[u] = acc;
+                }
+                static_assert(GP == 4, "wave_bfly4 sums four values");
+                const double R = wave_bfly4(S[0], S[1], S[2], S[3]);          // (rows hold the totals of S[0], S[2], S[1], S[3]: the bits of four wave_bfly)
+                {
+                    const int row = lane >> 4, u = (row == 1) ? 2 : (row == 2 ? 1 : row);
+                    if ((lane & 15) == 0 && i0 + u < n) lh[(i0 + u) * p.J + j] = -0.5 * R + p.mixF[j];
+                }
+            }
+        }
+        {
+            const int i = lane < n ? lane : 0;
+            double mx = -__builtin_huge_val();
+            for (int j = 0; j < p.J; ++j) { const double v = lh[i * p.J + j]; if (v > mx) mx = v; }
+            double dens = 0.0;
+            for (int j = 0; j < p.J; ++j) dens = dens + dexp(lh[i * p.J + j] - mx);
+            const double lk = nan_to_ninf(dlog(dens) + mx);
+            if (lane < n) out[lane] = lk;
+        }
+    }
+};
+
+template <bool PB, bool MG, class LK>
+DZ_DEV void generations_wave_body(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0, int64_t zappend, int seg0, const Publish& pub)
 {
     double* const publish = pub.to;
     const Params& p = *pp;
@@ -875,46 +924,7 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
                                                      rows, LDP, (phase ? rS : sS), (k == 1 ? dec + 5 : nullptr), (phase ? rP : sP), &pcs);
             else propose_set<NCH, false, false, 2>(p, phase, g, M, c, gc, 0, n, n, lane, base, grow, f.snk, f.cr_idx, 1, f.glev, ds,
                                                    rows, LDP, (phase ? rS : sS), (k == 1 ? dec + 5 : nullptr), (phase ? lh : sP));   // (flat priors: in phase 1 the prior slot is scratch)
-            // mt_evaluate_logps :278, :302 -- by this wave, for its own points.  The squared distances to the J means need the
-            // whole wave (one butterfly each); the log-sum-exp of a point is scalar work, so lane i does it for point i and
-            // the n points cost one pass of exp / log instead of n (same operations per point as k_logp_mix).
-            // (points in groups of GP: GP independent reductions in flight per component, and each mean is read once per group)
-            constexpr int GP = 4;
-            for (int i0 = 0; i0 < n; i0 += GP) {
-                double x0[GP], x1[GP];
-#pragma unroll
-                for (int u = 0; u < GP; ++u) {
-                    const double* row = rows + (size_t)min(i0 + u, n - 1) * LDP;
-                    x0[u] = 2 * lane < d ? row[2 * lane] : 0.0; x1[u] = 2 * lane + 1 < d ? row[2 * lane + 1] : 0.0;
-                }
-                for (int j = 0; j < p.J; ++j) {
-                    const double* mj = p.mu + (size_t)j * p.ld;
-                    const double m0 = 2 * lane < d ? mj[2 * lane] : 0.0, m1 = 2 * lane + 1 < d ? mj[2 * lane + 1] : 0.0;
-                    double S[GP];
-#pragma unroll
-                    for (int u = 0; u < GP; ++u) {
-                        double acc = 0.0;
-                        if (2 * lane < d) { const double t = x0[u] - m0; acc = fma(t, t, acc); }
-                        if (2 * lane + 1 < d) { const double t = x1[u] - m1; acc = fma(t, t, acc); }
-                        S[u] = acc;
-                    }
-                    static_assert(GP == 4, "wave_bfly4 sums four values");
-                    const double R = wave_bfly4(S[0], S[1], S[2], S[3]);          // (rows hold the totals of S[0], S[2], S[1], S[3]: the bits of four wave_bfly)
-                    {
-                        const int row = lane >> 4, u = (row == 1) ? 2 : (row == 2 ? 1 : row);
-                        if ((lane & 15) == 0 && i0 + u < n) lh[(i0 + u) * p.J + j] = -0.5 * R + p.mixF[j];
-                    }
-                }
-            }
-            {
-                const int i = lane < n ? lane : 0;
-                double mx = -__builtin_huge_val();
-                for (int j = 0; j < p.J; ++j) { const double v = lh[i * p.J + j]; if (v > mx) mx = v; }
-                double dens = 0.0;
-                for (int j = 0; j < p.J; ++j) dens = dens + dexp(lh[i * p.J + j] - mx);
-                const double lk = nan_to_ninf(dlog(dens) + mx);
-                if (lane < n) (phase ? rL : sL)[lane] = lk;
-            }
+            LK::eval(p, rows, LDP, n, lane, lh, phase ? rL : sL);                   // mt_evaluate_logps :278, :302 -- by this wave, for its own points
         }
         // ---- Metropolis step (:305-347), trace (core.py:114-116), record_history (:919-938)
         {
@@ -999,6 +1009,11 @@ __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restri
         adapt_unit_sums(p, s0, W, xo_area, LDP, min(16, p.nl - 16 * unit), [&](bool isg, int c_) { return (int)s0[(size_t)c_ * W + LDP - 1 + (isg ? 1 : 0)]; }, pub.shift,
                         pub.PR + (size_t)unit * adapt_nq(p) * ld, pub.PC + (size_t)unit * (p.ncr + p.ngamma), (int)threadIdx.x, (int)blockDim.x);
     }
+}
+template <bool PB, bool MG = false>
+__global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0, int64_t zappend, int seg0, Publish pub)
+{
+    generations_wave_body<PB, MG, MixLike>(pp, g0, ngen, M0, trace_slot0, zappend, seg0, pub);
 }
 #endif  // DZ_TEMPLATES_ONLY
 

@@ -106,6 +106,120 @@ def compile_device_kernel(source, out_path=None, extra_flags=(), arch="gfx950"):
     return out_path
 
 
+FUNCTION_SIGNATURE = '__device__ double NAME(const double* x, int d, const void* data, int lane)'
+
+# The translation unit around a user's wave-level device function: the batch kernel the engine's multi-kernel path launches (one wave per
+# point) and the persistent kernels -- csrc/dz_megakernel.h generations_wave_body, the kernel the built-in mixture runs in, with the user's
+# function in the likelihood's place.  The names of the latter carry the layout generation of the structures they take (DZ_USER_ABI).
+_FUNCTION_TU = r"""
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+#include "dz_device.h"
+__device__ __forceinline__ double dz_wave_sum(double v) { return dz::wave_bfly(v); }      // the xor butterfly over the wave's 64 lanes: every lane gets the total
+%(source)s
+#define DZ_TEMPLATES_ONLY
+#include "dz_kernels.h"
+#undef DZ_TEMPLATES_ONLY
+#include "dz_megakernel.h"
+namespace dz {
+struct UserLike {
+    DZ_DEV static void eval(const Params& p, const double* rows, int LDP, int n, int lane, double* lh, double* out)
+    {
+        for (int i = 0; i < n; ++i) {
+            const double v = %(name)s(rows + (size_t)i * LDP, p.d, p.udata, lane);
+            if (lane == 0) out[i] = nan_to_ninf(v);
+        }
+    }
+};
+}
+#define DZ_USER_CAT2(a, b) a##b
+#define DZ_USER_CAT(a, b) DZ_USER_CAT2(a, b)
+extern "C" __global__ __launch_bounds__(1024) void DZ_USER_CAT(dz_user_generations_v, DZ_USER_ABI)(const dz::Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0,
+                                                                                                     int64_t zappend, int seg0, dz::Publish pub)
+{
+    dz::generations_wave_body<false, false, dz::UserLike>(pp, g0, ngen, M0, trace_slot0, zappend, seg0, pub);
+}
+extern "C" __global__ __launch_bounds__(1024) void DZ_USER_CAT(dz_user_generations_full_v, DZ_USER_ABI)(const dz::Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0,
+                                                                                                          int64_t zappend, int seg0, dz::Publish pub)
+{
+    dz::generations_wave_body<true, false, dz::UserLike>(pp, g0, ngen, M0, trace_slot0, zappend, seg0, pub);
+}
+extern "C" __global__ __launch_bounds__(256) void dz_user_batch(const double* X, long long n, int d, int ld, double* like, const void* data)
+{
+    const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const double v = %(name)s(X + (size_t)i * ld, d, data, lane);
+    if (lane == 0) like[i] = v;
+}
+"""
+
+
+def csrc_dir():
+    import os
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+
+
+class DeviceFunctionLogLike:
+    """A user-written HIP DEVICE FUNCTION as the likelihood, evaluated by one wave per point -- and INSIDE the persistent generation kernel:
+
+        SRC = '''
+        __device__ double sphere(const double* x, int d, const void* data, int lane) {     // all 64 lanes call it; x: the point (d doubles)
+            const double* c = (const double*)data;
+            double acc = 0.0;
+            for (int j = lane; j < d; j += 64) { const double t = x[j] - c[j]; acc += t * t; }
+            return -0.5 * dz_wave_sum(acc);                                                // the same value in every lane
+        }'''
+        like = DeviceFunctionLogLike(SRC, "sphere", ndim=d, data=centre, always_finite=True)
+        sampled, log_ps = run_dream(parameters, like, nchains=4096, multitry=5, ...)
+
+    The function's signature is FUNCTION_SIGNATURE; x may point to LDS or global memory (d doubles; what follows them is not the
+    function's to read); `dz_wave_sum(double)` (the xor butterfly over the wave's 64 lanes, every lane gets the total) and the helpers of
+    csrc/dz_device.h (namespace dz) are in scope.  The source is compiled once (hipcc on first use, cached like compile_device_kernel's
+    objects; the key includes the engine's own headers) into a code object with (a) a batch kernel for the engine's multi-kernel path and
+    (b) the persistent kernels of csrc/dz_megakernel.h with this function in the place of the built-in mixture -- the same launches, the
+    same bits as (a), at the persistent kernels' rate instead of the multi-kernel path's.  They run where the mixture's would: d <= 128,
+    multitry 1 or 3..32 tries, and always_finite=True (a density that may be -inf for a whole proposal set needs the multi-kernel path's
+    redraw rounds, Dream.py:281-289).  host: an optional Python twin f(x[d]) -> float for calls on the host (Model.total_logp)."""
+
+    def __init__(self, source, name, ndim, data=None, always_finite=False, host=None, extra_flags=()):
+        self.name, self.d, self.source = name, int(ndim), source
+        self.data = None if data is None else np.ascontiguousarray(data)
+        self.always_finite, self.host, self.extra_flags = bool(always_finite), host, tuple(extra_flags)
+        self.path = None
+        self._eval_engine = None
+
+    def code_object(self):
+        if self.path is None:
+            import glob
+            import hashlib
+            import os
+            hdr = hashlib.sha256()
+            for h in sorted(glob.glob(os.path.join(csrc_dir(), "*.h"))):       # (the object is only as current as the headers it was built against)
+                with open(h, "rb") as fh:
+                    hdr.update(fh.read())
+            text = _FUNCTION_TU % dict(source=self.source, name=self.name) + "\n// headers " + hdr.hexdigest() + "\n"
+            self.path = compile_device_kernel(text, extra_flags=("-I" + csrc_dir(), "-Wno-unused-value", "-Wno-unused-result") + self.extra_flags)
+        return self.path
+
+    def _dz_apply(self, engine):
+        engine.set_likelihood_module(self.code_object(), "dz_user_batch", 64, self.data, self.always_finite)
+
+    def __call__(self, x):
+        if self.host is not None:
+            return self.host(np.asarray(x, dtype=float))
+        if self._eval_engine is None:
+            from . import _capi
+            self._eval_engine = _capi.Engine(nchains=3, ndim=self.d, history_capacity=8)
+            self._dz_apply(self._eval_engine)
+        return float(self._eval_engine.eval_logp(np.asarray(x, dtype=float).reshape(1, self.d))[1][0])
+
+    def __getstate__(self):
+        st = dict(self.__dict__); st["_eval_engine"] = None
+        return st
+
+
 class DeviceKernelLogLike:
     """A user-written HIP kernel as the likelihood -- the batched device callback for ANY model (the reference accepts any callable,
     pydream/model.py:17-32; a Python callable runs through the host callback at ~40 k proposals/s, this runs where the built-in

@@ -273,3 +273,31 @@ def test_a_user_kernel_compiles_to_a_gfx950_code_object_that_exports_it(tmp_path
     assert a == b and os.path.dirname(a) == str(tmp_path / "cache") and (t2 - t1) < 0.2 * (t1 - t0)
     assert compile_device_kernel(B.SOURCE, extra_flags=("-ffp-contract=fast",)) != a
     assert sorted(f for f in os.listdir(tmp_path / "cache")) == sorted(os.path.basename(x) for x in (a, compile_device_kernel(B.SOURCE, extra_flags=("-ffp-contract=fast",))))
+
+
+def test_a_user_device_function_compiles_into_the_persistent_kernels(tmp_path, monkeypatch):
+    """pydream_amd.likelihoods.DeviceFunctionLogLike (hipcc cross-compiles without a GPU): a wave-level device function becomes ONE code object
+    with the batch kernel of the multi-kernel path and the two persistent kernels (lean / full proposal code) whose names carry the layout
+    generation the engine looks them up by (csrc/dz_kernels.h DZ_USER_ABI); a compile error is the user's to read; the host twin answers
+    host calls."""
+    import re
+    import subprocess
+    from pydream_amd.likelihoods import DeviceFunctionLogLike
+    monkeypatch.setenv("DREAMZS_KERNEL_CACHE", str(tmp_path))
+    src = '''
+    __device__ double sq(const double* x, int d, const void* data, int lane)
+    {
+        double acc = 0.0;
+        for (int j = lane; j < d; j += 64) acc = acc + x[j] * x[j];
+        return -0.5 * dz_wave_sum(acc);
+    }'''
+    like = DeviceFunctionLogLike(src, "sq", 10, always_finite=True, host=lambda x: -0.5 * float(np.sum(x * x)))
+    out = like.code_object()
+    assert open(out, "rb").read(4) == b"\x7fELF" and like.code_object() == out
+    abi = int(re.search(r"#define DZ_USER_ABI (\d+)", open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pydream_amd", "csrc", "dz_kernels.h")).read()).group(1))
+    syms = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-s", out], capture_output=True, text=True).stdout
+    for name in ("dz_user_batch", "dz_user_generations_v%d" % abi, "dz_user_generations_full_v%d" % abi):
+        assert name + ".kd" in syms, name
+    assert like(np.ones(10)) == -5.0
+    with pytest.raises(Exception, match="hipcc failed"):
+        DeviceFunctionLogLike("__device__ double bad(const double* x, int d, const void* data, int lane) { return y; }", "bad", 3).code_object()

@@ -614,3 +614,76 @@ def test_run_dream_at_the_reference_examples_dimension(tmp_path, monkeypatch, mu
     np.testing.assert_array_equal(np.array(log_ps), np.array(l_o))
     acc = np.mean([np.any(np.diff(np.asarray(s), axis=0) != 0, axis=1).mean() for s in sampled])
     assert 0.01 < acc < 0.95
+
+
+USER_FN_SRC = r'''
+__device__ double weighted_sq(const double* x, int d, const void* data, int lane)
+{   // lane l adds its dimensions l, l + 64, ...; then the xor butterfly over the lanes (dz_wave_sum): -1/2 sum_j w_j (x_j - c_j)^2 + a quartic term
+    const double* c = (const double*)data; const double* w = c + d;
+    double acc = 0.0;
+    for (int j = lane; j < d; j += 64) { const double t = x[j] - c[j]; acc = acc + w[j] * (t * t) + 0.001 * ((t * t) * (t * t)); }
+    return -0.5 * dz_wave_sum(acc);
+}'''
+
+
+def _user_fn_twin(c, w):
+    def batch(X):          # the same operations in the same order, for a batch of points
+        X = np.asarray(X, dtype=float).reshape(-1, len(c))
+        part = np.zeros((len(X), 64))
+        for j in range(len(c)):
+            t = X[:, j] - c[j]
+            part[:, j % 64] = part[:, j % 64] + w[j] * (t * t) + 0.001 * ((t * t) * (t * t))
+        for o in (32, 16, 8, 4, 2, 1):
+            part = part + part[:, np.arange(64) ^ o]
+        return np.zeros(len(X)), -0.5 * part[:, 0]
+    return batch
+
+
+@pytest.mark.parametrize("N,k,prior,lag,persistent,variant", [
+    (1024, 5, "flat", 0, "1", "k_generations_user"),                      # the lean instantiation; the burn-in's unit sums by k_adapt_partials (blocks of 4 waves) ...
+    (4096, 5, "flat", 0, "1", "k_generations_user"),                      # ... or by the kernel's blocks of 16 themselves
+    (1000, 4, "normal", 3, "1", "k_generations_user<full> +ring"),        # priors: the full proposal code; adapt_lag: four burn-in generations per launch
+    (512, 1, "bounds", 2, "1", "k_generations_user<full> +ring"),         # multitry off, hard boundaries
+    (1024, 5, "flat", 0, "0", "multi-kernel path"),                       # DZ_MEGA_USER=0: the same function through the batch kernel
+])
+def test_a_user_device_function_inside_the_persistent_kernel(N, k, prior, lag, persistent, variant, monkeypatch, tmp_path):
+    """DeviceFunctionLogLike: a user's wave-level HIP device function compiled -- at run time, against the engine's own headers -- into the
+    persistent generation kernel the built-in mixture runs in (csrc/dz_megakernel.h generations_wave_body) and into a batch kernel for the
+    multi-kernel path.  Against the ORACLE with the same function, operation for operation, as a numpy host callback: states, log densities,
+    every decision, the archive and the adapted crossover probabilities equal bit for bit, whichever of the two carries the generations."""
+    from oracle import oracle as O
+    from pydream_amd import _capi as G
+    from pydream_amd.likelihoods import DeviceFunctionLogLike
+    monkeypatch.setenv("DZ_MEGA_USER", persistent)
+    monkeypatch.setenv("DREAMZS_KERNEL_CACHE", str(tmp_path))
+    d, n, seed = 100, 35, 9
+    c = np.linspace(-2.0, 2.0, d); w = 0.5 + np.arange(d) % 7 / 7.0
+    like = DeviceFunctionLogLike(USER_FN_SRC, "weighted_sq", d, data=np.concatenate([c, w]), always_finite=True, host=None)
+    twin = _user_fn_twin(c, w)
+    Z0 = np.random.default_rng(2).uniform(-6, 6, (10 * d + 2 * N, d))
+    out = []
+    for Cls in (G.Engine, O.Engine):
+        e = Cls(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
+                adapt_crossover=1, crossover_burnin=15, adapt_lag=lag)
+        if prior == "normal":
+            e.set_prior(np.full(d, 1, np.int32), np.linspace(-1.0, 1.0, d), np.full(d, 20.0))
+        elif prior == "bounds":
+            e.set_bounds(np.full(d, -7.0), np.full(d, 7.0))
+        e.set_history(Z0); e.set_state(Z0[:N])
+        if Cls is G.Engine:
+            like._dz_apply(e)
+        else:
+            e.set_likelihood_host(twin)
+        variants = set()
+        for m in (7, 13, 15):
+            e.step(m)
+            if Cls is G.Engine:
+                variants.add(e.last_kernel_variant())
+        out.append((e.get_trace(0, n), e.get_history(), e.get_cr_state(), variants))
+    for key in ("snooker", "cr_idx", "try_idx", "moved", "X", "logp"):
+        np.testing.assert_array_equal(out[0][0][key], out[1][0][key], err_msg=key)
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    for a, b in zip(out[0][2], out[1][2]):
+        np.testing.assert_array_equal(a, b)
+    assert variant in out[0][3], out[0][3]
+    assert 0.02 < out[0][0]["moved"].mean() < 0.95 and not np.allclose(out[0][2][0], 1 / 3.)

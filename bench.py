@@ -95,11 +95,27 @@ def setup_engine(Cls, args, n_global, n_local, offset, steps_total, device=0, **
             e.set_likelihood_mvn(np.zeros(d), np.linalg.cholesky((P + P.T) / 2).T, 1, 0.0)
         else:
             e.set_likelihood_mvn(np.zeros(d), P, 0, 0.0)
+    elif args.target == "user":          # a user's wave-level device function compiled into the persistent kernel (DeviceFunctionLogLike; needs hipcc at run time)
+        from pydream_amd.likelihoods import DeviceFunctionLogLike
+        c = np.linspace(-2.0, 2.0, d); w = 0.5 + np.arange(d) % 7 / 7.0
+        DeviceFunctionLogLike(USER_SRC, "weighted_sq", d, data=np.concatenate([c, w]), always_finite=True)._dz_apply(e)
     else:
         mu = np.array([np.full(d, m) for m in (-5.0, 0.0, 5.0)])
         logF = np.log(np.array([1 / 6., 1 / 3., 1 / 2.])) - (d / 2.) * np.log(2 * np.pi)
         e.set_likelihood_mixture(mu, logF)
     return e
+
+
+TARGET_NAMES = {"mvn": ("MVN", "correlated MVN"), "mix3": ("3-Gaussian mixture", "3-Gaussian mixture"),
+                "user": ("user device function (separable quartic)", "user-supplied device function -1/2 sum_j [w_j t_j^2 + 0.001 t_j^4], t = x - c, compiled into the persistent kernel at run time")}
+USER_SRC = r'''
+__device__ double weighted_sq(const double* x, int d, const void* data, int lane)
+{
+    const double* c = (const double*)data; const double* w = c + d;
+    double acc = 0.0;
+    for (int j = lane; j < d; j += 64) { const double t = x[j] - c[j]; acc = acc + w[j] * (t * t) + 0.001 * ((t * t) * (t * t)); }
+    return -0.5 * dz_wave_sum(acc);
+}'''
 
 
 def algorithmic_bytes(args, n_local):
@@ -237,7 +253,7 @@ def parse_args(argv=None):
     ap.add_argument("--multitry", type=int, default=5)
     ap.add_argument("--thin", type=int, default=10)
     ap.add_argument("--seed", type=int, default=20260929)
-    ap.add_argument("--target", choices=["mvn", "mix3"], default="mvn")
+    ap.add_argument("--target", choices=["mvn", "mix3", "user"], default="mvn")
     ap.add_argument("--mvn-kind", choices=["dense", "tri"], default="tri",
                     help="form of the MVN whitening matrix: tri = Cholesky factor of the precision (what "
                          "pydream_amd.likelihoods.MVNormalLogLike builds), dense = full precision matrix")
@@ -306,6 +322,8 @@ def workload_label(args, n_local, world):
         return "BASELINE north_star target / configs[3] per-GPU shard"
     if args.target == "mvn" and args.dim == 100 and n_local * world == 32768:
         return "BASELINE configs[3] as written (32768 chains) on %d GPU%s: the strong-scaling reading" % (world, "" if world == 1 else "s")
+    if args.target == "user":
+        return "not a BASELINE configuration: north_star's `batched device callback` for a density that is not built in"
     if args.target == "mvn" and args.dim == 200:
         return "the reference example's own dimension (dream_ex_ndim_gaussian.py:29), not a BASELINE configuration"
     return "variant of the BASELINE workloads"
@@ -360,7 +378,9 @@ def baseline_configs(args):
                       ("configs[3] @ 1 GPU", dict(chains_per_gpu=32768, rhat_cap=2000)),
                       ("configs[4] shard", dict(chains_per_gpu=512, dim=1000)),
                       # not a BASELINE configuration: the reference example's own dimension (dream_ex_ndim_gaussian.py:29), 4096 chains
-                      ("example d=200", dict(dim=200, rhat_cap=4000))):
+                      ("example d=200", dict(dim=200, rhat_cap=4000)),
+                      # not a BASELINE configuration either: a user's device likelihood inside the persistent kernel (north_star: "the user likelihood is evaluated as a batched device callback")
+                      ("user device likelihood", dict(target="user", rhat_cap=2000))):
         a = copy.copy(args)
         cap = over.pop("rhat_cap", None)
         for k_, v_ in over.items():
@@ -652,14 +672,14 @@ def measure(args, dist, world, rank, sub=False):
         flops_gen = n_local * (2 * args.multitry - 1) * (1.0 if args.mvn_kind == "tri" else 2.0) * float(args.dim) ** 2 if args.target == "mvn" else None
         out = {
             "metric": "proposals/sec (all chains), %dD %s logpdf, MT-DREAM(ZS) multitry=%d, history_lag=%d"
-                      % (args.dim, "MVN" if args.target == "mvn" else "3-Gaussian mixture", args.multitry, args.history_lag),
+                      % (args.dim, TARGET_NAMES[args.target][0], args.multitry, args.history_lag),
             "value": value, "unit": "proposals/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": 1e3 * med / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d chains/GPU x %d-D %s target (%s), multitry=%d, DE+snooker(%g), nCR=3, history_thin=%d, "
                                    "seed archive max(10d,2N) rows U(-5,15); %s"
-                                   % (n_local, args.dim, "correlated MVN" if args.target == "mvn" else "3-Gaussian mixture",
-                                      args.mvn_kind if args.target == "mvn" else "identity cov", args.multitry, args.snooker, args.thin,
+                                   % (n_local, args.dim, TARGET_NAMES[args.target][1],
+                                      {"mvn": args.mvn_kind, "mix3": "identity cov", "user": "one wave per point"}[args.target], args.multitry, args.snooker, args.thin,
                                       workload_label(args, n_local, world)),
                        "chains_global": n_global, "chains_per_gpu": n_local, "ndim": args.dim, "multitry": args.multitry,
                        "history_lag": args.history_lag,

@@ -630,9 +630,10 @@ def _user_fn_twin(c, w):
     def batch(X):          # the same operations in the same order, for a batch of points
         X = np.asarray(X, dtype=float).reshape(-1, len(c))
         part = np.zeros((len(X), 64))
-        for j in range(len(c)):
-            t = X[:, j] - c[j]
-            part[:, j % 64] = part[:, j % 64] + w[j] * (t * t) + 0.001 * ((t * t) * (t * t))
+        for j0 in range(0, len(c), 64):          # lane l's dimensions in ascending order: strips of 64 dimensions, all lanes of a strip at once
+            m = min(64, len(c) - j0)
+            t = X[:, j0:j0 + m] - c[j0:j0 + m]
+            part[:, :m] = part[:, :m] + w[j0:j0 + m] * (t * t) + 0.001 * ((t * t) * (t * t))
         for o in (32, 16, 8, 4, 2, 1):
             part = part + part[:, np.arange(64) ^ o]
         return np.zeros(len(X)), -0.5 * part[:, 0]

@@ -557,13 +557,15 @@ def test_bench_default_line_carries_every_single_gpu_baseline_config(tmp_path):
     d = json.loads([l for l in res.stdout.splitlines() if l.startswith('{"metric"')][0])
     assert "configs[3] per-GPU shard" in d["config"]["workload"]
     c = d["configs"]
-    assert set(c) == {"configs[1]", "configs[2]", "configs[3] @ 1 GPU", "configs[4] shard", "example d=200"}
+    assert set(c) == {"configs[1]", "configs[2]", "configs[3] @ 1 GPU", "configs[4] shard", "example d=200", "user device likelihood"}
     # (round 6) configs[3] as written is 32768 chains: its one-GPU point, the anchor of the strong-scaling reading (`strong_scaling` in the N > 1 lines)
     x = c["configs[3] @ 1 GPU"]
     assert "error" not in x, x
     assert "32768 chains" in x["workload"] and "strong-scaling" in x["workload"] and x["kernel_variant"] == "k_generations<7,tri,xlds,16,1,lean>"
     assert x["value"] > 0 and 0 < x["roofline"]["frac"] < 1 and np.isfinite(x["rhat_run_so_far"])
     assert c["example d=200"]["kernel_variant"] == "k_generations_d2<13,tri,xhbm,16,1,lean>" and c["example d=200"]["value"] > 0
+    # a user's device function compiled at run time into the persistent kernel (hipcc is on the GPU box): at least the built-in mixture's rate
+    assert c["user device likelihood"]["kernel_variant"] == "k_generations_user" and c["user device likelihood"]["value"] > 0.9 * c["configs[2]"]["value"]
     for key, variant, label in (("configs[1]", "k_generations_w4<7,tri,xlds,4,4,lean,ahead>", "BASELINE configs[1]"),
                                 ("configs[2]", "k_generations_mix", "BASELINE configs[2] as written"),
                                 ("configs[4] shard", "multi-kernel path", "BASELINE configs[4] per-GPU shard")):

@@ -688,3 +688,29 @@ def test_a_user_device_function_inside_the_persistent_kernel(N, k, prior, lag, p
         np.testing.assert_array_equal(a, b)
     assert variant in out[0][3], out[0][3]
     assert 0.02 < out[0][0]["moved"].mean() < 0.95 and not np.allclose(out[0][2][0], 1 / 3.)
+
+
+def test_run_dream_with_a_user_device_function_equals_its_python_twin(tmp_path):
+    """The drop-in path for a density that is not built in: run_dream(parameters, DeviceFunctionLogLike(...)) -- the function compiled into the
+    persistent kernel on first use, the reference's defaults otherwise (crossover adaptation on, burn-in = a tenth of the run) -- returns what
+    run_dream returns for the same function as a plain Python likelihood (the reference's own calling convention, model.py:31): the same
+    samples bit for bit, log densities to 1e-10 (scipy's prior on the host, the engine's own on the device)."""
+    from scipy.stats import norm
+    from pydream_amd import core
+    from pydream_amd.likelihoods import DeviceFunctionLogLike
+    d, N, n = 20, 64, 60
+    c = np.linspace(-1.0, 1.0, d); w = 0.5 + np.arange(d) % 7 / 7.0
+    twin = _user_fn_twin(c, w)
+    hist = str(tmp_path / "seed.npy")
+    np.save(hist, np.random.default_rng(4).uniform(-4, 4, (10 * d + 2 * N, d)))
+    kw = dict(nchains=N, niterations=n, verbose=False, save_history=False, history_file=hist, multitry=3, seed=5,
+              start=[np.full(d, 0.05 * i) for i in range(N)])
+    pri = [SampledParam(norm, loc=np.zeros(d), scale=np.full(d, 5.0))]
+    like = DeviceFunctionLogLike(USER_FN_SRC, "weighted_sq", d, data=np.concatenate([c, w]), always_finite=True, host=lambda x: float(twin(x)[1][0]))
+    s_dev, l_dev = run_dream(pri, like, **kw)
+    variant = core.last_kernel_variant
+    s_host, l_host = run_dream(pri, lambda x: float(twin(x)[1][0]), **kw)
+    np.testing.assert_array_equal(np.array(s_dev), np.array(s_host))
+    np.testing.assert_allclose(np.array(l_dev), np.array(l_host), rtol=0, atol=1e-10)
+    assert variant.startswith("k_generations_user<full>"), variant          # (SampledParam priors: the full proposal code)
+    assert like(np.zeros(d)) == twin(np.zeros(d))[1][0]                       # the host twin answers a host call

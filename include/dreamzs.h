@@ -119,11 +119,11 @@ int dz_set_likelihood_host(dz_engine* e, dz_logp_cb cb, void* user);
  * Priors given by dz_set_prior are added by the engine.  Generations with such a likelihood run the multi-kernel path -- unless the code
  * object also exports the persistent generation kernel instantiated around the same density (round 6):
  *     dz_user_generations_v<N>, dz_user_generations_full_v<N>      (N = DZ_USER_ABI of csrc/dz_kernels.h: the layout generation of the
- *                                                                   structures they take; other names are simply not found)
+ *     dz_user_generations_wide_v<N>, ..._wide_full_v<N>             structures they take; other names are simply not found; wide: 128 < d <= 256)
  * = csrc/dz_megakernel.h generations_wave_body<false | true, false, UserLike> -- the kernel the built-in mixture runs in, one wave per chain,
  * the user's wave-level device function `double f(const double* x, int d, const void* data, int lane)` in the likelihood's place
  * (pydream_amd.likelihoods.DeviceFunctionLogLike writes and compiles that translation unit at run time, against the headers next to this
- * library).  They carry the generations where the mixture's would (d <= 128, multitry 1 or 3..32, DZ_LIKE_ALWAYS_FINITE): same decisions,
+ * library).  They carry the generations where the mixture's would (d <= 256, multitry 1 or 3..32, DZ_LIKE_ALWAYS_FINITE): same decisions,
  * same bits as through the batch kernel, at the persistent kernels' rate (DZ_MEGA_USER=0 in the environment: never).  flags: DZ_LIKE_ALWAYS_FINITE promises that the density is finite wherever the priors are, so
  * the engine need not check every proposal set for "all tries impossible" (Dream.py:281-289) with a read-back per generation. */
 #define DZ_LIKE_ALWAYS_FINITE 1

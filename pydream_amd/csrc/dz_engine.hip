@@ -133,7 +133,7 @@ struct dz_engine {
     // a user-supplied DEVICE likelihood (dz_set_likelihood_module): a kernel of a code object the user built, launched where k_logp_* run
     hipModule_t lk_module = nullptr; hipFunction_t lk_fn = nullptr; void* d_lk_data = nullptr; int lk_lanes = 1; bool lk_finite = false;
     // ... and, when the code object has them, the persistent kernels with that density inlined (generations_wave_body<.., UserLike>): [0] lean, [1] full proposal code
-    hipFunction_t lk_gen_fn[2] = {nullptr, nullptr};
+    hipFunction_t lk_gen_fn[4] = {nullptr, nullptr, nullptr, nullptr};      // ([2], [3]: 128 < d <= 256)
     dz_exchange_cb xcb = nullptr; void* xcb_user = nullptr;
     ncclComm_t comm = nullptr; int rank = 0, world = 1;
     // peer transport (dz_peer_export / dz_peer_attach): the other ranks' archives, position buffers and flag words mapped into this
@@ -157,6 +157,7 @@ struct dz_engine {
     double* d_binsum = nullptr;     // k_adapt_update's scratch: [strips of 64 chains][ncr + ngamma] sums, then the same shape of counts
     // lockstep adaptation, contract v3 (dz_kernels.h adapt_unit_sums): the units' sums [units][nq][ld] and counts [units][ncr + ngamma], their totals
     double *d_PR = nullptr, *d_PC = nullptr, *d_TOT = nullptr, *d_CNT = nullptr;
+    bool mega_mix_wide = true;      // the wave-per-chain kernels (mixture, a user's device function) also at 128 < d <= 256 (DZ_MEGA_MIX_WIDE=0: the multi-kernel path there)
     bool adapt_fused = true;        // the persistent kernels make their block's unit sums themselves (DZ_ADAPT_FUSED=0: k_adapt_partials does)
     // dz_config.adapt_lag = L >= 1 (round 6): d_TOT / d_CNT are rings of L + 1 slots (slot = generation mod (L + 1); d_CNT rows of ad_nbp), d_DOT
     // [L + 1][ad_nbp] the bins' dot products (k_adapt_dots), d_PR / d_PC rings as well when launches hold several burn-in generations (ad_multi).
@@ -959,7 +960,8 @@ bool mega_mix_eligible(const dz_engine* e)
 {
     const dz::Params& p = e->p;
     const bool pbm = p.hard || p.have_prior || p.depairs > 1;
-    return e->mega && (e->lk == LK_MIX || (e->lk == LK_MODULE && e->lk_gen_fn[pbm ? 1 : 0])) && !redo_possible(e) && (!pbm || e->mega_mix_pb) && p.ld <= 128 && (p.k == 1 || p.k >= 3) && p.k <= dz::MAXK &&
+    return e->mega && (e->lk == LK_MIX || (e->lk == LK_MODULE && e->lk_gen_fn[(p.ld > 128 ? 2 : 0) + (pbm ? 1 : 0)])) && !redo_possible(e) && (!pbm || e->mega_mix_pb) &&
+           p.ld <= (e->mega_mix_wide ? 256 : 128) && (p.k == 1 || p.k >= 3) && p.k <= dz::MAXK &&
            p.nslots <= 64 && p.J <= 32;
 }
 // redraw rounds inside the persistent kernel: the instantiations with the full proposal code, multi-try, device MVN likelihood
@@ -1077,7 +1079,7 @@ int burnin_multi(const dz_engine* e)
     const bool ring_ok = e->ad_ring && sizeof(double) * (size_t)(e->c.adapt_lag + 2) * p.N * p.ld <= ((size_t)8 << 30);
     if (e->lk == LK_MIX || e->lk == LK_MODULE) {
         if (!mega_mix_eligible(e)) return 0;
-        if (e->lk == LK_MIX && e->adapt_fused && p.k >= 3 && mix_multi_lds(e) <= cap) return 1;
+        if (e->lk == LK_MIX && e->adapt_fused && p.k >= 3 && p.ld <= 128 && mix_multi_lds(e) <= cap) return 1;
         return (ring_ok && sizeof(double) * (size_t)dz::MIXW * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + tab <= cap) ? 2 : 0;
     }
     if (e->lk != LK_MVN || !e->mega) return 0;
@@ -1215,7 +1217,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         const size_t lds_probs = sizeof(double) * (size_t)((p.ncr + p.ngamma + 1) & ~1);
         const size_t lds_xo = sizeof(double) * (size_t)16 * (4 * ((p.d + 3) / 4) + 1);
         if (multi) mw = 16;
-        else if (publish && !ring && e->adapt_fused && (e->world == 1 || e->adapt_groups) && p.k >= 3 && sizeof(double) * (size_t)16 * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs + lds_xo <= (size_t)160 * 1024) { mw = 16; fuse_adapt(); }
+        else if (publish && !ring && e->adapt_fused && (e->world == 1 || e->adapt_groups) && p.k >= 3 && p.ld <= 128 && sizeof(double) * (size_t)16 * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + lds_probs + lds_xo <= (size_t)160 * 1024) { mw = 16; fuse_adapt(); }
         const dim3 gridm((p.nl + mw - 1) / mw), blockm(64 * mw);
         const size_t ldsm = multi ? mix_multi_lds(e) : sizeof(double) * (size_t)mw * dz::mega_mix_wave_doubles(p.d, p.k, p.J) + (rmulti ? sizeof(double) * (size_t)e->ad_R1 * e->ad_nbp : lds_probs) + (fused ? lds_xo : 0);
         const bool pbm = p.hard || p.have_prior || p.depairs > 1;
@@ -1225,15 +1227,19 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
             if (e->prof) {
                 hipEvent_t ka = prof_event(e), kb = prof_event(e);
                 e->ev[PR_GENERATIONS].emplace_back(ka, kb);
-                HIPCK(hipExtModuleLaunchKernel(e->lk_gen_fn[pbm ? 1 : 0], gridm.x * blockm.x, 1, 1, blockm.x, 1, 1, ldsm, e->stream, args, nullptr, ka, kb, 0));
-            } else HIPCK(hipModuleLaunchKernel(e->lk_gen_fn[pbm ? 1 : 0], gridm.x, 1, 1, blockm.x, 1, 1, (unsigned)ldsm, e->stream, args, nullptr));
+                HIPCK(hipExtModuleLaunchKernel(e->lk_gen_fn[(p.ld > 128 ? 2 : 0) + (pbm ? 1 : 0)], gridm.x * blockm.x, 1, 1, blockm.x, 1, 1, ldsm, e->stream, args, nullptr, ka, kb, 0));
+            } else HIPCK(hipModuleLaunchKernel(e->lk_gen_fn[(p.ld > 128 ? 2 : 0) + (pbm ? 1 : 0)], gridm.x, 1, 1, blockm.x, 1, 1, (unsigned)ldsm, e->stream, args, nullptr));
             DZCK(launch_check("dz_user_generations"));
             launched();
-            e->last_variant = std::string(pbm ? "k_generations_user<full>" : "k_generations_user") + (rmulti ? " +ring" : "");
+            e->last_variant = std::string(p.ld > 128 ? (pbm ? "k_generations_user<full,wide>" : "k_generations_user<wide>") : (pbm ? "k_generations_user<full>" : "k_generations_user")) + (rmulti ? " +ring" : "");
             DZCK(after_launch());
             if (slot0 >= 0) e->ntrace += n;
             return 0;
         }
+        if (p.ld > 128) {      // 128 < d <= 256: a lane owns four dimensions
+            if (pbm) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations_mix<true, false, 2>), gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, seg0, pub);
+            else DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations_mix<false, false, 2>), gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, seg0, pub);
+        } else
         if (multi) {
             if (pbm) DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations_mix<true, true>), gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, seg0, pub);
             else DZ_KLAUNCH(e, PR_GENERATIONS, e->stream, (dz::k_generations_mix<false, true>), gridm, blockm, ldsm, (const dz::Params*)e->d_params, g, n, (uint32_t)visible_rows(e), slot0, append_last ? e->M : (int64_t)-1, seg0, pub);
@@ -1243,6 +1249,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
         DZCK(launch_check("k_generations_mix"));
         launched();
         e->last_variant = multi ? (pbm ? "k_generations_mix<full,multi>" : "k_generations_mix<multi>") : (pbm ? "k_generations_mix<full>" : "k_generations_mix");
+        if (p.ld > 128) e->last_variant = pbm ? "k_generations_mix<full,wide>" : "k_generations_mix<wide>";
         if (rmulti) e->last_variant += " +ring";
         DZCK(after_launch());
         if (slot0 >= 0) e->ntrace += n;
@@ -1382,6 +1389,7 @@ int dz_create(const dz_config* cfg, dz_engine** out)
     if (const char* kv = getenv("DZ_MEGA_MIX_PB")) e->mega_mix_pb = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_SPLIT")) e->mega_split = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_ADAPT_RING")) e->ad_ring = atoi(kv) != 0;
+    if (const char* kv = getenv("DZ_MEGA_MIX_WIDE")) e->mega_mix_wide = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_W4")) e->mega_w4 = atoi(kv) != 0;
     if (const char* kv = getenv("DZ_MEGA_D2")) e->mega_d2 = atoi(kv);
     static_assert(dz::DZ_MAX_REDRAWS_DEV == DZ_MAX_REDRAWS && dz::DZ_REDRAW_KEY_STEP_DEV == DZ_REDRAW_KEY_STEP, "redraw constants");
@@ -1714,10 +1722,12 @@ int dz_set_likelihood_module(dz_engine* e, const char* code_object_path, const c
     if (err != hipSuccess) { (void)hipGetLastError(); return fail(std::string("hipModuleLoad(") + code_object_path + "): " + hipGetErrorString(err) + " (a gfx950 code object is expected: hipcc --offload-arch=gfx950 --genco)"); }
     err = hipModuleGetFunction(&fn, mod, kernel_name);
     if (err != hipSuccess) { (void)hipGetLastError(); (void)hipModuleUnload(mod); return fail(std::string("hipModuleGetFunction(") + kernel_name + "): " + hipGetErrorString(err) + " (the kernel must be extern \"C\")"); }
-    hipFunction_t gen[2] = {nullptr, nullptr};      // optional: the persistent kernels around the same density (a code object built by DeviceFunctionLogLike has them)
+    hipFunction_t gen[4] = {nullptr, nullptr, nullptr, nullptr};      // optional: the persistent kernels around the same density (a code object built by DeviceFunctionLogLike has them)
     if (hipModuleGetFunction(&gen[0], mod, "dz_user_generations_v" DZ_USER_STR(DZ_USER_ABI)) != hipSuccess) { (void)hipGetLastError(); gen[0] = nullptr; }
     if (hipModuleGetFunction(&gen[1], mod, "dz_user_generations_full_v" DZ_USER_STR(DZ_USER_ABI)) != hipSuccess) { (void)hipGetLastError(); gen[1] = nullptr; }
-    if (getenv("DZ_MEGA_USER") && atoi(getenv("DZ_MEGA_USER")) == 0) { gen[0] = nullptr; gen[1] = nullptr; }
+    if (hipModuleGetFunction(&gen[2], mod, "dz_user_generations_wide_v" DZ_USER_STR(DZ_USER_ABI)) != hipSuccess) { (void)hipGetLastError(); gen[2] = nullptr; }
+    if (hipModuleGetFunction(&gen[3], mod, "dz_user_generations_wide_full_v" DZ_USER_STR(DZ_USER_ABI)) != hipSuccess) { (void)hipGetLastError(); gen[3] = nullptr; }
+    if (getenv("DZ_MEGA_USER") && atoi(getenv("DZ_MEGA_USER")) == 0) for (auto& gfn : gen) gfn = nullptr;
     // the new data block first, into a temporary: the engine's module, function and data change together, and only once every step has
     // succeeded -- a failure leaves the engine as it was (advisor, round 5)
     void* d_new = nullptr;
@@ -1734,7 +1744,8 @@ int dz_set_likelihood_module(dz_engine* e, const char* code_object_path, const c
     if (e->lk_module) { (void)hipModuleUnload(e->lk_module); e->lk_module = nullptr; e->lk_fn = nullptr; }
     if (e->d_lk_data) { (void)hipFree(e->d_lk_data); e->d_lk_data = nullptr; }
     e->d_lk_data = d_new;
-    e->lk_gen_fn[0] = gen[0]; e->lk_gen_fn[1] = gen[1]; e->p.udata = d_new; e->p.J = 1;      // (J: the wave's scratch row in the persistent kernel's layout)
+    for (int i = 0; i < 4; ++i) e->lk_gen_fn[i] = gen[i];
+    e->p.udata = d_new; e->p.J = 1;      // (J: the wave's scratch row in the persistent kernel's layout)
     e->lk_module = mod; e->lk_fn = fn; e->lk_lanes = lanes_per_point; e->lk_finite = (flags & DZ_LIKE_ALWAYS_FINITE) != 0;
     e->lk = LK_MODULE; e->have_logp = false;
     return 0;

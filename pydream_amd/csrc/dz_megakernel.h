@@ -785,6 +785,7 @@ __host__ __device__ inline int mega_mix_wave_doubles(int d, int k, int J) { cons
 // scratch ([k][J] doubles).  MixLike: the built-in mixture.  A user's device function takes its place in a code object built at run time
 // (dz_user_generations.hip.in; pydream_amd.likelihoods.DeviceFunctionLogLike): the same kernel around ANY density a wave can evaluate.
 struct MixLike {
+    template <int NCH>
     DZ_DEV static void eval(const Params& p, const double* rows, int LDP, int n, int lane, double* lh, double* out)
     {
         const int d = p.d;
@@ -793,21 +794,28 @@ struct MixLike {
         // (points in groups of GP: GP independent reductions in flight per component, and each mean is read once per group)
         constexpr int GP = 4;
         for (int i0 = 0; i0 < n; i0 += GP) {
-            double x0[GP], x1[GP];
+            double x0[GP][NCH], x1[GP][NCH];      // (a lane's dimensions 128 it + 2 lane, + 1: in ascending order, as k_logp_mix adds them)
 #pragma unroll
             for (int u = 0; u < GP; ++u) {
                 const double* row = rows + (size_t)min(i0 + u, n - 1) * LDP;
-                x0[u] = 2 * lane < d ? row[2 * lane] : 0.0; x1[u] = 2 * lane + 1 < d ? row[2 * lane + 1] : 0.0;
+#pragma unroll
+                for (int it = 0; it < NCH; ++it) { const int jj = 128 * it + 2 * lane; x0[u][it] = jj < d ? row[jj] : 0.0; x1[u][it] = jj + 1 < d ? row[jj + 1] : 0.0; }
             }
             for (int j = 0; j < p.J; ++j) {
                 const double* mj = p.mu + (size_t)j * p.ld;
-                const double m0 = 2 * lane < d ? mj[2 * lane] : 0.0, m1 = 2 * lane + 1 < d ? mj[2 * lane + 1] : 0.0;
+                double m0[NCH], m1[NCH];
+#pragma unroll
+                for (int it = 0; it < NCH; ++it) { const int jj = 128 * it + 2 * lane; m0[it] = jj < d ? mj[jj] : 0.0; m1[it] = jj + 1 < d ? mj[jj + 1] : 0.0; }
                 double S[GP];
 #pragma unroll
                 for (int u = 0; u < GP; ++u) {
                     double acc = 0.0;
-                    if (2 * lane < d) { const double t = x0[u] - m0; acc = fma(t, t, acc); }
-                    if (2 * lane + 1 < d) { const double t = x1[u] - m1; acc = fma(t, t, acc); }
+#pragma unroll
+                    for (int it = 0; it < NCH; ++it) {
+                        const int jj = 128 * it + 2 * lane;
+                        if (jj < d) { const double t = x0[u][it] - m0[it]; acc = fma(t, t, acc); }
+                        if (jj + 1 < d) { const double t = x1[u][it] - m1[it]; acc = fma(t, t, acc); }
+                    }
                     S[u] = acc;
                 }
                 static_assert(GP == 4, "wave_bfly4 sums four values");
@@ -830,12 +838,12 @@ struct MixLike {
     }
 };
 
-template <bool PB, bool MG, class LK>
+template <bool PB, bool MG, class LK, int NCH = 1>
 DZ_DEV void generations_wave_body(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0, int64_t zappend, int seg0, const Publish& pub)
 {
     double* const publish = pub.to;
     const Params& p = *pp;
-    constexpr int NCH = 1;
+    static_assert(NCH == 1 || !MG, "the blocks' own unit sums: d <= 128");      // (NCH = 2, 128 < d <= 256: a lane owns four dimensions, 128 it + 2 lane, + 1)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int d = p.d, k = p.k, ld = p.ld;
     const int LDP = 4 * ((d + 3) / 4) + 1;
@@ -853,7 +861,7 @@ DZ_DEV void generations_wave_body(const Params* __restrict__ pp, uint32_t g0, in
     if (MG || RG) {
         if (wv == 0) adapt_pending_apply(p, pub.DOT, pub.CNTR, pub.nbp, pub.lag + 1, pub.pend0, pub.pend1, (long long)g0, ngen, pub.lag, pub.burnin, pub.sh, probs,
                                          blockIdx.x == 0 ? pub.sh_out : nullptr, lane);
-    } else if (pub.TOT) { if (wv == 0) adapt_apply_wave<1>(p, pub.TOT, pub.CNT, pub.sh, probs, blockIdx.x == 0 ? pub.sh_out : nullptr, lane); }
+    } else if (pub.TOT) { if (wv == 0) adapt_apply_wave<NCH>(p, pub.TOT, pub.CNT, pub.sh, probs, blockIdx.x == 0 ? pub.sh_out : nullptr, lane); }
     else {
         if ((int)threadIdx.x < p.ncr) probs[threadIdx.x] = pub.sh[threadIdx.x];
         if ((int)threadIdx.x < p.ngamma) probs[p.ncr + threadIdx.x] = pub.sh[3 * p.ncr + threadIdx.x];
@@ -868,7 +876,7 @@ DZ_DEV void generations_wave_body(const Params* __restrict__ pp, uint32_t g0, in
     double xs[NCH][2];                                                      // the chain's state lives in registers
     load_row<NCH>(p.X + (size_t)c * ld, ld, lane, xs);
     double* xo_area = probs + (MG ? (pub.lag + 1) * pub.nbp : ((p.ncr + p.ngamma + 1) & ~1));      // (crossover burn-in, blocks of 16: the states the launch started with, [16][LDP]; MG: the stash)
-    if (!MG && pub.PR) { if (2 * lane < d) xo_area[wv * LDP + 2 * lane] = xs[0][0]; if (2 * lane + 1 < d) xo_area[wv * LDP + 2 * lane + 1] = xs[0][1]; }
+    if (NCH == 1 && !MG && pub.PR) { if (2 * lane < d) xo_area[wv * LDP + 2 * lane] = xs[0][0]; if (2 * lane + 1 < d) xo_area[wv * LDP + 2 * lane + 1] = xs[0][1]; }
     double lpri = p.lprior[c], llik = p.llike[c];
     if (lane == 0) dec[6] = chain_T(p, c);                                  // the chain's temperature (Dream.astep's T)
     // (PB) the prior / boundary constants straight from global memory through the PBConsts interface of the block-staged kernels: the prior
@@ -879,7 +887,9 @@ DZ_DEV void generations_wave_body(const Params* __restrict__ pp, uint32_t g0, in
     if (PB && p.have_prior && p.prior_nonormal) {
         double acc = 0.0;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) { const int j = 2 * lane + s2; if (j < d) acc = acc + (p.pkind[j] == 2 ? -p.plogb[j] : 0.0); }
+        for (int it = 0; it < NCH; ++it)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) { const int j = 128 * it + 2 * lane + s2; if (j < d) acc = acc + (p.pkind[j] == 2 ? -p.plogb[j] : 0.0); }
         acc = wave_bfly(acc);
         if (lane == 0) rP[k - 1] = acc;
     }
@@ -906,16 +916,21 @@ DZ_DEV void generations_wave_body(const Params* __restrict__ pp, uint32_t g0, in
                 u.u_sel = u53(w2.x, w2.y); u.u_acc = u53(w2.z, w2.w);
                 f = step_flags_from(p, u, pr_g, pr_g + p.ncr);                      // Dream.py:246-256
                 if (lane == 0) { dec[0] = u.u_sel; dec[1] = u.u_acc; dec[2] = f.snk ? 1.0 : 0.0; dec[3] = (double)f.cr_idx; dec[4] = (double)f.glev; if (PB) dec[7] = (double)f.delta; }
-                base[0][0] = xs[0][0]; base[0][1] = xs[0][1];
+#pragma unroll
+                for (int it = 0; it < NCH; ++it) { base[it][0] = xs[it][0]; base[it][1] = xs[it][1]; }
             } else {
                 f.snk = dec[2] != 0.0; f.cr_idx = (int)dec[3]; f.delta = PB ? (int)dec[7] : 1; f.glev = (int)dec[4];
                 double lp = -__builtin_huge_val();
                 if (lane < k) lp = sP[lane] + dec[6] * sL[lane];                    // :279, mt_choose_proposal_pt :291
                 sel = mt_select_vals(k, lp, dec[0], lane, &fin);
                 const double* row = region + (size_t)sel * LDP;
-                base[0][0] = 2 * lane < d ? row[2 * lane] : 0.0; base[0][1] = 2 * lane + 1 < d ? row[2 * lane + 1] : 0.0;
-                if (2 * lane < d) region[2 * lane] = base[0][0];                    // the selected proposal now sits in row 0
-                if (2 * lane + 1 < d) region[2 * lane + 1] = base[0][1];
+#pragma unroll
+                for (int it = 0; it < NCH; ++it) {
+                    const int jj = 128 * it + 2 * lane;
+                    base[it][0] = jj < d ? row[jj] : 0.0; base[it][1] = jj + 1 < d ? row[jj + 1] : 0.0;
+                    if (jj < d) region[jj] = base[it][0];                           // the selected proposal now sits in row 0
+                    if (jj + 1 < d) region[jj + 1] = base[it][1];
+                }
             }
             const double* grow = gamma_row(p, f.glev, PB ? f.delta : 1);
             const int n = k - phase;
@@ -924,7 +939,7 @@ DZ_DEV void generations_wave_body(const Params* __restrict__ pp, uint32_t g0, in
                                                      rows, LDP, (phase ? rS : sS), (k == 1 ? dec + 5 : nullptr), (phase ? rP : sP), &pcs);
             else propose_set<NCH, false, false, 2>(p, phase, g, M, c, gc, 0, n, n, lane, base, grow, f.snk, f.cr_idx, 1, f.glev, ds,
                                                    rows, LDP, (phase ? rS : sS), (k == 1 ? dec + 5 : nullptr), (phase ? lh : sP));   // (flat priors: in phase 1 the prior slot is scratch)
-            LK::eval(p, rows, LDP, n, lane, lh, phase ? rL : sL);                   // mt_evaluate_logps :278, :302 -- by this wave, for its own points
+            LK::template eval<NCH>(p, rows, LDP, n, lane, lh, phase ? rL : sL);                   // mt_evaluate_logps :278, :302 -- by this wave, for its own points
         }
         // ---- Metropolis step (:305-347), trace (core.py:114-116), record_history (:919-938)
         {
@@ -951,20 +966,30 @@ DZ_DEV void generations_wave_body(const Params* __restrict__ pp, uint32_t g0, in
                 if (!fin) ratio = -__builtin_huge_val();                            // DESIGN.md deviation D1
             }
             const bool accept = is_finite(ratio) && (lu < ratio);                   // :993
-            const int jj = 2 * lane;
-            const double2 xo = {xs[0][0], xs[0][1]};
-            double2 xn = xo;
-            if (accept) { xn.x = jj < d ? region[jj] : 0.0; xn.y = jj + 1 < d ? region[jj + 1] : 0.0; }
-            const bool moved = __any((xn.x != xo.x) || (xn.y != xo.y));             // core.py:120
+            double2 xn[NCH];
+            bool diff = false;
+#pragma unroll
+            for (int it = 0; it < NCH; ++it) {
+                const int jj = 128 * it + 2 * lane;
+                const double2 xo = {xs[it][0], xs[it][1]};
+                xn[it] = xo;
+                if (accept) { xn[it].x = jj < d ? region[jj] : 0.0; xn[it].y = jj + 1 < d ? region[jj + 1] : 0.0; }
+                diff = diff || (xn[it].x != xo.x) || (xn[it].y != xo.y);
+                xs[it][0] = xn[it].x; xs[it][1] = xn[it].y;
+            }
+            const bool moved = __any(diff);                                          // core.py:120
             const double npri = accept ? sP[sel] : lpri, nlik = accept ? sL[sel] : llik;    // :345-347
-            xs[0][0] = xn.x; xs[0][1] = xn.y;
             if (active) {
-                if (jj < ld) {
-                    if (last) *reinterpret_cast<double2*>(p.X + (size_t)c * ld + jj) = xn;
-                    if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn);
-                    if (app) gstore2(p.Z + ((size_t)zappend + (M - M0) + gc) * ld + jj, xn);                         // record_history :933-936
-                    if (publish && (!MG || last)) gstore2(publish_g + (size_t)gc * ld + jj, xn);         // set_current_position_arr :447-449
-                    if (MG && gc == 0u) gstore2(pub.x0ring + (size_t)(g % (uint32_t)(2 * (pub.lag + 1))) * ld + jj, xn);      // global chain 0 after generation g: a later generation's shift
+#pragma unroll
+                for (int it = 0; it < NCH; ++it) {
+                    const int jj = 128 * it + 2 * lane;
+                    if (jj < ld) {
+                        if (last) *reinterpret_cast<double2*>(p.X + (size_t)c * ld + jj) = xn[it];
+                        if (trace_slot0 >= 0) gstore2(p.tX + ((size_t)c * p.tcap + (size_t)(trace_slot0 + gi)) * ld + jj, xn[it]);
+                        if (app) gstore2(p.Z + ((size_t)zappend + (M - M0) + gc) * ld + jj, xn[it]);                         // record_history :933-936
+                        if (publish && (!MG || last)) gstore2(publish_g + (size_t)gc * ld + jj, xn[it]);         // set_current_position_arr :447-449
+                        if (MG && gc == 0u) gstore2(pub.x0ring + (size_t)(g % (uint32_t)(2 * (pub.lag + 1))) * ld + jj, xn[it]);      // global chain 0 after generation g: a later generation's shift
+                    }
                 }
                 if (lane == 0) {
                     if (trace_slot0 >= 0) {
@@ -996,7 +1021,7 @@ DZ_DEV void generations_wave_body(const Params* __restrict__ pp, uint32_t g0, in
         }
         if (app) { next_app += p.thin; M += (uint32_t)p.N; }
     }
-    if (!MG && pub.PR) {   // crossover burn-in, blocks of 16 chains (one adaptation unit), k >= 3: the new state into the chain's (dead) row 1, its bins into that row's pad
+    if (NCH == 1 && !MG && pub.PR) {   // crossover burn-in, blocks of 16 chains (one adaptation unit), k >= 3: the new state into the chain's (dead) row 1, its bins into that row's pad
         int bc, bg;
         adapt_bins(p, g0, (int)gc, lane, bc, bg, probs, probs + p.ncr);
         double* sn = region + LDP;
@@ -1010,10 +1035,10 @@ DZ_DEV void generations_wave_body(const Params* __restrict__ pp, uint32_t g0, in
                         pub.PR + (size_t)unit * adapt_nq(p) * ld, pub.PC + (size_t)unit * (p.ncr + p.ngamma), (int)threadIdx.x, (int)blockDim.x);
     }
 }
-template <bool PB, bool MG = false>
+template <bool PB, bool MG = false, int NCH = 1>
 __global__ __launch_bounds__(1024) void k_generations_mix(const Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0, int64_t zappend, int seg0, Publish pub)
 {
-    generations_wave_body<PB, MG, MixLike>(pp, g0, ngen, M0, trace_slot0, zappend, seg0, pub);
+    generations_wave_body<PB, MG, MixLike, NCH>(pp, g0, ngen, M0, trace_slot0, zappend, seg0, pub);
 }
 #endif  // DZ_TEMPLATES_ONLY
 

@@ -124,6 +124,7 @@ __device__ __forceinline__ double dz_wave_sum(double v) { return dz::wave_bfly(v
 #include "dz_megakernel.h"
 namespace dz {
 struct UserLike {
+    template <int NCH>
     DZ_DEV static void eval(const Params& p, const double* rows, int LDP, int n, int lane, double* lh, double* out)
     {
         for (int i = 0; i < n; ++i) {
@@ -144,6 +145,17 @@ extern "C" __global__ __launch_bounds__(1024) void DZ_USER_CAT(dz_user_generatio
                                                                                                           int64_t zappend, int seg0, dz::Publish pub)
 {
     dz::generations_wave_body<true, false, dz::UserLike>(pp, g0, ngen, M0, trace_slot0, zappend, seg0, pub);
+}
+// ... and for 128 < d <= 256 (a lane owns four dimensions of the chain's state)
+extern "C" __global__ __launch_bounds__(1024) void DZ_USER_CAT(dz_user_generations_wide_v, DZ_USER_ABI)(const dz::Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0,
+                                                                                                          int64_t zappend, int seg0, dz::Publish pub)
+{
+    dz::generations_wave_body<false, false, dz::UserLike, 2>(pp, g0, ngen, M0, trace_slot0, zappend, seg0, pub);
+}
+extern "C" __global__ __launch_bounds__(1024) void DZ_USER_CAT(dz_user_generations_wide_full_v, DZ_USER_ABI)(const dz::Params* __restrict__ pp, uint32_t g0, int ngen, uint32_t M0, int64_t trace_slot0,
+                                                                                                               int64_t zappend, int seg0, dz::Publish pub)
+{
+    dz::generations_wave_body<true, false, dz::UserLike, 2>(pp, g0, ngen, M0, trace_slot0, zappend, seg0, pub);
 }
 extern "C" __global__ __launch_bounds__(256) void dz_user_batch(const double* X, long long n, int d, int ld, double* like, const void* data)
 {
@@ -179,7 +191,7 @@ class DeviceFunctionLogLike:
     csrc/dz_device.h (namespace dz) are in scope.  The source is compiled once (hipcc on first use, cached like compile_device_kernel's
     objects; the key includes the engine's own headers) into a code object with (a) a batch kernel for the engine's multi-kernel path and
     (b) the persistent kernels of csrc/dz_megakernel.h with this function in the place of the built-in mixture -- the same launches, the
-    same bits as (a), at the persistent kernels' rate instead of the multi-kernel path's.  They run where the mixture's would: d <= 128,
+    same bits as (a), at the persistent kernels' rate instead of the multi-kernel path's.  They run where the mixture's would: d <= 256,
     multitry 1 or 3..32 tries, and always_finite=True (a density that may be -inf for a whole proposal set needs the multi-kernel path's
     redraw rounds, Dream.py:281-289).  host: an optional Python twin f(x[d]) -> float for calls on the host (Model.total_logp)."""
 

@@ -641,6 +641,8 @@ def _user_fn_twin(c, w):
 
 
 @pytest.mark.parametrize("N,k,prior,lag,persistent,variant", [
+    (-600, 5, "flat", 0, "1", "k_generations_user<wide>"),                # (N < 0: at 200 dimensions) a lane owns four dimensions of the chain's state
+    (-512, 4, "normal", 2, "1", "k_generations_user<full,wide> +ring"),
     (1024, 5, "flat", 0, "1", "k_generations_user"),                      # the lean instantiation; the burn-in's unit sums by k_adapt_partials (blocks of 4 waves) ...
     (4096, 5, "flat", 0, "1", "k_generations_user"),                      # ... or by the kernel's blocks of 16 themselves
     (1000, 4, "normal", 3, "1", "k_generations_user<full> +ring"),        # priors: the full proposal code; adapt_lag: four burn-in generations per launch
@@ -657,7 +659,8 @@ def test_a_user_device_function_inside_the_persistent_kernel(N, k, prior, lag, p
     from pydream_amd.likelihoods import DeviceFunctionLogLike
     monkeypatch.setenv("DZ_MEGA_USER", persistent)
     monkeypatch.setenv("DREAMZS_KERNEL_CACHE", str(tmp_path))
-    d, n, seed = 100, 35, 9
+    d, n, seed = (200 if N < 0 else 100), 35, 9
+    N = abs(N)
     c = np.linspace(-2.0, 2.0, d); w = 0.5 + np.arange(d) % 7 / 7.0
     like = DeviceFunctionLogLike(USER_FN_SRC, "weighted_sq", d, data=np.concatenate([c, w]), always_finite=True, host=None)
     twin = _user_fn_twin(c, w)

@@ -559,11 +559,15 @@ def test_large_d_likelihood_kernels_against_oracle(G, O, N, d, tri, gemm, zero_m
     assert_traces_identical(out[0], out[1])
 
 
-@pytest.mark.parametrize("N,d,J,burnin,k", [(512, 100, 3, 0, 5), (70, 20, 2, 0, 5), (256, 100, 3, 15, 5), (512, 100, 3, 0, 1), (70, 20, 2, 12, 1), (64, 10, 2, 0, 3)])
+@pytest.mark.parametrize("N,d,J,burnin,k", [(512, 100, 3, 0, 5), (70, 20, 2, 0, 5), (256, 100, 3, 15, 5), (512, 100, 3, 0, 1), (70, 20, 2, 12, 1), (64, 10, 2, 0, 3),
+                                            (300, 200, 3, 0, 5), (130, 129, 2, 12, 4), (256, 256, 3, 0, 1), (200, 160, 2, -15, 5)])      # 128 < d <= 256 (round 6): <wide>; burnin < 0: with normal priors
 def test_persistent_mixture_kernel_equals_multi_kernel_path_and_oracle(G, O, N, d, J, burnin, k, monkeypatch):
     """k_generations_mix (mixture likelihood: every wave carries its chain on its own, no barriers) against the
     multi-kernel path and the oracle, bit for bit: across history appends, a ragged last block, and with a crossover
-    burn-in in front (configs[2] shape); multitry 5, 3 and off (one proposal per generation)."""
+    burn-in in front (configs[2] shape); multitry 5, 3 and off (one proposal per generation); up to 256 dimensions (a lane then owns four
+    dimensions of its chain's state: the <wide> instantiations)."""
+    priors = burnin < 0
+    burnin = abs(burnin)
     n, seed = 36, 41
     mu = np.array([np.full(d, m) for m in np.linspace(-5.0, 5.0, J)])
     logF = np.log(np.arange(1, J + 1) / np.arange(1, J + 1).sum()) - (d / 2.) * np.log(2 * np.pi)
@@ -573,6 +577,8 @@ def test_persistent_mixture_kernel_equals_multi_kernel_path_and_oracle(G, O, N, 
         monkeypatch.setenv("DZ_MEGA", "1" if mega else "0")
         e = Cls(nchains=N, ndim=d, multitry=k, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=seed,
                 adapt_crossover=1 if burnin else 0, crossover_burnin=burnin)
+        if priors:
+            e.set_prior(np.full(d, 1, np.int32), np.linspace(-1.0, 1.0, d), np.full(d, 15.0))
         e.set_history(Z0); e.set_state(Z0[:N]); e.set_likelihood_mixture(mu, logF)
         launches = None
         if Cls is G.Engine:
@@ -581,10 +587,11 @@ def test_persistent_mixture_kernel_equals_multi_kernel_path_and_oracle(G, O, N, 
         if Cls is G.Engine:
             launches = e.profile_get("generations")[1]
             e.profile_enable(False)
-        return e.get_trace(0, n), e.get_history(), e.get_cr_state()[0], launches
+        return e.get_trace(0, n), e.get_history(), e.get_cr_state()[0], launches, e.last_kernel_variant() if Cls is G.Engine else ""
 
     a, b, o = run(G.Engine, True), run(G.Engine, False), run(O.Engine, False)
     assert a[3] > 0 and b[3] == 0
+    assert a[4] == "k_generations_mix" + ("<full,wide>" if priors and d > 128 else "<wide>" if d > 128 else "<full>" if priors else "")
     for other in (b, o):
         assert_traces_identical(a[0], other[0])
         np.testing.assert_array_equal(a[1], other[1])
@@ -756,6 +763,7 @@ def test_crossover_burnin_at_4096_chains_against_oracle(G, O, variant, monkeypat
     ("mvn_k1", 4096, 9, 1, "1", "k_generations<7,tri,xlds,16,1,lean,k1> +ring"),     # multitry off (the reference's default)
     ("mvn_d200", 2048, 9, 1, "1", "k_generations_d2<13, +ring"),                # 128 < d <= 256
     ("mix_k1", 4096, 9, 1, "1", "k_generations_mix +ring"),                     # the mixture kernel without multi-try (blocks of 4 waves)
+    ("mix_d200", 1024, 9, 1, "1", "k_generations_mix<wide> +ring"),             # ... and at 128 < d <= 256
 ])
 def test_crossover_burnin_with_an_adapt_lag_against_oracle(G, O, target, N, lag, hlag, multi, variant, monkeypatch):
     """dz_config.adapt_lag = L (round 6): generation g of the burn-in decides with the probabilities as they were after the updates of

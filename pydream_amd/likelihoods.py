@@ -93,7 +93,11 @@ def compile_device_kernel(source, out_path=None, extra_flags=(), arch="gfx950"):
     with open(src, "w") as f:
         f.write(text)
     hipcc = next((c for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc") if c and os.path.exists(c)), "hipcc")
-    res = subprocess.run([hipcc] + flags + ["-o", tmp, src], capture_output=True, text=True)
+    try:
+        res = subprocess.run([hipcc] + flags + ["-o", tmp, src], capture_output=True, text=True)
+    except OSError as ex:          # (no compiler on this machine: say so -- a code object built elsewhere can be given by path)
+        os.remove(src)
+        raise Exception("hipcc failed for the device likelihood: cannot run %r (%s); set HIPCC, or build the code object where ROCm is installed and pass its path" % (hipcc, ex))
     try:
         os.remove(src) if cached else os.replace(src, out_path + ".hip")
     except OSError:

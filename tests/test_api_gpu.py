@@ -717,3 +717,32 @@ def test_run_dream_with_a_user_device_function_equals_its_python_twin(tmp_path):
     np.testing.assert_allclose(np.array(l_dev), np.array(l_host), rtol=0, atol=1e-10)
     assert variant.startswith("k_generations_user<full>"), variant          # (SampledParam priors: the full proposal code)
     assert like(np.zeros(d)) == twin(np.zeros(d))[1][0]                       # the host twin answers a host call
+
+
+def test_the_banana_example_as_a_device_function():
+    """pydream_amd/examples/banana: the same density as a wave-level device function (FUNCTION_SOURCE) -- the device evaluates it to the bits of its
+    Python twin, and a run with it goes through the persistent kernel and equals the ORACLE's run with the twin as a host callback."""
+    from oracle import oracle as O
+    from pydream_amd import _capi as G
+    from pydream_amd.examples.banana import banana_device as B
+    d, N, n = 12, 256, 30
+    like = B.make_function_likelihood(d)
+    X = np.random.default_rng(1).normal(scale=4.0, size=(50, d))
+    e = G.Engine(nchains=3, ndim=d, history_capacity=8)
+    like._dz_apply(e)
+    np.testing.assert_array_equal(e.eval_logp(X)[1], np.array([B.banana_host_wave(x) for x in X]))
+    Z0 = np.random.default_rng(2).uniform(-8, 8, (10 * d + 2 * N, d))
+    out = []
+    for Cls in (G.Engine, O.Engine):
+        e = Cls(nchains=N, ndim=d, multitry=5, history_capacity=len(Z0) + N * (n // 10 + 2), trace_capacity=n, seed=3, adapt_crossover=1, crossover_burnin=10)
+        e.set_history(Z0); e.set_state(Z0[:N])
+        if Cls is G.Engine:
+            like._dz_apply(e)
+        else:
+            e.set_likelihood_host(lambda Xb: (np.zeros(len(Xb)), np.array([B.banana_host_wave(x) for x in Xb])))
+        e.step(n)
+        out.append((e.get_trace(0, n), e.get_history(), e.last_kernel_variant() if Cls is G.Engine else ""))
+    for key in ("snooker", "cr_idx", "try_idx", "moved", "X", "logp"):
+        np.testing.assert_array_equal(out[0][0][key], out[1][0][key], err_msg=key)
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    assert out[0][2] == "k_generations_user"

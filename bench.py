@@ -305,8 +305,9 @@ def parse_args(argv=None):
         args.appends_per_launch = max(1, (args.history_lag + 1) // 2)
     # (the engine's cap on history appends per launch -- one GPU alone could hold history_lag + 1: the same launches at every N)
     os.environ["DZ_MEGA_SEGS"] = str(args.appends_per_launch)
-    if args.adapt_lag is None:      # as many burn-in generations per launch as the launches behind the burn-in hold generations -- on one GPU: sharded engines
-        args.adapt_lag = max(0, args.appends_per_launch * args.thin - 1) if args.gpus == 1 else 0      # run one burn-in generation per launch at any lag
+    if args.adapt_lag is None:      # as many burn-in generations per launch as the launches behind the burn-in hold generations -- at every N whose ranks own whole
+        # groups of 256 chains (their groups' sums of a whole launch travel in one exchange); other shards run one burn-in generation per launch at any lag
+        args.adapt_lag = max(0, args.appends_per_launch * args.thin - 1) if (args.gpus == 1 or args.chains_per_gpu % 256 == 0) else 0
     return args
 
 

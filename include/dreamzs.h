@@ -59,8 +59,9 @@ typedef struct dz_config {
                                * scheduler-dependent delay (Dream.py:371-378 under core.py:80); a fixed L lets one launch of the
                                * persistent kernels hold L + 1 burn-in generations instead of one -- on one
                                * GPU, every configuration the persistent kernels run (mixture or MVN likelihood, d <= 256; burn-in 1.3x to
-                               * 2.4x faster at L = 19).  The multi-kernel path (d > 256, host likelihoods) and sharded runs
-                               * keep one generation per launch under the same schedule (no gain, 6-12 % slower: leave it 0) */
+                               * 2.4x faster at L = 19).  Several GPUs: ranks that own whole groups of 256 chains do the same (their
+                               * groups' sums of a whole launch travel in one exchange).  The multi-kernel path (d > 256, host likelihoods) and
+                               * other shards keep one generation per launch under the same schedule (no gain, 6-12 % slower: leave it 0) */
     int32_t reserved0;        /* must be 0 (keeps the 64-bit fields aligned)                   */
     int64_t history_capacity; /* rows the Z archive can hold (core.py:260-268)                 */
     int64_t trace_capacity;   /* generations the device trace buffer holds (0 = no trace)      */

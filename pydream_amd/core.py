@@ -32,8 +32,8 @@ def run_dream(parameters, likelihood, nchains=5, niterations=50000, start=None, 
         longer kernel launches, a few percent faster with a device likelihood; see include/dreamzs.h dz_config.history_lag),
         ``adapt_lag`` (int, default 0: every generation of the crossover burn-in decides with the probabilities all earlier generations'
         updates left -- the reference in lockstep; L >= 1: with those of generations <= g - 1 - L, which lets one kernel launch hold
-        L + 1 burn-in generations -- the burn-in then runs nearly as fast as the rest of the run; pays on one GPU wherever the
-        persistent kernels run (device likelihoods, d <= 256), no gain elsewhere; dz_config.adapt_lag).
+        L + 1 burn-in generations -- the burn-in then runs nearly as fast as the rest of the run; pays wherever the persistent kernels
+        run (device likelihoods, d <= 256; sharded: ranks of whole groups of 256 chains), no gain elsewhere; dz_config.adapt_lag).
 
     Returns
     -------

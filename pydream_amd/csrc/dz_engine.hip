@@ -173,7 +173,7 @@ struct dz_engine {
     // k_group_totals) instead of its positions.  d_GS[parity of the generation]: [world][gs_rec] records (two buffers: a peer may be one
     // generation ahead); d_shift[parity]: global chain 0's position after that generation (the shift of the next one's column sums)
     bool adapt_groups = false; double* d_GS[2] = {nullptr, nullptr}; double* d_shift[2] = {nullptr, nullptr}; size_t gs_rec = 0; int gs_nbp = 0;
-    int64_t gs_pushed = 0, gs_last_gen = -1;
+    int64_t gs_pushed = 0, gs_last_gen = -1, gs_launches = 0;
     int64_t bytes_z = 0, bytes_pos = 0, bytes_sums = 0;      // bytes this rank has sent to EACH other rank, by kind (dz_exchange_bytes)
     dz::Params* d_params = nullptr;  // device copy of `p` for kernels that take it by pointer
     double *d_scratch = nullptr; size_t scratch_rows = 0;   // debug / eval staging [rows, ld]
@@ -467,13 +467,14 @@ double gate_timeout_s()
 // peer transport: this rank's rows of `buf` (global layout [N,ld], rows [off, off+nl) at `row0`) go to every peer's copy of the
 // buffer, each followed by this rank's flag word for exchange number `seq` of that kind
 // (XK_SUMS: `buf` = d_GS[which_cp], this rank's record of gs_rec doubles at rank * gs_rec)
-int peer_push(dz_engine* e, int kind, double* buf, int which_cp, size_t row0, unsigned long long seq)
+int peer_push(dz_engine* e, int kind, double* buf, int which_cp, size_t row0, unsigned long long seq, size_t sums_cnt = 0)
 {
     if ((int64_t)seq >= e->seq_cap) return fail("peer exchange: sequence capacity exceeded");
     hipEvent_t ev = e->push_ev[e->push_n++ & 7];
     HIPCK(hipEventRecord(ev, e->stream));
-    const size_t first = kind == XK_SUMS ? (size_t)e->rank * e->gs_rec : (row0 + (size_t)e->p.off) * e->p.ld;
-    const size_t cnt = kind == XK_SUMS ? e->gs_rec : (size_t)e->p.nl * e->p.ld;
+    const size_t srec = sums_cnt ? sums_cnt : e->gs_rec;      // (a launch of several burn-in generations: that many records per rank, back to back)
+    const size_t first = kind == XK_SUMS ? (size_t)e->rank * srec : (row0 + (size_t)e->p.off) * e->p.ld;
+    const size_t cnt = kind == XK_SUMS ? srec : (size_t)e->p.nl * e->p.ld;
     for (int r = 0; r < e->world; ++r) {
         if (r == e->rank) continue;
         dz_engine::Peer& pr = e->peers[r];
@@ -521,18 +522,19 @@ int ensure_visible(dz_engine* e, int ahead = 0)
 //   peer: pushed by the copy engines into the peers' mapped buffers -- history appends are waited for only when their rows become
 //   sampleable (ensure_visible: with history_lag >= 1 a whole thin-cycle later), published positions at once.
 // XK_SUMS (sharded crossover burn-in): buf = d_GS[which], [world][gs_rec]; this rank's record is replicated, waited for at once.
-int exchange_rows(dz_engine* e, int kind, double* buf, size_t row0, int which = 0)
+int exchange_rows(dz_engine* e, int kind, double* buf, size_t row0, int which = 0, size_t sums_cnt = 0)
 {
     if (!e->comm && !e->peer_on && e->p.nl == e->p.N) return 0;     // single GPU, no communicator: the kernels wrote the rows in place
     ProfScope ps(e, PR_EXCHANGE);
-    const size_t cnt = kind == XK_SUMS ? e->gs_rec : (size_t)e->p.nl * e->p.ld;
+    const size_t srec = sums_cnt ? sums_cnt : e->gs_rec;      // (XK_SUMS: doubles per rank -- one record, or the records of a launch's generations back to back)
+    const size_t cnt = kind == XK_SUMS ? srec : (size_t)e->p.nl * e->p.ld;
     double* base = kind == XK_SUMS ? buf : buf + row0 * e->p.ld;
-    double* mine = kind == XK_SUMS ? buf + (size_t)e->rank * e->gs_rec : base + (size_t)e->p.off * e->p.ld;
+    double* mine = kind == XK_SUMS ? buf + (size_t)e->rank * srec : base + (size_t)e->p.off * e->p.ld;
     (kind == XK_Z ? e->bytes_z : kind == XK_SUMS ? e->bytes_sums : e->bytes_pos) += (int64_t)(sizeof(double) * cnt);
     if (e->peer_on) {
         if (kind == XK_Z) { DZCK(peer_push(e, XK_Z, buf, 0, row0, (unsigned long long)(e->z_pushed + 1))); e->z_pushed++; return 0; }
         if (kind == XK_SUMS) {
-            DZCK(peer_push(e, XK_SUMS, buf, which, 0, (unsigned long long)(e->gs_pushed + 1))); e->gs_pushed++;
+            DZCK(peer_push(e, XK_SUMS, buf, which, 0, (unsigned long long)(e->gs_pushed + 1), srec)); e->gs_pushed++;
             return peer_gate(e, XK_SUMS, (unsigned long long)e->gs_pushed);
         }
         DZCK(peer_push(e, XK_POS, buf, e->cp_idx, row0, (unsigned long long)(e->pos_pushed + 1))); e->pos_pushed++;
@@ -621,6 +623,26 @@ const double* adapt_shift(const dz_engine* e, uint32_t g)
     }
     return (e->adapt_groups && g > 0) ? e->d_shift[(g - 1u) & 1u] : e->p.cp_prev;
 }
+// Sharded (whole groups per rank), adapt_lag >= 1, a launch of n burn-in generations g .. g + n - 1 whose units' sums (this rank's units) sit in the
+// rings' slots: every generation's group sums into one record each, the n records of every rank everywhere in ONE exchange, then the totals of
+// every generation (the same additions in the same order as adapt_generation makes them one generation at a time) and their dot products.
+// Buffers by the parity of the LAUNCH (a peer may be one launch ahead); rank r's records of this launch at r * n * gs_rec.
+int adapt_finish_groups(dz_engine* e, uint32_t g, int n)
+{
+    const dz::Params& p = e->p;
+    const int units_l = p.nl / 16, gl = p.nl / 256, nq = 2 + p.ncr + p.ngamma, nb = p.ncr + p.ngamma, nbp = e->gs_nbp, R1 = e->ad_R1;
+    const int par = (int)(e->gs_launches++ & 1);
+    const size_t rstride = (size_t)n * e->gs_rec;
+    hipLaunchKernelGGL(dz::k_adapt_groups, dim3((gl * nq * p.d + gl * nbp + p.ld + 255) / 256, n), dim3(256), 0, e->stream, (const double*)e->d_PR, (const double*)e->d_PC, units_l, nq, p.d, p.ld, nb, nbp,
+                       (const double*)e->d_x0ring, e->d_GS[par] + (size_t)e->rank * rstride, (long long)g, R1, (long long)e->ad_pr_stride, (long long)e->ad_pc_stride, (long long)e->gs_rec, 2 * R1);
+    DZCK(launch_check("k_adapt_groups"));
+    DZCK(exchange_rows(e, XK_SUMS, e->d_GS[par], 0, par, rstride));
+    hipLaunchKernelGGL(dz::k_group_totals, dim3((nq * p.d + nb + p.ld + 255) / 256, n), dim3(256), 0, e->stream, (const double*)e->d_GS[par], e->world, rstride, gl, nq, p.d, p.ld, nb, nbp,
+                       e->d_TOT, e->d_CNT, e->d_x0ring, (long long)g, R1, (long long)e->gs_rec, (long long)e->ad_tot_stride, (long long)e->ad_nbp, 2 * R1);
+    DZCK(launch_check("k_group_totals"));
+    e->gs_last_gen = (int64_t)g + n - 1;
+    return adapt_dots(e, g, n);
+}
 // fused = the generation's persistent launch has already left its units' sums in d_PR / d_PC (adapt_unit_sums in its epilogue)
 int adapt_generation(dz_engine* e, uint32_t g, int gc0, int ngc, bool fused = false, bool defer = false)
 {
@@ -643,11 +665,11 @@ int adapt_generation(dz_engine* e, uint32_t g, int gc0, int ngc, bool fused = fa
             DZCK(launch_check("k_adapt_partials"));
         }
         hipLaunchKernelGGL(dz::k_adapt_groups, dim3((gl * nq * p.d + gl * nbp + p.ld + 255) / 256), dim3(256), 0, e->stream, (const double*)e->d_PR, (const double*)e->d_PC, units_l, nq, p.d, p.ld, nb, nbp,
-                           (const double*)(p.cp_new + (size_t)p.off * p.ld), e->d_GS[par] + (size_t)e->rank * e->gs_rec);
+                           (const double*)(p.cp_new + (size_t)p.off * p.ld), e->d_GS[par] + (size_t)e->rank * e->gs_rec, 0ll, 1, 0ll, 0ll, 0ll, 0);
         DZCK(launch_check("k_adapt_groups"));
         DZCK(exchange_rows(e, XK_SUMS, e->d_GS[par], 0, par));
         hipLaunchKernelGGL(dz::k_group_totals, dim3((nq * p.d + nb + p.ld + 255) / 256), dim3(256), 0, e->stream, (const double*)e->d_GS[par], e->world, e->gs_rec, gl, nq, p.d, p.ld, nb, nbp,
-                           e->d_TOT + (size_t)slot * e->ad_tot_stride, e->d_CNT + (size_t)slot * e->ad_nbp, ring ? x0_out : e->d_shift[par]);
+                           e->d_TOT + (size_t)slot * e->ad_tot_stride, e->d_CNT + (size_t)slot * e->ad_nbp, ring ? x0_out : e->d_shift[par], 0ll, 1, 0ll, 0ll, 0ll, 0);
         DZCK(launch_check("k_group_totals"));
         e->gs_last_gen = (int64_t)g;
         if (ring) return adapt_dots(e, g, 1);
@@ -1160,7 +1182,7 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
     if (rmulti) {      // the ring of published positions; the positions before this launch's first generation are the chains' states now
         if (!e->d_posring) { DZCK(ealloc(e, &e->d_posring, (size_t)RP * pos_stride)); DZCK(ealloc(e, &e->d_PG, (size_t)e->ad_R1 * e->ad_nbp)); }
         if (e->posring_gen != (int64_t)g - 1)
-            HIPCK(hipMemcpyAsync(e->d_posring + (size_t)(((int64_t)g - 1 + RP) % RP) * pos_stride, p.X, sizeof(double) * pos_stride, hipMemcpyDeviceToDevice, e->stream));
+            HIPCK(hipMemcpyAsync(e->d_posring + (size_t)(((int64_t)g - 1 + RP) % RP) * pos_stride + (size_t)p.off * p.ld, p.X, sizeof(double) * (size_t)p.nl * p.ld, hipMemcpyDeviceToDevice, e->stream));
     }
     const int64_t slot0 = e->c.trace_capacity ? e->ntrace : -1;
     dz::Publish pub; pub.to = publish ? p.cp_new : nullptr; pub.shift = nullptr; pub.PR = nullptr; pub.PC = nullptr;
@@ -1186,13 +1208,14 @@ int run_mega_segment(dz_engine* e, uint32_t g, int n, bool mega_follows)
     bool fused = false;
     auto fuse_adapt = [&]() { fused = true; pub.shift = adapt_shift(e, g); pub.PR = e->d_PR; pub.PC = e->d_PC; };
     auto after_launch = [&]() -> int {      // end of the generation(s): positions -> adaptation -> history append (schedule S2)
-        if (multi) { ProfScope ps(e, PR_ADAPT); DZCK(adapt_finish(e, false, g, n, true)); }      // the totals and dot products of the launch's n generations (one GPU: nothing to exchange)
+        const bool sharded = e->world > 1;      // (then the ranks own whole groups: their groups' sums travel, one exchange per launch -- adapt_finish_groups)
+        if (multi) { ProfScope ps(e, PR_ADAPT); DZCK(sharded ? adapt_finish_groups(e, g, n) : adapt_finish(e, false, g, n, true)); }      // the totals and dot products of the launch's n generations
         else if (rmulti) {
             ProfScope ps(e, PR_ADAPT);
-            hipLaunchKernelGGL(dz::k_adapt_partials_ring, dim3((p.N + 15) / 16, n), dim3(1024), 0, e->stream, p, g, e->ad_R1, (const double*)e->d_posring, (long long)pos_stride,
-                               (const double*)e->d_PG, e->ad_nbp, e->d_PR, e->d_PC, (long long)e->ad_pr_stride, (long long)e->ad_pc_stride, e->d_x0ring, (const double*)e->d_x0start);
+            hipLaunchKernelGGL(dz::k_adapt_partials_ring, dim3(sharded ? p.nl / 16 : (p.N + 15) / 16, n), dim3(1024), 0, e->stream, p, g, e->ad_R1, (const double*)e->d_posring, (long long)pos_stride,
+                               (const double*)e->d_PG, e->ad_nbp, e->d_PR, e->d_PC, (long long)e->ad_pr_stride, (long long)e->ad_pc_stride, e->d_x0ring, (const double*)e->d_x0start, p.off / 16);
             DZCK(launch_check("k_adapt_partials_ring"));
-            DZCK(adapt_finish(e, false, g, n, true));
+            DZCK(sharded ? adapt_finish_groups(e, g, n) : adapt_finish(e, false, g, n, true));
             e->posring_gen = (int64_t)g + n - 1;
             p.cp_new = e->d_posring + (size_t)(e->posring_gen % RP) * pos_stride;      // (what a later launch that is not of this kind measures its jumps from)
         }
@@ -1473,7 +1496,11 @@ int dz_create(const dz_config* cfg, dz_engine** out)
         const size_t nq = 2 + (size_t)cfg->ncr + cfg->ngamma, units = (N + 15) / 16;
         // adapt_lag = L >= 1: rings of L + 1 generations (engine fields ad_*); several burn-in generations per launch on one GPU (ad_multi)
         e->ad_R1 = cfg->adapt_lag + 1; e->ad_nbp = (cfg->ncr + cfg->ngamma + 1) & ~1;
-        e->ad_multi = cfg->adapt_lag > 0 && e->world == 1 && !(getenv("DZ_ADAPT_MULTI") && atoi(getenv("DZ_ADAPT_MULTI")) == 0);
+        // sharded, and this rank owns whole groups of 256 chains (then every rank does: equal shards): the burn-in exchanges group sums
+        const bool groups_on = !(getenv("DZ_ADAPT_GROUPS") && atoi(getenv("DZ_ADAPT_GROUPS")) == 0);
+        const bool groups = e->world > 1 && groups_on && p.off % 256 == 0 && p.nl % 256 == 0;
+        // (several GPUs: only ranks that exchange group sums -- the records of a launch's generations travel in one exchange, adapt_finish_groups)
+        e->ad_multi = cfg->adapt_lag > 0 && (e->world == 1 || groups) && !(getenv("DZ_ADAPT_MULTI") && atoi(getenv("DZ_ADAPT_MULTI")) == 0);
         e->ad_tot_stride = cfg->adapt_lag > 0 ? nq * ld : 0;
         e->ad_pr_stride = units * nq * ld; e->ad_pc_stride = units * (size_t)(cfg->ncr + cfg->ngamma);
         const size_t prs = e->ad_multi ? (size_t)e->ad_R1 : 1;
@@ -1483,13 +1510,12 @@ int dz_create(const dz_config* cfg, dz_engine** out)
             rc |= ealloc(e, &e->d_DOT, (size_t)e->ad_R1 * e->ad_nbp);
             rc |= ealloc(e, &e->d_x0ring, (size_t)2 * e->ad_R1 * ld); rc |= ealloc(e, &e->d_x0start, ld);
         }
-        // sharded, and this rank owns whole groups of 256 chains (then every rank does: equal shards): the burn-in exchanges group sums
-        const bool groups_on = !(getenv("DZ_ADAPT_GROUPS") && atoi(getenv("DZ_ADAPT_GROUPS")) == 0);
-        if (e->world > 1 && groups_on && p.off % 256 == 0 && p.nl % 256 == 0) {
+        if (groups) {
             e->adapt_groups = true;
             e->gs_nbp = (cfg->ncr + cfg->ngamma + 15) / 16 * 16;
             e->gs_rec = (size_t)(p.nl / 256) * (nq * ld + (size_t)e->gs_nbp) + ld;
-            for (int i = 0; i < 2; ++i) { rc |= ealloc(e, &e->d_GS[i], (size_t)e->world * e->gs_rec); rc |= ealloc(e, &e->d_shift[i], ld); }
+            // (adapt_lag = L >= 1: room for the records of a launch of L + 1 generations from every rank)
+            for (int i = 0; i < 2; ++i) { rc |= ealloc(e, &e->d_GS[i], (size_t)e->world * e->gs_rec * (e->ad_multi ? (size_t)e->ad_R1 : 1)); rc |= ealloc(e, &e->d_shift[i], ld); }
         }
     }
     if (tc) {

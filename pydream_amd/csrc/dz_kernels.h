@@ -2248,10 +2248,11 @@ __global__ __launch_bounds__(1024) void k_adapt_partials(Params p, uint32_t g, d
 // position in x0ring (slot g mod 2 R1: no generation of this launch reads a slot this launch writes).
 __global__ __launch_bounds__(1024) void k_adapt_partials_ring(Params p, uint32_t g0, int R1, const double* __restrict__ pos, long long pos_stride, const double* __restrict__ PG, int nbp,
                                                               double* __restrict__ PR, double* __restrict__ PC, long long pr_stride, long long pc_stride,
-                                                              double* __restrict__ x0ring, const double* __restrict__ x0start)
+                                                              double* __restrict__ x0ring, const double* __restrict__ x0start, int unit0 = 0)
 {
+    // (unit0: sharded -- this rank's first GLOBAL unit; its units' sums go to rows 0 .. of the ring slot, as k_adapt_partials leaves them)
     __shared__ int s_bc[16], s_bg[16];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, unit = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, unit = unit0 + blockIdx.x;
     const uint32_t g = g0 + blockIdx.y;
     const int R = R1 + 1;
     const int gcn = 16 * unit + wv;
@@ -2267,7 +2268,7 @@ __global__ __launch_bounds__(1024) void k_adapt_partials_ring(Params p, uint32_t
     const double* shift = hs < 0 ? x0start : x0ring + (size_t)(hs % (2 * R1)) * p.ld;
     const int slot = (int)(g % (uint32_t)R1);
     adapt_unit_sums(p, xn, p.ld, xp, p.ld, nc, [&](bool isg, int c) { return isg ? s_bg[c] : s_bc[c]; }, shift,
-                    PR + (size_t)slot * pr_stride + (size_t)unit * nq * p.ld, PC + (size_t)slot * pc_stride + (size_t)unit * (p.ncr + p.ngamma), threadIdx.x, 1024);
+                    PR + (size_t)slot * pr_stride + (size_t)blockIdx.x * nq * p.ld, PC + (size_t)slot * pc_stride + (size_t)blockIdx.x * (p.ncr + p.ngamma), threadIdx.x, 1024);
     if (unit == 0)
         for (int j = threadIdx.x; j < p.ld; j += 1024) x0ring[(size_t)(g % (uint32_t)(2 * R1)) * p.ld + j] = xn[j];
 }
@@ -2282,9 +2283,18 @@ __global__ __launch_bounds__(1024) void k_adapt_partials_ring(Params p, uint32_t
 // A rank's record (rec doubles): [groups][nq][ld] sums | [groups][nbp] bin counts (nbp = nb rounded up to 16) | [ld] the new position of
 // the rank's first chain (rank 0's is global chain 0's: the shift of the NEXT generation's column sums).
 // thread (group, column): the group's units in order from 0.0
+// (adapt_lag >= 1, a sharded launch of several burn-in generations: grid.y = the launch's generations g0 .. -- generation g0 + i reads the units' sums
+//  of ring slot (g0 + i) mod R1 (strides pr_stride / pc_stride), takes x0 from slot (g0 + i) mod x0_R of the ring `x0` (x0_R = 0: `x0` is the row) and
+//  writes record i of this rank, rec + i rec_stride)
 __global__ __launch_bounds__(256) void k_adapt_groups(const double* __restrict__ PR, const double* __restrict__ PC, int nunits, int nq, int d, int ld, int nb, int nbp,
-                                                      const double* __restrict__ x0, double* __restrict__ rec)
+                                                      const double* __restrict__ x0, double* __restrict__ rec,
+                                                      long long g0 = 0, int R1 = 1, long long pr_stride = 0, long long pc_stride = 0, long long rec_stride = 0, int x0_R = 0)
 {
+    {
+        const long long g = g0 + blockIdx.y;
+        PR += (size_t)(g % R1) * pr_stride; PC += (size_t)(g % R1) * pc_stride; rec += (size_t)blockIdx.y * rec_stride;
+        if (x0_R) x0 += (size_t)(g % x0_R) * ld;
+    }
     const int ngroups = (nunits + 15) / 16, ncol = nq * d;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const size_t ustride = (size_t)nq * ld;
@@ -2314,9 +2324,17 @@ __global__ __launch_bounds__(256) void k_adapt_groups(const double* __restrict__
 }
 // ... and every rank's totals from all ranks' records: thread column adds the groups in global order (rank by rank) from 0.0 -- k_adapt_totals'
 // last stage --; the counts; the next generation's shift (rank 0's first chain)
+// (grid.y = the launch's generations: generation g0 + i reads record i of every rank -- GS + i gen_stride, the ranks `rec` apart -- and writes the totals'
+//  ring slot (g0 + i) mod R1 and chain 0's position into slot (g0 + i) mod x0_R of the ring `shift_out`; x0_R = 0: the pointers as they are)
 __global__ __launch_bounds__(256) void k_group_totals(const double* __restrict__ GS, int world, size_t rec, int gl, int nq, int d, int ld, int nb, int nbp,
-                                                      double* __restrict__ TOT, double* __restrict__ CNT, double* __restrict__ shift_out)
+                                                      double* __restrict__ TOT, double* __restrict__ CNT, double* __restrict__ shift_out,
+                                                      long long g0 = 0, int R1 = 1, long long gen_stride = 0, long long tot_stride = 0, long long cnt_stride = 0, int x0_R = 0)
 {
+    {
+        const long long g = g0 + blockIdx.y;
+        GS += (size_t)blockIdx.y * gen_stride; TOT += (size_t)(g % R1) * tot_stride; CNT += (size_t)(g % R1) * cnt_stride;
+        if (x0_R) shift_out += (size_t)(g % x0_R) * ld;
+    }
     const int ncol = nq * d;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const size_t ustride = (size_t)nq * ld;

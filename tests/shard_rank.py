@@ -28,8 +28,9 @@ CONFIGS = {   # (chains, d, mvn kind)
     "a512": (512, 100, "tri"), "a1k": (1024, 100, "tri"), "a2k": (2048, 100, "tri"), "a2k_mix": (2048, 100, "mix"), "a512_k1": (512, 100, "tri"),
     "a768": (768, 100, "tri"),        # 2 ranks x 384 chains: NOT whole groups -- the positions travel (the round-4 path)
     "a2k_d200": (2048, 200, "tri"),   # the multi-kernel path's generations (d > 128) with the group exchange
+    "a8k": (8192, 100, "tri"),        # 2 ranks x 4096 chains: blocks of 16 chains (with an adapt_lag: the kernels' own unit sums, several generations per launch)
 }
-ADAPT = {"a512": 5, "a1k": 5, "a2k": 5, "a2k_mix": 5, "a512_k1": 1, "a768": 5, "a2k_d200": 5}       # config -> multitry
+ADAPT = {"a512": 5, "a1k": 5, "a2k": 5, "a2k_mix": 5, "a512_k1": 1, "a768": 5, "a2k_d200": 5, "a8k": 5}       # config -> multitry
 BURNIN = 24
 SEED, K, THIN = 20260930, 5, 10
 
@@ -52,7 +53,7 @@ def build(config, rank, world, generations, lag, device=0, M=None, engine_cls=No
     nl = N // world
     m0 = max(10 * d, 2 * N)                                  # Dream.py:168-170, core.py:270-273
     Z0 = np.random.default_rng(SEED).uniform(-5.0, 15.0, (m0, d))
-    extra = dict(adapt_crossover=1, crossover_burnin=BURNIN) if config in ADAPT else {}
+    extra = dict(adapt_crossover=1, crossover_burnin=BURNIN, adapt_lag=int(os.environ.get("DZ_TEST_ADAPT_LAG", "0"))) if config in ADAPT else {}
     e = engine_cls(nchains=N, nchains_local=nl, chain_offset=rank * nl, ndim=d, multitry=ADAPT.get(config, K), history_thin=THIN,
                    history_capacity=m0 + N * (generations // THIN + 2), trace_capacity=generations, seed=SEED, device=device,
                    history_lag=lag, **extra)

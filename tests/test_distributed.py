@@ -373,6 +373,63 @@ def test_sharded_crossover_burnin_exchanges_group_sums(tmp_path, config, world, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("config,world,transport,lag,alag,against,kind", [
+    ("a512", 2, "peer", 1, 3, "oracle", "ring"),        # 256 chains per rank (blocks of 4 chains x 4 waves): every generation's positions into the ring, the unit sums behind the launch
+    ("a2k", 2, "peer", 1, 9, "oracle", "ring"),         # 1024 chains per rank, ten generations per launch
+    ("a2k_mix", 2, "host", 0, 5, "engine", "multi"),    # the mixture kernel's blocks of 16 make their unit sums themselves; host transport
+    ("a2k", 8, "peer", 3, 19, "engine", "ring"),        # eight ranks, twenty generations per launch where the history appends allow
+    ("a8k", 2, "peer", 3, 19, "engine", "multi"),       # 4096 chains per rank: k_generations<..,multi>
+    ("a768", 2, "peer", 1, 3, "oracle", "single"),      # not whole groups: the positions travel, one burn-in generation per launch
+])
+def test_sharded_crossover_burnin_with_an_adapt_lag(tmp_path, monkeypatch, config, world, transport, lag, alag, against, kind):
+    """dz_config.adapt_lag on several GPUs (round 6): ranks that own whole groups of 256 chains run up to adapt_lag + 1 burn-in generations per launch
+    like one GPU does -- the group sums of ALL the launch's generations travel in one exchange (adapt_finish_groups), every rank forms every
+    generation's totals from all ranks' records in order and applies them when they are due.  Every rank's states, log densities, decisions,
+    adapted probabilities and accumulators equal the oracle's (or the unsharded engine's) bit for bit, all archive replicas are identical, and
+    the burn-in took fewer launches than generations."""
+    from tests import shard_rank as SR
+    G = 47
+    monkeypatch.setenv("DZ_TEST_ADAPT_LAG", str(alag))
+    renv = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DZ_PEER_TIMEOUT_S="200", DZ_SHARD_DEVICE="0", DZ_TEST_ADAPT_LAG=str(alag))
+    M = SR.matrix(config)
+    np.save(tmp_path / "matrix.npy", M)
+    _launch_ranks([os.path.join(ROOT, "tests", "shard_rank.py"), config, str(tmp_path), transport, str(lag), str(G)], world, renv, str(tmp_path), timeout=300)
+    N, d, _ = SR.CONFIGS[config]
+    if against == "oracle":
+        from oracle import oracle as O
+        o = SR.build(config, 0, 1, G, lag, M=M, engine_cls=O.Engine)
+        o.step(G)
+        X, pr, lk = o.get_state()
+        tr = o.get_trace(0, G)
+        ref = dict(X=X, prior=pr, like=lk, logp=tr["logp"], moved=tr["moved"], try_idx=tr["try_idx"], cr_idx=tr["cr_idx"], snooker=tr["snooker"], Z=o.get_history())
+        ref["cr_probs"], ref["cr_delta"], ref["cr_n"] = o.get_cr_state()
+    else:
+        e = SR.build(config, 0, 1, G, lag, M=M)
+        e.step(G)
+        ref = SR.results(e, G, with_history=True)
+        e.close()
+    assert not np.allclose(ref["cr_probs"], 1 / 3.) and ref["cr_n"].sum() > N
+    nl = N // world
+    sums0 = None
+    for r in range(world):
+        got = np.load(tmp_path / ("rank%d.npz" % r))
+        sl = slice(r * nl, (r + 1) * nl)
+        for key in ("X", "prior", "like"):
+            np.testing.assert_array_equal(got[key], ref[key][sl], err_msg="%s of rank %d" % (key, r))
+        for key in ("logp", "moved", "try_idx", "cr_idx", "snooker"):
+            np.testing.assert_array_equal(got[key], ref[key][:, sl], err_msg="%s of rank %d" % (key, r))
+        for key in ("cr_probs", "cr_delta", "cr_n"):
+            np.testing.assert_array_equal(got[key], ref[key], err_msg="%s of rank %d" % (key, r))
+        if r == 0:
+            np.testing.assert_array_equal(got["Z"], ref["Z"])
+            sums0 = (int(got["checksum"][0]), int(got["rows"][0]))
+        assert (int(got["checksum"][0]), int(got["rows"][0])) == sums0, "archive replica of rank %d" % r
+        launches = int(got["launches"][0])
+        if kind == "single":
+            assert launches >= SR.BURNIN + 1, launches                 # one launch per burn-in generation (0 .. 24) and the thin-cycles behind
+        else:
+            assert launches <= (SR.BURNIN + 1) // 2 + 6, (launches, kind)      # several burn-in generations per launch
+@pytest.mark.gpu
 def test_history_checksum_is_the_documented_sum_and_sees_a_single_changed_element():
     from pydream_amd import _capi
     from tests import helpers as H

@@ -644,7 +644,7 @@ def test_bench_default_line_carries_every_single_gpu_baseline_config(tmp_path):
 def test_bench_two_ranks_with_crossover_adaptation_exchange_group_sums(tmp_path):
     """`bench.py --gpus 2 --adapt` (two ranks sharing device 0, 512 chains each = two whole groups per rank): `burnin_value` is reported,
     the ranks' replicas and adapted probabilities agree, and what travels per burn-in generation is the groups' sums -- under 100 KB per
-    rank -- while the positions travel once."""
+    rank, those of a whole launch of generations in one exchange (bench.py's adapt_lag) -- while the positions travel once."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
@@ -655,7 +655,8 @@ def test_bench_two_ranks_with_crossover_adaptation_exchange_group_sums(tmp_path)
     assert res.returncode == 0, res.stderr[-3000:]
     d = json.loads([l for l in res.stdout.splitlines() if l.startswith('{"metric"')][0])
     assert d["n_gpus"] == 2 and d["transport"] == "peer" and d["replicas_identical"] is True
-    assert d["burnin_value"] > 0 and d["burnin"]["kernel_variant"] == "k_generations_w4<7,tri,xlds,4,4,lean,ahead>"
+    # ranks of whole groups of 256 chains: the same adapt_lag as on one GPU (twenty burn-in generations per launch, their group sums in one exchange)
+    assert d["burnin_value"] > 0 and d["burnin"]["kernel_variant"] == "k_generations_w4<7,tri,xlds,4,4,lean,ahead> +ring" and d["config"]["adapt_lag"] == 19
     assert not np.allclose(d["burnin"]["cr_probs_after_burnin"], 1 / 3.)
     xb = d["exchange_bytes_to_each_peer"]
     assert xb["positions"] == 512 * 112 * 8 and 0 < xb["per_burnin_generation"] <= 100 * 1024

@@ -104,6 +104,9 @@ struct Publish {
     double* PG = nullptr; long long pos_stride = 0;
 };
 
+// (a code object built at run time around a user's device function takes both structures: whoever changes their layout raises DZ_USER_ABI with it)
+static_assert(sizeof(Params) == 784 && sizeof(Publish) == 168, "Params / Publish changed: raise DZ_USER_ABI (a stale user code object must not be looked up by the old name) and these sizes");
+
 // per-phase cycle stamps: defined by dz_experiments.h in instrumented builds only (tools/variants.sh), no-ops in the product
 #ifdef DZ_EXPERIMENTS
 #include "dz_experiments.h"

@@ -21,7 +21,7 @@ DIMS = [2, 3, 5, 10, 16, 17, 31, 32, 33, 48, 64, 65, 100, 100, 100, 112, 127, 12
 CHAINS = [3, 4, 5, 15, 16, 17, 48, 63, 64, 65, 100, 250, 256, 1000, 1024, 1100, 2048]
 
 
-def draw_config(rng, long=False, dims=None, chains=None, adapt_lag_arm=False):
+def draw_config(rng, long=False, dims=None, chains=None, adapt_lag_arm=False, sharded_arm=False):
     d = int(rng.choice(dims or DIMS))
     N = int(rng.choice(chains or (CHAINS + ([3000, 4096, 4096] if long else []))))
     if d > 128 and not chains:                                # (oracle time; --chains lifts it: the k_generations_d2 regime is 128 < d <= 228)
@@ -53,7 +53,7 @@ def draw_config(rng, long=False, dims=None, chains=None, adapt_lag_arm=False):
     # chains sharded over W engines (one per rank in production; here W threads of one process, rows exchanged through the host
     # transport): the result must not depend on W
     cfg["world"] = 1
-    if not cfg["pt"] and rng.random() < 0.12:
+    if not cfg["pt"] and (sharded_arm or rng.random() < 0.12):
         ws = [w for w in (2, 3, 4) if N % w == 0 and N // w >= 2]
         if ws:
             cfg["world"] = int(rng.choice(ws))
@@ -146,7 +146,12 @@ def run_sharded(G, c):
             e = build(G.Engine, c, dict(nchains_local=nl, chain_offset=r * nl))
             e.set_exchange(xch.callback(r))
             half = n // 2
-            e.step(half); e.step(n - half)
+            e.step(half)
+            if r == 0:
+                tally(e.last_kernel_variant())
+            e.step(n - half)
+            if r == 0:
+                tally(e.last_kernel_variant())
             res[r] = (e.get_trace(0, n), e.get_history(), e.get_cr_state(), e.get_gamma_state(), e.get_state())
             e.close()
         except Exception as ex:
@@ -223,6 +228,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=0.0, help="stop after this long (0: run all --n)")
     ap.add_argument("--long", action="store_true", help="three times the generations, populations up to 4096 chains")
     ap.add_argument("--adapt-lag", action="store_true", help="every configuration with an adaptation and an adapt_lag (lockstep, no tempering): the launches that hold several burn-in generations")
+    ap.add_argument("--sharded", action="store_true", help="every configuration that can be sharded is (2..4 engines of one process, rows exchanged through the host transport); with --chains 512,1024,2048 the ranks own whole groups of 256 chains")
     ap.add_argument("--dims", default="", help="comma-separated dimensions to draw from instead of the built-in list")
     ap.add_argument("--chains", default="", help="comma-separated chain counts to draw from (also lifts the 256-chain cap of d > 128)")
     args = ap.parse_args()
@@ -233,7 +239,7 @@ def main():
     rng = np.random.default_rng(args.seed)
     t0 = time.time(); bad = 0; done = 0
     for i in range(args.n):
-        c = draw_config(rng, args.long, dims, chains, args.adapt_lag)
+        c = draw_config(rng, args.long, dims, chains, args.adapt_lag, args.sharded)
         try:
             r = run_one(G, O, c)
         except Exception as ex:                                 # an engine refusing a configuration must refuse it on both sides: report

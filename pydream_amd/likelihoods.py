@@ -199,11 +199,15 @@ class DeviceFunctionLogLike:
     multitry 1 or 3..32 tries, and always_finite=True (a density that may be -inf for a whole proposal set needs the multi-kernel path's
     redraw rounds, Dream.py:281-289).  host: an optional Python twin f(x[d]) -> float for calls on the host (Model.total_logp)."""
 
-    def __init__(self, source, name, ndim, data=None, always_finite=False, host=None, extra_flags=()):
+    def __init__(self, source, name, ndim, data=None, always_finite=False, host=None, extra_flags=(), path=None):
+        """path: a code object built beforehand from this source (`DeviceFunctionLogLike(...).code_object()` on a machine with hipcc and THIS
+        version of the package: the persistent kernels' names carry the layout generation, a stale object just runs the multi-kernel path)"""
+        if source is None and path is None:
+            raise ValueError("give the device function's HIP source (or the path of a code object built from it)")
         self.name, self.d, self.source = name, int(ndim), source
         self.data = None if data is None else np.ascontiguousarray(data)
         self.always_finite, self.host, self.extra_flags = bool(always_finite), host, tuple(extra_flags)
-        self.path = None
+        self.path = path
         self._eval_engine = None
 
     def code_object(self):

@@ -299,5 +299,8 @@ def test_a_user_device_function_compiles_into_the_persistent_kernels(tmp_path, m
     for name in ("dz_user_batch", "dz_user_generations_v%d" % abi, "dz_user_generations_full_v%d" % abi):
         assert name + ".kd" in syms, name
     assert like(np.ones(10)) == -5.0
+    assert DeviceFunctionLogLike(None, "sq", 10, path=out).code_object() == out          # a code object built beforehand
+    with pytest.raises(ValueError):
+        DeviceFunctionLogLike(None, "sq", 10)
     with pytest.raises(Exception, match="hipcc failed"):
         DeviceFunctionLogLike("__device__ double bad(const double* x, int d, const void* data, int lane) { return y; }", "bad", 3).code_object()
